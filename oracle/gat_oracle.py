@@ -1,0 +1,235 @@
+"""CPU oracle for the GAT attention layer hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this file.  The product (pygat_amd/) never does; it fails loudly when the HIP
+library is missing.
+
+PARITY UNPINNED.  The reference (ArielleRosinski/pyGAT) ships no tests, golden
+vectors or fixtures for this path, and its module `layers.py` cannot be
+imported in the build container: `layers.py:5` imports `torch_scatter`
+(rusty1s/pytorch_scatter, not pinned in the reference's requirements.txt),
+which is not installed and stays absent.  This file is therefore a restatement,
+in our own words, of the algorithm as read from the reference source:
+
+  dense formulation   layers.py:32-64   (GraphAttentionLayer.forward and
+                                         _prepare_attentional_mechanism_input)
+  sparse formulation  layers.py:125-173 (SpGraphAttentionLayer.forward) with
+                      layers.py:72-90   (SpecialSpmmFunction fwd/bwd) and the
+                      published semantics of torch_scatter.scatter_max
+                      (out[i] = max over {src[k] : index[k] == i})
+  multi-head model    models.py:29-35   (concat for hidden levels, mean of the
+                                         stacked heads for the last level)
+
+What pins it instead (tests/test_oracle.py): the two formulations agree with
+each other; the hand-derived CSR gradients (`csr_layer_fwd_bwd`) agree with
+stock torch autograd run through the dense formulation in fp64; gradcheck.
+
+All functions take/return CPU torch tensors; dtype follows the inputs
+(fp32 like the reference, or fp64 for ground truth).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------
+# single head, dense formulation -- layers.py:32-64
+# --------------------------------------------------------------------------
+def dense_head_forward(h, adj, W, a, alpha, concat, W_skip=None,
+                       mask_x=None, mask_wh=None, mask_att=None):
+    """One head of GraphAttentionLayer.
+
+    h [N,Fin]; adj [N,N] (only `adj > 0` is used, layers.py:41); W [Fin,F];
+    a [2F,1] (layers.py:23); W_skip [Fin,F] or None (layers.py:26-28).
+    mask_* are pre-scaled dropout masks (0 or 1/(1-p)) standing in for the
+    three F.dropout calls at layers.py:34,37,43; None == eval mode.
+    """
+    Fo = W.shape[1]
+    if mask_x is not None:                       # layers.py:34
+        h = h * mask_x
+    Wh = h @ W                                   # layers.py:35
+    if mask_wh is not None:                      # layers.py:37
+        Wh = Wh * mask_wh
+    a = a.reshape(-1)
+    s = Wh @ a[:Fo]                              # layers.py:60
+    t = Wh @ a[Fo:]                              # layers.py:61
+    e = F.leaky_relu(s[:, None] + t[None, :], alpha)      # layers.py:63-64
+    att = torch.where(adj > 0, e, torch.full_like(e, -9e15))  # layers.py:40-41
+    att = torch.softmax(att, dim=1)              # layers.py:42
+    if mask_att is not None:                     # layers.py:43 (dense [N,N] mask)
+        att = att * mask_att
+    hp = att @ Wh                                # layers.py:44
+    if W_skip is not None:                       # layers.py:47-48 (h is post-dropout)
+        hp = hp + h @ W_skip
+    return F.elu(hp) if concat else hp           # layers.py:50-53
+
+
+# --------------------------------------------------------------------------
+# single head, sparse (edge-list) formulation -- layers.py:125-173
+# --------------------------------------------------------------------------
+def sparse_head_forward(h, rowptr, col, W, a, alpha, concat, W_skip=None,
+                        mask_x=None, mask_wh=None, mask_edge=None):
+    """One head of SpGraphAttentionLayer over a CSR pattern.
+
+    The reference derives `edge = adj.nonzero().t()` (layers.py:129), which is
+    row-major, i.e. exactly CSR order; edge[0] = row (i), edge[1] = col (j).
+    a is [1,2F] here (layers.py:114).  mask_edge [E] stands in for the dropout
+    on the numerators AFTER the row sum is taken (layers.py:150-153).
+    """
+    N = h.shape[0]
+    rowptr = torch.as_tensor(rowptr, dtype=torch.int64)
+    col = torch.as_tensor(col, dtype=torch.int64)
+    deg = rowptr[1:] - rowptr[:-1]
+    src = torch.repeat_interleave(torch.arange(N), deg)   # edge[0]
+    Fo = W.shape[1]
+    if mask_x is not None:                       # layers.py:132
+        h = h * mask_x
+    Wh = h @ W                                   # layers.py:134
+    if mask_wh is not None:                      # layers.py:136
+        Wh = Wh * mask_wh
+    a = a.reshape(-1)
+    # layers.py:141-144: a . [Wh_i ; Wh_j]  ==  a[:F].Wh_i + a[F:].Wh_j
+    edge_e = F.leaky_relu((Wh @ a[:Fo])[src] + (Wh @ a[Fo:])[col], alpha)
+    # layers.py:145: torch_scatter.scatter_max(edge_e, edge[0]) -> per-row max
+    m = torch.full((N,), -float("inf"), dtype=h.dtype).scatter_reduce(
+        0, src, edge_e.detach(), "amax", include_self=True)
+    p = torch.exp(edge_e - m[src])               # layers.py:146
+    Z = torch.zeros(N, dtype=h.dtype).index_add(0, src, p)   # layers.py:150
+    if mask_edge is not None:                    # layers.py:153
+        p = p * mask_edge
+    hp = torch.zeros(N, Fo, dtype=h.dtype).index_add(0, src, p[:, None] * Wh[col])  # layers.py:156
+    hp = hp / Z[:, None]                         # layers.py:160
+    if W_skip is not None:                       # layers.py:165-166
+        hp = hp + h @ W_skip
+    return F.elu(hp) if concat else hp           # layers.py:168-173
+
+
+# --------------------------------------------------------------------------
+# one GAT level = all heads of one layer -- models.py:29-35
+# --------------------------------------------------------------------------
+def level_forward(x, graph, Ws, As, alpha, concat, W_skips=None,
+                  formulation="sparse", masks=None):
+    """All heads of one level.  Ws [H,Fin,F], As [H,2F], W_skips [H,Fin,F]|None.
+
+    concat=True  -> hidden level: cat(heads, dim=1), each head ELU'd (models.py:32)
+    concat=False -> last level: mean(stack(heads, 1), 1), no ELU     (models.py:34)
+    graph: (rowptr, col) for "sparse", dense adj for "dense".
+    masks: optional dict of per-head pre-scaled masks {"x":[H,N,Fin],
+           "wh":[H,N,F], "att":[H,E] (sparse) or [H,N,N] (dense)}.
+    """
+    outs = []
+    for hd in range(Ws.shape[0]):
+        mk = {} if masks is None else {k: v[hd] for k, v in masks.items() if v is not None}
+        sk = None if W_skips is None else W_skips[hd]
+        if formulation == "dense":
+            o = dense_head_forward(x, graph, Ws[hd], As[hd].reshape(-1, 1), alpha, concat, sk,
+                                   mk.get("x"), mk.get("wh"), mk.get("att"))
+        else:
+            o = sparse_head_forward(x, graph[0], graph[1], Ws[hd], As[hd].reshape(1, -1), alpha,
+                                    concat, sk, mk.get("x"), mk.get("wh"), mk.get("att"))
+        outs.append(o)
+    if concat:
+        return torch.cat(outs, dim=1)
+    return torch.mean(torch.stack(outs, dim=1), dim=1)
+
+
+def model_forward(x, graph, levels, alpha, formulation="sparse"):
+    """models.GAT.forward (eval mode): `levels` is a list of dicts
+    {"W":[H,Fin,F], "a":[H,2F], "skip":[H,Fin,F]|None}; every level but the
+    last concatenates (models.py:23,30-34)."""
+    for li, lv in enumerate(levels):
+        x = level_forward(x, graph, lv["W"], lv["a"], alpha, li < len(levels) - 1,
+                          lv.get("skip"), formulation)
+    return x
+
+
+# --------------------------------------------------------------------------
+# hand-derived CSR forward+backward (the math the HIP kernels implement)
+# --------------------------------------------------------------------------
+def csr_layer_fwd_bwd(X, rowptr, col, Ws, As, alpha, concat, G, W_skips=None):
+    """Multi-head level, eval mode / dropout 0, explicit gradients (numpy).
+
+    Follows the same forward as sparse_head_forward; the backward is the chain
+    rule through layers.py:134-170 and SpecialSpmmFunction.backward
+    (layers.py:81-90) written per edge, never forming N x N:
+        dp_ij = G'_i . Wh_j ; D_i = sum_j alpha_ij dp_ij
+        de_ij = alpha_ij (dp_ij - D_i) ; dz_ij = de_ij * (z_ij > 0 ? 1 : alpha)
+        ds_i = sum_j dz_ij ; dt_j = sum_i dz_ij
+        dWh_j = sum_i alpha_ij G'_i + ds_j a_src + dt_j a_dst
+        da_src = sum_i ds_i Wh_i ; da_dst = sum_j dt_j Wh_j
+        dW = X^T dWh ; dX = dWh W^T (+ G' W_skip^T) ; dW_skip = X^T G'
+    G is dL/d(out) with out [N,H*F] (concat) or [N,F] (mean).
+    Returns dict(out, dX, dW [H,Fin,F], da [H,2F], dW_skip).
+    """
+    X = np.asarray(X); dt_ = X.dtype
+    rowptr = np.asarray(rowptr, dtype=np.int64); col = np.asarray(col, dtype=np.int64)
+    Ws = np.asarray(Ws, dtype=dt_); As = np.asarray(As, dtype=dt_); G = np.asarray(G, dtype=dt_)
+    N = X.shape[0]; H, Fin, Fo = Ws.shape
+    deg = np.diff(rowptr); src = np.repeat(np.arange(N), deg)
+    outs = []; dX = np.zeros_like(X); dW = np.zeros_like(Ws); dA = np.zeros_like(As)
+    dSk = None if W_skips is None else np.zeros_like(np.asarray(W_skips, dtype=dt_))
+    for h in range(H):
+        W = Ws[h]; a_s = As[h, :Fo]; a_d = As[h, Fo:]
+        Wh = X @ W
+        s = Wh @ a_s; t = Wh @ a_d
+        z = s[src] + t[col]
+        e = np.where(z > 0, z, alpha * z)
+        m = np.full(N, -np.inf, dtype=dt_); np.maximum.at(m, src, e)
+        p = np.exp(e - m[src])
+        Z = np.zeros(N, dtype=dt_); np.add.at(Z, src, p)
+        al = p / Z[src]
+        hp = np.zeros((N, Fo), dtype=dt_); np.add.at(hp, src, al[:, None] * Wh[col])
+        pre = hp if W_skips is None else hp + X @ np.asarray(W_skips[h], dtype=dt_)
+        out = np.where(pre > 0, pre, np.expm1(np.minimum(pre, 0))) if concat else pre
+        outs.append(out)
+        # ---- backward
+        Gh = G[:, h * Fo:(h + 1) * Fo] if concat else G / H
+        Gp = Gh * np.where(pre > 0, 1.0, np.exp(np.minimum(pre, 0))).astype(dt_) if concat else Gh
+        dp = np.einsum("ef,ef->e", Gp[src], Wh[col])
+        D = np.zeros(N, dtype=dt_); np.add.at(D, src, al * dp)
+        de = al * (dp - D[src])
+        dz = de * np.where(z > 0, 1.0, alpha).astype(dt_)
+        ds = np.zeros(N, dtype=dt_); np.add.at(ds, src, dz)
+        dtt = np.zeros(N, dtype=dt_); np.add.at(dtt, col, dz)
+        dWh = np.zeros((N, Fo), dtype=dt_); np.add.at(dWh, col, al[:, None] * Gp[src])
+        dWh += ds[:, None] * a_s[None, :] + dtt[:, None] * a_d[None, :]
+        dA[h, :Fo] = ds @ Wh; dA[h, Fo:] = dtt @ Wh
+        dW[h] = X.T @ dWh
+        dX += dWh @ W.T
+        if W_skips is not None:
+            Sk = np.asarray(W_skips[h], dtype=dt_)
+            dSk[h] = X.T @ Gp
+            dX += Gp @ Sk.T
+    out = np.concatenate(outs, 1) if concat else np.mean(np.stack(outs, 1), 1)
+    return dict(out=out, dX=dX, dW=dW, da=dA, dW_skip=dSk)
+
+
+# --------------------------------------------------------------------------
+# graph helpers used by tests and by bench.py's CPU leg
+# --------------------------------------------------------------------------
+def dense_from_csr(rowptr, col, N, dtype=torch.float32):
+    adj = torch.zeros(N, N, dtype=dtype)
+    deg = np.diff(np.asarray(rowptr))
+    src = np.repeat(np.arange(N), deg)
+    adj[torch.as_tensor(src), torch.as_tensor(np.asarray(col, dtype=np.int64))] = 1.0
+    return adj
+
+
+def random_symmetric_csr(N, avg_deg, seed, hub=None):
+    """Random symmetric pattern + self loops (the shape utils.py:49-52 produces).
+    hub: optional (node, degree) to force one heavy row."""
+    rng = np.random.default_rng(seed)
+    n_e = max(1, int(N * avg_deg / 2))
+    r = rng.integers(0, N, n_e); c = rng.integers(0, N, n_e)
+    if hub is not None:
+        hn, hd = hub
+        nb = rng.choice(N, size=min(hd, N), replace=False)
+        r = np.concatenate([r, np.full(nb.shape, hn)]); c = np.concatenate([c, nb])
+    rr = np.concatenate([r, c, np.arange(N)]); cc = np.concatenate([c, r, np.arange(N)])
+    key = np.unique(rr.astype(np.int64) * N + cc)
+    rr = (key // N).astype(np.int32); cc = (key % N).astype(np.int32)
+    rowptr = np.zeros(N + 1, dtype=np.int32); np.add.at(rowptr, rr + 1, 1)
+    rowptr = np.cumsum(rowptr).astype(np.int32)
+    return rowptr, cc

@@ -1,0 +1,184 @@
+/*
+ * pygat_amd.h -- C ABI of the MI355X (gfx950) GAT attention-layer hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch types.  The
+ * reference (ArielleRosinski/pyGAT) is pure Python and owns no FFI; the entry
+ * points below replace the ATen call sequences of its layer/op boundary:
+ *
+ *   GraphAttentionLayer.forward          layers.py:32-53   (dense N x N path)
+ *   _prepare_attentional_mechanism_input layers.py:55-64   (s_i + t_j split)
+ *   SpecialSpmmFunction.forward/backward layers.py:72-90   (COO spmm + its grads)
+ *   SpGraphAttentionLayer.forward        layers.py:125-173 (edge-list path)
+ *   GAT.forward head concat / head mean  models.py:29-35
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless marked "host"; the caller owns all
+ *     memory including workspaces; nothing here allocates, frees or synchronises.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); kernels
+ *     are only enqueued, never waited for.
+ *   - return 0 on success, a negative PYGAT_E* code otherwise; the message of the
+ *     last error on the calling thread is at pygat_last_error().  Nothing throws.
+ *   - floats are fp32, indices int32.  Feature tables are row-major and PADDED:
+ *     a level with H heads of F' outputs uses Fp = pygat_padded_width(F') columns
+ *     per head and R = H*Fp floats per node row ("head-interleaved row").
+ *   - graph = CSR pattern of the adjacency: row i lists the j with adj[i][j] != 0
+ *     (layers.py:129: edge[0] = i = softmax row, edge[1] = j = gathered node).
+ */
+#ifndef PYGAT_AMD_H
+#define PYGAT_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PYGAT_ABI_VERSION 1
+
+enum {
+  PYGAT_OK = 0,
+  PYGAT_EINVAL = -1,   /* bad argument (null pointer, size, alignment, unsupported width) */
+  PYGAT_EHIP = -2,     /* a HIP launch failed; message holds hipGetErrorString */
+  PYGAT_ENODEV = -3    /* no gfx950 device / code object not loadable */
+};
+
+/* flags for pygat_gat_forward / pygat_gat_backward */
+enum {
+  PYGAT_F_ELU = 1,      /* apply ELU to (attention + skip): concat=True, layers.py:50-51,168-170 */
+  PYGAT_F_SKIP = 2      /* add the skip projection rows `sk` (layers.py:47-48,165-166) */
+};
+
+int pygat_abi_version(void);
+const char* pygat_last_error(void);
+/* Fp for a head width F' (power of two >= 4, <= 256); 0 if unsupported. */
+int pygat_padded_width(int f_out);
+/* number of HIP devices visible / name of the current one (host buffers). */
+int pygat_device_count(void);
+int pygat_device_name(char* host_buf, int len);
+
+/* ------------------------------------------------------------------ K0: graph
+ * Replaces `adj.nonzero().t()` (layers.py:129), run ONCE per graph instead of
+ * once per head per forward, and the `adj > 0` mask of layers.py:41.
+ * mode 0: pattern = (adj != 0) (sparse layer), mode 1: pattern = (adj > 0) (dense layer).
+ */
+/* counts[i] = nnz of row i of the dense n x n matrix (ld = row stride in floats). */
+int pygat_dense_row_counts(const float* adj, int n, int64_t ld, int mode,
+                           int32_t* counts, void* stream);
+/* exclusive scan: out[0] = 0, out[i+1] = sum(in[0..i]); in/out length n / n+1.
+ * ws: >= pygat_scan_workspace_bytes(n) bytes. */
+size_t pygat_scan_workspace_bytes(int64_t n);
+int pygat_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, void* ws, void* stream);
+/* col[rowptr[i] ...] = sorted column indices of row i's pattern. */
+int pygat_dense_fill_cols(const float* adj, int n, int64_t ld, int mode,
+                          const int32_t* rowptr, int32_t* col, void* stream);
+/* For a structurally symmetric CSR with sorted rows: perm[k] = position of edge
+ * (j,i) for the edge k = (i,j); flags[0] is set to 1 if some edge has no mirror
+ * (pattern not symmetric), flags[1] to 1 if some row is empty. flags must be zeroed. */
+int pygat_csr_symmetric_perm(int n, const int32_t* rowptr, const int32_t* col,
+                             int32_t* perm, int32_t* flags, void* stream);
+
+/* ------------------------------------------------------------ K1: projection
+ * Replaces torch.mm(h, W) per head (layers.py:35,134), the skip torch.mm
+ * (layers.py:48,166) and the two a-halves matmuls (layers.py:60-61):
+ *   C[M x N] = op(A) * op(B) (+ C if accumulate), fp32 MFMA, row-major.
+ * Output columns can be routed to up to 4 destination tables (seg_*): columns
+ * [seg_col[s], seg_col[s+1]) of C go to seg_ptr[s] with row stride seg_ld[s].
+ */
+typedef struct {
+  int nseg;                 /* 1..4 */
+  int32_t col_start[5];     /* col_start[0] = 0, col_start[nseg] = N */
+  float* ptr[4];
+  int64_t ld[4];
+} pygat_out_segments;
+
+/* transA: A is stored [K x M]; transB: B is stored [N x K]. split_k >= 1: when >1 the
+ * K range is cut in split_k slabs whose partial products go to `ws`
+ * (>= pygat_gemm_workspace_bytes) and are then summed in slab order (deterministic). */
+size_t pygat_gemm_workspace_bytes(int M, int N, int split_k);
+int pygat_gemm_f32(int transA, int transB, int M, int N, int64_t K,
+                   const float* A, int64_t lda, const float* B, int64_t ldb,
+                   const pygat_out_segments* out, int accumulate,
+                   int split_k, void* ws, void* stream);
+
+/* Pack the per-head parameters of one level into the projection operand
+ *   Wcat [Fin x ldw], columns: [0,R) W heads (padded to Fp), [R,2R) skip heads if
+ *   w_skip != NULL, then H columns W_h a_src_h and H columns W_h a_dst_h (so the
+ *   projection also yields s and t), zero padded up to ldw (multiple of 4);
+ *   a_pad [H x 2 x Fp]: a_src then a_dst per head, zero padded.
+ * W [H x Fin x F'], a [H x 2F'] (a[:F'] = a_src multiplies Wh_i, layers.py:60),
+ * w_skip [H x Fin x F'] or NULL. */
+int pygat_pack_params(int H, int Fin, int Fo, const float* W, const float* a,
+                      const float* w_skip, float* Wcat, int64_t ldw, float* a_pad,
+                      void* stream);
+/* Inverse for gradients: dW[H x Fin x F'] (+)= columns of dWcat [Fin x ld]. */
+int pygat_unpack_wgrad(int H, int Fin, int Fo, const float* dWcat, int64_t ld,
+                       int col_offset, float* dW, void* stream);
+
+/* ---------------------------------------------- K2: fused edge-softmax + aggregate
+ * Replaces layers.py:141-170 (and 40-51): per row i and head h
+ *   e_ij = LeakyReLU(s_i + t_j), m_i = max_j e_ij, p_ij = exp(e_ij - m_i),
+ *   Z_i = sum_j p_ij, hattn_i = (sum_j p_ij Wh_j) / Z_i,
+ *   out_i = [ELU](hattn_i [+ sk_i]).
+ * graph rows longer than `chunk` edges are split: the caller passes the heavy-row
+ * work list (see pygat_heavy_*), and `part` workspace for their partial sums.
+ */
+typedef struct {
+  int n;                     /* nodes */
+  int64_t nnz;               /* edges */
+  const int32_t* rowptr;     /* [n+1] */
+  const int32_t* col;        /* [nnz] */
+  /* rows with more than `chunk` edges, cut in items of <= chunk edges */
+  int chunk;
+  int n_heavy;               /* heavy rows */
+  int n_items;               /* total items over all heavy rows */
+  const int32_t* heavy_row;  /* [n_heavy] */
+  const int32_t* heavy_item_ptr; /* [n_heavy+1] first item of each heavy row */
+  const int32_t* item_row_slot;  /* [n_items] index into heavy_row */
+  const int32_t* item_begin;     /* [n_items] first edge */
+  const int32_t* item_end;       /* [n_items] one past last edge */
+} pygat_graph;
+
+/* bytes of `part` workspace needed by forward/backward for this graph and row width */
+size_t pygat_partials_bytes(int n_items, int H, int Fp);
+
+/* Wh [n x R], s,t [n x H], sk [n x R] or NULL.
+ * out [n x H*F'] compact (may be NULL), hattn [n x R] padded (may be NULL; needed for
+ * backward and for the head mean), m,Z [n x H] (may be NULL together in eval).  */
+int pygat_gat_forward(const pygat_graph* g, int H, int Fo, float alpha, int flags,
+                      const float* Wh, const float* s, const float* t, const float* sk,
+                      float* out, float* hattn, float* m, float* Z,
+                      void* part, void* stream);
+
+/* models.py:34: out[n x F'] = mean over heads of (hattn [+ sk]) (padded inputs). */
+int pygat_head_mean(int n, int H, int Fo, const float* hattn, const float* sk,
+                    float* out, void* stream);
+
+/* ------------------------------------------------ K3/K4: backward, no N x N, no atomics
+ * Replaces SpecialSpmmFunction.backward (layers.py:81-90) and the autograd of
+ * layers.py:141-170.  mean_mode = 0: G is [n x H*F'] (concat); 1: G is [n x F']
+ * and each head receives G/H (models.py:34).
+ *   K3 row pass  : Gp = G * ELU'(hattn+sk); D_i = Gp_i . hattn_i;
+ *                  alpha_ij, dz_ij per edge -> ebuf; ds_i = sum_j dz_ij
+ *   K4 col pass  : dWh_j = sum_i alpha_ij Gp_i + ds_j a_src + dt_j a_dst, dt_j = sum_i dz_ij
+ *                  over the transposed pattern gT with perm_t[k] = forward edge of gT's edge k.
+ * ebuf: [nnz x 2 x H] floats (alpha then dz per edge).  */
+int pygat_gat_backward_row(const pygat_graph* g, int H, int Fo, float alpha, int flags,
+                           int mean_mode, const float* G, const float* Wh, const float* s,
+                           const float* t, const float* sk, const float* hattn,
+                           const float* m, const float* Z,
+                           float* Gp, float* ebuf, float* ds, void* part, void* stream);
+int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm_t, int H, int Fo,
+                           const float* Gp, const float* ebuf, const float* ds,
+                           const float* a_pad, float* dWh, float* dt,
+                           void* part, void* stream);
+/* da[H x 2F'] : da_src = sum_i ds_i Wh_i, da_dst = sum_j dt_j Wh_j (per head).
+ * ws >= pygat_agrad_workspace_bytes(H, Fo). */
+size_t pygat_agrad_workspace_bytes(int H, int Fo);
+int pygat_a_grad(int n, int H, int Fo, const float* Wh, const float* ds, const float* dt,
+                 float* da, void* ws, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYGAT_AMD_H */

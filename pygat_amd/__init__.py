@@ -1,0 +1,15 @@
+"""pygat_amd -- MI355X-native GAT attention layer (hand-written HIP for gfx950).
+
+Drop-in for the hot path of ArielleRosinski/pyGAT: `GraphAttentionLayer`,
+`SpGraphAttentionLayer` (reference layers.py) and `GAT` (reference models.py).
+Importing this package loads libpygat_amd.so and fails loudly when it is absent:
+there is no CPU / eager fallback.
+"""
+from ._lib import lib, LIB_PATH, padded_width          # noqa: F401  (raises if the .so is missing)
+from .graph import CSRGraph, as_graph                   # noqa: F401
+from .ops import gat_level, GATLevelFn, gemm            # noqa: F401
+from .layers import GraphAttentionLayer, SpGraphAttentionLayer  # noqa: F401
+from .models import GAT                                 # noqa: F401
+
+__all__ = ["CSRGraph", "as_graph", "gat_level", "GATLevelFn", "gemm", "GraphAttentionLayer",
+           "SpGraphAttentionLayer", "GAT", "padded_width", "LIB_PATH"]

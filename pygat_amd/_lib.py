@@ -1,0 +1,102 @@
+"""ctypes binding of libpygat_amd.so (the C ABI in include/pygat_amd.h).
+
+There is NO fallback: if the HIP library is missing or does not export the
+expected symbols, importing this module raises.  PyTorch is used by the callers
+only to own device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpygat_amd.so")
+
+ABI_VERSION = 1
+F_ELU = 1
+F_SKIP = 2
+
+# every entry point declared in include/pygat_amd.h
+SYMBOLS = [
+    "pygat_abi_version", "pygat_last_error", "pygat_padded_width", "pygat_device_count",
+    "pygat_device_name", "pygat_dense_row_counts", "pygat_scan_workspace_bytes",
+    "pygat_exclusive_scan_i32", "pygat_dense_fill_cols", "pygat_csr_symmetric_perm",
+    "pygat_gemm_workspace_bytes", "pygat_gemm_f32", "pygat_pack_params", "pygat_unpack_wgrad",
+    "pygat_partials_bytes", "pygat_gat_forward", "pygat_head_mean", "pygat_gat_backward_row",
+    "pygat_gat_backward_col", "pygat_agrad_workspace_bytes", "pygat_a_grad",
+]
+
+
+class OutSegments(C.Structure):
+    _fields_ = [("nseg", C.c_int), ("col_start", C.c_int32 * 5), ("ptr", C.c_void_p * 4),
+                ("ld", C.c_int64 * 4)]
+
+
+class Graph(C.Structure):
+    _fields_ = [("n", C.c_int), ("nnz", C.c_int64), ("rowptr", C.c_void_p), ("col", C.c_void_p),
+                ("chunk", C.c_int), ("n_heavy", C.c_int), ("n_items", C.c_int),
+                ("heavy_row", C.c_void_p), ("heavy_item_ptr", C.c_void_p),
+                ("item_row_slot", C.c_void_p), ("item_begin", C.c_void_p), ("item_end", C.c_void_p)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"pygat_amd: {LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` or `make -C pygat_amd/csrc`. There is no CPU/PyTorch fallback for the hot path.")
+    lib = C.CDLL(LIB_PATH)
+    missing = [s for s in SYMBOLS if not hasattr(lib, s)]
+    if missing:
+        raise ImportError(f"pygat_amd: {LIB_PATH} lacks symbols {missing}")
+    p, i, i64, f, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+    lib.pygat_abi_version.restype = i
+    lib.pygat_last_error.restype = C.c_char_p
+    lib.pygat_padded_width.argtypes = [i]
+    lib.pygat_device_name.argtypes = [C.c_char_p, i]
+    lib.pygat_dense_row_counts.argtypes = [p, i, i64, i, p, p]
+    lib.pygat_scan_workspace_bytes.argtypes = [i64]
+    lib.pygat_scan_workspace_bytes.restype = sz
+    lib.pygat_exclusive_scan_i32.argtypes = [p, i64, p, p, p]
+    lib.pygat_dense_fill_cols.argtypes = [p, i, i64, i, p, p, p]
+    lib.pygat_csr_symmetric_perm.argtypes = [i, p, p, p, p, p]
+    lib.pygat_gemm_workspace_bytes.argtypes = [i, i, i]
+    lib.pygat_gemm_workspace_bytes.restype = sz
+    lib.pygat_gemm_f32.argtypes = [i, i, i, i, i64, p, i64, p, i64, C.POINTER(OutSegments), i, i, p, p]
+    lib.pygat_pack_params.argtypes = [i, i, i, p, p, p, p, i64, p, p]
+    lib.pygat_unpack_wgrad.argtypes = [i, i, i, p, i64, i, p, p]
+    lib.pygat_partials_bytes.argtypes = [i, i, i]
+    lib.pygat_partials_bytes.restype = sz
+    lib.pygat_gat_forward.argtypes = [C.POINTER(Graph), i, i, f, i, p, p, p, p, p, p, p, p, p, p]
+    lib.pygat_head_mean.argtypes = [i, i, i, p, p, p, p]
+    lib.pygat_gat_backward_row.argtypes = [C.POINTER(Graph), i, i, f, i, i, p, p, p, p, p, p, p, p, p, p, p, p, p]
+    lib.pygat_gat_backward_col.argtypes = [C.POINTER(Graph), p, i, i, p, p, p, p, p, p, p, p]
+    lib.pygat_agrad_workspace_bytes.argtypes = [i, i]
+    lib.pygat_agrad_workspace_bytes.restype = sz
+    lib.pygat_a_grad.argtypes = [i, i, i, p, p, p, p, p, p]
+    for s in SYMBOLS:
+        fn = getattr(lib, s)
+        if fn.restype is C.c_int or s in ("pygat_abi_version", "pygat_padded_width", "pygat_device_count"):
+            fn.restype = i
+    if lib.pygat_abi_version() != ABI_VERSION:
+        raise ImportError(f"pygat_amd: ABI version {lib.pygat_abi_version()} != {ABI_VERSION}")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str = "") -> None:
+    """Turn a negative C return code into the reference-style Python error."""
+    if rc == 0:
+        return
+    msg = lib.pygat_last_error().decode(errors="replace")
+    if rc == -1:
+        raise ValueError(f"pygat_amd {what}: {msg}")
+    raise RuntimeError(f"pygat_amd {what}: {msg} (code {rc})")
+
+
+def padded_width(f_out: int) -> int:
+    fp = lib.pygat_padded_width(int(f_out))
+    if fp == 0:
+        raise ValueError(f"pygat_amd: head width {f_out} unsupported (1..256)")
+    return fp

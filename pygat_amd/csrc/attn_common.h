@@ -1,0 +1,136 @@
+// Lane mapping shared by the fused attention kernels K2 (forward), K3 (row
+// backward) and K4 (column backward).
+//
+// A node row is R = H*Fp floats (all local heads interleaved, each padded to
+// Fp = power of two), i.e. NCH = R/4 float4 "chunks".  One wave works on one
+// CSR row (or one <=chunk-edge item of a heavy row):
+//   LPR  lanes per gathered row  = pow2 >= NCH, capped at 64
+//   EPW  = 64 / LPR edges are gathered by one wave instruction (edge slots)
+//   VEC  chunks per lane (only when NCH > 64, LPR = 64): chunk c = c0 + 64*v
+// Lane l: slot = l / LPR, c0 = l % LPR.  A float4 never straddles heads
+// (Fp % 4 == 0); the head of chunk c is (4c) / Fp and the LPH = Fp/4 lanes of a
+// head are consecutive and aligned, so per-head reductions are DPP butterflies.
+#pragma once
+#include "common.h"
+
+namespace pygat {
+
+constexpr float NEG_BIG = -1.0e30f;  // running-max seed: exp(NEG_BIG - x) == 0, exp(NEG_BIG - NEG_BIG) == 1
+
+struct RowShape {
+  int H, Fo, Fp, R, NCH;  // heads, true width, padded width, H*Fp, R/4
+  int fp_shift;           // log2(Fp)
+  int lph;                // lanes per head = Fp/4 (power of two, may exceed 64 only if Fp > 256: rejected)
+};
+
+static inline bool make_row_shape(int H, int Fo, RowShape* rs) {
+  int Fp = padded_width(Fo);
+  if (H <= 0 || Fp == 0) return false;
+  rs->H = H; rs->Fo = Fo; rs->Fp = Fp; rs->R = H * Fp; rs->NCH = rs->R / 4;
+  rs->fp_shift = ilog2(Fp); rs->lph = Fp / 4;
+  return rs->NCH <= 256;  // VEC <= 4
+}
+
+// (LPR, VEC) for a row shape
+static inline void pick_lanes(const RowShape& rs, int* lpr, int* vec) {
+  if (rs.NCH <= 64) {
+    int l = 1;
+    while (l < rs.NCH) l <<= 1;
+    *lpr = l; *vec = 1;
+  } else {
+    *lpr = 64; *vec = (rs.NCH + 63) / 64;
+  }
+}
+
+#define PYGAT_DISPATCH_LANES(LPRV, VECV, CALL)                      \
+  do {                                                              \
+    if ((VECV) == 1) {                                              \
+      switch (LPRV) {                                               \
+        case 1: { constexpr int LPR = 1, VEC = 1; CALL; } break;    \
+        case 2: { constexpr int LPR = 2, VEC = 1; CALL; } break;    \
+        case 4: { constexpr int LPR = 4, VEC = 1; CALL; } break;    \
+        case 8: { constexpr int LPR = 8, VEC = 1; CALL; } break;    \
+        case 16: { constexpr int LPR = 16, VEC = 1; CALL; } break;  \
+        case 32: { constexpr int LPR = 32, VEC = 1; CALL; } break;  \
+        default: { constexpr int LPR = 64, VEC = 1; CALL; } break;  \
+      }                                                             \
+    } else if ((VECV) == 2) { constexpr int LPR = 64, VEC = 2; CALL; \
+    } else if ((VECV) == 3) { constexpr int LPR = 64, VEC = 3; CALL; \
+    } else { constexpr int LPR = 64, VEC = 4; CALL; }               \
+  } while (0)
+
+struct GraphDev {  // device view of pygat_graph
+  int n;
+  const int32_t* rowptr;
+  const int32_t* col;
+  int chunk, n_heavy, n_items;
+  const int32_t* heavy_row;
+  const int32_t* heavy_item_ptr;
+  const int32_t* item_row_slot;
+  const int32_t* item_begin;
+  const int32_t* item_end;
+};
+
+static inline int check_graph(const pygat_graph* g, GraphDev* d) {
+  if (!g || !g->rowptr || !g->col || g->n <= 0 || g->nnz <= 0) {
+    set_error("graph: null or empty (n=%d nnz=%lld)", g ? g->n : -1, g ? (long long)g->nnz : -1LL);
+    return PYGAT_EINVAL;
+  }
+  if (g->nnz >= (int64_t)1 << 31) {
+    set_error("graph: nnz %lld exceeds int32 edge indexing", (long long)g->nnz);
+    return PYGAT_EINVAL;
+  }
+  if (g->chunk < 1 || g->n_heavy < 0 || g->n_items < 0 ||
+      (g->n_heavy > 0 && !(g->heavy_row && g->heavy_item_ptr && g->item_row_slot && g->item_begin && g->item_end))) {
+    set_error("graph: bad heavy-row work list (chunk=%d n_heavy=%d n_items=%d)", g->chunk, g->n_heavy, g->n_items);
+    return PYGAT_EINVAL;
+  }
+  d->n = g->n; d->rowptr = g->rowptr; d->col = g->col; d->chunk = g->chunk;
+  d->n_heavy = g->n_heavy; d->n_items = g->n_items; d->heavy_row = g->heavy_row;
+  d->heavy_item_ptr = g->heavy_item_ptr; d->item_row_slot = g->item_row_slot;
+  d->item_begin = g->item_begin; d->item_end = g->item_end;
+  return PYGAT_OK;
+}
+
+#ifdef __HIPCC__
+template <int VEC>
+struct LaneCols {
+  int cofs[VEC];   // float offset of the lane's chunk inside a padded row (clamped when invalid)
+  int head[VEC];
+  bool valid[VEC];
+};
+
+template <int LPR, int VEC>
+__device__ __forceinline__ LaneCols<VEC> lane_cols(const RowShape& rs) {
+  LaneCols<VEC> lc;
+  const int c0 = (threadIdx.x & 63) & (LPR - 1);
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    int c = c0 + 64 * v;
+    lc.valid[v] = c < rs.NCH;
+    int cc = lc.valid[v] ? c : 0;
+    lc.cofs[v] = 4 * cc;
+    lc.head[v] = (4 * cc) >> rs.fp_shift;
+  }
+  return lc;
+}
+
+// sum / online-softmax merge across the EPW edge slots of a wave (lanes l and l^off, off >= LPR)
+template <int LPR>
+__device__ __forceinline__ float slot_sum(float x) {
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) x += __shfl_xor(x, off);
+  return x;
+}
+template <int LPR>
+__device__ __forceinline__ float4 slot_sum4(float4 v) {
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+    v.x += __shfl_xor(v.x, off); v.y += __shfl_xor(v.y, off);
+    v.z += __shfl_xor(v.z, off); v.w += __shfl_xor(v.w, off);
+  }
+  return v;
+}
+#endif
+
+}  // namespace pygat

@@ -1,0 +1,40 @@
+// Error string, version and device queries of the C ABI (include/pygat_amd.h).
+#include "common.h"
+#include <string.h>
+
+namespace pygat {
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+}  // namespace pygat
+
+extern "C" int pygat_abi_version(void) { return PYGAT_ABI_VERSION; }
+extern "C" const char* pygat_last_error(void) { return pygat::g_err; }
+extern "C" int pygat_padded_width(int f_out) { return pygat::padded_width(f_out); }
+
+extern "C" int pygat_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+extern "C" int pygat_device_name(char* host_buf, int len) {
+  if (!host_buf || len <= 0) return PYGAT_EINVAL;
+  int dev = 0;
+  hipDeviceProp_t p;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    pygat::set_error("no HIP device");
+    return PYGAT_ENODEV;
+  }
+  snprintf(host_buf, (size_t)len, "%s (%s)", p.name, p.gcnArchName);
+  return PYGAT_OK;
+}

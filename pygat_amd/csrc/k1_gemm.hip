@@ -1,0 +1,284 @@
+// K1 / K5 -- fp32 MFMA GEMM for the dense projections of the GAT layer (gfx950).
+//
+// Replaces, per level and for all local heads at once:
+//   Wh = h W              (reference layers.py:35,134)      C = X * Wcat
+//   h W_skip              (layers.py:48,166)                extra columns of Wcat
+//   Wh a[:F'], Wh a[F':]  (layers.py:60-61)                 extra columns W_h a_src_h, W_h a_dst_h
+// and in the backward the weight / input gradients the reference gets from ATen autograd:
+//   dW = X^T dWh (transA, split-K), dX = dWh Wcat^T (transB).
+//
+// v_mfma_f32_32x32x2_f32: exact fp32 (k-ordered fma chain), 64 FLOP/clk/SIMD.
+// Work-group = 4 waves, tile 128 x (32*NT) x 16; wave w owns rows [32w, 32w+32)
+// and all NT column blocks.  LDS images are k-major (As[k][m], Bs[k][n]) so a
+// fragment read is 32 consecutive floats per half-wave: conflict-free ds_read_b32.
+#include "common.h"
+
+namespace pygat {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;
+constexpr int BK = 16;
+constexpr int PAD = 4;  // (BM+PAD)*4 mod 32 == 16 -> the 4-scalar transposing LDS writes are 2-way at worst
+
+struct GemmArgs {
+  int M, N;
+  int64_t K;
+  const float* A;
+  int64_t lda;
+  const float* B;
+  int64_t ldb;
+  pygat_out_segments out;
+  int accumulate;
+  int64_t k_per_split;
+  float* ws;        // != nullptr: partial tile results go to ws[z][M][N]
+  int a_vec, b_vec; // 16-B vector loads allowed (base and ld aligned)
+};
+
+// operand stored [rows x K] (K contiguous): tile ROWS x 16, staged transposed into S[k][row]
+template <int ROWS, int NV>
+__device__ __forceinline__ void load_kcontig(const float* __restrict__ P, int64_t ld, int vec, int row0,
+                                             int nrows, int64_t k0, int64_t kend, float4 (&r)[NV]) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int idx = threadIdx.x + 256 * i;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (idx < ROWS * 4) {
+      int row = row0 + (idx >> 2);
+      int64_t k = k0 + (idx & 3) * 4;
+      if (row < nrows && k < kend) {
+        const float* p = P + (int64_t)row * ld + k;
+        if (vec && k + 3 < kend) {
+          v = ld4(p);
+        } else {
+          v.x = p[0];
+          if (k + 1 < kend) v.y = p[1];
+          if (k + 2 < kend) v.z = p[2];
+          if (k + 3 < kend) v.w = p[3];
+        }
+      }
+    }
+    r[i] = v;
+  }
+}
+template <int ROWS, int NV, int LDS_LD>
+__device__ __forceinline__ void store_kcontig(float* S, const float4 (&r)[NV]) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int idx = threadIdx.x + 256 * i;
+    if (idx < ROWS * 4) {
+      int row = idx >> 2, kq = (idx & 3) * 4;
+      S[(kq + 0) * LDS_LD + row] = r[i].x;
+      S[(kq + 1) * LDS_LD + row] = r[i].y;
+      S[(kq + 2) * LDS_LD + row] = r[i].z;
+      S[(kq + 3) * LDS_LD + row] = r[i].w;
+    }
+  }
+}
+
+// operand stored [K x cols] (K strided): tile 16 x COLS, staged as is into S[k][col]
+template <int COLS, int NV>
+__device__ __forceinline__ void load_kstrided(const float* __restrict__ P, int64_t ld, int vec, int col0,
+                                              int ncols, int64_t k0, int64_t kend, float4 (&r)[NV]) {
+  constexpr int Q = COLS / 4;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int idx = threadIdx.x + 256 * i;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (idx < BK * Q) {
+      int64_t k = k0 + idx / Q;
+      int c = col0 + (idx % Q) * 4;
+      if (k < kend && c < ncols) {
+        const float* p = P + k * ld + c;
+        if (vec && c + 3 < ncols) {
+          v = ld4(p);
+        } else {
+          v.x = p[0];
+          if (c + 1 < ncols) v.y = p[1];
+          if (c + 2 < ncols) v.z = p[2];
+          if (c + 3 < ncols) v.w = p[3];
+        }
+      }
+    }
+    r[i] = v;
+  }
+}
+template <int COLS, int NV, int LDS_LD>
+__device__ __forceinline__ void store_kstrided(float* S, const float4 (&r)[NV]) {
+  constexpr int Q = COLS / 4;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int idx = threadIdx.x + 256 * i;
+    if (idx < BK * Q) st4(S + (idx / Q) * LDS_LD + (idx % Q) * 4, r[i]);
+  }
+}
+
+template <bool TA, bool TB, int NT>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+  constexpr int BN = 32 * NT;
+  constexpr int LDAS = BM + PAD, LDBS = BN + PAD;
+  constexpr int NVA = 2;             // 128*16/4/256
+  constexpr int NVB = (NT + 1) / 2;  // BN*16/4/256 rounded up
+  __shared__ __attribute__((aligned(16))) float As[2][BK * LDAS];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDBS];
+
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
+  const int64_t kend = (kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  float4 ra[NVA], rb[NVB];
+  auto gload = [&](int64_t k0) {
+    if constexpr (TA) load_kstrided<BM, NVA>(g.A, g.lda, g.a_vec, m0, g.M, k0, kend, ra);
+    else load_kcontig<BM, NVA>(g.A, g.lda, g.a_vec, m0, g.M, k0, kend, ra);
+    if constexpr (TB) load_kcontig<BN, NVB>(g.B, g.ldb, g.b_vec, n0, g.N, k0, kend, rb);
+    else load_kstrided<BN, NVB>(g.B, g.ldb, g.b_vec, n0, g.N, k0, kend, rb);
+  };
+  auto sstore = [&](int buf) {
+    if constexpr (TA) store_kstrided<BM, NVA, LDAS>(As[buf], ra);
+    else store_kcontig<BM, NVA, LDAS>(As[buf], ra);
+    if constexpr (TB) store_kcontig<BN, NVB, LDBS>(Bs[buf], rb);
+    else store_kstrided<BN, NVB, LDBS>(Bs[buf], rb);
+  };
+
+  const int64_t nkt = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
+  if (nkt > 0) {
+    gload(kbeg);
+    sstore(0);
+  }
+  __syncthreads();
+  const int fr = lane & 31, fk = lane >> 5;
+  for (int64_t kt = 0; kt < nkt; ++kt) {
+    const int buf = (int)(kt & 1);
+    if (kt + 1 < nkt) gload(kbeg + (kt + 1) * BK);
+    const float* as = As[buf] + fk * LDAS + 32 * w + fr;
+    const float* bs = Bs[buf] + fk * LDBS + fr;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a = as[kk * LDAS];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float b = bs[kk * LDBS + 32 * nt];
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[nt], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nkt) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = n0 + 32 * nt + fr;
+    if (col >= g.N) continue;
+    float* base;
+    int64_t ld;
+    if (g.ws) {
+      base = g.ws + ((int64_t)blockIdx.z * g.M) * g.N + col;
+      ld = g.N;
+    } else {
+      int s = 0;
+#pragma unroll
+      for (int q = 1; q < 4; ++q)
+        if (q < g.out.nseg && col >= g.out.col_start[q]) s = q;
+      base = g.out.ptr[s] + (col - g.out.col_start[s]);
+      ld = g.out.ld[s];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * fk;
+      if (row < g.M) {
+        float* p = base + (int64_t)row * ld;
+        if (!g.ws && g.accumulate) *p += acc[nt][r];
+        else *p = acc[nt][r];
+      }
+    }
+  }
+}
+
+// deterministic slab-order reduction of split-K partials, routed to the segments
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(int M, int N, int splits,
+                                                                 const float* __restrict__ ws,
+                                                                 pygat_out_segments out, int accumulate) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)M * N) return;
+  int row = (int)(i / N), col = (int)(i % N);
+  float v = 0.f;
+  for (int z = 0; z < splits; ++z) v += ws[(int64_t)z * M * N + i];
+  int s = 0;
+  for (int q = 1; q < out.nseg; ++q)
+    if (col >= out.col_start[q]) s = q;
+  float* p = out.ptr[s] + (int64_t)row * out.ld[s] + (col - out.col_start[s]);
+  if (accumulate) *p += v; else *p = v;
+}
+
+template <bool TA, bool TB>
+static int launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
+  const int nt_needed = (int)cdiv(g.N, 32);
+  int NT = nt_needed <= 1 ? 1 : nt_needed <= 2 ? 2 : nt_needed <= 3 ? 3 : nt_needed <= 4 ? 4
+         : nt_needed <= 5 ? 5 : nt_needed <= 6 ? 6 : nt_needed <= 8 ? 8 : 4;
+  dim3 grid((unsigned)cdiv(g.M, BM), (unsigned)cdiv(g.N, 32 * NT), (unsigned)splits);
+  switch (NT) {
+    case 1: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 1>), grid, dim3(256), 0, st, g); break;
+    case 2: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 2>), grid, dim3(256), 0, st, g); break;
+    case 3: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 3>), grid, dim3(256), 0, st, g); break;
+    case 4: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 4>), grid, dim3(256), 0, st, g); break;
+    case 5: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 5>), grid, dim3(256), 0, st, g); break;
+    case 6: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 6>), grid, dim3(256), 0, st, g); break;
+    default: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 8>), grid, dim3(256), 0, st, g); break;
+  }
+  return 0;
+}
+
+}  // namespace pygat
+
+using namespace pygat;
+
+extern "C" size_t pygat_gemm_workspace_bytes(int M, int N, int split_k) {
+  if (split_k <= 1) return 0;
+  return (size_t)split_k * (size_t)M * (size_t)N * sizeof(float);
+}
+
+extern "C" int pygat_gemm_f32(int transA, int transB, int M, int N, int64_t K, const float* A, int64_t lda,
+                              const float* B, int64_t ldb, const pygat_out_segments* out, int accumulate,
+                              int split_k, void* ws, void* stream) {
+  PYGAT_REQUIRE(A && B && out, "gemm: null pointer");
+  PYGAT_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad sizes M=%d N=%d K=%lld", M, N, (long long)K);
+  PYGAT_REQUIRE(out->nseg >= 1 && out->nseg <= 4 && out->col_start[0] == 0 && out->col_start[out->nseg] == N,
+                "gemm: output segments must cover [0,N) (nseg=%d)", out->nseg);
+  for (int s = 0; s < out->nseg; ++s)
+    PYGAT_REQUIRE(out->ptr[s] && out->col_start[s + 1] > out->col_start[s] &&
+                      out->ld[s] >= out->col_start[s + 1] - out->col_start[s],
+                  "gemm: bad output segment %d", s);
+  PYGAT_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N), "gemm: leading dimension too small");
+  if (split_k < 1) split_k = 1;
+  PYGAT_REQUIRE(split_k == 1 || ws, "gemm: split_k > 1 needs a workspace");
+  GemmArgs g;
+  g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.out = *out;
+  g.accumulate = accumulate;
+  int64_t kps = cdiv(cdiv(K, split_k), BK) * BK;
+  int splits = (int)cdiv(K, kps);
+  g.k_per_split = kps;
+  g.ws = (splits > 1) ? (float*)ws : nullptr;
+  g.a_vec = aligned16(A) && (lda % 4 == 0);
+  g.b_vec = aligned16(B) && (ldb % 4 == 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (!transA && !transB) launch_gemm<false, false>(g, splits, st);
+  else if (transA && !transB) launch_gemm<true, false>(g, splits, st);
+  else if (!transA && transB) launch_gemm<false, true>(g, splits, st);
+  else { pygat::set_error("gemm: transA && transB is not built"); return PYGAT_EINVAL; }
+  PYGAT_CHECK_LAUNCH("gemm_f32");
+  if (splits > 1) {
+    int64_t tot = (int64_t)M * N;
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, st, M, N, splits,
+                       (const float*)ws, *out, accumulate);
+    PYGAT_CHECK_LAUNCH("gemm_splitk_reduce");
+  }
+  return PYGAT_OK;
+}

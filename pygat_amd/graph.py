@@ -1,0 +1,181 @@
+"""Graph intake: adjacency -> cached CSR pattern on the GPU.
+
+The reference hands every layer a dense [N,N] float adjacency (utils.py:55,
+load_data_ppi.py:153) and re-derives the edge list from it in every forward of
+every head (`adj.nonzero().t()`, layers.py:129), or masks with `adj > 0`
+(layers.py:41).  Only the PATTERN is ever used.  Here the pattern is extracted
+once (K0 kernels) and cached; all kernels then work on CSR:
+
+  row i of the CSR  = softmax row i  = { j : adj[i, j] != 0 }   (edge[0]=i, edge[1]=j)
+
+For the atomics-free backward the transposed pattern and, per transposed edge,
+the index of its forward edge are needed.  All reference graphs are symmetric
+(utils.py:49, load_data_ppi.py:157), where the transpose has the same CSR and
+only a mirror permutation is built (HIP binary search); asymmetric patterns are
+accepted and transposed with a device sort.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+DEFAULT_CHUNK = 256   # rows with more edges are cut into items of this many edges
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class _Pattern:
+    """rowptr/col plus the heavy-row work list, as the pygat_graph struct."""
+
+    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, chunk: int):
+        self.rowptr, self.col, self.chunk = rowptr, col, chunk
+        self.n = rowptr.numel() - 1
+        self.nnz = col.numel()
+        deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+        heavy = torch.nonzero(deg > chunk).flatten()
+        self.n_heavy = int(heavy.numel())
+        if self.n_heavy:
+            nit = (deg[heavy] + chunk - 1) // chunk
+            iptr = torch.zeros(self.n_heavy + 1, dtype=torch.int64, device=rowptr.device)
+            iptr[1:] = torch.cumsum(nit, 0)
+            self.n_items = int(iptr[-1].item())
+            slot = torch.repeat_interleave(torch.arange(self.n_heavy, device=rowptr.device), nit)
+            k = torch.arange(self.n_items, device=rowptr.device) - iptr[slot]
+            begin = rowptr[heavy[slot]].to(torch.int64) + k * chunk
+            end = torch.minimum(begin + chunk, rowptr[heavy[slot] + 1].to(torch.int64))
+            i32 = lambda t: t.to(torch.int32).contiguous()
+            self.heavy_row, self.heavy_item_ptr = i32(heavy), i32(iptr)
+            self.item_row_slot, self.item_begin, self.item_end = i32(slot), i32(begin), i32(end)
+        else:
+            self.n_items = 0
+            self.heavy_row = self.heavy_item_ptr = self.item_row_slot = self.item_begin = self.item_end = None
+        self.struct = _lib.Graph(self.n, self.nnz, _ptr(rowptr), _ptr(col), chunk, self.n_heavy, self.n_items,
+                                 _ptr(self.heavy_row), _ptr(self.heavy_item_ptr), _ptr(self.item_row_slot),
+                                 _ptr(self.item_begin), _ptr(self.item_end))
+
+    def ref(self):
+        return C.byref(self.struct)
+
+
+class CSRGraph:
+    """Device-resident CSR pattern (+ transpose info) consumed by the HIP kernels."""
+
+    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, chunk: int = DEFAULT_CHUNK,
+                 validate: bool = True):
+        if not (rowptr.is_cuda and col.is_cuda):
+            raise ValueError("CSRGraph: rowptr/col must live on the GPU (there is no CPU path)")
+        rowptr = rowptr.to(torch.int32).contiguous()
+        col = col.to(torch.int32).contiguous()
+        if rowptr.dim() != 1 or col.dim() != 1 or rowptr.numel() < 2:
+            raise ValueError("CSRGraph: rowptr [N+1] and col [E] expected")
+        self.device = rowptr.device
+        self.n = rowptr.numel() - 1
+        self.nnz = col.numel()
+        if self.nnz == 0:
+            raise ValueError("CSRGraph: empty pattern")
+        self.chunk = chunk
+        self.fwd = _Pattern(rowptr, col, chunk)
+        # mirror permutation (symmetric pattern, sorted rows) via the HIP binary search
+        perm = torch.empty(self.nnz, dtype=torch.int32, device=self.device)
+        flags = torch.zeros(2, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib.pygat_csr_symmetric_perm(self.n, rowptr.data_ptr(), col.data_ptr(), perm.data_ptr(),
+                                               flags.data_ptr(), _stream()), "csr_symmetric_perm")
+        asym, empty = (int(v) for v in flags.tolist())
+        if validate and empty:
+            # the reference NaN-asserts (sparse layer, layers.py:157,162) or silently attends to
+            # ALL nodes (dense layer, softmax of a constant -9e15 row) on an empty row
+            raise ValueError("CSRGraph: some node has no neighbour (add self loops as utils.py:52 does)")
+        self.symmetric = not asym
+        if self.symmetric:
+            self.bwd, self.perm_t = self.fwd, perm
+        else:
+            self._build_transpose()
+
+    def _build_transpose(self):
+        rowptr, col = self.fwd.rowptr.long(), self.fwd.col.long()
+        deg = rowptr[1:] - rowptr[:-1]
+        src = torch.repeat_interleave(torch.arange(self.n, device=self.device), deg)
+        key = col * self.n + src                       # sort by (j, i): stable order inside a column
+        order = torch.argsort(key, stable=True)
+        cnt = torch.bincount(col, minlength=self.n)
+        rp_t = torch.zeros(self.n + 1, dtype=torch.int64, device=self.device)
+        rp_t[1:] = torch.cumsum(cnt, 0)
+        self.bwd = _Pattern(rp_t.to(torch.int32), src[order].to(torch.int32).contiguous(), self.chunk)
+        self.perm_t = order.to(torch.int32).contiguous()
+
+    # ------------------------------------------------------------------ builders
+    @staticmethod
+    def from_dense(adj: torch.Tensor, mode: str = "nonzero", chunk: int = DEFAULT_CHUNK) -> "CSRGraph":
+        """mode "nonzero": pattern adj != 0 (SpGraphAttentionLayer, layers.py:129);
+        mode "positive": pattern adj > 0 (GraphAttentionLayer, layers.py:41)."""
+        if adj.dim() != 2 or adj.shape[0] != adj.shape[1]:
+            raise ValueError("adjacency must be square [N,N]")
+        if not adj.is_cuda:
+            raise ValueError("adjacency must live on the GPU (there is no CPU path)")
+        a = adj if (adj.dtype == torch.float32 and adj.stride(1) == 1) else adj.float().contiguous()
+        n, ld, m = a.shape[0], a.stride(0), (1 if mode == "positive" else 0)
+        dev = a.device
+        with torch.cuda.device(dev):
+            counts = torch.empty(n, dtype=torch.int32, device=dev)
+            check(lib.pygat_dense_row_counts(a.data_ptr(), n, ld, m, counts.data_ptr(), _stream()), "row_counts")
+            rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+            ws = torch.empty(lib.pygat_scan_workspace_bytes(n), dtype=torch.uint8, device=dev)
+            check(lib.pygat_exclusive_scan_i32(counts.data_ptr(), n, rowptr.data_ptr(), ws.data_ptr(), _stream()),
+                  "scan")
+            nnz = int(rowptr[-1].item())
+            if nnz == 0:
+                raise ValueError("adjacency has no edges")
+            col = torch.empty(nnz, dtype=torch.int32, device=dev)
+            check(lib.pygat_dense_fill_cols(a.data_ptr(), n, ld, m, rowptr.data_ptr(), col.data_ptr(), _stream()),
+                  "fill_cols")
+        return CSRGraph(rowptr, col, chunk)
+
+    @staticmethod
+    def from_edge_index(row: torch.Tensor, col: torch.Tensor, n: int, chunk: int = DEFAULT_CHUNK) -> "CSRGraph":
+        """COO (row=i, col=j), duplicates removed, rows sorted."""
+        key = torch.unique(row.long() * n + col.long())
+        r, c = key // n, key % n
+        rowptr = torch.zeros(n + 1, dtype=torch.int64, device=row.device)
+        rowptr[1:] = torch.cumsum(torch.bincount(r, minlength=n), 0)
+        return CSRGraph(rowptr.to(torch.int32), c.to(torch.int32), chunk)
+
+
+# ---------------------------------------------------------------------------
+# cache: the reference passes the same dense adj tensor to every head of every
+# level in every epoch; convert once.
+# ---------------------------------------------------------------------------
+_cache: "dict[Tuple, Tuple[weakref.ref, CSRGraph]]" = {}
+
+
+def as_graph(adj, mode: str = "nonzero") -> CSRGraph:
+    """Accepts a CSRGraph, a (rowptr, col) pair, a torch sparse CSR tensor, or a dense [N,N] tensor."""
+    if isinstance(adj, CSRGraph):
+        return adj
+    if isinstance(adj, (tuple, list)) and len(adj) == 2:
+        return CSRGraph(adj[0], adj[1])
+    if isinstance(adj, torch.Tensor) and adj.layout == torch.sparse_csr:
+        return CSRGraph(adj.crow_indices(), adj.col_indices())
+    if not isinstance(adj, torch.Tensor):
+        raise TypeError(f"unsupported adjacency type {type(adj)}")
+    key = (adj.data_ptr(), tuple(adj.shape), adj._version, str(adj.device), mode)
+    hit = _cache.get(key)
+    if hit is not None and hit[0]() is adj:
+        return hit[1]
+    g = CSRGraph.from_dense(adj, mode)
+    if len(_cache) > 16:
+        _cache.clear()
+    _cache[key] = (weakref.ref(adj), g)
+    return g

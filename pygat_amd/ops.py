@@ -1,0 +1,193 @@
+"""torch.autograd.Function over the C ABI: one GAT level (all local heads) per call.
+
+This is the op boundary that replaces `SpecialSpmmFunction` (reference
+layers.py:70-90) and the ATen op sequence of `GraphAttentionLayer.forward` /
+`SpGraphAttentionLayer.forward` (layers.py:32-53, 125-173) for ALL heads of a
+level at once (the reference loops over heads in Python, models.py:32,34).
+
+    out = gat_level(x, graph, Ws, As, Wskips, alpha, concat)
+
+concat=True  -> [N, H*F'], each head ELU'd         (hidden level, models.py:32)
+concat=False -> [N, F'], mean over heads, no ELU   (last level, models.py:34)
+
+PyTorch owns memory and the stream; every FLOP of the path runs in the HIP
+library.  There is no CPU or eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import lib, check, padded_width
+from .graph import CSRGraph
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _segments(cols_ptr_ld) -> _lib.OutSegments:
+    seg = _lib.OutSegments()
+    seg.nseg = len(cols_ptr_ld)
+    c = 0
+    for k, (ncol, t, ld) in enumerate(cols_ptr_ld):
+        seg.col_start[k] = c
+        seg.ptr[k] = t.data_ptr()
+        seg.ld[k] = ld
+        c += ncol
+    seg.col_start[len(cols_ptr_ld)] = c
+    return seg
+
+
+def gemm(transA: bool, transB: bool, M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor,
+         ldb: int, segments, accumulate: bool = False, split_k: Optional[int] = None) -> None:
+    """C = op(A) op(B) on the fp32 MFMA kernel; `segments` = [(ncols, tensor, ld), ...]."""
+    if split_k is None:
+        nt = -(-N // 32)
+        bn = 32 * (nt if nt <= 8 else 4)
+        tiles = -(-M // 128) * -(-N // bn)
+        split_k = max(1, min(512 // tiles, K // 256)) if tiles < 256 else 1
+    ws = None
+    if split_k > 1:
+        ws = torch.empty(lib.pygat_gemm_workspace_bytes(M, N, split_k) // 4, dtype=torch.float32, device=A.device)
+    seg = _segments(segments)
+    check(lib.pygat_gemm_f32(int(transA), int(transB), M, N, K, A.data_ptr(), lda, B.data_ptr(), ldb,
+                             C.byref(seg), int(accumulate), split_k, _ptr(ws), _stream()), "gemm_f32")
+
+
+class _Level:
+    """Shapes and packed operands of one call."""
+
+    def __init__(self, x, H, Fo, skip):
+        self.N, self.Fin = x.shape
+        self.H, self.Fo, self.skip = H, Fo, skip
+        self.Fp = padded_width(Fo)
+        self.R = H * self.Fp
+        if self.R > 1024:
+            raise ValueError(f"pygat_amd: H*pad(F') = {self.R} > 1024 per call; shard the heads")
+        self.ldw = -(-(self.R * (2 if skip else 1) + 2 * H) // 4) * 4
+
+
+class GATLevelFn(torch.autograd.Function):
+    """forward(x, W[H,Fin,F'], a[H,2F'], Wskip[H,Fin,F']|None, graph, alpha, concat) -> out."""
+
+    @staticmethod
+    def forward(ctx, x, W, a, Wskip, graph: CSRGraph, alpha: float, concat: bool):
+        if not x.is_cuda:
+            raise RuntimeError("pygat_amd: inputs must be on the GPU; the hot path has no CPU fallback")
+        x = x.contiguous().float()
+        W = W.contiguous().float(); a = a.contiguous().float()
+        H, Fin, Fo = W.shape
+        if x.shape[1] != Fin or a.shape != (H, 2 * Fo):
+            raise ValueError(f"shape mismatch: x {tuple(x.shape)}, W {tuple(W.shape)}, a {tuple(a.shape)}")
+        if x.shape[0] != graph.n:
+            raise ValueError(f"x has {x.shape[0]} rows but the graph has {graph.n} nodes")
+        skip = Wskip is not None
+        if skip:
+            Wskip = Wskip.contiguous().float()
+        L = _Level(x, H, Fo, skip)
+        dev, f32 = x.device, torch.float32
+        need_grad = any(ctx.needs_input_grad[:4])
+        with torch.cuda.device(dev):
+            st = _stream()
+            Wcat = torch.empty(Fin, L.ldw, dtype=f32, device=dev)
+            a_pad = torch.empty(H, 2, L.Fp, dtype=f32, device=dev)
+            check(lib.pygat_pack_params(H, Fin, Fo, W.data_ptr(), a.data_ptr(), _ptr(Wskip), Wcat.data_ptr(), L.ldw,
+                                        a_pad.data_ptr(), st), "pack_params")
+            # K1: [Wh | Sk | s | t] = x @ Wcat
+            Wh = torch.empty(L.N, L.R, dtype=f32, device=dev)
+            Sk = torch.empty(L.N, L.R, dtype=f32, device=dev) if skip else None
+            s = torch.empty(L.N, H, dtype=f32, device=dev)
+            t = torch.empty(L.N, H, dtype=f32, device=dev)
+            segs = [(L.R, Wh, L.R)] + ([(L.R, Sk, L.R)] if skip else []) + [(H, s, H), (H, t, H)]
+            ncols = L.R * (2 if skip else 1) + 2 * H
+            gemm(False, False, L.N, ncols, Fin, x, Fin, Wcat, L.ldw, segs)
+            # K2
+            flags = (_lib.F_ELU if concat else 0) | (_lib.F_SKIP if skip else 0)
+            keep_hattn = need_grad or not concat
+            hattn = torch.empty(L.N, L.R, dtype=f32, device=dev) if keep_hattn else None
+            m = torch.empty(L.N, H, dtype=f32, device=dev) if need_grad else None
+            Z = torch.empty(L.N, H, dtype=f32, device=dev) if need_grad else None
+            out = torch.empty(L.N, H * Fo if concat else Fo, dtype=f32, device=dev)
+            part = None
+            if graph.fwd.n_items:
+                part = torch.empty(lib.pygat_partials_bytes(max(graph.fwd.n_items, graph.bwd.n_items), H, L.Fp) // 4,
+                                   dtype=f32, device=dev)
+            check(lib.pygat_gat_forward(graph.fwd.ref(), H, Fo, float(alpha), flags, Wh.data_ptr(), s.data_ptr(),
+                                        t.data_ptr(), _ptr(Sk), out.data_ptr() if concat else None, _ptr(hattn),
+                                        _ptr(m), _ptr(Z), _ptr(part), st), "gat_forward")
+            if not concat:
+                check(lib.pygat_head_mean(L.N, H, Fo, hattn.data_ptr(), _ptr(Sk), out.data_ptr(), st), "head_mean")
+        if need_grad:
+            ctx.save_for_backward(x, Wcat, a_pad, Wh, s, t, Sk, hattn, m, Z)
+            ctx.graph, ctx.L, ctx.alpha, ctx.concat, ctx.flags = graph, L, float(alpha), concat, flags
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        x, Wcat, a_pad, Wh, s, t, Sk, hattn, m, Z = ctx.saved_tensors
+        graph, L, H, Fo = ctx.graph, ctx.L, ctx.L.H, ctx.L.Fo
+        dev, f32 = x.device, torch.float32
+        G = G.contiguous().float()
+        with torch.cuda.device(dev):
+            st = _stream()
+            Gp = torch.empty(L.N, L.R, dtype=f32, device=dev)
+            ebuf = torch.empty(graph.nnz, 2, H, dtype=f32, device=dev)
+            ds = torch.empty(L.N, H, dtype=f32, device=dev)
+            dt = torch.empty(L.N, H, dtype=f32, device=dev)
+            dWh = torch.empty(L.N, L.R, dtype=f32, device=dev)
+            part = None
+            nit = max(graph.fwd.n_items, graph.bwd.n_items)
+            if nit:
+                part = torch.empty(lib.pygat_partials_bytes(nit, H, L.Fp) // 4, dtype=f32, device=dev)
+            # K3 row pass, K4 column pass
+            check(lib.pygat_gat_backward_row(graph.fwd.ref(), H, Fo, ctx.alpha, ctx.flags, 0 if ctx.concat else 1,
+                                             G.data_ptr(), Wh.data_ptr(), s.data_ptr(), t.data_ptr(), _ptr(Sk),
+                                             hattn.data_ptr(), m.data_ptr(), Z.data_ptr(), Gp.data_ptr(),
+                                             ebuf.data_ptr(), ds.data_ptr(), _ptr(part), st), "gat_backward_row")
+            check(lib.pygat_gat_backward_col(graph.bwd.ref(), graph.perm_t.data_ptr(), H, Fo, Gp.data_ptr(),
+                                             ebuf.data_ptr(), ds.data_ptr(), a_pad.data_ptr(), dWh.data_ptr(),
+                                             dt.data_ptr(), _ptr(part), st), "gat_backward_col")
+            # da
+            da = torch.empty(H, 2 * Fo, dtype=f32, device=dev)
+            ws = torch.empty(lib.pygat_agrad_workspace_bytes(H, Fo) // 4, dtype=f32, device=dev)
+            check(lib.pygat_a_grad(L.N, H, Fo, Wh.data_ptr(), ds.data_ptr(), dt.data_ptr(), da.data_ptr(),
+                                   ws.data_ptr(), st), "a_grad")
+            # dW = x^T dWh (split-K over the nodes), dWskip = x^T Gp
+            dW = dWs = dx = None
+            if ctx.needs_input_grad[1]:
+                dWc = torch.empty(L.Fin, L.R, dtype=f32, device=dev)
+                gemm(True, False, L.Fin, L.R, L.N, x, L.Fin, dWh, L.R, [(L.R, dWc, L.R)])
+                dW = torch.empty(H, L.Fin, Fo, dtype=f32, device=dev)
+                check(lib.pygat_unpack_wgrad(H, L.Fin, Fo, dWc.data_ptr(), L.R, 0, dW.data_ptr(), st), "unpack")
+            if L.skip and ctx.needs_input_grad[3]:
+                dSc = torch.empty(L.Fin, L.R, dtype=f32, device=dev)
+                gemm(True, False, L.Fin, L.R, L.N, x, L.Fin, Gp, L.R, [(L.R, dSc, L.R)])
+                dWs = torch.empty(H, L.Fin, Fo, dtype=f32, device=dev)
+                check(lib.pygat_unpack_wgrad(H, L.Fin, Fo, dSc.data_ptr(), L.R, 0, dWs.data_ptr(), st), "unpack")
+            # dx = dWh Wcat[:, :R]^T (+ Gp Wcat[:, R:2R]^T)
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty(L.N, L.Fin, dtype=f32, device=dev)
+                gemm(False, True, L.N, L.Fin, L.R, dWh, L.R, Wcat, L.ldw, [(L.Fin, dx, L.Fin)])
+                if L.skip:
+                    gemm(False, True, L.N, L.Fin, L.R, Gp, L.R, Wcat[:, L.R:], L.ldw, [(L.Fin, dx, L.Fin)],
+                         accumulate=True, split_k=1)
+        return dx, dW, (da if ctx.needs_input_grad[2] else None), dWs, None, None, None
+
+
+def gat_level(x: torch.Tensor, graph: CSRGraph, Ws: Sequence[torch.Tensor], As: Sequence[torch.Tensor],
+              Wskips: Optional[Sequence[torch.Tensor]], alpha: float, concat: bool) -> torch.Tensor:
+    """All heads of one level. Ws: H tensors [Fin,F']; As: H tensors with 2F' elements
+    ([2F',1] as in GraphAttentionLayer, layers.py:23, or [1,2F'] as in SpGraphAttentionLayer,
+    layers.py:114); Wskips: H tensors [Fin,F'] or None."""
+    W = torch.stack(list(Ws), 0)
+    a = torch.stack([p.reshape(-1) for p in As], 0)
+    Wskip = torch.stack(list(Wskips), 0) if Wskips is not None else None
+    return GATLevelFn.apply(x, W, a, Wskip, graph, alpha, concat)

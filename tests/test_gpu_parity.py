@@ -1,0 +1,289 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle.
+
+Oracle = oracle/gat_oracle.py (PARITY UNPINNED, see its header: the reference
+cannot be imported here and ships no fixtures; the oracle restates
+layers.py:32-64 / 125-173 / models.py:29-35).  Ground truth is the oracle in
+fp64; tolerance is the north star's 1e-5 (fp32), scaled by the magnitude of the
+reference tensor when that exceeds 1:   |got - ref| <= 1e-5 * max(1, max|ref|).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gat_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def pg():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: run with gpurun")
+    import pygat_amd
+    return pygat_amd
+
+
+def close(got, ref, what, tol=TOL):
+    got = got.detach().double().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, f"{what}: shape {got.shape} vs {ref.shape}"
+    assert np.isfinite(got).all(), f"{what}: non-finite values"
+    scale = max(1.0, float(np.abs(ref).max()))
+    err = float(np.abs(got - ref).max())
+    assert err <= tol * scale, f"{what}: max err {err:.3e} > {tol * scale:.3e} (scale {scale:.3g})"
+    return err
+
+
+def params(H, Fin, Fo, skip, seed):
+    g = torch.Generator().manual_seed(seed)
+    W = torch.randn(H, Fin, Fo, generator=g, dtype=torch.float64) * (1.414 * (2.0 / (Fin + Fo)) ** 0.5)
+    a = torch.randn(H, 2 * Fo, generator=g, dtype=torch.float64) * (1.414 * (2.0 / (1 + 2 * Fo)) ** 0.5)
+    Sk = torch.randn(H, Fin, Fo, generator=g, dtype=torch.float64) * (1.414 * (6.0 / (Fin + Fo)) ** 0.5) if skip else None
+    return W, a, Sk
+
+
+def run_level(pg, x64, rowptr, col, W, a, Sk, concat, G64, chunk=256, need_dx=True):
+    dev = "cuda:0"
+    g = pg.CSRGraph(torch.as_tensor(rowptr, device=dev), torch.as_tensor(col, device=dev), chunk=chunk)
+    x = x64.float().to(dev).requires_grad_(need_dx)
+    Wd = W.float().to(dev).requires_grad_(True)
+    ad = a.float().to(dev).requires_grad_(True)
+    Sd = Sk.float().to(dev).requires_grad_(True) if Sk is not None else None
+    out = pg.GATLevelFn.apply(x, Wd, ad, Sd, g, 0.2, concat)
+    out.backward(G64.float().to(dev))
+    torch.cuda.synchronize()
+    return out, x.grad, Wd.grad, ad.grad, (Sd.grad if Sd is not None else None)
+
+
+# ------------------------------------------------------------------- K0 graph
+def test_dense_to_csr_and_perm(pg):
+    N = 300
+    rowptr, col = O.random_symmetric_csr(N, 6, 3, hub=(5, 200))
+    adj = O.dense_from_csr(rowptr, col, N)
+    adj[adj > 0] = torch.rand(int((adj > 0).sum())) + 0.1       # values are irrelevant, only the pattern
+    g = pg.CSRGraph.from_dense(adj.cuda(), "nonzero")
+    assert g.symmetric and g.n == N and g.nnz == len(col)
+    assert np.array_equal(g.fwd.rowptr.cpu().numpy(), rowptr)
+    assert np.array_equal(g.fwd.col.cpu().numpy(), col)
+    # mirror permutation: edge k=(i,j) -> position of (j,i)
+    src = np.repeat(np.arange(N), np.diff(rowptr))
+    perm = g.perm_t.cpu().numpy()
+    assert np.array_equal(src[perm], col) and np.array_equal(col[perm], src)
+    # "adj > 0" (dense layer) ignores negative entries, "adj != 0" (sparse layer) keeps them
+    adj2 = adj.clone(); adj2[0, 1] = adj2[1, 0] = -1.0
+    gp = pg.CSRGraph.from_dense(adj2.cuda(), "positive")
+    gn = pg.CSRGraph.from_dense(adj2.cuda(), "nonzero")
+    assert gn.nnz - gp.nnz in (0, 2) and gn.nnz >= g.nnz
+
+
+def test_scan_large(pg):
+    from pygat_amd._lib import lib, check
+    n = 1_000_003
+    v = torch.randint(0, 7, (n,), dtype=torch.int32, device="cuda")
+    out = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    ws = torch.empty(lib.pygat_scan_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    check(lib.pygat_exclusive_scan_i32(v.data_ptr(), n, out.data_ptr(), ws.data_ptr(), None))
+    ref = np.concatenate([[0], np.cumsum(v.cpu().numpy().astype(np.int64))])
+    assert np.array_equal(out.cpu().numpy().astype(np.int64), ref)   # bit exact (integer work)
+
+
+def test_empty_row_rejected(pg):
+    rowptr = torch.tensor([0, 1, 1, 2], dtype=torch.int32, device="cuda")
+    col = torch.tensor([0, 2], dtype=torch.int32, device="cuda")
+    with pytest.raises(ValueError):
+        pg.CSRGraph(rowptr, col)
+
+
+def test_asymmetric_pattern_transpose(pg):
+    N, Fin, Fo, H = 64, 8, 8, 2
+    rng = np.random.default_rng(0)
+    dense = (rng.random((N, N)) < 0.08) | np.eye(N, dtype=bool)
+    rowptr = np.concatenate([[0], np.cumsum(dense.sum(1))]).astype(np.int32)
+    col = np.nonzero(dense)[1].astype(np.int32)
+    W, a, _ = params(H, Fin, Fo, False, 1)
+    gen = torch.Generator().manual_seed(2)
+    x = torch.randn(N, Fin, dtype=torch.float64, generator=gen)
+    G = torch.randn(N, H * Fo, dtype=torch.float64, generator=gen)
+    ref = O.csr_layer_fwd_bwd(x.numpy(), rowptr, col, W.numpy(), a.numpy(), 0.2, True, G.numpy())
+    out, dx, dW, da, _ = run_level(pg, x, rowptr, col, W, a, None, True, G)
+    close(out, ref["out"], "out"); close(dx, ref["dX"], "dX"); close(dW, ref["dW"], "dW"); close(da, ref["da"], "da")
+
+
+# ------------------------------------------------------------------- K1 GEMM
+@pytest.mark.parametrize("tA,tB,M,N,K", [
+    (False, False, 300, 80, 1433), (False, False, 1000, 144, 128), (False, False, 257, 272, 50),
+    (True, False, 128, 128, 5000), (True, False, 1433, 64, 2708), (False, True, 999, 50, 1024),
+    (False, True, 2708, 1433, 64), (False, False, 5, 3, 7),
+])
+def test_gemm(pg, tA, tB, M, N, K):
+    gen = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn((K, M) if tA else (M, K), generator=gen)
+    B = torch.randn((N, K) if tB else (K, N), generator=gen)
+    ref = (A.double().t() if tA else A.double()) @ (B.double().t() if tB else B.double())
+    Ad, Bd = A.cuda(), B.cuda()
+    C1 = torch.full((M, N), float("nan"), device="cuda")
+    pg.gemm(tA, tB, M, N, K, Ad, Ad.shape[1], Bd, Bd.shape[1], [(N, C1, N)])
+    # two column segments + accumulate
+    n1 = max(1, N // 3)
+    S1 = torch.ones(M, n1, device="cuda"); S2 = torch.ones(M, N - n1 + 2, device="cuda") if N > n1 else None
+    segs = [(n1, S1, n1)] + ([(N - n1, S2, N - n1 + 2)] if N > n1 else [])
+    pg.gemm(tA, tB, M, N, K, Ad, Ad.shape[1], Bd, Bd.shape[1], segs, accumulate=True, split_k=1)
+    torch.cuda.synchronize()
+    tol = 2e-6 * (K ** 0.5)
+    close(C1, ref.numpy(), "C", tol)
+    close(S1, ref[:, :n1].numpy() + 1, "seg0", tol)
+    if S2 is not None:
+        close(S2[:, :N - n1], ref[:, n1:].numpy() + 1, "seg1", tol)
+        assert bool((S2[:, N - n1:] == 1).all())
+
+
+# ------------------------------------------------------------------- fused level
+SHAPES = [  # (H, Fin, Fo, skip, concat)
+    (8, 16, 8, False, True),     # Cora level 1 shape (R=64)
+    (1, 64, 7, False, False),    # Cora level 2: 1 head, F'=7 (padded), mean
+    (8, 64, 3, False, False),    # Pubmed level 2: 8 heads x 3, mean
+    (8, 32, 16, False, True),    # RMAT headline shape (R=128)
+    (4, 50, 256, True, True),    # PPI level 1: skip, R=1024 (VEC=4)
+    (6, 40, 121, True, False),   # PPI level 3: 6 heads x 121, mean, skip (VEC=3)
+    (1, 12, 16, True, True),     # one head of 16 (8-GPU shard of the headline shape)
+    (2, 9, 4, False, True),
+    (3, 10, 8, True, True),      # NCH = 6: idle lanes in the group
+    (8, 24, 64, False, True),    # R = 512 (VEC=2)
+]
+
+
+@pytest.mark.parametrize("H,Fin,Fo,skip,concat", SHAPES)
+@pytest.mark.parametrize("chunk", [256, 8])
+def test_level_fwd_bwd_small(pg, H, Fin, Fo, skip, concat, chunk):
+    N = 96
+    rowptr, col = O.random_symmetric_csr(N, 5, 11 + H, hub=(3, 70))
+    W, a, Sk = params(H, Fin, Fo, skip, 12 + Fo)
+    gen = torch.Generator().manual_seed(13)
+    x = torch.randn(N, Fin, dtype=torch.float64, generator=gen)
+    G = torch.randn(N, H * Fo if concat else Fo, dtype=torch.float64, generator=gen)
+    ref = O.csr_layer_fwd_bwd(x.numpy(), rowptr, col, W.numpy(), a.numpy(), 0.2, concat, G.numpy(),
+                              None if Sk is None else Sk.numpy())
+    out, dx, dW, da, dS = run_level(pg, x, rowptr, col, W, a, Sk, concat, G, chunk=chunk)
+    close(out, ref["out"], "out"); close(dx, ref["dX"], "dX"); close(dW, ref["dW"], "dW"); close(da, ref["da"], "da")
+    if skip:
+        close(dS, ref["dW_skip"], "dW_skip")
+
+
+def test_eval_matches_both_oracle_formulations(pg):
+    """dense (layers.py:32-64) and sparse (layers.py:125-173) oracles, eval mode."""
+    N, Fin, Fo, H = 120, 20, 8, 4
+    rowptr, col = O.random_symmetric_csr(N, 6, 5)
+    W, a, _ = params(H, Fin, Fo, False, 6)
+    x = torch.randn(N, Fin, dtype=torch.float64, generator=torch.Generator().manual_seed(7))
+    yd = O.level_forward(x, O.dense_from_csr(rowptr, col, N, torch.float64), W, a, 0.2, True, None, "dense")
+    ys = O.level_forward(x, (rowptr, col), W, a, 0.2, True, None, "sparse")
+    g = pg.CSRGraph(torch.as_tensor(rowptr).cuda(), torch.as_tensor(col).cuda())
+    with torch.no_grad():
+        y = pg.gat_level(x.float().cuda(), g, list(W.float().cuda()), list(a.float().cuda()), None, 0.2, True)
+    close(y, yd.numpy(), "vs dense oracle"); close(y, ys.numpy(), "vs sparse oracle")
+
+
+@pytest.mark.parametrize("name,Fin,H,Fo", [("cora", 1433, 8, 8), ("citeseer", 3703, 8, 8), ("pubmed", 500, 8, 8)])
+def test_real_topology_level1(pg, topologies, name, Fin, H, Fo):
+    """Real Cora / Citeseer / Pubmed topology (tests/golden/*_csr.npz), synthetic row-normalised
+    sparse features (the reference's feature blobs are missing), level-1 shape of train.py:47-87."""
+    rowptr, col = topologies[name]
+    N = len(rowptr) - 1
+    gen = torch.Generator().manual_seed(72)
+    x = (torch.rand(N, Fin, generator=gen) < 0.013).double()
+    x = x / x.sum(1, keepdim=True).clamp(min=1)
+    W, a, _ = params(H, Fin, Fo, False, 72)
+    G = torch.randn(N, H * Fo, dtype=torch.float64, generator=gen)
+    ref = O.csr_layer_fwd_bwd(x.numpy(), rowptr, col, W.numpy(), a.numpy(), 0.2, True, G.numpy())
+    out, dx, dW, da, _ = run_level(pg, x, rowptr, col, W, a, None, True, G, need_dx=(name != "citeseer"))
+    close(out, ref["out"], "out"); close(dW, ref["dW"], "dW"); close(da, ref["da"], "da")
+    if dx is not None:
+        close(dx, ref["dX"], "dX")
+
+
+def test_hub_and_degree_one_rows(pg):
+    """Heavy-row splitting (hub of 5000 edges, chunk 256) and rows that only have their self loop."""
+    N, Fin, Fo, H = 6000, 16, 16, 8
+    rng = np.random.default_rng(1)
+    nb = rng.choice(np.arange(1, N), size=5000, replace=False)
+    r = np.concatenate([np.zeros(5000, dtype=np.int64), nb, np.arange(N)])
+    c = np.concatenate([nb, np.zeros(5000, dtype=np.int64), np.arange(N)])
+    key = np.unique(r * N + c)
+    rr, cc = key // N, (key % N).astype(np.int32)
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(rr, minlength=N))]).astype(np.int32)
+    assert (np.diff(rowptr) == 1).sum() > 900 and np.diff(rowptr).max() == 5001
+    W, a, _ = params(H, Fin, Fo, False, 3)
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(N, Fin, dtype=torch.float64, generator=gen)
+    G = torch.randn(N, H * Fo, dtype=torch.float64, generator=gen)
+    ref = O.csr_layer_fwd_bwd(x.numpy(), rowptr, cc, W.numpy(), a.numpy(), 0.2, True, G.numpy())
+    out, dx, dW, da, _ = run_level(pg, x, rowptr, cc, W, a, None, True, G)
+    close(out, ref["out"], "out"); close(dx, ref["dX"], "dX"); close(dW, ref["dW"], "dW"); close(da, ref["da"], "da")
+
+
+def test_softmax_shift_invariance_and_extreme_logits(pg):
+    """Large |e_ij| must not overflow: the row max is subtracted (layers.py:145-146)."""
+    N, Fin, Fo, H = 64, 8, 8, 2
+    rowptr, col = O.random_symmetric_csr(N, 6, 9)
+    W, a, _ = params(H, Fin, Fo, False, 10)
+    x = torch.randn(N, Fin, dtype=torch.float64, generator=torch.Generator().manual_seed(11)) * 40.0
+    G = torch.ones(N, H * Fo, dtype=torch.float64)
+    ref = O.csr_layer_fwd_bwd(x.numpy(), rowptr, col, W.numpy(), a.numpy(), 0.2, True, G.numpy())
+    out, dx, dW, da, _ = run_level(pg, x, rowptr, col, W, a, None, True, G)
+    close(out, ref["out"], "out", 2e-5)
+
+
+# ------------------------------------------------------------------- drop-in classes
+def test_dropin_model_state_dict_and_logits(pg, topologies):
+    """models.GAT drop-in: same state_dict keys/shapes (models.py:27, layers.py:21-28,111-119) and
+    eval logits equal to the oracle's model_forward on the Cora topology."""
+    rowptr, col = topologies["cora"]
+    N, nfeat, nheads = len(rowptr) - 1, [1433, 8, 7], [8, 1]
+    for cls, ashape in ((pg.SpGraphAttentionLayer, (1, 16)), (pg.GraphAttentionLayer, (16, 1))):
+        torch.manual_seed(72)
+        model = pg.GAT(nfeat, nheads, 2, 0.6, 0.2, cls).cuda().eval()
+        sd = model.state_dict()
+        assert set(sd) == {f"attention_layer_1_head_{j}.{p}" for j in range(1, 9) for p in "Wa"} | \
+            {"attention_layer_2_head_1.W", "attention_layer_2_head_1.a"}
+        assert tuple(sd["attention_layer_1_head_1.W"].shape) == (1433, 8)
+        assert tuple(sd["attention_layer_1_head_1.a"].shape) == ashape
+        assert tuple(sd["attention_layer_2_head_1.W"].shape) == (64, 7)
+        gen = torch.Generator().manual_seed(1)
+        x = (torch.rand(N, 1433, generator=gen) < 0.013).float()
+        x = x / x.sum(1, keepdim=True).clamp(min=1)
+        adj = O.dense_from_csr(rowptr, col, N)
+        with torch.no_grad():
+            y = model(x.cuda(), adj.cuda())
+            y2 = model(x.cuda(), adj.cuda())          # cached graph
+        levels = []
+        for li, nh in enumerate(nheads):
+            Ws = torch.stack([sd[f"attention_layer_{li+1}_head_{j+1}.W"].double().cpu() for j in range(nh)])
+            As = torch.stack([sd[f"attention_layer_{li+1}_head_{j+1}.a"].double().cpu().reshape(-1) for j in range(nh)])
+            levels.append(dict(W=Ws, a=As))
+        ref = O.model_forward(x.double(), (rowptr, col), levels, 0.2)
+        assert y.shape == (N, 7)
+        close(y, ref.numpy(), f"{cls.__name__} logits")
+        assert torch.equal(y, y2)                      # deterministic: no atomics anywhere
+
+
+def test_single_layer_dropin_matches_oracle_head(pg):
+    N, Fin, Fo = 80, 12, 8
+    rowptr, col = O.random_symmetric_csr(N, 5, 2)
+    adj = O.dense_from_csr(rowptr, col, N)
+    x = torch.randn(N, Fin, generator=torch.Generator().manual_seed(3))
+    for cls, form in ((pg.GraphAttentionLayer, "dense"), (pg.SpGraphAttentionLayer, "sparse")):
+        for concat in (True, False):
+            torch.manual_seed(5)
+            layer = cls(Fin, Fo, 0.0, 0.2, concat=concat, skip_connection=True).cuda()
+            y = layer(x.cuda(), adj.cuda())
+            W, a, sk = (layer.W.detach().double().cpu(), layer.a.detach().double().cpu(),
+                        layer.skip_projection.detach().double().cpu())
+            if form == "dense":
+                ref = O.dense_head_forward(x.double(), adj.double(), W, a, 0.2, concat, sk)
+            else:
+                ref = O.sparse_head_forward(x.double(), rowptr, col, W, a, 0.2, concat, sk)
+            close(y, ref.numpy(), f"{cls.__name__} concat={concat}")
+            y.sum().backward()
+            assert layer.W.grad is not None and layer.a.grad.shape == layer.a.shape

@@ -1,0 +1,45 @@
+"""ctypes wrapper of oracle/gat_oracle.c (TEST INFRASTRUCTURE / cpu_baseline only; parity unpinned,
+see gat_oracle.py).  Built by `make -C oracle` (also from __graft_entry__.build())."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_SO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libgat_oracle.so")
+
+
+def load():
+    lib = C.CDLL(_SO)
+    p = C.c_void_p
+    lib.gat_oracle_level.argtypes = [C.c_int64, C.c_int64, p, p, p, p, p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                     C.c_int, p, p, p, p, p, p, p, p]
+    lib.gat_oracle_level.restype = C.c_int
+    lib.gat_oracle_threads.restype = C.c_int
+    return lib
+
+
+def transpose_pattern(rowptr, col):
+    """(rowptr_t, col_t, perm_t) with perm_t[k] = forward edge index of transposed edge k."""
+    rowptr = np.asarray(rowptr, dtype=np.int64); col = np.asarray(col, dtype=np.int64)
+    n = len(rowptr) - 1
+    src = np.repeat(np.arange(n), np.diff(rowptr))
+    order = np.argsort(col * n + src, kind="stable")
+    rp_t = np.concatenate([[0], np.cumsum(np.bincount(col, minlength=n))])
+    return rp_t.astype(np.int32), src[order].astype(np.int32), order.astype(np.int32)
+
+
+def level(X, rowptr, col, W, a, alpha, concat, G, want_dx=True, lib=None, tp=None):
+    lib = lib or load()
+    X = np.ascontiguousarray(X, dtype=np.float32); W = np.ascontiguousarray(W, dtype=np.float32)
+    a = np.ascontiguousarray(a, dtype=np.float32); G = np.ascontiguousarray(G, dtype=np.float32)
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32); col = np.ascontiguousarray(col, dtype=np.int32)
+    rp_t, col_t, perm_t = tp if tp is not None else transpose_pattern(rowptr, col)
+    N, Fin = X.shape; H, _, F = W.shape
+    out = np.empty_like(G); dW = np.empty_like(W); da = np.empty_like(a)
+    dX = np.empty_like(X) if want_dx else None
+    ptr = lambda v: None if v is None else v.ctypes.data
+    rc = lib.gat_oracle_level(N, len(col), ptr(rowptr), ptr(col), ptr(rp_t), ptr(col_t), ptr(perm_t), Fin, H, F,
+                              alpha, int(concat), ptr(X), ptr(W), ptr(a), ptr(G), ptr(out), ptr(dW), ptr(da), ptr(dX))
+    if rc != 0:
+        raise MemoryError("gat_oracle_level: allocation failed")
+    return dict(out=out, dW=dW, da=da, dX=dX)

@@ -1,0 +1,206 @@
+/*
+ * gat_oracle.c -- plain C (OpenMP) restatement of one GAT level, forward + backward.
+ *
+ * TEST INFRASTRUCTURE ONLY: linked/called from tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py.  The product (pygat_amd/) never touches it.
+ *
+ * PARITY UNPINNED (same status as oracle/gat_oracle.py): the reference's layers.py cannot be
+ * imported in the build container (layers.py:5 needs torch_scatter, absent) and the reference
+ * ships no fixtures.  This file is pinned against gat_oracle.py (tests/test_oracle_c.py), which
+ * restates the reference line by line.
+ *
+ * It is the only CPU path that can run the 1M-node / 10M-edge configuration: the reference
+ * itself needs a dense N x N adjacency (utils.py:55) and a dense N x N gradient (layers.py:85).
+ *
+ * Algorithm (per head h; see SURVEY.md 8(a) a11 for the gradient derivation):
+ *   Wh = X W_h                                     layers.py:134
+ *   s = Wh a[:F], t = Wh a[F:]                     layers.py:60-61 (== a . [Wh_i ; Wh_j], layers.py:141-144)
+ *   e_ij = LeakyReLU(s_i + t_j), m_i = max_j e_ij  layers.py:144-145
+ *   p_ij = exp(e_ij - m_i), Z_i = sum_j p_ij       layers.py:146,150
+ *   hp_i = sum_j p_ij Wh_j / Z_i                   layers.py:156-160
+ *   out  = ELU(hp) if concat else hp               layers.py:168-173; heads concatenated
+ *          (models.py:32) or averaged (models.py:34)
+ *   backward = chain rule through the above, per edge (no N x N as in layers.py:85).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+int gat_oracle_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* C[M x N] = A[M x K] * B[K x N] (row-major), or with A transposed: C[M x N] = A[K x M]^T B[K x N] */
+static void gemm_nn(int64_t M, int N, int K, const float* A, const float* B, float* C) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < M; ++i) {
+    float* c = C + i * N;
+    for (int n = 0; n < N; ++n) c[n] = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float a = A[i * K + k];
+      const float* b = B + (int64_t)k * N;
+      for (int n = 0; n < N; ++n) c[n] += a * b[n];
+    }
+  }
+}
+
+/* dW[K x N] = X[M x K]^T dWh[M x N]: per-thread private accumulators, reduced in thread order */
+static void gemm_tn(int64_t M, int N, int K, const float* X, const float* D, float* out) {
+  int nt = gat_oracle_threads();
+  double* acc = (double*)calloc((size_t)nt * K * N, sizeof(double));
+#pragma omp parallel
+  {
+#ifdef _OPENMP
+    int tid = omp_get_thread_num();
+#else
+    int tid = 0;
+#endif
+    double* a = acc + (size_t)tid * K * N;
+#pragma omp for schedule(static)
+    for (int64_t i = 0; i < M; ++i)
+      for (int k = 0; k < K; ++k) {
+        const double x = X[i * K + k];
+        if (x == 0.0) continue;
+        const float* d = D + i * N;
+        double* r = a + (size_t)k * N;
+        for (int n = 0; n < N; ++n) r[n] += x * d[n];
+      }
+  }
+  for (int64_t q = 0; q < (int64_t)K * N; ++q) {
+    double s = 0;
+    for (int t = 0; t < nt; ++t) s += acc[(size_t)t * K * N + q];
+    out[q] = (float)s;
+  }
+  free(acc);
+}
+
+/*
+ * One level, H heads, eval mode / dropout 0.
+ *   X [N x Fin], W [H x Fin x F], a [H x 2F], G [N x H*F] (concat) or [N x F] (mean)
+ *   rowptr [N+1], col [E]; rowptr_t/col_t/perm_t: transposed pattern and, per transposed
+ *   edge, the index of its forward edge (for a symmetric pattern rowptr_t == rowptr).
+ * outputs: out (same shape as G), dW [H x Fin x F], da [H x 2F], dX [N x Fin] (may be NULL).
+ * returns 0, or -1 on allocation failure.
+ */
+int gat_oracle_level(int64_t N, int64_t E, const int32_t* rowptr, const int32_t* col,
+                     const int32_t* rowptr_t, const int32_t* col_t, const int32_t* perm_t,
+                     int Fin, int H, int F, float alpha, int concat,
+                     const float* X, const float* W, const float* a, const float* G,
+                     float* out, float* dW, float* da, float* dX) {
+  float* Wh = (float*)malloc((size_t)N * F * sizeof(float));
+  float* s = (float*)malloc((size_t)N * sizeof(float));
+  float* t = (float*)malloc((size_t)N * sizeof(float));
+  float* hp = (float*)malloc((size_t)N * F * sizeof(float));
+  float* Gp = (float*)malloc((size_t)N * F * sizeof(float));
+  float* al = (float*)malloc((size_t)E * sizeof(float));
+  float* dz = (float*)malloc((size_t)E * sizeof(float));
+  float* ds = (float*)malloc((size_t)N * sizeof(float));
+  float* dt = (float*)malloc((size_t)N * sizeof(float));
+  float* dWh = (float*)malloc((size_t)N * F * sizeof(float));
+  if (!Wh || !s || !t || !hp || !Gp || !al || !dz || !ds || !dt || !dWh) return -1;
+  const int OC = concat ? H * F : F;
+  if (!concat) memset(out, 0, (size_t)N * F * sizeof(float));
+  if (dX) memset(dX, 0, (size_t)N * Fin * sizeof(float));
+
+  for (int h = 0; h < H; ++h) {
+    const float* Wm = W + (size_t)h * Fin * F;
+    const float* as = a + (size_t)h * 2 * F;
+    const float* ad = as + F;
+    gemm_nn(N, F, Fin, X, Wm, Wh);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N; ++i) {
+      float x = 0.f, y = 0.f;
+      for (int f = 0; f < F; ++f) { x += Wh[i * F + f] * as[f]; y += Wh[i * F + f] * ad[f]; }
+      s[i] = x; t[i] = y;
+    }
+    /* forward row pass + row part of the backward */
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t i = 0; i < N; ++i) {
+      const int b = rowptr[i], e = rowptr[i + 1];
+      float m = -INFINITY;
+      for (int k = b; k < e; ++k) {
+        float z = s[i] + t[col[k]];
+        float ev = z > 0.f ? z : alpha * z;
+        al[k] = ev;
+        if (ev > m) m = ev;
+      }
+      float Z = 0.f;
+      for (int k = b; k < e; ++k) { al[k] = expf(al[k] - m); Z += al[k]; }
+      float* hr = hp + i * F;
+      for (int f = 0; f < F; ++f) hr[f] = 0.f;
+      for (int k = b; k < e; ++k) {
+        const float* wj = Wh + (int64_t)col[k] * F;
+        for (int f = 0; f < F; ++f) hr[f] += al[k] * wj[f];
+      }
+      float D = 0.f;
+      for (int f = 0; f < F; ++f) {
+        hr[f] /= Z;
+        float g, o;
+        if (concat) {
+          o = hr[f] > 0.f ? hr[f] : expm1f(hr[f]);
+          out[i * OC + h * F + f] = o;
+          g = G[i * OC + h * F + f] * (hr[f] > 0.f ? 1.f : expf(hr[f]));
+        } else {
+          out[i * OC + f] += hr[f] / (float)H;
+          g = G[i * OC + f] / (float)H;
+        }
+        Gp[i * F + f] = g;
+        D += g * hr[f];
+      }
+      float dsi = 0.f;
+      for (int k = b; k < e; ++k) {
+        const float* wj = Wh + (int64_t)col[k] * F;
+        float dp = 0.f;
+        for (int f = 0; f < F; ++f) dp += Gp[i * F + f] * wj[f];
+        al[k] /= Z;
+        float z = s[i] + t[col[k]];
+        dz[k] = al[k] * (dp - D) * (z > 0.f ? 1.f : alpha);
+        dsi += dz[k];
+      }
+      ds[i] = dsi;
+    }
+    /* column pass over the transposed pattern */
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t j = 0; j < N; ++j) {
+      float* dr = dWh + j * F;
+      for (int f = 0; f < F; ++f) dr[f] = 0.f;
+      float dtj = 0.f;
+      for (int k = rowptr_t[j]; k < rowptr_t[j + 1]; ++k) {
+        const int pe = perm_t[k];
+        const float* gi = Gp + (int64_t)col_t[k] * F;
+        for (int f = 0; f < F; ++f) dr[f] += al[pe] * gi[f];
+        dtj += dz[pe];
+      }
+      dt[j] = dtj;
+      for (int f = 0; f < F; ++f) dr[f] += ds[j] * as[f] + dtj * ad[f];
+    }
+    /* da */
+    for (int f = 0; f < F; ++f) {
+      double x = 0, y = 0;
+#pragma omp parallel for reduction(+ : x, y) schedule(static)
+      for (int64_t i = 0; i < N; ++i) { x += (double)ds[i] * Wh[i * F + f]; y += (double)dt[i] * Wh[i * F + f]; }
+      da[(size_t)h * 2 * F + f] = (float)x;
+      da[(size_t)h * 2 * F + F + f] = (float)y;
+    }
+    gemm_tn(N, F, Fin, X, dWh, dW + (size_t)h * Fin * F);
+    if (dX) {
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < N; ++i)
+        for (int k = 0; k < Fin; ++k) {
+          float acc = 0.f;
+          for (int f = 0; f < F; ++f) acc += dWh[i * F + f] * Wm[(size_t)k * F + f];
+          dX[i * Fin + k] += acc;
+        }
+    }
+  }
+  free(Wh); free(s); free(t); free(hp); free(Gp); free(al); free(dz); free(ds); free(dt); free(dWh);
+  return 0;
+}

@@ -1,0 +1,135 @@
+"""Head-parallel GAT levels: one process per GPU, heads sharded over the ranks.
+
+The reference has no parallelism at all (single process, heads looped in Python,
+models.py:32,34).  Heads are independent given the input x and the graph, so the
+natural MI355X mapping is head-per-GPU:
+
+  hidden level (models.py:32, torch.cat):   rank r computes its heads' columns, then an
+      RCCL ALL-GATHER over xGMI concatenates them; its backward is the matching
+      REDUCE-SCATTER (each rank back-propagated only its own next-level heads, so the
+      incoming gradients are partial sums).
+  last level (models.py:34, mean of stack): every rank averages its local heads, scaled by
+      h_loc/H; an ALL-REDUCE(sum) finishes the mean; backward is the identity.
+
+Parameter gradients stay local (model parallelism: no gradient all-reduce).  x and
+the CSR graph are replicated.  `level_fn` lets the CPU tests (gloo, world_size 2)
+swap the HIP level for the oracle to check the sharding algebra without a GPU.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def partition_heads(H: int, world: int) -> List[Tuple[int, int]]:
+    """Balanced contiguous blocks; the first H % world ranks get one head more."""
+    base, rem = divmod(H, world)
+    out, s = [], 0
+    for r in range(world):
+        n = base + (1 if r < rem else 0)
+        out.append((s, s + n))
+        s += n
+    return out
+
+
+def _world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def all_gather_columns_raw(local: torch.Tensor, widths: Sequence[int]) -> torch.Tensor:
+    """[N, widths[rank]] on every rank -> [N, sum(widths)] on every rank (no autograd)."""
+    rank, world = _world()
+    if world == 1:
+        return local
+    N, wmax = local.shape[0], max(widths)
+    if all(w == wmax for w in widths):
+        buf = torch.empty(world, N, wmax, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(buf, local.contiguous())
+        return buf.permute(1, 0, 2).reshape(N, world * wmax)
+    pad = torch.zeros(N, wmax, dtype=local.dtype, device=local.device)
+    pad[:, :widths[rank]] = local
+    buf = torch.empty(world, N, wmax, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(buf, pad)
+    return torch.cat([buf[r, :, :widths[r]] for r in range(world)], dim=1)
+
+
+class AllGatherColumns(torch.autograd.Function):
+    """forward: all-gather of column blocks; backward: reduce-scatter(sum) of the gradient."""
+
+    @staticmethod
+    def forward(ctx, local, widths):
+        ctx.widths = tuple(widths)
+        return all_gather_columns_raw(local, widths)
+
+    @staticmethod
+    def backward(ctx, G):
+        rank, world = _world()
+        widths = ctx.widths
+        if world == 1:
+            return G, None
+        N, wmax = G.shape[0], max(widths)
+        offs = [0]
+        for w in widths:
+            offs.append(offs[-1] + w)
+        stacked = torch.zeros(world, N, wmax, dtype=G.dtype, device=G.device)
+        for r in range(world):
+            stacked[r, :, :widths[r]] = G[:, offs[r]:offs[r + 1]]
+        out = torch.empty(N, wmax, dtype=G.dtype, device=G.device)
+        if G.is_cuda:
+            dist.reduce_scatter_tensor(out, stacked, op=dist.ReduceOp.SUM)
+        else:  # gloo has no reduce_scatter: all-reduce then slice (CPU tests only)
+            dist.all_reduce(stacked, op=dist.ReduceOp.SUM)
+            out = stacked[rank]
+        return out[:, :widths[rank]].contiguous(), None
+
+
+class AllReduceSum(torch.autograd.Function):
+    """forward: all-reduce(sum); backward: identity (the result is replicated)."""
+
+    @staticmethod
+    def forward(ctx, t):
+        _, world = _world()
+        if world == 1:
+            return t
+        t = t.contiguous().clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+
+    @staticmethod
+    def backward(ctx, G):
+        return G
+
+
+def gat_level_head_parallel(x, graph, Ws, As, Wskips, alpha: float, concat: bool, dropout: float = 0.0,
+                            level_fn: Optional[Callable] = None) -> torch.Tensor:
+    """One level with its heads sharded over the ranks; returns the full (replicated) output."""
+    rank, world = _world()
+    H = len(Ws)
+    Fo = Ws[0].shape[1]
+    parts = partition_heads(H, world)
+    s, e = parts[rank]
+    if level_fn is None:
+        if dropout > 0.0:
+            from .dropout import gat_level_dropout
+            level_fn = lambda x_, g_, W_, a_, sk_, al_, cc_: gat_level_dropout(  # noqa: E731
+                x_, g_, W_, a_, sk_, al_, cc_, dropout, head_mean=not cc_)
+        else:
+            from .ops import gat_level
+            level_fn = gat_level
+    sk = None if Wskips is None else list(Wskips[s:e])
+    if concat:
+        if e > s:
+            local = level_fn(x, graph, list(Ws[s:e]), list(As[s:e]), sk, alpha, True)
+        else:
+            # no local head: still take part in the backward reduce-scatter
+            local = x.new_zeros(x.shape[0], 0).requires_grad_(True)
+        return AllGatherColumns.apply(local, [(b - a) * Fo for a, b in parts])
+    if e > s:
+        local = level_fn(x, graph, list(Ws[s:e]), list(As[s:e]), sk, alpha, False) * ((e - s) / H)
+    else:
+        local = x.new_zeros(x.shape[0], Fo)
+    return AllReduceSum.apply(local)

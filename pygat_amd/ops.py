@@ -29,6 +29,40 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """Optional HIP-event spans around the kernel launches (bench.py uses it for the roofline
+    figure).  Events are recorded on the stream the kernels are launched on."""
+
+    def __init__(self):
+        self.spans = []   # (name, start_event, end_event)
+
+    def times_ms(self):
+        out = {}
+        for name, a, b in self.spans:
+            out.setdefault(name, []).append(a.elapsed_time(b))
+        return out
+
+
+TIMER: Optional[KernelTimer] = None
+
+
+class _span:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if TIMER is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if TIMER is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            TIMER.spans.append((self.name, self.a, b))
+        return False
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -108,7 +142,8 @@ class GATLevelFn(torch.autograd.Function):
             t = torch.empty(L.N, H, dtype=f32, device=dev)
             segs = [(L.R, Wh, L.R)] + ([(L.R, Sk, L.R)] if skip else []) + [(H, s, H), (H, t, H)]
             ncols = L.R * (2 if skip else 1) + 2 * H
-            gemm(False, False, L.N, ncols, Fin, x, Fin, Wcat, L.ldw, segs)
+            with _span("k1_project"):
+                gemm(False, False, L.N, ncols, Fin, x, Fin, Wcat, L.ldw, segs)
             # K2
             flags = (_lib.F_ELU if concat else 0) | (_lib.F_SKIP if skip else 0)
             keep_hattn = need_grad or not concat
@@ -120,9 +155,10 @@ class GATLevelFn(torch.autograd.Function):
             if graph.fwd.n_items:
                 part = torch.empty(lib.pygat_partials_bytes(max(graph.fwd.n_items, graph.bwd.n_items), H, L.Fp) // 4,
                                    dtype=f32, device=dev)
-            check(lib.pygat_gat_forward(graph.fwd.ref(), H, Fo, float(alpha), flags, Wh.data_ptr(), s.data_ptr(),
-                                        t.data_ptr(), _ptr(Sk), out.data_ptr() if concat else None, _ptr(hattn),
-                                        _ptr(m), _ptr(Z), _ptr(part), st), "gat_forward")
+            with _span("k2_forward"):
+                check(lib.pygat_gat_forward(graph.fwd.ref(), H, Fo, float(alpha), flags, Wh.data_ptr(), s.data_ptr(),
+                                            t.data_ptr(), _ptr(Sk), out.data_ptr() if concat else None, _ptr(hattn),
+                                            _ptr(m), _ptr(Z), _ptr(part), st), "gat_forward")
             if not concat:
                 check(lib.pygat_head_mean(L.N, H, Fo, hattn.data_ptr(), _ptr(Sk), out.data_ptr(), st), "head_mean")
         if need_grad:
@@ -148,13 +184,15 @@ class GATLevelFn(torch.autograd.Function):
             if nit:
                 part = torch.empty(lib.pygat_partials_bytes(nit, H, L.Fp) // 4, dtype=f32, device=dev)
             # K3 row pass, K4 column pass
-            check(lib.pygat_gat_backward_row(graph.fwd.ref(), H, Fo, ctx.alpha, ctx.flags, 0 if ctx.concat else 1,
-                                             G.data_ptr(), Wh.data_ptr(), s.data_ptr(), t.data_ptr(), _ptr(Sk),
-                                             hattn.data_ptr(), m.data_ptr(), Z.data_ptr(), Gp.data_ptr(),
-                                             ebuf.data_ptr(), ds.data_ptr(), _ptr(part), st), "gat_backward_row")
-            check(lib.pygat_gat_backward_col(graph.bwd.ref(), graph.perm_t.data_ptr(), H, Fo, Gp.data_ptr(),
-                                             ebuf.data_ptr(), ds.data_ptr(), a_pad.data_ptr(), dWh.data_ptr(),
-                                             dt.data_ptr(), _ptr(part), st), "gat_backward_col")
+            with _span("k3_backward_row"):
+                check(lib.pygat_gat_backward_row(graph.fwd.ref(), H, Fo, ctx.alpha, ctx.flags, 0 if ctx.concat else 1,
+                                                 G.data_ptr(), Wh.data_ptr(), s.data_ptr(), t.data_ptr(), _ptr(Sk),
+                                                 hattn.data_ptr(), m.data_ptr(), Z.data_ptr(), Gp.data_ptr(),
+                                                 ebuf.data_ptr(), ds.data_ptr(), _ptr(part), st), "gat_backward_row")
+            with _span("k4_backward_col"):
+                check(lib.pygat_gat_backward_col(graph.bwd.ref(), graph.perm_t.data_ptr(), H, Fo, Gp.data_ptr(),
+                                                 ebuf.data_ptr(), ds.data_ptr(), a_pad.data_ptr(), dWh.data_ptr(),
+                                                 dt.data_ptr(), _ptr(part), st), "gat_backward_col")
             # da
             da = torch.empty(H, 2 * Fo, dtype=f32, device=dev)
             ws = torch.empty(lib.pygat_agrad_workspace_bytes(H, Fo) // 4, dtype=f32, device=dev)
@@ -164,7 +202,8 @@ class GATLevelFn(torch.autograd.Function):
             dW = dWs = dx = None
             if ctx.needs_input_grad[1]:
                 dWc = torch.empty(L.Fin, L.R, dtype=f32, device=dev)
-                gemm(True, False, L.Fin, L.R, L.N, x, L.Fin, dWh, L.R, [(L.R, dWc, L.R)])
+                with _span("k5_wgrad"):
+                    gemm(True, False, L.Fin, L.R, L.N, x, L.Fin, dWh, L.R, [(L.R, dWc, L.R)])
                 dW = torch.empty(H, L.Fin, Fo, dtype=f32, device=dev)
                 check(lib.pygat_unpack_wgrad(H, L.Fin, Fo, dWc.data_ptr(), L.R, 0, dW.data_ptr(), st), "unpack")
             if L.skip and ctx.needs_input_grad[3]:

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Kernel-level micro-benchmarks for K2/K3/K4 on the headline workload (development tool).
+
+    python tools/kbench.py [--graph rmat|regular] [--chunk 256] [--iters 20] [--heads 8 --fout 16]
+
+Times each kernel through the C ABI with HIP events (median of --iters) and prints algorithmic
+GB/s (SURVEY.md 8(d) byte model).  Also usable under `rocprofv3 --pmc ... -- python3 tools/kbench.py`.
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--graph", default="rmat")
+    ap.add_argument("--scale", type=int, default=20)
+    ap.add_argument("--chunk", type=int, default=256)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--heads", type=int, default=8)
+    ap.add_argument("--fout", type=int, default=16)
+    ap.add_argument("--fin", type=int, default=128)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    import pygat_amd as pg
+    from pygat_amd import _lib
+    from pygat_amd._lib import lib, check
+    from pygat_amd.rmat import rmat_csr
+    dev = torch.device("cuda", 0)
+    H, Fo = args.heads, args.fout
+    if args.graph == "rmat":
+        rowptr, col = rmat_csr(args.scale, 5_000_000 * (1 << args.scale) // (1 << 20), seed=1, device=dev)
+    else:  # every row: self loop + 9 random neighbours (not symmetric; forward-only experiments)
+        n = 1 << args.scale
+        g = torch.Generator(device=dev).manual_seed(1)
+        nb = torch.randint(0, n, (n, 9), generator=g, device=dev)
+        cols = torch.cat([torch.arange(n, device=dev)[:, None], nb], 1).sort(1).values
+        rowptr = (torch.arange(n + 1, device=dev) * 10).to(torch.int32)
+        col = cols.reshape(-1).to(torch.int32)
+    graph = pg.CSRGraph(rowptr, col, chunk=args.chunk)
+    N, E = graph.n, graph.nnz
+    Fp = pg.padded_width(Fo); R = H * Fp
+    g2 = torch.Generator(device=dev).manual_seed(2)
+    Wh = torch.randn(N, R, generator=g2, device=dev)
+    s = torch.randn(N, H, generator=g2, device=dev); t = torch.randn(N, H, generator=g2, device=dev)
+    G = torch.randn(N, H * Fo, generator=g2, device=dev)
+    a_pad = torch.randn(H, 2, Fp, generator=g2, device=dev)
+    out = torch.empty(N, H * Fo, device=dev); hattn = torch.empty(N, R, device=dev)
+    m = torch.empty(N, H, device=dev); Z = torch.empty(N, H, device=dev)
+    Gp = torch.empty(N, R, device=dev); ebuf = torch.empty(E, 2, H, device=dev)
+    ds = torch.empty(N, H, device=dev); dt = torch.empty(N, H, device=dev); dWh = torch.empty(N, R, device=dev)
+    nit = max(graph.fwd.n_items, graph.bwd.n_items)
+    part = torch.empty(max(1, lib.pygat_partials_bytes(nit, H, Fp) // 4), device=dev)
+    P = lambda x: None if x is None else x.data_ptr()
+
+    def k2(train=True):
+        check(lib.pygat_gat_forward(graph.fwd.ref(), H, Fo, 0.2, _lib.F_ELU, P(Wh), P(s), P(t), None, P(out),
+                                    P(hattn) if train else None, P(m) if train else None, P(Z) if train else None,
+                                    P(part), None))
+
+    def k3():
+        check(lib.pygat_gat_backward_row(graph.fwd.ref(), H, Fo, 0.2, _lib.F_ELU, 0, P(G), P(Wh), P(s), P(t), None,
+                                         P(hattn), P(m), P(Z), P(Gp), P(ebuf), P(ds), P(part), None))
+
+    def k4():
+        check(lib.pygat_gat_backward_col(graph.bwd.ref(), P(graph.perm_t), H, Fo, P(Gp), P(ebuf), P(ds), P(a_pad),
+                                         P(dWh), P(dt), P(part), None))
+
+    b_fwd = E * (4 + 4 * H + 4 * R) + N * (4 + 4 * H + 4 * R + 8 * H)
+    b_k3 = E * (4 + 4 * R + 8 * H) + N * (4 + 8 * R + 16 * H)
+    b_k4 = E * (8 + 4 * R + 8 * H) + N * (4 + 8 * R + 8 * H)
+    runs = [("k2_train", lambda: k2(True), b_fwd), ("k2_eval", lambda: k2(False), b_fwd - N * 8 * H),
+            ("k3_row", k3, b_k3), ("k4_col", k4, b_k4)]
+    if args.only:
+        runs = [r for r in runs if r[0] in args.only.split(",")]
+    deg = (rowptr[1:] - rowptr[:-1])
+    res = {"graph": args.graph, "N": N, "E": E, "chunk": args.chunk, "H": H, "Fo": Fo, "n_heavy": graph.fwd.n_heavy,
+           "n_items": graph.fwd.n_items, "max_deg": int(deg.max())}
+    for name, fn, nbytes in runs:
+        for _ in range(3):
+            fn()
+        ts = []
+        for _ in range(args.iters):
+            a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+            a.record(); fn(); b.record(); torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        med = float(np.median(ts))
+        res[name] = {"ms": round(med, 4), "alg_GBps": round(nbytes / med / 1e6, 1), "frac_8TBps": round(nbytes / med / 1e6 / 8000, 4)}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

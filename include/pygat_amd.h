@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PYGAT_ABI_VERSION 1
+#define PYGAT_ABI_VERSION 2
 
 enum {
   PYGAT_OK = 0,
@@ -120,31 +120,29 @@ int pygat_unpack_wgrad(int H, int Fin, int Fo, const float* dWcat, int64_t ld,
  *   e_ij = LeakyReLU(s_i + t_j), m_i = max_j e_ij, p_ij = exp(e_ij - m_i),
  *   Z_i = sum_j p_ij, hattn_i = (sum_j p_ij Wh_j) / Z_i,
  *   out_i = [ELU](hattn_i [+ sk_i]).
- * graph rows longer than `chunk` edges are split: the caller passes the heavy-row
- * work list (see pygat_heavy_*), and `part` workspace for their partial sums.
+ * Work is split by EDGES, not rows ("nnz split"): the CSR edge list is cut into
+ * slots of `slot_edges` consecutive edges; a slot walks its edges with the
+ * online-softmax recurrence and finishes every row that lies wholly inside it.
+ * Rows cut by a slot border leave partial (m, Z, acc) records in `part`, merged in
+ * slot order by a second small launch (deterministic, no atomics).
  */
 typedef struct {
   int n;                     /* nodes */
   int64_t nnz;               /* edges */
   const int32_t* rowptr;     /* [n+1] */
-  const int32_t* col;        /* [nnz] */
-  /* rows with more than `chunk` edges, cut in items of <= chunk edges */
-  int chunk;
-  int n_heavy;               /* heavy rows */
-  int n_items;               /* total items over all heavy rows */
-  const int32_t* heavy_row;  /* [n_heavy] */
-  const int32_t* heavy_item_ptr; /* [n_heavy+1] first item of each heavy row */
-  const int32_t* item_row_slot;  /* [n_items] index into heavy_row */
-  const int32_t* item_begin;     /* [n_items] first edge */
-  const int32_t* item_end;       /* [n_items] one past last edge */
+  const int32_t* edge_rc;    /* [nnz][2]: (row i, column j) of every edge, CSR order (pygat_edge_pairs) */
+  int slot_edges;            /* edges per slot: multiple of 4, >= 4 */
 } pygat_graph;
 
-/* bytes of `part` workspace needed by forward/backward for this graph and row width */
-size_t pygat_partials_bytes(int n_items, int H, int Fp);
+/* edge_rc[k] = (i, col[k]) for rowptr[i] <= k < rowptr[i+1] */
+int pygat_edge_pairs(int n, const int32_t* rowptr, const int32_t* col, int32_t* edge_rc, void* stream);
+
+/* bytes of `part` workspace needed by forward / column backward for this graph and row width */
+size_t pygat_partials_bytes(int64_t nnz, int slot_edges, int H, int Fp);
 
 /* Wh [n x R], s,t [n x H], sk [n x R] or NULL.
- * out [n x H*F'] compact (may be NULL), hattn [n x R] padded (may be NULL; needed for
- * backward and for the head mean), m,Z [n x H] (may be NULL together in eval).  */
+ * out [n x H*F'] compact (may be NULL), hattn [n x R] padded (may be NULL; needed for the
+ * head mean), m,Z [n x H] (may be NULL together in eval).  */
 int pygat_gat_forward(const pygat_graph* g, int H, int Fo, float alpha, int flags,
                       const float* Wh, const float* s, const float* t, const float* sk,
                       float* out, float* hattn, float* m, float* Z,
@@ -156,22 +154,29 @@ int pygat_head_mean(int n, int H, int Fo, const float* hattn, const float* sk,
 
 /* ------------------------------------------------ K3/K4: backward, no N x N, no atomics
  * Replaces SpecialSpmmFunction.backward (layers.py:81-90) and the autograd of
- * layers.py:141-170.  mean_mode = 0: G is [n x H*F'] (concat); 1: G is [n x F']
- * and each head receives G/H (models.py:34).
- *   K3 row pass  : Gp = G * ELU'(hattn+sk); D_i = Gp_i . hattn_i;
- *                  alpha_ij, dz_ij per edge -> ebuf; ds_i = sum_j dz_ij
- *   K4 col pass  : dWh_j = sum_i alpha_ij Gp_i + ds_j a_src + dt_j a_dst, dt_j = sum_i dz_ij
- *                  over the transposed pattern gT with perm_t[k] = forward edge of gT's edge k.
- * ebuf: [nnz x 2 x H] floats (alpha then dz per edge).  */
-int pygat_gat_backward_row(const pygat_graph* g, int H, int Fo, float alpha, int flags,
-                           int mean_mode, const float* G, const float* Wh, const float* s,
-                           const float* t, const float* sk, const float* hattn,
-                           const float* m, const float* Z,
-                           float* Gp, float* ebuf, float* ds, void* part, void* stream);
-int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm_t, int H, int Fo,
-                           const float* Gp, const float* ebuf, const float* ds,
-                           const float* a_pad, float* dWh, float* dt,
-                           void* part, void* stream);
+ * layers.py:141-170.
+ *   K3a prepare (per row):  Gp_i = G_i * ELU'(.), D_i = Gp_i . hattn_i, rowtab_i = (s_i, m_i, 1/Z_i, D_i)
+ *        mean_mode 0: G is [n x H*F'] and y is the forward OUTPUT out [n x H*F'] (hattn is
+ *                     recovered from it: out > 0 ? out : log1p(out), minus sk);
+ *        mean_mode 1: G is [n x F'] (every head receives G/H, models.py:34), y is hattn [n x R].
+ *   K3b edge pass (nnz split, no reduction): alpha_ij, dz_ij = alpha_ij (Gp_i.Wh_j - D_i) LeakyReLU'(s_i+t_j)
+ *        -> ebuf [nnz][2][H] (alpha then dz per edge).
+ *   K4 column pass over the transposed pattern gT, perm_t[k] = forward edge of gT's edge k:
+ *        dWh_j = sum_i alpha_ij Gp_i + ds_j a_src + dt_j a_dst, dt_j = sum_i dz_ij, ds_j = sum_k dz_jk.
+ *        symmetric != 0: gT has the forward pattern's layout, so ds_j is summed from ebuf at gT's own
+ *        edge positions and written to ds; symmetric == 0: ds must already hold pygat_row_sum_dz.
+ */
+int pygat_gat_backward_prepare(int n, int H, int Fo, int flags, int mean_mode,
+                               const float* G, const float* y, const float* sk,
+                               const float* s, const float* m, const float* Z,
+                               float* Gp, float* rowtab, void* stream);
+int pygat_gat_backward_edge(const pygat_graph* g, int H, int Fo, float alpha,
+                            const float* Wh, const float* t, const float* Gp, const float* rowtab,
+                            float* ebuf, void* stream);
+int pygat_row_sum_dz(const pygat_graph* g, int H, const float* ebuf, float* ds, void* stream);
+int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm_t, int symmetric, int H, int Fo,
+                           const float* Gp, const float* ebuf, const float* a_pad,
+                           float* dWh, float* ds, float* dt, void* part, void* stream);
 /* da[H x 2F'] : da_src = sum_i ds_i Wh_i, da_dst = sum_j dt_j Wh_j (per head).
  * ws >= pygat_agrad_workspace_bytes(H, Fo). */
 size_t pygat_agrad_workspace_bytes(int H, int Fo);

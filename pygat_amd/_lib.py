@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpygat_amd.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 F_ELU = 1
 F_SKIP = 2
 
@@ -22,8 +22,9 @@ SYMBOLS = [
     "pygat_device_name", "pygat_dense_row_counts", "pygat_scan_workspace_bytes",
     "pygat_exclusive_scan_i32", "pygat_dense_fill_cols", "pygat_csr_symmetric_perm",
     "pygat_gemm_workspace_bytes", "pygat_gemm_f32", "pygat_pack_params", "pygat_unpack_wgrad",
-    "pygat_partials_bytes", "pygat_gat_forward", "pygat_head_mean", "pygat_gat_backward_row",
-    "pygat_gat_backward_col", "pygat_agrad_workspace_bytes", "pygat_a_grad",
+    "pygat_edge_pairs", "pygat_partials_bytes", "pygat_gat_forward", "pygat_head_mean",
+    "pygat_gat_backward_prepare", "pygat_gat_backward_edge", "pygat_row_sum_dz", "pygat_gat_backward_col",
+    "pygat_agrad_workspace_bytes", "pygat_a_grad",
 ]
 
 
@@ -33,10 +34,8 @@ class OutSegments(C.Structure):
 
 
 class Graph(C.Structure):
-    _fields_ = [("n", C.c_int), ("nnz", C.c_int64), ("rowptr", C.c_void_p), ("col", C.c_void_p),
-                ("chunk", C.c_int), ("n_heavy", C.c_int), ("n_items", C.c_int),
-                ("heavy_row", C.c_void_p), ("heavy_item_ptr", C.c_void_p),
-                ("item_row_slot", C.c_void_p), ("item_begin", C.c_void_p), ("item_end", C.c_void_p)]
+    _fields_ = [("n", C.c_int), ("nnz", C.c_int64), ("rowptr", C.c_void_p), ("edge_rc", C.c_void_p),
+                ("slot_edges", C.c_int)]
 
 
 def _load():
@@ -64,12 +63,15 @@ def _load():
     lib.pygat_gemm_f32.argtypes = [i, i, i, i, i64, p, i64, p, i64, C.POINTER(OutSegments), i, i, p, p]
     lib.pygat_pack_params.argtypes = [i, i, i, p, p, p, p, i64, p, p]
     lib.pygat_unpack_wgrad.argtypes = [i, i, i, p, i64, i, p, p]
-    lib.pygat_partials_bytes.argtypes = [i, i, i]
+    lib.pygat_edge_pairs.argtypes = [i, p, p, p, p]
+    lib.pygat_partials_bytes.argtypes = [i64, i, i, i]
     lib.pygat_partials_bytes.restype = sz
     lib.pygat_gat_forward.argtypes = [C.POINTER(Graph), i, i, f, i, p, p, p, p, p, p, p, p, p, p]
     lib.pygat_head_mean.argtypes = [i, i, i, p, p, p, p]
-    lib.pygat_gat_backward_row.argtypes = [C.POINTER(Graph), i, i, f, i, i, p, p, p, p, p, p, p, p, p, p, p, p, p]
-    lib.pygat_gat_backward_col.argtypes = [C.POINTER(Graph), p, i, i, p, p, p, p, p, p, p, p]
+    lib.pygat_gat_backward_prepare.argtypes = [i, i, i, i, i, p, p, p, p, p, p, p, p, p]
+    lib.pygat_gat_backward_edge.argtypes = [C.POINTER(Graph), i, i, f, p, p, p, p, p, p]
+    lib.pygat_row_sum_dz.argtypes = [C.POINTER(Graph), i, p, p, p]
+    lib.pygat_gat_backward_col.argtypes = [C.POINTER(Graph), p, i, i, i, p, p, p, p, p, p, p, p]
     lib.pygat_agrad_workspace_bytes.argtypes = [i, i]
     lib.pygat_agrad_workspace_bytes.restype = sz
     lib.pygat_a_grad.argtypes = [i, i, i, p, p, p, p, p, p]

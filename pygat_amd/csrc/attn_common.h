@@ -2,12 +2,13 @@
 // backward) and K4 (column backward).
 //
 // A node row is R = H*Fp floats (all local heads interleaved, each padded to
-// Fp = power of two), i.e. NCH = R/4 float4 "chunks".  One wave works on one
-// CSR row (or one <=chunk-edge item of a heavy row):
+// Fp = power of two), i.e. NCH = R/4 float4 "chunks".  The CSR edge list is cut
+// into SLOTS of `ts` consecutive edges; a lane group of LPR lanes owns one slot
+// and walks its edges (nnz split: perfect balance whatever the degree skew):
 //   LPR  lanes per gathered row  = pow2 >= NCH, capped at 64
-//   EPW  = 64 / LPR edges are gathered by one wave instruction (edge slots)
+//   EPW  = 64 / LPR slots per wave (independent lane groups, no shuffles between them)
 //   VEC  chunks per lane (only when NCH > 64, LPR = 64): chunk c = c0 + 64*v
-// Lane l: slot = l / LPR, c0 = l % LPR.  A float4 never straddles heads
+// Lane l: slot-in-wave = l / LPR, c0 = l % LPR.  A float4 never straddles heads
 // (Fp % 4 == 0); the head of chunk c is (4c) / Fp and the LPH = Fp/4 lanes of a
 // head are consecutive and aligned, so per-head reductions are DPP butterflies.
 #pragma once
@@ -61,18 +62,14 @@ static inline void pick_lanes(const RowShape& rs, int* lpr, int* vec) {
 
 struct GraphDev {  // device view of pygat_graph
   int n;
+  int64_t nnz;
   const int32_t* rowptr;
-  const int32_t* col;
-  int chunk, n_heavy, n_items;
-  const int32_t* heavy_row;
-  const int32_t* heavy_item_ptr;
-  const int32_t* item_row_slot;
-  const int32_t* item_begin;
-  const int32_t* item_end;
+  const int2* rc;   // (row, col) per edge
+  int ts;           // edges per slot
 };
 
 static inline int check_graph(const pygat_graph* g, GraphDev* d) {
-  if (!g || !g->rowptr || !g->col || g->n <= 0 || g->nnz <= 0) {
+  if (!g || !g->rowptr || !g->edge_rc || g->n <= 0 || g->nnz <= 0) {
     set_error("graph: null or empty (n=%d nnz=%lld)", g ? g->n : -1, g ? (long long)g->nnz : -1LL);
     return PYGAT_EINVAL;
   }
@@ -80,17 +77,16 @@ static inline int check_graph(const pygat_graph* g, GraphDev* d) {
     set_error("graph: nnz %lld exceeds int32 edge indexing", (long long)g->nnz);
     return PYGAT_EINVAL;
   }
-  if (g->chunk < 1 || g->n_heavy < 0 || g->n_items < 0 ||
-      (g->n_heavy > 0 && !(g->heavy_row && g->heavy_item_ptr && g->item_row_slot && g->item_begin && g->item_end))) {
-    set_error("graph: bad heavy-row work list (chunk=%d n_heavy=%d n_items=%d)", g->chunk, g->n_heavy, g->n_items);
+  if (g->slot_edges < 4 || (g->slot_edges & 3)) {
+    set_error("graph: slot_edges=%d must be a multiple of 4, >= 4", g->slot_edges);
     return PYGAT_EINVAL;
   }
-  d->n = g->n; d->rowptr = g->rowptr; d->col = g->col; d->chunk = g->chunk;
-  d->n_heavy = g->n_heavy; d->n_items = g->n_items; d->heavy_row = g->heavy_row;
-  d->heavy_item_ptr = g->heavy_item_ptr; d->item_row_slot = g->item_row_slot;
-  d->item_begin = g->item_begin; d->item_end = g->item_end;
+  d->n = g->n; d->nnz = g->nnz; d->rowptr = g->rowptr; d->rc = reinterpret_cast<const int2*>(g->edge_rc);
+  d->ts = g->slot_edges;
   return PYGAT_OK;
 }
+
+static inline int64_t num_slots(const GraphDev& g) { return (g.nnz + g.ts - 1) / g.ts; }
 
 #ifdef __HIPCC__
 template <int VEC>

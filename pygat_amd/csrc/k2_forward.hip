@@ -9,13 +9,15 @@
 //   layers.py:165-170 (+ skip) and ELU                            epilogue
 // and the dense equivalents layers.py:40-51, for all local heads in one pass.
 //
-// One wave per CSR row: the wave's EPW edge slots each gather one whole
-// head-interleaved Wh row (16 B per lane, coalesced) per instruction, keep
-// (m, Z, acc) in registers with the online-softmax recurrence, and merge the
-// slots at the end with a shuffle.  No LDS, no atomics, no [2F',E] or [N,N]
-// temporaries.  Rows longer than g.chunk are cut into items handled by extra
-// waves of the same launch; a second tiny launch merges their partials in item
-// order (deterministic).
+// nnz split: the edge list (row,col pairs in CSR order) is cut into slots of `ts`
+// edges.  A lane group (LPR lanes = one head-interleaved row of 16 B per lane) owns
+// a slot: it issues U independent (s_i, t_j, Wh_j) gathers at a time -- the memory
+// parallelism does not depend on the degree of the rows it happens to cross --
+// and folds them into the online-softmax state (m, Z, acc) of the current row.
+// When the row id changes the finished row is normalised and stored; the first
+// / last row of a slot may continue in a neighbouring slot, then its state goes
+// to `part` and gat_fwd_fixup_kernel merges the pieces in slot order.
+// No LDS, no atomics, no [2F',E] or [N,N] temporaries, bitwise reproducible.
 #include "attn_common.h"
 
 namespace pygat {
@@ -33,116 +35,52 @@ struct FwdArgs {
   float* hattn;
   float* m;
   float* Z;
-  float* part;  // [n_items][R + 2H]
+  float* part;  // [2 * nslots][R + 2H]: record 2k = head piece of slot k, 2k+1 = tail piece
 };
 
 __device__ __forceinline__ float lrelu(float z, float alpha) { return z > 0.f ? z : alpha * z; }
 
+// fold one edge (logit ev, row w) into the running softmax state; one exp per edge
+__device__ __forceinline__ void fold_edge(float& m, float& z, float4& a, float ev, float4 w) {
+  const float d = ev - m;
+  const float ex = __expf(-fabsf(d));
+  const bool up = d > 0.f;
+  const float sc = up ? ex : 1.f, p = up ? 1.f : ex;
+  z = fmaf(z, sc, p);
+  a.x = fmaf(a.x, sc, p * w.x); a.y = fmaf(a.y, sc, p * w.y);
+  a.z = fmaf(a.z, sc, p * w.z); a.w = fmaf(a.w, sc, p * w.w);
+  m = up ? ev : m;
+}
+
 // online-softmax merge of (m2,z2,a2) into (m,z,a)
 __device__ __forceinline__ void merge_state(float& m, float& z, float4& a, float m2, float z2, float4 a2) {
-  float mn = fmaxf(m, m2);
-  float sa = __expf(m - mn), sb = __expf(m2 - mn);
+  const float mn = fmaxf(m, m2);
+  const float sa = __expf(m - mn), sb = __expf(m2 - mn);
   z = z * sa + z2 * sb;
   a.x = a.x * sa + a2.x * sb; a.y = a.y * sa + a2.y * sb;
   a.z = a.z * sa + a2.z * sb; a.w = a.w * sa + a2.w * sb;
   m = mn;
 }
 
-// accumulate the edges [e0,e1) of row i into the lane state; on return every lane of
-// slot 0 (and all other slots) holds the totals for its chunk(s).
-template <int LPR, int VEC>
-__device__ __forceinline__ void fwd_range(const FwdArgs& a, const LaneCols<VEC>& lc, int i, int e0, int e1,
-                                          float (&m)[VEC], float (&z)[VEC], float4 (&acc)[VEC]) {
-  constexpr int EPW = 64 / LPR;
-  constexpr int U = (VEC == 1) ? 4 : 2;
-  const int slot = (threadIdx.x & 63) / LPR;
-  const int H = a.rs.H, R = a.rs.R;
-  float si[VEC];
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) {
-    si[v] = a.s[(int64_t)i * H + lc.head[v]];
-    m[v] = NEG_BIG; z[v] = 0.f; acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  int e = e0 + slot;
-  for (; e + (U - 1) * EPW < e1; e += U * EPW) {
-    int j[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) j[u] = a.g.col[e + u * EPW];
-    float tv[U][VEC];
-    float4 wv[U][VEC];
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        tv[u][v] = a.t[(int64_t)j[u] * H + lc.head[v]];
-        wv[u][v] = ld4(a.Wh + (int64_t)j[u] * R + lc.cofs[v]);
-      }
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      float ev[U];
-      float mn = m[v];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        ev[u] = lrelu(si[v] + tv[u][v], a.alpha);
-        mn = fmaxf(mn, ev[u]);
-      }
-      float sc = __expf(m[v] - mn);
-      float zz = z[v] * sc;
-      float4 ac = make_float4(acc[v].x * sc, acc[v].y * sc, acc[v].z * sc, acc[v].w * sc);
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        float p = __expf(ev[u] - mn);
-        zz += p;
-        ac.x = fmaf(p, wv[u][v].x, ac.x); ac.y = fmaf(p, wv[u][v].y, ac.y);
-        ac.z = fmaf(p, wv[u][v].z, ac.z); ac.w = fmaf(p, wv[u][v].w, ac.w);
-      }
-      m[v] = mn; z[v] = zz; acc[v] = ac;
-    }
-  }
-  for (; e < e1; e += EPW) {
-    const int j = a.g.col[e];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      float tj = a.t[(int64_t)j * H + lc.head[v]];
-      float4 w = ld4(a.Wh + (int64_t)j * R + lc.cofs[v]);
-      float ev = lrelu(si[v] + tj, a.alpha);
-      float mn = fmaxf(m[v], ev);
-      float sc = __expf(m[v] - mn), p = __expf(ev - mn);
-      z[v] = z[v] * sc + p;
-      acc[v].x = fmaf(p, w.x, acc[v].x * sc); acc[v].y = fmaf(p, w.y, acc[v].y * sc);
-      acc[v].z = fmaf(p, w.z, acc[v].z * sc); acc[v].w = fmaf(p, w.w, acc[v].w * sc);
-      m[v] = mn;
-    }
-  }
-  // merge the edge slots (all lanes reconverged here)
-#pragma unroll
-  for (int off = LPR; off < 64; off <<= 1) {
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      float m2 = __shfl_xor(m[v], off), z2 = __shfl_xor(z[v], off);
-      float4 a2;
-      a2.x = __shfl_xor(acc[v].x, off); a2.y = __shfl_xor(acc[v].y, off);
-      a2.z = __shfl_xor(acc[v].z, off); a2.w = __shfl_xor(acc[v].w, off);
-      merge_state(m[v], z[v], acc[v], m2, z2, a2);
-    }
-  }
+// ELU: expm1 by a short series near 0 (where exp(x)-1 cancels), fast exp elsewhere
+__device__ __forceinline__ float elu1(float x) {
+  if (x > 0.f) return x;
+  if (x > -0.03125f) return x * (1.f + x * (0.5f + x * (0.16666667f + x * 0.041666668f)));
+  return __expf(x) - 1.f;
 }
 
-__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
-
-// normalise, epilogue (skip, ELU) and stores for row i; executed by the slot-0 lanes
-template <int LPR, int VEC>
+// normalise, epilogue (skip, ELU) and stores of a finished row i (all lanes of the group)
+template <int VEC>
 __device__ __forceinline__ void fwd_finish(const FwdArgs& a, const LaneCols<VEC>& lc, int i,
                                            const float (&m)[VEC], const float (&z)[VEC],
                                            const float4 (&acc)[VEC]) {
-  const int slot = (threadIdx.x & 63) / LPR;
-  if (slot != 0) return;
   const int H = a.rs.H, R = a.rs.R, Fo = a.rs.Fo, Fp = a.rs.Fp;
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
     if (!lc.valid[v]) continue;
     const int co = lc.cofs[v], h = lc.head[v];
-    float4 hat = make_float4(acc[v].x / z[v], acc[v].y / z[v], acc[v].z / z[v], acc[v].w / z[v]);
+    const float rz = 1.0f / z[v];
+    float4 hat = make_float4(acc[v].x * rz, acc[v].y * rz, acc[v].z * rz, acc[v].w * rz);
     if (a.hattn) st4(a.hattn + (int64_t)i * R + co, hat);
     if (a.out) {
       float4 pre = hat;
@@ -169,24 +107,13 @@ __device__ __forceinline__ void fwd_finish(const FwdArgs& a, const LaneCols<VEC>
   }
 }
 
-template <int LPR, int VEC>
-__global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
-  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
-  float m[VEC], z[VEC];
-  float4 acc[VEC];
-  if (gw < a.g.n) {
-    const int e0 = a.g.rowptr[gw], e1 = a.g.rowptr[gw + 1];
-    if (e1 - e0 > a.g.chunk || e1 == e0) return;  // heavy rows: items below; empty rows are rejected on the host
-    fwd_range<LPR, VEC>(a, lc, gw, e0, e1, m, z, acc);
-    fwd_finish<LPR, VEC>(a, lc, gw, m, z, acc);
-  } else {
-    const int it = gw - a.g.n;
-    if (it >= a.g.n_items) return;
-    const int i = a.g.heavy_row[a.g.item_row_slot[it]];
-    fwd_range<LPR, VEC>(a, lc, i, a.g.item_begin[it], a.g.item_end[it], m, z, acc);
-    if ((threadIdx.x & 63) / LPR != 0) return;
-    float* p = a.part + (int64_t)it * (a.rs.R + 2 * a.rs.H);
+// row finished inside the slot -> final stores; row continuing in a neighbour slot -> partial record
+template <int VEC>
+__device__ __forceinline__ void fwd_flush(const FwdArgs& a, const LaneCols<VEC>& lc, int64_t k, int i,
+                                          bool is_head, bool is_tail, const float (&m)[VEC],
+                                          const float (&z)[VEC], const float4 (&acc)[VEC]) {
+  if (is_head || is_tail) {
+    float* p = a.part + (2 * k + (is_head ? 0 : 1)) * (int64_t)(a.rs.R + 2 * a.rs.H);
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       if (!lc.valid[v]) continue;
@@ -196,27 +123,116 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
         p[a.rs.R + a.rs.H + lc.head[v]] = z[v];
       }
     }
+  } else {
+    fwd_finish<VEC>(a, lc, i, m, z, acc);
   }
 }
 
-// one wave per heavy row: merge its item partials in item order, then the normal epilogue
 template <int LPR, int VEC>
-__global__ __launch_bounds__(256) void gat_fwd_combine_kernel(FwdArgs a) {
-  const int hr = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (hr >= a.g.n_heavy) return;
+__global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
+  constexpr int EPW = 64 / LPR;
+  constexpr int U = (VEC == 1) ? 4 : 2;
+  const int lane = threadIdx.x & 63;
+  const int64_t k = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * EPW + lane / LPR;  // slot id
+  const int64_t e0 = k * a.g.ts;
+  if (e0 >= a.g.nnz) return;  // lane groups are independent: no cross-lane op below
+  const int64_t e1 = (e0 + a.g.ts < a.g.nnz) ? e0 + a.g.ts : a.g.nnz;
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
+  const int H = a.rs.H, R = a.rs.R;
+  const int2* __restrict__ rc = a.g.rc;
+
+  const int r_first = rc[e0].x;
+  const bool head_partial = a.g.rowptr[r_first] < e0;
+  int cur = r_first;
   float m[VEC], z[VEC];
   float4 acc[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) { m[v] = NEG_BIG; z[v] = 0.f; acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); }
-  const int PS = a.rs.R + 2 * a.rs.H;
-  for (int it = a.g.heavy_item_ptr[hr]; it < a.g.heavy_item_ptr[hr + 1]; ++it) {
-    const float* p = a.part + (int64_t)it * PS;
+
+  for (int64_t e = e0; e < e1; e += U) {
+    int2 p[U];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v)
-      merge_state(m[v], z[v], acc[v], p[a.rs.R + lc.head[v]], p[a.rs.R + a.rs.H + lc.head[v]], ld4(p + lc.cofs[v]));
+    for (int u = 0; u < U; ++u) p[u] = rc[(e + u < e1) ? e + u : e1 - 1];
+    float sv[U][VEC], tv[U][VEC];
+    float4 wv[U][VEC];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        sv[u][v] = a.s[(int64_t)p[u].x * H + lc.head[v]];
+        tv[u][v] = a.t[(int64_t)p[u].y * H + lc.head[v]];
+        wv[u][v] = ld4(a.Wh + (int64_t)p[u].y * R + lc.cofs[v]);
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (e + u < e1) {
+        if (p[u].x != cur) {
+          fwd_flush<VEC>(a, lc, k, cur, cur == r_first && head_partial, false, m, z, acc);
+          cur = p[u].x;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) { m[v] = NEG_BIG; z[v] = 0.f; acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) fold_edge(m[v], z[v], acc[v], lrelu(sv[u][v] + tv[u][v], a.alpha), wv[u][v]);
+      }
+    }
   }
-  fwd_finish<LPR, VEC>(a, lc, a.g.heavy_row[hr], m, z, acc);
+  const bool tail_partial = a.g.rowptr[cur + 1] > e1;
+  fwd_flush<VEC>(a, lc, k, cur, cur == r_first && head_partial, tail_partial, m, z, acc);
+}
+
+// One wave per slot k: if the last row of slot k starts inside it and continues beyond, this
+// wave owns that row and merges its pieces in slot order: tail(k), head(k+1), ..., head(k_e).
+// The wave's EPW lane groups take the pieces round-robin and are merged with shuffles.
+template <int LPR, int VEC>
+__global__ __launch_bounds__(256) void gat_fwd_fixup_kernel(FwdArgs a) {
+  constexpr int EPW = 64 / LPR;
+  const int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t e0 = k * a.g.ts;
+  if (e0 >= a.g.nnz) return;
+  const int64_t e1 = (e0 + a.g.ts < a.g.nnz) ? e0 + a.g.ts : a.g.nnz;
+  const int r = a.g.rc[e1 - 1].x;
+  const int64_t row_end = a.g.rowptr[r + 1];
+  if (row_end <= e1) return;                 // the slot's last row ends here: nothing to merge
+  if ((int64_t)a.g.rowptr[r] < e0) return;   // the row began in an earlier slot: not the owner
+  const int64_t k_e = (row_end - 1) / a.g.ts;
+  const int npieces = (int)(k_e - k) + 1;
+  const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
+  const int slot = (threadIdx.x & 63) / LPR;
+  const int64_t PS = a.rs.R + 2 * a.rs.H;
+  float m[VEC], z[VEC];
+  float4 acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { m[v] = NEG_BIG; z[v] = 0.f; acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); }
+  for (int q = slot; q < npieces; q += 2 * EPW) {
+    const int q2 = q + EPW;
+    const float* p1 = a.part + (q == 0 ? 2 * k + 1 : 2 * (k + q)) * PS;
+    const float* p2 = a.part + 2 * (k + (q2 < npieces ? q2 : q)) * PS;
+    float m1[VEC], z1[VEC], m2[VEC], z2[VEC];
+    float4 a1[VEC], a2[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      m1[v] = p1[a.rs.R + lc.head[v]]; z1[v] = p1[a.rs.R + a.rs.H + lc.head[v]]; a1[v] = ld4(p1 + lc.cofs[v]);
+      m2[v] = p2[a.rs.R + lc.head[v]]; z2[v] = p2[a.rs.R + a.rs.H + lc.head[v]]; a2[v] = ld4(p2 + lc.cofs[v]);
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      merge_state(m[v], z[v], acc[v], m1[v], z1[v], a1[v]);
+      if (q2 < npieces) merge_state(m[v], z[v], acc[v], m2[v], z2[v], a2[v]);
+    }
+  }
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      float mo = __shfl_xor(m[v], off), zo = __shfl_xor(z[v], off);
+      float4 ao;
+      ao.x = __shfl_xor(acc[v].x, off); ao.y = __shfl_xor(acc[v].y, off);
+      ao.z = __shfl_xor(acc[v].z, off); ao.w = __shfl_xor(acc[v].w, off);
+      merge_state(m[v], z[v], acc[v], mo, zo, ao);
+    }
+  }
+  if (slot == 0) fwd_finish<VEC>(a, lc, r, m, z, acc);
 }
 
 // models.py:34 -- mean over heads of (hattn [+ sk]); one thread per output element
@@ -239,13 +255,31 @@ __global__ __launch_bounds__(256) void head_mean_kernel(int n, int H, int Fo, in
   out[idx] = acc / (float)H;
 }
 
+// K0 helper: (row, col) pair per edge
+__global__ __launch_bounds__(256) void edge_pairs_kernel(int n, const int32_t* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ col, int2* __restrict__ rc) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  for (int k = rowptr[i] + lane; k < rowptr[i + 1]; k += 64) rc[k] = make_int2(i, col[k]);
+}
+
 }  // namespace pygat
 
 using namespace pygat;
 
-extern "C" size_t pygat_partials_bytes(int n_items, int H, int Fp) {
-  if (n_items <= 0) return 0;
-  return (size_t)n_items * (size_t)(H * Fp + 2 * H) * sizeof(float);
+extern "C" int pygat_edge_pairs(int n, const int32_t* rowptr, const int32_t* col, int32_t* edge_rc, void* stream) {
+  PYGAT_REQUIRE(n > 0 && rowptr && col && edge_rc, "edge_pairs: bad arguments");
+  hipLaunchKernelGGL(edge_pairs_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, n, rowptr, col,
+                     reinterpret_cast<int2*>(edge_rc));
+  PYGAT_CHECK_LAUNCH("edge_pairs");
+  return PYGAT_OK;
+}
+
+extern "C" size_t pygat_partials_bytes(int64_t nnz, int slot_edges, int H, int Fp) {
+  if (nnz <= 0 || slot_edges <= 0) return 0;
+  const int64_t nslots = (nnz + slot_edges - 1) / slot_edges;
+  return (size_t)(2 * nslots) * (size_t)(H * Fp + 2 * H) * sizeof(float);
 }
 
 extern "C" int pygat_gat_forward(const pygat_graph* g, int H, int Fo, float alpha, int flags, const float* Wh,
@@ -255,29 +289,27 @@ extern "C" int pygat_gat_forward(const pygat_graph* g, int H, int Fo, float alph
   int rc = check_graph(g, &a.g);
   if (rc) return rc;
   PYGAT_REQUIRE(make_row_shape(H, Fo, &a.rs), "gat_forward: unsupported H=%d F'=%d (need H*pad(F') <= 1024, F' <= 256)", H, Fo);
-  PYGAT_REQUIRE(Wh && s && t, "gat_forward: null Wh/s/t");
+  PYGAT_REQUIRE(Wh && s && t && part, "gat_forward: null Wh/s/t/part");
   PYGAT_REQUIRE(out || hattn, "gat_forward: need out and/or hattn");
   PYGAT_REQUIRE(!(flags & PYGAT_F_SKIP) || sk, "gat_forward: PYGAT_F_SKIP without sk");
   PYGAT_REQUIRE((m == nullptr) == (Z == nullptr), "gat_forward: m and Z must be given together");
-  PYGAT_REQUIRE(aligned16(Wh) && (!sk || aligned16(sk)) && (!hattn || aligned16(hattn)) &&
+  PYGAT_REQUIRE(aligned16(Wh) && aligned16(part) && (!sk || aligned16(sk)) && (!hattn || aligned16(hattn)) &&
                     (!out || a.rs.Fo != a.rs.Fp || aligned16(out)),
                 "gat_forward: row tables must be 16-byte aligned");
-  PYGAT_REQUIRE(a.g.n_items == 0 || part, "gat_forward: heavy rows present but no partials workspace");
   a.alpha = alpha; a.flags = flags; a.Wh = Wh; a.s = s; a.t = t; a.sk = sk;
   a.out = out; a.hattn = hattn; a.m = m; a.Z = Z; a.part = (float*)part;
   int lpr, vec;
   pick_lanes(a.rs, &lpr, &vec);
   hipStream_t st = (hipStream_t)stream;
-  const unsigned blocks = (unsigned)cdiv((int64_t)a.g.n + a.g.n_items, 4);
+  const int64_t nslots = num_slots(a.g);
+  const unsigned blocks = (unsigned)cdiv(cdiv(nslots, 64 / lpr), 4);
   PYGAT_DISPATCH_LANES(lpr, vec,
                        hipLaunchKernelGGL((gat_fwd_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0, st, a));
   PYGAT_CHECK_LAUNCH("gat_forward");
-  if (a.g.n_heavy > 0) {
-    const unsigned cb = (unsigned)cdiv(a.g.n_heavy, 4);
-    PYGAT_DISPATCH_LANES(lpr, vec,
-                         hipLaunchKernelGGL((gat_fwd_combine_kernel<LPR, VEC>), dim3(cb), dim3(256), 0, st, a));
-    PYGAT_CHECK_LAUNCH("gat_forward_combine");
-  }
+  const unsigned fb = (unsigned)cdiv(nslots, 4);
+  PYGAT_DISPATCH_LANES(lpr, vec,
+                       hipLaunchKernelGGL((gat_fwd_fixup_kernel<LPR, VEC>), dim3(fb), dim3(256), 0, st, a));
+  PYGAT_CHECK_LAUNCH("gat_forward_fixup");
   return PYGAT_OK;
 }
 

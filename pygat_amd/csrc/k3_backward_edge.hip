@@ -1,0 +1,224 @@
+// K3 -- backward, row-side quantities and the per-edge pass (gfx950, wave64).
+//
+// Replaces SpecialSpmmFunction.backward's grad_values (reference layers.py:84-87), which the
+// reference obtains from a DENSE N x N product `grad_output.matmul(b.t())` gathered at the edges,
+// and the ATen autograd of layers.py:144-170 (LeakyReLU, exp, row normalisation, ELU).
+//
+//   K3a (one lane group per row)   Gp_i = G_i * ELU'(pre_i),  D_i = Gp_i . hattn_i  (= sum_j alpha_ij dp_ij)
+//                                  rowtab_i = (s_i, m_i, 1/Z_i, D_i) per head
+//   K3b (nnz split, no reduction)  dp_ij = Gp_i . Wh_j        (the (i,j) entry of layers.py:85)
+//                                  alpha_ij = exp(e_ij - m_i) / Z_i
+//                                  dz_ij = alpha_ij (dp_ij - D_i) * LeakyReLU'(s_i + t_j)
+//                                  ebuf[k] = (alpha, dz) per head for edge k
+// In concat mode hattn is not stored by the forward: it is recovered from the output,
+// pre = out > 0 ? out : log1p(out), hattn = pre - sk, ELU'(pre) = out > 0 ? 1 : out + 1.
+#include "attn_common.h"
+
+namespace pygat {
+
+struct PrepArgs {
+  int n;
+  RowShape rs;
+  int flags, mean_mode;
+  const float* G;
+  const float* y;   // forward output (concat) or hattn (mean)
+  const float* sk;
+  const float* s;
+  const float* m;
+  const float* Z;
+  float* Gp;
+  float* rowtab;    // [n][H][4]
+};
+
+template <int LPR, int VEC>
+__global__ __launch_bounds__(256) void gat_bwd_prepare_kernel(PrepArgs a) {
+  constexpr int EPW = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int64_t i = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * EPW + lane / LPR;
+  if (i >= a.n) return;  // whole lane groups leave together: the DPP sums below stay inside a group
+  const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
+  const int H = a.rs.H, R = a.rs.R, Fo = a.rs.Fo, Fp = a.rs.Fp;
+  const int lph = a.rs.lph < 64 ? a.rs.lph : 64;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    const int co = lc.cofs[v], h = lc.head[v], f0 = co & (Fp - 1);
+    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f), hat = g4;
+    if (lc.valid[v]) {
+      if (a.mean_mode) {
+        hat = ld4(a.y + i * R + co);
+        const float* gr = a.G + i * Fo + f0;
+        const float inv = 1.0f / (float)H;
+        if (f0 + 0 < Fo) g4.x = gr[0] * inv;
+        if (f0 + 1 < Fo) g4.y = gr[1] * inv;
+        if (f0 + 2 < Fo) g4.z = gr[2] * inv;
+        if (f0 + 3 < Fo) g4.w = gr[3] * inv;
+      } else {
+        float4 y4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (Fo == Fp) {
+          g4 = ld4(a.G + i * R + co);
+          y4 = ld4(a.y + i * R + co);
+        } else {
+          const int64_t o = i * H * Fo + (int64_t)h * Fo + f0;
+          if (f0 + 0 < Fo) { g4.x = a.G[o + 0]; y4.x = a.y[o + 0]; }
+          if (f0 + 1 < Fo) { g4.y = a.G[o + 1]; y4.y = a.y[o + 1]; }
+          if (f0 + 2 < Fo) { g4.z = a.G[o + 2]; y4.z = a.y[o + 2]; }
+          if (f0 + 3 < Fo) { g4.w = a.G[o + 3]; y4.w = a.y[o + 3]; }
+        }
+        hat = y4;
+        if (a.flags & PYGAT_F_ELU) {
+          // out = ELU(pre): pre = out > 0 ? out : log1p(out); ELU'(pre) = out > 0 ? 1 : out + 1.
+          // out == -1 (pre < -17): the gradient factor is exactly 0, keep hattn finite.
+          const float o4[4] = {y4.x, y4.y, y4.z, y4.w};
+          float gq[4] = {g4.x, g4.y, g4.z, g4.w}, pq[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float d = o4[q] > 0.f ? 1.f : o4[q] + 1.f;
+            pq[q] = o4[q] > 0.f ? o4[q] : (d > 0.f ? log1pf(o4[q]) : 0.f);
+            gq[q] *= d;
+          }
+          g4 = make_float4(gq[0], gq[1], gq[2], gq[3]);
+          hat = make_float4(pq[0], pq[1], pq[2], pq[3]);
+        }
+        if (a.flags & PYGAT_F_SKIP) {
+          const float4 k4 = ld4(a.sk + i * R + co);
+          hat.x -= k4.x; hat.y -= k4.y; hat.z -= k4.z; hat.w -= k4.w;
+        }
+      }
+      st4(a.Gp + i * R + co, g4);
+    }
+    const float D = group_sum_rt(dot4(g4, hat), lph);
+    if (lc.valid[v] && ((co >> 2) & (a.rs.lph - 1)) == 0) {
+      const int64_t q = i * H + h;
+      st4(a.rowtab + q * 4, make_float4(a.s[q], a.m[q], 1.0f / a.Z[q], D));
+    }
+  }
+}
+
+struct EdgeArgs {
+  GraphDev g;
+  RowShape rs;
+  float alpha;
+  const float* Wh;
+  const float* t;
+  const float* Gp;
+  const float* rowtab;
+  float* ebuf;
+};
+
+template <int LPR, int VEC>
+__global__ __launch_bounds__(256) void gat_bwd_edge_kernel(EdgeArgs a) {
+  constexpr int EPW = 64 / LPR;
+  constexpr int U = 2;
+  const int lane = threadIdx.x & 63;
+  const int64_t k = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * EPW + lane / LPR;
+  const int64_t e0 = k * a.g.ts;
+  if (e0 >= a.g.nnz) return;
+  const int64_t e1 = (e0 + a.g.ts < a.g.nnz) ? e0 + a.g.ts : a.g.nnz;
+  const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
+  const int H = a.rs.H, R = a.rs.R;
+  const int lph = a.rs.lph < 64 ? a.rs.lph : 64;
+  const int2* __restrict__ rc = a.g.rc;
+  bool lead[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) lead[v] = lc.valid[v] && (((lc.cofs[v] >> 2) & (a.rs.lph - 1)) == 0);
+
+  for (int64_t e = e0; e < e1; e += U) {  // same trip count for every lane of the group
+    int2 p[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) p[u] = rc[(e + u < e1) ? e + u : e1 - 1];
+    float tv[U][VEC];
+    float4 rt[U][VEC], wv[U][VEC], gv[U][VEC];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        rt[u][v] = ld4(a.rowtab + ((int64_t)p[u].x * H + lc.head[v]) * 4);
+        tv[u][v] = a.t[(int64_t)p[u].y * H + lc.head[v]];
+        wv[u][v] = ld4(a.Wh + (int64_t)p[u].y * R + lc.cofs[v]);
+        gv[u][v] = ld4(a.Gp + (int64_t)p[u].x * R + lc.cofs[v]);
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const float part = lc.valid[v] ? dot4(gv[u][v], wv[u][v]) : 0.f;
+        const float dp = group_sum_rt(part, lph);
+        const float zz = rt[u][v].x + tv[u][v];
+        const float ev = zz > 0.f ? zz : a.alpha * zz;
+        const float al = __expf(ev - rt[u][v].y) * rt[u][v].z;
+        const float dz = al * (dp - rt[u][v].w) * (zz > 0.f ? 1.f : a.alpha);
+        if (lead[v] && e + u < e1) {
+          float* eb = a.ebuf + (e + u) * 2 * H + lc.head[v];
+          eb[0] = al;
+          eb[H] = dz;
+        }
+      }
+  }
+}
+
+// fallback for structurally asymmetric patterns: ds_i = sum over row i of dz (one thread per (row, head))
+__global__ __launch_bounds__(256) void row_sum_dz_kernel(int n, int H, const int32_t* __restrict__ rowptr,
+                                                         const float* __restrict__ ebuf, float* __restrict__ ds) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)n * H) return;
+  const int i = (int)(idx / H), h = (int)(idx % H);
+  float acc = 0.f;
+  for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) acc += ebuf[k * 2 * H + H + h];
+  ds[idx] = acc;
+}
+
+}  // namespace pygat
+
+using namespace pygat;
+
+extern "C" int pygat_gat_backward_prepare(int n, int H, int Fo, int flags, int mean_mode, const float* G,
+                                          const float* y, const float* sk, const float* s, const float* m,
+                                          const float* Z, float* Gp, float* rowtab, void* stream) {
+  PrepArgs a;
+  PYGAT_REQUIRE(make_row_shape(H, Fo, &a.rs), "gat_backward_prepare: unsupported H=%d F'=%d", H, Fo);
+  PYGAT_REQUIRE(n > 0 && G && y && s && m && Z && Gp && rowtab, "gat_backward_prepare: null pointer");
+  PYGAT_REQUIRE(!(flags & PYGAT_F_SKIP) || sk, "gat_backward_prepare: PYGAT_F_SKIP without sk");
+  PYGAT_REQUIRE(!(mean_mode && (flags & PYGAT_F_ELU)), "gat_backward_prepare: the head mean never carries an ELU (models.py:23)");
+  PYGAT_REQUIRE(aligned16(Gp) && aligned16(rowtab) && (!sk || aligned16(sk)) &&
+                    (mean_mode ? aligned16(y) : (a.rs.Fo != a.rs.Fp || (aligned16(G) && aligned16(y)))),
+                "gat_backward_prepare: row tables must be 16-byte aligned");
+  a.n = n; a.flags = flags; a.mean_mode = mean_mode; a.G = G; a.y = y; a.sk = sk; a.s = s; a.m = m; a.Z = Z;
+  a.Gp = Gp; a.rowtab = rowtab;
+  int lpr, vec;
+  pick_lanes(a.rs, &lpr, &vec);
+  const unsigned blocks = (unsigned)cdiv(cdiv(n, 64 / lpr), 4);
+  PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_bwd_prepare_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0,
+                                                    (hipStream_t)stream, a));
+  PYGAT_CHECK_LAUNCH("gat_backward_prepare");
+  return PYGAT_OK;
+}
+
+extern "C" int pygat_gat_backward_edge(const pygat_graph* g, int H, int Fo, float alpha, const float* Wh,
+                                       const float* t, const float* Gp, const float* rowtab, float* ebuf,
+                                       void* stream) {
+  EdgeArgs a;
+  int rc = check_graph(g, &a.g);
+  if (rc) return rc;
+  PYGAT_REQUIRE(make_row_shape(H, Fo, &a.rs), "gat_backward_edge: unsupported H=%d F'=%d", H, Fo);
+  PYGAT_REQUIRE(Wh && t && Gp && rowtab && ebuf, "gat_backward_edge: null pointer");
+  PYGAT_REQUIRE(aligned16(Wh) && aligned16(Gp) && aligned16(rowtab), "gat_backward_edge: row tables must be 16-byte aligned");
+  a.alpha = alpha; a.Wh = Wh; a.t = t; a.Gp = Gp; a.rowtab = rowtab; a.ebuf = ebuf;
+  int lpr, vec;
+  pick_lanes(a.rs, &lpr, &vec);
+  const unsigned blocks = (unsigned)cdiv(cdiv(num_slots(a.g), 64 / lpr), 4);
+  PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_bwd_edge_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0,
+                                                    (hipStream_t)stream, a));
+  PYGAT_CHECK_LAUNCH("gat_backward_edge");
+  return PYGAT_OK;
+}
+
+extern "C" int pygat_row_sum_dz(const pygat_graph* g, int H, const float* ebuf, float* ds, void* stream) {
+  GraphDev d;
+  int rc = check_graph(g, &d);
+  if (rc) return rc;
+  PYGAT_REQUIRE(H > 0 && ebuf && ds, "row_sum_dz: bad arguments");
+  hipLaunchKernelGGL(row_sum_dz_kernel, dim3((unsigned)cdiv((int64_t)d.n * H, 256)), dim3(256), 0, (hipStream_t)stream,
+                     d.n, H, d.rowptr, ebuf, ds);
+  PYGAT_CHECK_LAUNCH("row_sum_dz");
+  return PYGAT_OK;
+}

@@ -1,0 +1,210 @@
+// K4 -- backward, column pass: dWh, dt, ds (gfx950, wave64).
+//
+// Replaces `grad_b = a.t().matmul(grad_output)` of SpecialSpmmFunction.backward (reference
+// layers.py:89) -- the transposed SpMM -- plus the autograd of the two a-halves matmuls
+// (layers.py:60-61):
+//     dWh_j = sum_i alpha_ij Gp_i + ds_j a_src + dt_j a_dst
+//     dt_j  = sum_i dz_ij          (column sums of dz)
+//     ds_j  = sum_k dz_jk          (row sums of dz)
+// nnz split over the TRANSPOSED pattern: slot walks transposed edges (j <- i), gathers Gp_i (one
+// head-interleaved row, 16 B per lane) and the (alpha, dz) pair of the forward edge perm_t[k].
+// For a symmetric pattern the transposed CSR has the forward layout, so position k is also the
+// forward edge (j, col[k]) and ds_j is accumulated from ebuf[k] on the way -- no atomics, no
+// second pass.  Rows cut by a slot border go through `part` + a fix-up launch (fixed order).
+#include "attn_common.h"
+
+namespace pygat {
+
+struct ColArgs {
+  GraphDev g;  // transposed pattern
+  RowShape rs;
+  const int32_t* perm;
+  int symmetric;
+  const float* Gp;
+  const float* ebuf;
+  const float* a_pad;
+  float* dWh;
+  float* ds;
+  float* dt;
+  float* part;  // [2 * nslots][R + 2H]: acc[R], dt[H], ds[H]
+};
+
+template <int VEC>
+__device__ __forceinline__ void col_finish(const ColArgs& a, const LaneCols<VEC>& lc, int j,
+                                           const float4 (&acc)[VEC], const float (&dt)[VEC],
+                                           const float (&ds)[VEC]) {
+  const int H = a.rs.H, R = a.rs.R, Fp = a.rs.Fp;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    if (!lc.valid[v]) continue;
+    const int co = lc.cofs[v], h = lc.head[v], f0 = co & (Fp - 1);
+    const float dsj = a.symmetric ? ds[v] : a.ds[(int64_t)j * H + h];
+    const float4 as = ld4(a.a_pad + (int64_t)h * 2 * Fp + f0);
+    const float4 ad = ld4(a.a_pad + (int64_t)h * 2 * Fp + Fp + f0);
+    float4 o;
+    o.x = acc[v].x + dsj * as.x + dt[v] * ad.x;
+    o.y = acc[v].y + dsj * as.y + dt[v] * ad.y;
+    o.z = acc[v].z + dsj * as.z + dt[v] * ad.z;
+    o.w = acc[v].w + dsj * as.w + dt[v] * ad.w;
+    st4(a.dWh + (int64_t)j * R + co, o);
+    if (((co >> 2) & (a.rs.lph - 1)) == 0) {
+      a.dt[(int64_t)j * H + h] = dt[v];
+      if (a.symmetric) a.ds[(int64_t)j * H + h] = ds[v];
+    }
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void col_flush(const ColArgs& a, const LaneCols<VEC>& lc, int64_t k, int j,
+                                          bool is_head, bool is_tail, const float4 (&acc)[VEC],
+                                          const float (&dt)[VEC], const float (&ds)[VEC]) {
+  if (is_head || is_tail) {
+    float* p = a.part + (2 * k + (is_head ? 0 : 1)) * (int64_t)(a.rs.R + 2 * a.rs.H);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      if (!lc.valid[v]) continue;
+      st4(p + lc.cofs[v], acc[v]);
+      if (((lc.cofs[v] >> 2) & (a.rs.lph - 1)) == 0) {
+        p[a.rs.R + lc.head[v]] = dt[v];
+        p[a.rs.R + a.rs.H + lc.head[v]] = ds[v];
+      }
+    }
+  } else {
+    col_finish<VEC>(a, lc, j, acc, dt, ds);
+  }
+}
+
+template <int LPR, int VEC>
+__global__ __launch_bounds__(256) void gat_bwd_col_kernel(ColArgs a) {
+  constexpr int EPW = 64 / LPR;
+  constexpr int U = (VEC == 1) ? 4 : 2;
+  const int lane = threadIdx.x & 63;
+  const int64_t k = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * EPW + lane / LPR;
+  const int64_t e0 = k * a.g.ts;
+  if (e0 >= a.g.nnz) return;
+  const int64_t e1 = (e0 + a.g.ts < a.g.nnz) ? e0 + a.g.ts : a.g.nnz;
+  const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
+  const int H = a.rs.H, R = a.rs.R;
+  const int2* __restrict__ rc = a.g.rc;
+  const int r_first = rc[e0].x;
+  const bool head_partial = a.g.rowptr[r_first] < e0;
+  int cur = r_first;
+  float4 acc[VEC];
+  float dt[VEC], ds[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); dt[v] = 0.f; ds[v] = 0.f; }
+
+  for (int64_t e = e0; e < e1; e += U) {
+    int2 p[U];
+    int pe[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t ee = (e + u < e1) ? e + u : e1 - 1;
+      p[u] = rc[ee];
+      pe[u] = a.perm[ee];
+    }
+    float al[U][VEC], dz[U][VEC], dzo[U][VEC];
+    float4 gv[U][VEC];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const float* eb = a.ebuf + (int64_t)pe[u] * 2 * H + lc.head[v];
+        al[u][v] = eb[0];
+        dz[u][v] = eb[H];
+        const int64_t ee = (e + u < e1) ? e + u : e1 - 1;
+        dzo[u][v] = a.symmetric ? a.ebuf[ee * 2 * H + H + lc.head[v]] : 0.f;
+        gv[u][v] = ld4(a.Gp + (int64_t)p[u].y * R + lc.cofs[v]);
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (e + u < e1) {
+        if (p[u].x != cur) {
+          col_flush<VEC>(a, lc, k, cur, cur == r_first && head_partial, false, acc, dt, ds);
+          cur = p[u].x;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) { acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); dt[v] = 0.f; ds[v] = 0.f; }
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          acc[v].x = fmaf(al[u][v], gv[u][v].x, acc[v].x); acc[v].y = fmaf(al[u][v], gv[u][v].y, acc[v].y);
+          acc[v].z = fmaf(al[u][v], gv[u][v].z, acc[v].z); acc[v].w = fmaf(al[u][v], gv[u][v].w, acc[v].w);
+          dt[v] += dz[u][v];
+          ds[v] += dzo[u][v];
+        }
+      }
+    }
+  }
+  const bool tail_partial = a.g.rowptr[cur + 1] > e1;
+  col_flush<VEC>(a, lc, k, cur, cur == r_first && head_partial, tail_partial, acc, dt, ds);
+}
+
+// owner = slot where the cut row starts; sums tail(k), head(k+1), ..., head(k_e) in that order
+template <int LPR, int VEC>
+__global__ __launch_bounds__(256) void gat_bwd_col_fixup_kernel(ColArgs a) {
+  constexpr int EPW = 64 / LPR;
+  const int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t e0 = k * a.g.ts;
+  if (e0 >= a.g.nnz) return;
+  const int64_t e1 = (e0 + a.g.ts < a.g.nnz) ? e0 + a.g.ts : a.g.nnz;
+  const int r = a.g.rc[e1 - 1].x;
+  const int64_t row_end = a.g.rowptr[r + 1];
+  if (row_end <= e1) return;
+  if ((int64_t)a.g.rowptr[r] < e0) return;
+  const int64_t k_e = (row_end - 1) / a.g.ts;
+  const int npieces = (int)(k_e - k) + 1;
+  const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
+  const int slot = (threadIdx.x & 63) / LPR;
+  const int64_t PS = a.rs.R + 2 * a.rs.H;
+  float4 acc[VEC];
+  float dt[VEC], ds[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); dt[v] = 0.f; ds[v] = 0.f; }
+  for (int q = slot; q < npieces; q += EPW) {
+    const float* p = a.part + (q == 0 ? 2 * k + 1 : 2 * (k + q)) * PS;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const float4 x = ld4(p + lc.cofs[v]);
+      acc[v].x += x.x; acc[v].y += x.y; acc[v].z += x.z; acc[v].w += x.w;
+      dt[v] += p[a.rs.R + lc.head[v]];
+      ds[v] += p[a.rs.R + a.rs.H + lc.head[v]];
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    acc[v] = slot_sum4<LPR>(acc[v]);
+    dt[v] = slot_sum<LPR>(dt[v]);
+    ds[v] = slot_sum<LPR>(ds[v]);
+  }
+  if (slot == 0) col_finish<VEC>(a, lc, r, acc, dt, ds);
+}
+
+}  // namespace pygat
+
+using namespace pygat;
+
+extern "C" int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm_t, int symmetric, int H, int Fo,
+                                      const float* Gp, const float* ebuf, const float* a_pad, float* dWh,
+                                      float* ds, float* dt, void* part, void* stream) {
+  ColArgs a;
+  int rc = check_graph(gT, &a.g);
+  if (rc) return rc;
+  PYGAT_REQUIRE(make_row_shape(H, Fo, &a.rs), "gat_backward_col: unsupported H=%d F'=%d", H, Fo);
+  PYGAT_REQUIRE(perm_t && Gp && ebuf && ds && a_pad && dWh && dt && part, "gat_backward_col: null pointer");
+  PYGAT_REQUIRE(aligned16(Gp) && aligned16(dWh) && aligned16(a_pad) && aligned16(part),
+                "gat_backward_col: row tables must be 16-byte aligned");
+  a.perm = perm_t; a.symmetric = symmetric; a.Gp = Gp; a.ebuf = ebuf; a.a_pad = a_pad; a.dWh = dWh; a.ds = ds;
+  a.dt = dt; a.part = (float*)part;
+  int lpr, vec;
+  pick_lanes(a.rs, &lpr, &vec);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nslots = num_slots(a.g);
+  const unsigned blocks = (unsigned)cdiv(cdiv(nslots, 64 / lpr), 4);
+  PYGAT_DISPATCH_LANES(lpr, vec,
+                       hipLaunchKernelGGL((gat_bwd_col_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0, st, a));
+  PYGAT_CHECK_LAUNCH("gat_backward_col");
+  PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_bwd_col_fixup_kernel<LPR, VEC>),
+                                                    dim3((unsigned)cdiv(nslots, 4)), dim3(256), 0, st, a));
+  PYGAT_CHECK_LAUNCH("gat_backward_col_fixup");
+  return PYGAT_OK;
+}

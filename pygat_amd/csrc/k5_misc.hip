@@ -1,0 +1,151 @@
+// K5 helpers -- attention-vector gradient and parameter (un)packing (gfx950).
+//
+// da = autograd of the two a-halves matmuls `Wh a[:F']`, `Wh a[F':]` (reference layers.py:60-61 /
+// `a.mm(edge_h)` layers.py:144); pack/unpack move between the reference's per-head parameters
+// (W [Fin,F'], a [2F'], skip_projection [Fin,F'], layers.py:21-28,111-119) and the padded,
+// head-interleaved operand of the fused projection.
+#include "attn_common.h"
+
+namespace pygat {
+
+// ------------------------------------------------------------------- da reduction
+// da_src[h][f] = sum_i ds[i][h] Wh[i][h*Fp+f], da_dst likewise with dt (layers.py:60-61 autograd).
+constexpr int AG_BLOCKS = 512;
+
+__global__ __launch_bounds__(256) void a_grad_partial_kernel(int n, RowShape rs, const float* __restrict__ Wh,
+                                                             const float* __restrict__ ds,
+                                                             const float* __restrict__ dt,
+                                                             float* __restrict__ ws) {
+  // TPR threads per row (power of two >= NCH, <= 256), 256/TPR rows in flight per block
+  int tpr = 1;
+  while (tpr < rs.NCH) tpr <<= 1;
+  const int rpb = 256 / tpr;
+  const int c = threadIdx.x % tpr, rg = threadIdx.x / tpr;
+  const bool valid = c < rs.NCH;
+  const int co = valid ? 4 * c : 0, h = co >> rs.fp_shift;
+  const int64_t rows_per_block = cdiv(n, AG_BLOCKS);
+  const int64_t r0 = blockIdx.x * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < n) ? r0 + rows_per_block : n;
+  float4 as = make_float4(0.f, 0.f, 0.f, 0.f), ad = as;
+  for (int64_t i = r0 + rg; i < r1; i += rpb) {
+    const float4 w = ld4(Wh + i * rs.R + co);
+    const float a1 = ds[i * rs.H + h], a2 = dt[i * rs.H + h];
+    as.x = fmaf(a1, w.x, as.x); as.y = fmaf(a1, w.y, as.y); as.z = fmaf(a1, w.z, as.z); as.w = fmaf(a1, w.w, as.w);
+    ad.x = fmaf(a2, w.x, ad.x); ad.y = fmaf(a2, w.y, ad.y); ad.z = fmaf(a2, w.z, ad.z); ad.w = fmaf(a2, w.w, ad.w);
+  }
+  __shared__ float4 sm[2][256];
+  sm[0][threadIdx.x] = as;
+  sm[1][threadIdx.x] = ad;
+  __syncthreads();
+  if (rg == 0 && valid) {
+    for (int g = 1; g < rpb; ++g) {  // fixed order: deterministic
+      float4 q = sm[0][g * tpr + c], r = sm[1][g * tpr + c];
+      as.x += q.x; as.y += q.y; as.z += q.z; as.w += q.w;
+      ad.x += r.x; ad.y += r.y; ad.z += r.z; ad.w += r.w;
+    }
+    float* o = ws + (int64_t)blockIdx.x * 2 * rs.R;
+    st4(o + co, as);
+    st4(o + rs.R + co, ad);
+  }
+}
+
+__global__ __launch_bounds__(256) void a_grad_final_kernel(RowShape rs, const float* __restrict__ ws,
+                                                           float* __restrict__ da) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // over H * 2 * Fo
+  if (idx >= rs.H * 2 * rs.Fo) return;
+  const int h = idx / (2 * rs.Fo), r = idx % (2 * rs.Fo);
+  const int which = r / rs.Fo, f = r % rs.Fo;
+  float acc = 0.f;
+  for (int b = 0; b < AG_BLOCKS; ++b) acc += ws[(int64_t)b * 2 * rs.R + which * rs.R + h * rs.Fp + f];
+  da[idx] = acc;
+}
+
+// ------------------------------------------------------------- parameter packing
+__global__ __launch_bounds__(256) void pack_params_kernel(int H, int Fin, int Fo, int Fp,
+                                                          const float* __restrict__ W,
+                                                          const float* __restrict__ a,
+                                                          const float* __restrict__ w_skip,
+                                                          float* __restrict__ Wcat, int64_t ldw,
+                                                          float* __restrict__ a_pad) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int R = H * Fp, Rs = w_skip ? R : 0;
+  if (idx < (int64_t)H * 2 * Fp) {  // a_pad[h][which][f]
+    const int h = (int)(idx / (2 * Fp)), r = (int)(idx % (2 * Fp)), which = r / Fp, f = r % Fp;
+    a_pad[idx] = f < Fo ? a[(int64_t)h * 2 * Fo + which * Fo + f] : 0.f;
+  }
+  if (idx >= (int64_t)Fin * ldw) return;
+  const int k = (int)(idx / ldw), col = (int)(idx % ldw);
+  float v = 0.f;
+  if (col < R) {
+    const int h = col / Fp, f = col % Fp;
+    if (f < Fo) v = W[((int64_t)h * Fin + k) * Fo + f];
+  } else if (col < R + Rs) {
+    const int h = (col - R) / Fp, f = (col - R) % Fp;
+    if (f < Fo) v = w_skip[((int64_t)h * Fin + k) * Fo + f];
+  } else if (col < R + Rs + 2 * H) {
+    const int c = col - R - Rs, h = c % H, which = c / H;
+    const float* wr = W + ((int64_t)h * Fin + k) * Fo;
+    const float* ar = a + (int64_t)h * 2 * Fo + which * Fo;
+    for (int f = 0; f < Fo; ++f) v = fmaf(wr[f], ar[f], v);
+  }
+  Wcat[idx] = v;
+}
+
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(int H, int Fin, int Fo, int Fp,
+                                                           const float* __restrict__ dWcat, int64_t ld,
+                                                           int col_offset, float* __restrict__ dW) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)H * Fin * Fo) return;
+  const int f = (int)(idx % Fo);
+  const int k = (int)((idx / Fo) % Fin);
+  const int h = (int)(idx / ((int64_t)Fo * Fin));
+  dW[idx] = dWcat[(int64_t)k * ld + col_offset + h * Fp + f];
+}
+
+}  // namespace pygat
+
+using namespace pygat;
+
+extern "C" size_t pygat_agrad_workspace_bytes(int H, int Fo) {
+  int Fp = padded_width(Fo);
+  if (H <= 0 || Fp == 0) return 0;
+  return (size_t)AG_BLOCKS * 2 * (size_t)(H * Fp) * sizeof(float);
+}
+
+extern "C" int pygat_a_grad(int n, int H, int Fo, const float* Wh, const float* ds, const float* dt, float* da,
+                            void* ws, void* stream) {
+  RowShape rs;
+  PYGAT_REQUIRE(make_row_shape(H, Fo, &rs), "a_grad: unsupported H=%d F'=%d", H, Fo);
+  PYGAT_REQUIRE(n > 0 && Wh && ds && dt && da && ws && aligned16(Wh) && aligned16(ws), "a_grad: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(a_grad_partial_kernel, dim3(AG_BLOCKS), dim3(256), 0, st, n, rs, Wh, ds, dt, (float*)ws);
+  hipLaunchKernelGGL(a_grad_final_kernel, dim3((unsigned)cdiv(rs.H * 2 * rs.Fo, 256)), dim3(256), 0, st, rs,
+                     (const float*)ws, da);
+  PYGAT_CHECK_LAUNCH("a_grad");
+  return PYGAT_OK;
+}
+
+extern "C" int pygat_pack_params(int H, int Fin, int Fo, const float* W, const float* a, const float* w_skip,
+                                 float* Wcat, int64_t ldw, float* a_pad, void* stream) {
+  int Fp = padded_width(Fo);
+  PYGAT_REQUIRE(H > 0 && Fin > 0 && Fp > 0 && W && a && Wcat && a_pad, "pack_params: bad arguments");
+  const int need = H * Fp * (w_skip ? 2 : 1) + 2 * H;
+  PYGAT_REQUIRE(ldw >= need && ldw % 4 == 0, "pack_params: ldw=%lld must be a multiple of 4 and >= %d", (long long)ldw, need);
+  int64_t tot = (int64_t)Fin * ldw;
+  if (tot < (int64_t)H * 2 * Fp) tot = (int64_t)H * 2 * Fp;
+  hipLaunchKernelGGL(pack_params_kernel, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, H, Fin, Fo,
+                     Fp, W, a, w_skip, Wcat, ldw, a_pad);
+  PYGAT_CHECK_LAUNCH("pack_params");
+  return PYGAT_OK;
+}
+
+extern "C" int pygat_unpack_wgrad(int H, int Fin, int Fo, const float* dWcat, int64_t ld, int col_offset, float* dW,
+                                  void* stream) {
+  int Fp = padded_width(Fo);
+  PYGAT_REQUIRE(H > 0 && Fin > 0 && Fp > 0 && dWcat && dW && col_offset >= 0 && ld >= col_offset + H * Fp,
+                "unpack_wgrad: bad arguments");
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((unsigned)cdiv((int64_t)H * Fin * Fo, 256)), dim3(256), 0,
+                     (hipStream_t)stream, H, Fin, Fo, Fp, dWcat, ld, col_offset, dW);
+  PYGAT_CHECK_LAUNCH("unpack_wgrad");
+  return PYGAT_OK;
+}

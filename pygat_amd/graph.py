@@ -25,7 +25,7 @@ import torch
 from . import _lib
 from ._lib import lib, check
 
-DEFAULT_CHUNK = 64    # rows with more edges are cut into items of this many edges (64 beat 256/1024 on RMAT)
+DEFAULT_SLOT_EDGES = 64   # edges per work slot of the nnz-split kernels (multiple of 4)
 
 
 def _stream() -> int:
@@ -37,33 +37,17 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 class _Pattern:
-    """rowptr/col plus the heavy-row work list, as the pygat_graph struct."""
+    """rowptr/col plus the (row, col) edge pairs, as the pygat_graph struct."""
 
-    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, chunk: int):
-        self.rowptr, self.col, self.chunk = rowptr, col, chunk
+    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, slot_edges: int):
+        self.rowptr, self.col, self.slot_edges = rowptr, col, slot_edges
         self.n = rowptr.numel() - 1
         self.nnz = col.numel()
-        deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
-        heavy = torch.nonzero(deg > chunk).flatten()
-        self.n_heavy = int(heavy.numel())
-        if self.n_heavy:
-            nit = (deg[heavy] + chunk - 1) // chunk
-            iptr = torch.zeros(self.n_heavy + 1, dtype=torch.int64, device=rowptr.device)
-            iptr[1:] = torch.cumsum(nit, 0)
-            self.n_items = int(iptr[-1].item())
-            slot = torch.repeat_interleave(torch.arange(self.n_heavy, device=rowptr.device), nit)
-            k = torch.arange(self.n_items, device=rowptr.device) - iptr[slot]
-            begin = rowptr[heavy[slot]].to(torch.int64) + k * chunk
-            end = torch.minimum(begin + chunk, rowptr[heavy[slot] + 1].to(torch.int64))
-            i32 = lambda t: t.to(torch.int32).contiguous()
-            self.heavy_row, self.heavy_item_ptr = i32(heavy), i32(iptr)
-            self.item_row_slot, self.item_begin, self.item_end = i32(slot), i32(begin), i32(end)
-        else:
-            self.n_items = 0
-            self.heavy_row = self.heavy_item_ptr = self.item_row_slot = self.item_begin = self.item_end = None
-        self.struct = _lib.Graph(self.n, self.nnz, _ptr(rowptr), _ptr(col), chunk, self.n_heavy, self.n_items,
-                                 _ptr(self.heavy_row), _ptr(self.heavy_item_ptr), _ptr(self.item_row_slot),
-                                 _ptr(self.item_begin), _ptr(self.item_end))
+        self.edge_rc = torch.empty(self.nnz, 2, dtype=torch.int32, device=rowptr.device)
+        with torch.cuda.device(rowptr.device):
+            check(lib.pygat_edge_pairs(self.n, rowptr.data_ptr(), col.data_ptr(), self.edge_rc.data_ptr(), _stream()),
+                  "edge_pairs")
+        self.struct = _lib.Graph(self.n, self.nnz, _ptr(rowptr), _ptr(self.edge_rc), slot_edges)
 
     def ref(self):
         return C.byref(self.struct)
@@ -72,7 +56,7 @@ class _Pattern:
 class CSRGraph:
     """Device-resident CSR pattern (+ transpose info) consumed by the HIP kernels."""
 
-    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, chunk: int = DEFAULT_CHUNK,
+    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, slot_edges: int = DEFAULT_SLOT_EDGES,
                  validate: bool = True):
         if not (rowptr.is_cuda and col.is_cuda):
             raise ValueError("CSRGraph: rowptr/col must live on the GPU (there is no CPU path)")
@@ -85,8 +69,10 @@ class CSRGraph:
         self.nnz = col.numel()
         if self.nnz == 0:
             raise ValueError("CSRGraph: empty pattern")
-        self.chunk = chunk
-        self.fwd = _Pattern(rowptr, col, chunk)
+        if slot_edges < 4 or slot_edges % 4:
+            raise ValueError("slot_edges must be a multiple of 4, >= 4")
+        self.slot_edges = slot_edges
+        self.fwd = _Pattern(rowptr, col, slot_edges)
         # mirror permutation (symmetric pattern, sorted rows) via the HIP binary search
         perm = torch.empty(self.nnz, dtype=torch.int32, device=self.device)
         flags = torch.zeros(2, dtype=torch.int32, device=self.device)
@@ -113,12 +99,12 @@ class CSRGraph:
         cnt = torch.bincount(col, minlength=self.n)
         rp_t = torch.zeros(self.n + 1, dtype=torch.int64, device=self.device)
         rp_t[1:] = torch.cumsum(cnt, 0)
-        self.bwd = _Pattern(rp_t.to(torch.int32), src[order].to(torch.int32).contiguous(), self.chunk)
+        self.bwd = _Pattern(rp_t.to(torch.int32), src[order].to(torch.int32).contiguous(), self.slot_edges)
         self.perm_t = order.to(torch.int32).contiguous()
 
     # ------------------------------------------------------------------ builders
     @staticmethod
-    def from_dense(adj: torch.Tensor, mode: str = "nonzero", chunk: int = DEFAULT_CHUNK) -> "CSRGraph":
+    def from_dense(adj: torch.Tensor, mode: str = "nonzero", slot_edges: int = DEFAULT_SLOT_EDGES) -> "CSRGraph":
         """mode "nonzero": pattern adj != 0 (SpGraphAttentionLayer, layers.py:129);
         mode "positive": pattern adj > 0 (GraphAttentionLayer, layers.py:41)."""
         if adj.dim() != 2 or adj.shape[0] != adj.shape[1]:
@@ -141,16 +127,17 @@ class CSRGraph:
             col = torch.empty(nnz, dtype=torch.int32, device=dev)
             check(lib.pygat_dense_fill_cols(a.data_ptr(), n, ld, m, rowptr.data_ptr(), col.data_ptr(), _stream()),
                   "fill_cols")
-        return CSRGraph(rowptr, col, chunk)
+        return CSRGraph(rowptr, col, slot_edges)
 
     @staticmethod
-    def from_edge_index(row: torch.Tensor, col: torch.Tensor, n: int, chunk: int = DEFAULT_CHUNK) -> "CSRGraph":
+    def from_edge_index(row: torch.Tensor, col: torch.Tensor, n: int,
+                        slot_edges: int = DEFAULT_SLOT_EDGES) -> "CSRGraph":
         """COO (row=i, col=j), duplicates removed, rows sorted."""
         key = torch.unique(row.long() * n + col.long())
         r, c = key // n, key % n
         rowptr = torch.zeros(n + 1, dtype=torch.int64, device=row.device)
         rowptr[1:] = torch.cumsum(torch.bincount(r, minlength=n), 0)
-        return CSRGraph(rowptr.to(torch.int32), c.to(torch.int32), chunk)
+        return CSRGraph(rowptr.to(torch.int32), c.to(torch.int32), slot_edges)
 
 
 # ---------------------------------------------------------------------------

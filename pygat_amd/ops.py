@@ -146,58 +146,61 @@ class GATLevelFn(torch.autograd.Function):
                 gemm(False, False, L.N, ncols, Fin, x, Fin, Wcat, L.ldw, segs)
             # K2
             flags = (_lib.F_ELU if concat else 0) | (_lib.F_SKIP if skip else 0)
-            keep_hattn = need_grad or not concat
-            hattn = torch.empty(L.N, L.R, dtype=f32, device=dev) if keep_hattn else None
+            hattn = torch.empty(L.N, L.R, dtype=f32, device=dev) if not concat else None
             m = torch.empty(L.N, H, dtype=f32, device=dev) if need_grad else None
             Z = torch.empty(L.N, H, dtype=f32, device=dev) if need_grad else None
             out = torch.empty(L.N, H * Fo if concat else Fo, dtype=f32, device=dev)
-            part = None
-            if graph.fwd.n_items:
-                part = torch.empty(lib.pygat_partials_bytes(max(graph.fwd.n_items, graph.bwd.n_items), H, L.Fp) // 4,
-                                   dtype=f32, device=dev)
+            part = torch.empty(lib.pygat_partials_bytes(graph.nnz, graph.slot_edges, H, L.Fp) // 4, dtype=f32,
+                               device=dev)
             with _span("k2_forward"):
                 check(lib.pygat_gat_forward(graph.fwd.ref(), H, Fo, float(alpha), flags, Wh.data_ptr(), s.data_ptr(),
                                             t.data_ptr(), _ptr(Sk), out.data_ptr() if concat else None, _ptr(hattn),
-                                            _ptr(m), _ptr(Z), _ptr(part), st), "gat_forward")
+                                            _ptr(m), _ptr(Z), part.data_ptr(), st), "gat_forward")
             if not concat:
                 check(lib.pygat_head_mean(L.N, H, Fo, hattn.data_ptr(), _ptr(Sk), out.data_ptr(), st), "head_mean")
         if need_grad:
-            ctx.save_for_backward(x, Wcat, a_pad, Wh, s, t, Sk, hattn, m, Z)
+            # concat: the backward recovers hattn from `out` (no second [N,R] table is written)
+            ctx.save_for_backward(x, Wcat, a_pad, Wh, s, t, Sk, out if concat else hattn, m, Z)
             ctx.graph, ctx.L, ctx.alpha, ctx.concat, ctx.flags = graph, L, float(alpha), concat, flags
         return out
 
     @staticmethod
     def backward(ctx, G):
-        x, Wcat, a_pad, Wh, s, t, Sk, hattn, m, Z = ctx.saved_tensors
+        x, Wcat, a_pad, Wh, s, t, Sk, y, m, Z = ctx.saved_tensors
         graph, L, H, Fo = ctx.graph, ctx.L, ctx.L.H, ctx.L.Fo
         dev, f32 = x.device, torch.float32
         G = G.contiguous().float()
         with torch.cuda.device(dev):
             st = _stream()
             Gp = torch.empty(L.N, L.R, dtype=f32, device=dev)
+            rowtab = torch.empty(L.N, H, 4, dtype=f32, device=dev)
             ebuf = torch.empty(graph.nnz, 2, H, dtype=f32, device=dev)
             ds = torch.empty(L.N, H, dtype=f32, device=dev)
             dt = torch.empty(L.N, H, dtype=f32, device=dev)
             dWh = torch.empty(L.N, L.R, dtype=f32, device=dev)
-            part = None
-            nit = max(graph.fwd.n_items, graph.bwd.n_items)
-            if nit:
-                part = torch.empty(lib.pygat_partials_bytes(nit, H, L.Fp) // 4, dtype=f32, device=dev)
-            # K3 row pass, K4 column pass
-            with _span("k3_backward_row"):
-                check(lib.pygat_gat_backward_row(graph.fwd.ref(), H, Fo, ctx.alpha, ctx.flags, 0 if ctx.concat else 1,
-                                                 G.data_ptr(), Wh.data_ptr(), s.data_ptr(), t.data_ptr(), _ptr(Sk),
-                                                 hattn.data_ptr(), m.data_ptr(), Z.data_ptr(), Gp.data_ptr(),
-                                                 ebuf.data_ptr(), ds.data_ptr(), _ptr(part), st), "gat_backward_row")
+            part = torch.empty(lib.pygat_partials_bytes(graph.nnz, graph.slot_edges, H, L.Fp) // 4, dtype=f32,
+                               device=dev)
+            with _span("k3a_prepare"):
+                check(lib.pygat_gat_backward_prepare(L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(),
+                                                     y.data_ptr(), _ptr(Sk), s.data_ptr(), m.data_ptr(), Z.data_ptr(),
+                                                     Gp.data_ptr(), rowtab.data_ptr(), st), "gat_backward_prepare")
+            with _span("k3b_edge"):
+                check(lib.pygat_gat_backward_edge(graph.fwd.ref(), H, Fo, ctx.alpha, Wh.data_ptr(), t.data_ptr(),
+                                                  Gp.data_ptr(), rowtab.data_ptr(), ebuf.data_ptr(), st),
+                      "gat_backward_edge")
+            if not graph.symmetric:
+                check(lib.pygat_row_sum_dz(graph.fwd.ref(), H, ebuf.data_ptr(), ds.data_ptr(), st), "row_sum_dz")
             with _span("k4_backward_col"):
-                check(lib.pygat_gat_backward_col(graph.bwd.ref(), graph.perm_t.data_ptr(), H, Fo, Gp.data_ptr(),
-                                                 ebuf.data_ptr(), ds.data_ptr(), a_pad.data_ptr(), dWh.data_ptr(),
-                                                 dt.data_ptr(), _ptr(part), st), "gat_backward_col")
+                check(lib.pygat_gat_backward_col(graph.bwd.ref(), graph.perm_t.data_ptr(), int(graph.symmetric), H, Fo,
+                                                 Gp.data_ptr(), ebuf.data_ptr(), a_pad.data_ptr(), dWh.data_ptr(),
+                                                 ds.data_ptr(), dt.data_ptr(), part.data_ptr(), st),
+                      "gat_backward_col")
             # da
             da = torch.empty(H, 2 * Fo, dtype=f32, device=dev)
             ws = torch.empty(lib.pygat_agrad_workspace_bytes(H, Fo) // 4, dtype=f32, device=dev)
-            check(lib.pygat_a_grad(L.N, H, Fo, Wh.data_ptr(), ds.data_ptr(), dt.data_ptr(), da.data_ptr(),
-                                   ws.data_ptr(), st), "a_grad")
+            with _span("k5_agrad"):
+                check(lib.pygat_a_grad(L.N, H, Fo, Wh.data_ptr(), ds.data_ptr(), dt.data_ptr(), da.data_ptr(),
+                                       ws.data_ptr(), st), "a_grad")
             # dW = x^T dWh (split-K over the nodes), dWskip = x^T Gp
             dW = dWs = dx = None
             if ctx.needs_input_grad[1]:
@@ -214,10 +217,11 @@ class GATLevelFn(torch.autograd.Function):
             # dx = dWh Wcat[:, :R]^T (+ Gp Wcat[:, R:2R]^T)
             if ctx.needs_input_grad[0]:
                 dx = torch.empty(L.N, L.Fin, dtype=f32, device=dev)
-                gemm(False, True, L.N, L.Fin, L.R, dWh, L.R, Wcat, L.ldw, [(L.Fin, dx, L.Fin)])
-                if L.skip:
-                    gemm(False, True, L.N, L.Fin, L.R, Gp, L.R, Wcat[:, L.R:], L.ldw, [(L.Fin, dx, L.Fin)],
-                         accumulate=True, split_k=1)
+                with _span("k5_xgrad"):
+                    gemm(False, True, L.N, L.Fin, L.R, dWh, L.R, Wcat, L.ldw, [(L.Fin, dx, L.Fin)])
+                    if L.skip:
+                        gemm(False, True, L.N, L.Fin, L.R, Gp, L.R, Wcat[:, L.R:], L.ldw, [(L.Fin, dx, L.Fin)],
+                             accumulate=True, split_k=1)
         return dx, dW, (da if ctx.needs_input_grad[2] else None), dWs, None, None, None
 
 

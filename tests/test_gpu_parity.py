@@ -44,9 +44,9 @@ def params(H, Fin, Fo, skip, seed):
     return W, a, Sk
 
 
-def run_level(pg, x64, rowptr, col, W, a, Sk, concat, G64, chunk=256, need_dx=True):
+def run_level(pg, x64, rowptr, col, W, a, Sk, concat, G64, slot=64, need_dx=True):
     dev = "cuda:0"
-    g = pg.CSRGraph(torch.as_tensor(rowptr, device=dev), torch.as_tensor(col, device=dev), chunk=chunk)
+    g = pg.CSRGraph(torch.as_tensor(rowptr, device=dev), torch.as_tensor(col, device=dev), slot_edges=slot)
     x = x64.float().to(dev).requires_grad_(need_dx)
     Wd = W.float().to(dev).requires_grad_(True)
     ad = a.float().to(dev).requires_grad_(True)
@@ -155,7 +155,7 @@ SHAPES = [  # (H, Fin, Fo, skip, concat)
 
 
 @pytest.mark.parametrize("H,Fin,Fo,skip,concat", SHAPES)
-@pytest.mark.parametrize("chunk", [256, 8])
+@pytest.mark.parametrize("chunk", [64, 8])
 def test_level_fwd_bwd_small(pg, H, Fin, Fo, skip, concat, chunk):
     N = 96
     rowptr, col = O.random_symmetric_csr(N, 5, 11 + H, hub=(3, 70))
@@ -165,7 +165,7 @@ def test_level_fwd_bwd_small(pg, H, Fin, Fo, skip, concat, chunk):
     G = torch.randn(N, H * Fo if concat else Fo, dtype=torch.float64, generator=gen)
     ref = O.csr_layer_fwd_bwd(x.numpy(), rowptr, col, W.numpy(), a.numpy(), 0.2, concat, G.numpy(),
                               None if Sk is None else Sk.numpy())
-    out, dx, dW, da, dS = run_level(pg, x, rowptr, col, W, a, Sk, concat, G, chunk=chunk)
+    out, dx, dW, da, dS = run_level(pg, x, rowptr, col, W, a, Sk, concat, G, slot=chunk)
     close(out, ref["out"], "out"); close(dx, ref["dX"], "dX"); close(dW, ref["dW"], "dW"); close(da, ref["da"], "da")
     if skip:
         close(dS, ref["dW_skip"], "dW_skip")
@@ -204,7 +204,7 @@ def test_real_topology_level1(pg, topologies, name, Fin, H, Fo):
 
 
 def test_hub_and_degree_one_rows(pg):
-    """Heavy-row splitting (hub of 5000 edges, chunk 256) and rows that only have their self loop."""
+    """Rows cut across many slots (hub of 5000 edges, 64-edge slots) and rows that only have their self loop."""
     N, Fin, Fo, H = 6000, 16, 16, 8
     rng = np.random.default_rng(1)
     nb = rng.choice(np.arange(1, N), size=5000, replace=False)

@@ -20,7 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--graph", default="rmat")
     ap.add_argument("--scale", type=int, default=20)
-    ap.add_argument("--chunk", type=int, default=256)
+    ap.add_argument("--ts", type=int, default=64)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--heads", type=int, default=8)
     ap.add_argument("--fout", type=int, default=16)
@@ -42,7 +42,7 @@ def main():
         cols = torch.cat([torch.arange(n, device=dev)[:, None], nb], 1).sort(1).values
         rowptr = (torch.arange(n + 1, device=dev) * 10).to(torch.int32)
         col = cols.reshape(-1).to(torch.int32)
-    graph = pg.CSRGraph(rowptr, col, chunk=args.chunk)
+    graph = pg.CSRGraph(rowptr, col, slot_edges=args.ts)
     N, E = graph.n, graph.nnz
     Fp = pg.padded_width(Fo); R = H * Fp
     g2 = torch.Generator(device=dev).manual_seed(2)
@@ -53,34 +53,36 @@ def main():
     out = torch.empty(N, H * Fo, device=dev); hattn = torch.empty(N, R, device=dev)
     m = torch.empty(N, H, device=dev); Z = torch.empty(N, H, device=dev)
     Gp = torch.empty(N, R, device=dev); ebuf = torch.empty(E, 2, H, device=dev)
+    rowtab = torch.empty(N, H, 4, device=dev)
     ds = torch.empty(N, H, device=dev); dt = torch.empty(N, H, device=dev); dWh = torch.empty(N, R, device=dev)
-    nit = max(graph.fwd.n_items, graph.bwd.n_items)
-    part = torch.empty(max(1, lib.pygat_partials_bytes(nit, H, Fp) // 4), device=dev)
+    part = torch.empty(max(1, lib.pygat_partials_bytes(E, args.ts, H, Fp) // 4), device=dev)
     P = lambda x: None if x is None else x.data_ptr()
 
     def k2(train=True):
         check(lib.pygat_gat_forward(graph.fwd.ref(), H, Fo, 0.2, _lib.F_ELU, P(Wh), P(s), P(t), None, P(out),
-                                    P(hattn) if train else None, P(m) if train else None, P(Z) if train else None,
-                                    P(part), None))
+                                    None, P(m) if train else None, P(Z) if train else None, P(part), None))
 
-    def k3():
-        check(lib.pygat_gat_backward_row(graph.fwd.ref(), H, Fo, 0.2, _lib.F_ELU, 0, P(G), P(Wh), P(s), P(t), None,
-                                         P(hattn), P(m), P(Z), P(Gp), P(ebuf), P(ds), P(part), None))
+    def k3a():
+        check(lib.pygat_gat_backward_prepare(N, H, Fo, _lib.F_ELU, 0, P(G), P(out), None, P(s), P(m), P(Z), P(Gp),
+                                             P(rowtab), None))
+
+    def k3b():
+        check(lib.pygat_gat_backward_edge(graph.fwd.ref(), H, Fo, 0.2, P(Wh), P(t), P(Gp), P(rowtab), P(ebuf), None))
 
     def k4():
-        check(lib.pygat_gat_backward_col(graph.bwd.ref(), P(graph.perm_t), H, Fo, P(Gp), P(ebuf), P(ds), P(a_pad),
-                                         P(dWh), P(dt), P(part), None))
+        check(lib.pygat_gat_backward_col(graph.bwd.ref(), P(graph.perm_t), int(graph.symmetric), H, Fo, P(Gp), P(ebuf),
+                                         P(a_pad), P(dWh), P(ds), P(dt), P(part), None))
 
     b_fwd = E * (4 + 4 * H + 4 * R) + N * (4 + 4 * H + 4 * R + 8 * H)
+    b_k3a = N * (12 * R + 12 * H + 16 * H)
     b_k3 = E * (4 + 4 * R + 8 * H) + N * (4 + 8 * R + 16 * H)
     b_k4 = E * (8 + 4 * R + 8 * H) + N * (4 + 8 * R + 8 * H)
     runs = [("k2_train", lambda: k2(True), b_fwd), ("k2_eval", lambda: k2(False), b_fwd - N * 8 * H),
-            ("k3_row", k3, b_k3), ("k4_col", k4, b_k4)]
+            ("k3a_prep", k3a, b_k3a), ("k3b_edge", k3b, b_k3 - b_k3a), ("k4_col", k4, b_k4)]
     if args.only:
         runs = [r for r in runs if r[0] in args.only.split(",")]
     deg = (rowptr[1:] - rowptr[:-1])
-    res = {"graph": args.graph, "N": N, "E": E, "chunk": args.chunk, "H": H, "Fo": Fo, "n_heavy": graph.fwd.n_heavy,
-           "n_items": graph.fwd.n_items, "max_deg": int(deg.max())}
+    res = {"graph": args.graph, "N": N, "E": E, "ts": args.ts, "H": H, "Fo": Fo, "max_deg": int(deg.max())}
     for name, fn, nbytes in runs:
         for _ in range(3):
             fn()

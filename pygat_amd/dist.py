@@ -47,13 +47,14 @@ def all_gather_columns_raw(local: torch.Tensor, widths: Sequence[int]) -> torch.
         return local
     N, wmax = local.shape[0], max(widths)
     if all(w == wmax for w in widths):
-        buf = torch.empty(world, N, wmax, dtype=local.dtype, device=local.device)
+        buf = torch.empty(world * N, wmax, dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(buf, local.contiguous())
-        return buf.permute(1, 0, 2).reshape(N, world * wmax)
+        return buf.view(world, N, wmax).permute(1, 0, 2).reshape(N, world * wmax)
     pad = torch.zeros(N, wmax, dtype=local.dtype, device=local.device)
     pad[:, :widths[rank]] = local
-    buf = torch.empty(world, N, wmax, dtype=local.dtype, device=local.device)
+    buf = torch.empty(world * N, wmax, dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(buf, pad)
+    buf = buf.view(world, N, wmax)
     return torch.cat([buf[r, :, :widths[r]] for r in range(world)], dim=1)
 
 
@@ -80,7 +81,7 @@ class AllGatherColumns(torch.autograd.Function):
             stacked[r, :, :widths[r]] = G[:, offs[r]:offs[r + 1]]
         out = torch.empty(N, wmax, dtype=G.dtype, device=G.device)
         if G.is_cuda:
-            dist.reduce_scatter_tensor(out, stacked, op=dist.ReduceOp.SUM)
+            dist.reduce_scatter_tensor(out, stacked.view(world * N, wmax), op=dist.ReduceOp.SUM)
         else:  # gloo has no reduce_scatter: all-reduce then slice (CPU tests only)
             dist.all_reduce(stacked, op=dist.ReduceOp.SUM)
             out = stacked[rank]
@@ -125,11 +126,14 @@ def gat_level_head_parallel(x, graph, Ws, As, Wskips, alpha: float, concat: bool
         if e > s:
             local = level_fn(x, graph, list(Ws[s:e]), list(As[s:e]), sk, alpha, True)
         else:
-            # no local head: still take part in the backward reduce-scatter
-            local = x.new_zeros(x.shape[0], 0).requires_grad_(True)
+            # no local head: stay connected to x so this rank still takes part in the backward
+            # reduce-scatter of the previous level (with a zero contribution)
+            local = x[:, :0] * 0.0
+            if not local.requires_grad:     # x is a graph input: become a leaf so backward still runs here
+                local = local.detach().requires_grad_(True)
         return AllGatherColumns.apply(local, [(b - a) * Fo for a, b in parts])
     if e > s:
         local = level_fn(x, graph, list(Ws[s:e]), list(As[s:e]), sk, alpha, False) * ((e - s) / H)
     else:
-        local = x.new_zeros(x.shape[0], Fo)
+        local = x[:, :1].expand(x.shape[0], Fo) * 0.0   # zero contribution, autograd-connected to x
     return AllReduceSum.apply(local)

@@ -1,0 +1,93 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/pygat_amd.h declares; argument validation works without a GPU (no compute is launched)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    so = os.path.join(ROOT, "pygat_amd", "libpygat_amd.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "pygat_amd", "csrc"), "-j4"], check=True, capture_output=True)
+    from pygat_amd import _lib
+    return _lib
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "pygat_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pygat_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = header_functions()
+    assert len(names) >= 20
+    raw = C.CDLL(lib.LIB_PATH)
+    missing = [n for n in names if not hasattr(raw, n)]
+    assert not missing, missing
+    assert sorted(lib.SYMBOLS) == names       # the python binding covers the whole header
+
+
+def test_abi_version_and_padding(lib):
+    assert lib.lib.pygat_abi_version() == lib.ABI_VERSION
+    assert [lib.lib.pygat_padded_width(f) for f in (1, 3, 4, 7, 8, 16, 121, 256, 257, 0)] == \
+        [4, 4, 4, 8, 8, 16, 128, 256, 0, 0]
+
+
+def test_argument_validation_returns_einval(lib):
+    L = lib.lib
+    # null pointers / bad sizes are rejected before anything is launched
+    assert L.pygat_dense_row_counts(None, 4, 4, 0, None, None) == -1
+    assert b"bad arguments" in L.pygat_last_error()
+    assert L.pygat_gemm_f32(0, 0, 4, 4, 4, None, 4, None, 4, None, 0, 1, None, None) == -1
+    g = lib.Graph(0, 0, None, None, 64)
+    assert L.pygat_gat_forward(C.byref(g), 8, 16, 0.2, 1, None, None, None, None, None, None, None, None, None, None) == -1
+    assert b"graph" in L.pygat_last_error()
+    g2 = lib.Graph(4, 4, 1, 1, 6)             # slot_edges not a multiple of 4
+    assert L.pygat_gat_forward(C.byref(g2), 8, 16, 0.2, 1, None, None, None, None, None, None, None, None, None, None) == -1
+    assert b"slot_edges" in L.pygat_last_error()
+    with pytest.raises(ValueError):
+        lib.check(-1, "x")
+    with pytest.raises(RuntimeError):
+        lib.check(-2, "x")
+    assert lib.lib.pygat_partials_bytes(1000, 64, 8, 16) == 2 * 16 * (128 + 16) * 4
+    assert lib.lib.pygat_gemm_workspace_bytes(128, 128, 4) == 4 * 128 * 128 * 4
+
+
+def test_no_cpu_fallback(lib):
+    """The product path fails loudly off-GPU instead of silently computing elsewhere."""
+    import torch
+    import pygat_amd as pg
+    x = torch.randn(4, 3)
+    with pytest.raises((ValueError, RuntimeError)):
+        pg.CSRGraph(torch.tensor([0, 1, 2, 3, 4], dtype=torch.int32), torch.tensor([0, 1, 2, 3], dtype=torch.int32))
+    layer = pg.SpGraphAttentionLayer(3, 2, 0.0, 0.2)
+    with pytest.raises((ValueError, RuntimeError)):
+        layer(x, torch.eye(4))
+
+
+def test_dropin_constructor_and_state_dict_cpu(lib):
+    """Parameter names, shapes and initialisers of the drop-ins (reference layers.py:21-28,111-119,
+    models.py:27) -- checked on CPU, no kernel involved."""
+    import torch
+    import pygat_amd as pg
+    torch.manual_seed(0)
+    d = pg.GraphAttentionLayer(in_features=5, out_features=3, dropout=0.6, alpha=0.2, concat=True, skip_connection=True)
+    s = pg.SpGraphAttentionLayer(in_features=5, out_features=3, dropout=0.6, alpha=0.2, concat=False)
+    assert tuple(d.W.shape) == (5, 3) and tuple(d.a.shape) == (6, 1) and tuple(d.skip_projection.shape) == (5, 3)
+    assert tuple(s.W.shape) == (5, 3) and tuple(s.a.shape) == (1, 6) and not hasattr(s, "skip_projection")
+    assert repr(d) == "GraphAttentionLayer (5 -> 3)" and repr(s) == "SpGraphAttentionLayer (5 -> 3)"
+    # xavier_uniform with gain 1.414 bounds |W| by gain*sqrt(6/(fan_in+fan_out))
+    assert float(d.W.abs().max()) <= 1.414 * (6 / 8) ** 0.5 + 1e-6
+    m = pg.GAT(nfeat=[50, 256, 256, 121], nheads=[4, 4, 6], nlayers=3, dropout=0.0, alpha=0.2,
+               layer_type=pg.GraphAttentionLayer, skip_connection=True)
+    keys = set(m.state_dict())
+    assert "attention_layer_3_head_6.skip_projection" in keys and len(keys) == (4 + 4 + 6) * 3
+    assert tuple(m.state_dict()["attention_layer_2_head_1.W"].shape) == (1024, 256)
+    assert tuple(m.state_dict()["attention_layer_3_head_1.W"].shape) == (1024, 121)

@@ -111,6 +111,10 @@ int pygat_gemm_f32(int transA, int transB, int M, int N, int64_t K,
 int pygat_pack_params(int H, int Fin, int Fo, const float* W, const float* a,
                       const float* w_skip, float* Wcat, int64_t ldw, float* a_pad,
                       void* stream);
+/* s[n x H], t[n x H] from an (already masked) Wh table: s_ih = Wh_ih . a_src_h, t_ih = Wh_ih . a_dst_h
+ * (layers.py:60-61 after the Wh dropout of layers.py:37,136).  a_pad as written by pygat_pack_params. */
+int pygat_attn_scores(int n, int H, int Fo, const float* Wh, const float* a_pad,
+                      float* s, float* t, void* stream);
 /* Inverse for gradients: dW[H x Fin x F'] (+)= columns of dWcat [Fin x ld]. */
 int pygat_unpack_wgrad(int H, int Fin, int Fo, const float* dWcat, int64_t ld,
                        int col_offset, float* dW, void* stream);
@@ -145,6 +149,7 @@ size_t pygat_partials_bytes(int64_t nnz, int slot_edges, int H, int Fp);
  * head mean), m,Z [n x H] (may be NULL together in eval).  */
 int pygat_gat_forward(const pygat_graph* g, int H, int Fo, float alpha, int flags,
                       const float* Wh, const float* s, const float* t, const float* sk,
+                      const float* att_mask,
                       float* out, float* hattn, float* m, float* Z,
                       void* part, void* stream);
 
@@ -172,7 +177,7 @@ int pygat_gat_backward_prepare(int n, int H, int Fo, int flags, int mean_mode,
                                float* Gp, float* rowtab, void* stream);
 int pygat_gat_backward_edge(const pygat_graph* g, int H, int Fo, float alpha,
                             const float* Wh, const float* t, const float* Gp, const float* rowtab,
-                            float* ebuf, void* stream);
+                            const float* att_mask, float* ebuf, void* stream);
 int pygat_row_sum_dz(const pygat_graph* g, int H, const float* ebuf, float* ds, void* stream);
 int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm_t, int symmetric, int H, int Fo,
                            const float* Gp, const float* ebuf, const float* a_pad,

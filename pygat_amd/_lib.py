@@ -21,7 +21,8 @@ SYMBOLS = [
     "pygat_abi_version", "pygat_last_error", "pygat_padded_width", "pygat_device_count",
     "pygat_device_name", "pygat_dense_row_counts", "pygat_scan_workspace_bytes",
     "pygat_exclusive_scan_i32", "pygat_dense_fill_cols", "pygat_csr_symmetric_perm",
-    "pygat_gemm_workspace_bytes", "pygat_gemm_f32", "pygat_pack_params", "pygat_unpack_wgrad",
+    "pygat_gemm_workspace_bytes", "pygat_gemm_f32", "pygat_pack_params", "pygat_attn_scores",
+    "pygat_unpack_wgrad",
     "pygat_edge_pairs", "pygat_partials_bytes", "pygat_gat_forward", "pygat_head_mean",
     "pygat_gat_backward_prepare", "pygat_gat_backward_edge", "pygat_row_sum_dz", "pygat_gat_backward_col",
     "pygat_agrad_workspace_bytes", "pygat_a_grad",
@@ -63,13 +64,14 @@ def _load():
     lib.pygat_gemm_f32.argtypes = [i, i, i, i, i64, p, i64, p, i64, C.POINTER(OutSegments), i, i, p, p]
     lib.pygat_pack_params.argtypes = [i, i, i, p, p, p, p, i64, p, p]
     lib.pygat_unpack_wgrad.argtypes = [i, i, i, p, i64, i, p, p]
+    lib.pygat_attn_scores.argtypes = [i, i, i, p, p, p, p, p]
     lib.pygat_edge_pairs.argtypes = [i, p, p, p, p]
     lib.pygat_partials_bytes.argtypes = [i64, i, i, i]
     lib.pygat_partials_bytes.restype = sz
-    lib.pygat_gat_forward.argtypes = [C.POINTER(Graph), i, i, f, i, p, p, p, p, p, p, p, p, p, p]
+    lib.pygat_gat_forward.argtypes = [C.POINTER(Graph), i, i, f, i, p, p, p, p, p, p, p, p, p, p, p]
     lib.pygat_head_mean.argtypes = [i, i, i, p, p, p, p]
     lib.pygat_gat_backward_prepare.argtypes = [i, i, i, i, i, p, p, p, p, p, p, p, p, p]
-    lib.pygat_gat_backward_edge.argtypes = [C.POINTER(Graph), i, i, f, p, p, p, p, p, p]
+    lib.pygat_gat_backward_edge.argtypes = [C.POINTER(Graph), i, i, f, p, p, p, p, p, p, p]
     lib.pygat_row_sum_dz.argtypes = [C.POINTER(Graph), i, p, p, p]
     lib.pygat_gat_backward_col.argtypes = [C.POINTER(Graph), p, i, i, i, p, p, p, p, p, p, p, p]
     lib.pygat_agrad_workspace_bytes.argtypes = [i, i]

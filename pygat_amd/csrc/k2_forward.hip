@@ -31,6 +31,7 @@ struct FwdArgs {
   const float* s;
   const float* t;
   const float* sk;
+  const float* mask;  // [nnz][H] attention dropout mask (pre-scaled) or nullptr
   float* out;
   float* hattn;
   float* m;
@@ -41,14 +42,16 @@ struct FwdArgs {
 __device__ __forceinline__ float lrelu(float z, float alpha) { return z > 0.f ? z : alpha * z; }
 
 // fold one edge (logit ev, row w) into the running softmax state; one exp per edge
-__device__ __forceinline__ void fold_edge(float& m, float& z, float4& a, float ev, float4 w) {
+// (mk = dropout mask on alpha: scales the aggregated term only, Z is taken before it, layers.py:150-153)
+__device__ __forceinline__ void fold_edge(float& m, float& z, float4& a, float ev, float4 w, float mk) {
   const float d = ev - m;
   const float ex = __expf(-fabsf(d));
   const bool up = d > 0.f;
   const float sc = up ? ex : 1.f, p = up ? 1.f : ex;
   z = fmaf(z, sc, p);
-  a.x = fmaf(a.x, sc, p * w.x); a.y = fmaf(a.y, sc, p * w.y);
-  a.z = fmaf(a.z, sc, p * w.z); a.w = fmaf(a.w, sc, p * w.w);
+  const float pm = p * mk;
+  a.x = fmaf(a.x, sc, pm * w.x); a.y = fmaf(a.y, sc, pm * w.y);
+  a.z = fmaf(a.z, sc, pm * w.z); a.w = fmaf(a.w, sc, pm * w.w);
   m = up ? ev : m;
 }
 
@@ -153,12 +156,13 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
     int2 p[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) p[u] = rc[(e + u < e1) ? e + u : e1 - 1];
-    float sv[U][VEC], tv[U][VEC];
+    float sv[U][VEC], tv[U][VEC], mk[U][VEC];
     float4 wv[U][VEC];
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
+        mk[u][v] = a.mask ? a.mask[((e + u < e1) ? e + u : e1 - 1) * H + lc.head[v]] : 1.f;
         sv[u][v] = a.s[(int64_t)p[u].x * H + lc.head[v]];
         tv[u][v] = a.t[(int64_t)p[u].y * H + lc.head[v]];
         wv[u][v] = ld4(a.Wh + (int64_t)p[u].y * R + lc.cofs[v]);
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
           for (int v = 0; v < VEC; ++v) { m[v] = NEG_BIG; z[v] = 0.f; acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); }
         }
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) fold_edge(m[v], z[v], acc[v], lrelu(sv[u][v] + tv[u][v], a.alpha), wv[u][v]);
+        for (int v = 0; v < VEC; ++v) fold_edge(m[v], z[v], acc[v], lrelu(sv[u][v] + tv[u][v], a.alpha), wv[u][v], mk[u][v]);
       }
     }
   }
@@ -283,8 +287,8 @@ extern "C" size_t pygat_partials_bytes(int64_t nnz, int slot_edges, int H, int F
 }
 
 extern "C" int pygat_gat_forward(const pygat_graph* g, int H, int Fo, float alpha, int flags, const float* Wh,
-                                 const float* s, const float* t, const float* sk, float* out, float* hattn,
-                                 float* m, float* Z, void* part, void* stream) {
+                                 const float* s, const float* t, const float* sk, const float* att_mask,
+                                 float* out, float* hattn, float* m, float* Z, void* part, void* stream) {
   FwdArgs a;
   int rc = check_graph(g, &a.g);
   if (rc) return rc;
@@ -296,7 +300,7 @@ extern "C" int pygat_gat_forward(const pygat_graph* g, int H, int Fo, float alph
   PYGAT_REQUIRE(aligned16(Wh) && aligned16(part) && (!sk || aligned16(sk)) && (!hattn || aligned16(hattn)) &&
                     (!out || a.rs.Fo != a.rs.Fp || aligned16(out)),
                 "gat_forward: row tables must be 16-byte aligned");
-  a.alpha = alpha; a.flags = flags; a.Wh = Wh; a.s = s; a.t = t; a.sk = sk;
+  a.alpha = alpha; a.flags = flags; a.Wh = Wh; a.s = s; a.t = t; a.sk = sk; a.mask = att_mask;
   a.out = out; a.hattn = hattn; a.m = m; a.Z = Z; a.part = (float*)part;
   int lpr, vec;
   pick_lanes(a.rs, &lpr, &vec);

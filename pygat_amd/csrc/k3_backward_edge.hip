@@ -102,6 +102,7 @@ struct EdgeArgs {
   const float* t;
   const float* Gp;
   const float* rowtab;
+  const float* mask;  // [nnz][H] attention dropout mask or nullptr
   float* ebuf;
 };
 
@@ -146,10 +147,13 @@ __global__ __launch_bounds__(256) void gat_bwd_edge_kernel(EdgeArgs a) {
         const float zz = rt[u][v].x + tv[u][v];
         const float ev = zz > 0.f ? zz : a.alpha * zz;
         const float al = __expf(ev - rt[u][v].y) * rt[u][v].z;
-        const float dz = al * (dp - rt[u][v].w) * (zz > 0.f ? 1.f : a.alpha);
         if (lead[v] && e + u < e1) {
+          // with attention dropout the aggregated weight is alpha*mask: d(alpha) = mask*dp, and K4
+          // needs the masked weight; the softmax Jacobian keeps the un-masked alpha
+          const float mk = a.mask ? a.mask[(e + u) * H + lc.head[v]] : 1.f;
+          const float dz = al * (mk * dp - rt[u][v].w) * (zz > 0.f ? 1.f : a.alpha);
           float* eb = a.ebuf + (e + u) * 2 * H + lc.head[v];
-          eb[0] = al;
+          eb[0] = al * mk;
           eb[H] = dz;
         }
       }
@@ -194,15 +198,15 @@ extern "C" int pygat_gat_backward_prepare(int n, int H, int Fo, int flags, int m
 }
 
 extern "C" int pygat_gat_backward_edge(const pygat_graph* g, int H, int Fo, float alpha, const float* Wh,
-                                       const float* t, const float* Gp, const float* rowtab, float* ebuf,
-                                       void* stream) {
+                                       const float* t, const float* Gp, const float* rowtab,
+                                       const float* att_mask, float* ebuf, void* stream) {
   EdgeArgs a;
   int rc = check_graph(g, &a.g);
   if (rc) return rc;
   PYGAT_REQUIRE(make_row_shape(H, Fo, &a.rs), "gat_backward_edge: unsupported H=%d F'=%d", H, Fo);
   PYGAT_REQUIRE(Wh && t && Gp && rowtab && ebuf, "gat_backward_edge: null pointer");
   PYGAT_REQUIRE(aligned16(Wh) && aligned16(Gp) && aligned16(rowtab), "gat_backward_edge: row tables must be 16-byte aligned");
-  a.alpha = alpha; a.Wh = Wh; a.t = t; a.Gp = Gp; a.rowtab = rowtab; a.ebuf = ebuf;
+  a.alpha = alpha; a.Wh = Wh; a.t = t; a.Gp = Gp; a.rowtab = rowtab; a.mask = att_mask; a.ebuf = ebuf;
   int lpr, vec;
   pick_lanes(a.rs, &lpr, &vec);
   const unsigned blocks = (unsigned)cdiv(cdiv(num_slots(a.g), 64 / lpr), 4);

@@ -60,6 +60,25 @@ __global__ __launch_bounds__(256) void a_grad_final_kernel(RowShape rs, const fl
   da[idx] = acc;
 }
 
+// s, t from a (masked) Wh table: one thread per (node, head)
+__global__ __launch_bounds__(256) void attn_scores_kernel(int n, int H, int Fp, const float* __restrict__ Wh,
+                                                          const float* __restrict__ a_pad, float* __restrict__ s,
+                                                          float* __restrict__ t) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)n * H) return;
+  const int h = (int)(idx % H);
+  const float* w = Wh + idx * Fp;               // row i, head h: offset (i*H + h)*Fp
+  const float* as = a_pad + (int64_t)h * 2 * Fp;
+  float x = 0.f, y = 0.f;
+  for (int f = 0; f < Fp; f += 4) {
+    const float4 w4 = ld4(w + f), a4 = ld4(as + f), d4 = ld4(as + Fp + f);
+    x += dot4(w4, a4);
+    y += dot4(w4, d4);
+  }
+  s[idx] = x;
+  t[idx] = y;
+}
+
 // ------------------------------------------------------------- parameter packing
 __global__ __launch_bounds__(256) void pack_params_kernel(int H, int Fin, int Fo, int Fp,
                                                           const float* __restrict__ W,
@@ -122,6 +141,17 @@ extern "C" int pygat_a_grad(int n, int H, int Fo, const float* Wh, const float* 
   hipLaunchKernelGGL(a_grad_final_kernel, dim3((unsigned)cdiv(rs.H * 2 * rs.Fo, 256)), dim3(256), 0, st, rs,
                      (const float*)ws, da);
   PYGAT_CHECK_LAUNCH("a_grad");
+  return PYGAT_OK;
+}
+
+extern "C" int pygat_attn_scores(int n, int H, int Fo, const float* Wh, const float* a_pad, float* s, float* t,
+                                 void* stream) {
+  int Fp = padded_width(Fo);
+  PYGAT_REQUIRE(n > 0 && H > 0 && Fp > 0 && Wh && a_pad && s && t && aligned16(Wh) && aligned16(a_pad),
+                "attn_scores: bad arguments");
+  hipLaunchKernelGGL(attn_scores_kernel, dim3((unsigned)cdiv((int64_t)n * H, 256)), dim3(256), 0, (hipStream_t)stream, n,
+                     H, Fp, Wh, a_pad, s, t);
+  PYGAT_CHECK_LAUNCH("attn_scores");
   return PYGAT_OK;
 }
 

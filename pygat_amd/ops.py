@@ -154,7 +154,7 @@ class GATLevelFn(torch.autograd.Function):
                                device=dev)
             with _span("k2_forward"):
                 check(lib.pygat_gat_forward(graph.fwd.ref(), H, Fo, float(alpha), flags, Wh.data_ptr(), s.data_ptr(),
-                                            t.data_ptr(), _ptr(Sk), out.data_ptr() if concat else None, _ptr(hattn),
+                                            t.data_ptr(), _ptr(Sk), None, out.data_ptr() if concat else None, _ptr(hattn),
                                             _ptr(m), _ptr(Z), part.data_ptr(), st), "gat_forward")
             if not concat:
                 check(lib.pygat_head_mean(L.N, H, Fo, hattn.data_ptr(), _ptr(Sk), out.data_ptr(), st), "head_mean")
@@ -186,7 +186,7 @@ class GATLevelFn(torch.autograd.Function):
                                                      Gp.data_ptr(), rowtab.data_ptr(), st), "gat_backward_prepare")
             with _span("k3b_edge"):
                 check(lib.pygat_gat_backward_edge(graph.fwd.ref(), H, Fo, ctx.alpha, Wh.data_ptr(), t.data_ptr(),
-                                                  Gp.data_ptr(), rowtab.data_ptr(), ebuf.data_ptr(), st),
+                                                  Gp.data_ptr(), rowtab.data_ptr(), None, ebuf.data_ptr(), st),
                       "gat_backward_edge")
             if not graph.symmetric:
                 check(lib.pygat_row_sum_dz(graph.fwd.ref(), H, ebuf.data_ptr(), ds.data_ptr(), st), "row_sum_dz")

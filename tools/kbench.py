@@ -59,7 +59,7 @@ def main():
     P = lambda x: None if x is None else x.data_ptr()
 
     def k2(train=True):
-        check(lib.pygat_gat_forward(graph.fwd.ref(), H, Fo, 0.2, _lib.F_ELU, P(Wh), P(s), P(t), None, P(out),
+        check(lib.pygat_gat_forward(graph.fwd.ref(), H, Fo, 0.2, _lib.F_ELU, P(Wh), P(s), P(t), None, None, P(out),
                                     None, P(m) if train else None, P(Z) if train else None, P(part), None))
 
     def k3a():
@@ -67,7 +67,7 @@ def main():
                                              P(rowtab), None))
 
     def k3b():
-        check(lib.pygat_gat_backward_edge(graph.fwd.ref(), H, Fo, 0.2, P(Wh), P(t), P(Gp), P(rowtab), P(ebuf), None))
+        check(lib.pygat_gat_backward_edge(graph.fwd.ref(), H, Fo, 0.2, P(Wh), P(t), P(Gp), P(rowtab), None, P(ebuf), None))
 
     def k4():
         check(lib.pygat_gat_backward_col(graph.bwd.ref(), P(graph.perm_t), int(graph.symmetric), H, Fo, P(Gp), P(ebuf),

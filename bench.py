@@ -78,9 +78,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import pygat_amd as pg
     from pygat_amd import ops
@@ -108,17 +109,28 @@ def main():
     G_loc = G[:, hs * Fo:he * Fo].contiguous()
     Xb = X.requires_grad_(True) if args.dx else X
 
+    use_pg = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    gbuf = torch.empty(world * N, h_loc * Fo, device=dev) if use_pg else None
+
     def step():
         W_loc.grad = a_loc.grad = None
         if args.dx:
             Xb.grad = None
         out = pg.GATLevelFn.apply(Xb, W_loc, a_loc, None, graph, 0.2, True)
-        full = all_gather_columns_raw(out.detach(), widths) if world > 1 else out
-        out.backward(G_loc)
+        if use_pg:
+            # RCCL all-gather of the head outputs (models.py:32 torch.cat) on RCCL's own stream; this
+            # level's backward does not depend on it, so it overlaps K3/K4/K5 and is joined at the end.
+            work = dist.all_gather_into_tensor(gbuf, out.detach(), async_op=True)
+            out.backward(G_loc)
+            work.wait()
+            full = gbuf.view(world, N, h_loc * Fo).permute(1, 0, 2).reshape(N, world * h_loc * Fo)
+        else:
+            out.backward(G_loc)
+            full = out
         return full
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -171,7 +183,7 @@ def main():
                 line["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": os.cpu_count(), "kind": "port",
                                         "sample": f"failed: {ex!r}"}
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

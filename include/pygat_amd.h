@@ -148,7 +148,7 @@ size_t pygat_partials_bytes(int64_t nnz, int slot_edges, int H, int Fp);
  * out [n x H*F'] compact (may be NULL), hattn [n x R] padded (may be NULL; needed for the
  * head mean), m,Z [n x H] (may be NULL together in eval).  */
 int pygat_gat_forward(const pygat_graph* g, int H, int Fo, float alpha, int flags,
-                      const float* Wh, const float* s, const float* t, const float* sk,
+                      const float* Wh, const float* s, const float* a_pad, const float* sk,
                       const float* att_mask,
                       float* out, float* hattn, float* m, float* Z,
                       void* part, void* stream);
@@ -165,22 +165,28 @@ int pygat_head_mean(int n, int H, int Fo, const float* hattn, const float* sk,
  *                     recovered from it: out > 0 ? out : log1p(out), minus sk);
  *        mean_mode 1: G is [n x F'] (every head receives G/H, models.py:34), y is hattn [n x R].
  *   K3b edge pass (nnz split, no reduction): alpha_ij, dz_ij = alpha_ij (Gp_i.Wh_j - D_i) LeakyReLU'(s_i+t_j)
- *        -> ebuf [nnz][2][H] (alpha then dz per edge).
- *   K4 column pass over the transposed pattern gT, perm_t[k] = forward edge of gT's edge k:
+ *        -> ebuf [nnz][2][H] (alpha then dz per edge); dz_f [nnz][H] = dz in forward order, written
+ *           only when ebuf is scattered (it then feeds the row sums ds; may be NULL otherwise).
+ *           ebuf order: perm_f == NULL: forward edge order, K4 then gathers it through perm_t;
+ *           perm_f != NULL: scattered to the TRANSPOSED position perm_f[k] of each edge, K4 then
+ *           streams it (perm_t == NULL).  Gather wins for wide rows, scatter for narrow ones
+ *           (few heads per GPU), where a second random sector per edge in K4 costs the most.
+ *   K4 column pass over the transposed pattern gT:
  *        dWh_j = sum_i alpha_ij Gp_i + ds_j a_src + dt_j a_dst, dt_j = sum_i dz_ij, ds_j = sum_k dz_jk.
- *        symmetric != 0: gT has the forward pattern's layout, so ds_j is summed from ebuf at gT's own
- *        edge positions and written to ds; symmetric == 0: ds must already hold pygat_row_sum_dz.
+ *        symmetric != 0: gT has the forward pattern's layout, so ds_j is summed from dz_f at gT's own
+ *        edge positions and written to ds; symmetric == 0: ds must already hold pygat_row_sum_dz(dz_f).
  */
 int pygat_gat_backward_prepare(int n, int H, int Fo, int flags, int mean_mode,
                                const float* G, const float* y, const float* sk,
                                const float* s, const float* m, const float* Z,
                                float* Gp, float* rowtab, void* stream);
 int pygat_gat_backward_edge(const pygat_graph* g, int H, int Fo, float alpha,
-                            const float* Wh, const float* t, const float* Gp, const float* rowtab,
-                            const float* att_mask, float* ebuf, void* stream);
-int pygat_row_sum_dz(const pygat_graph* g, int H, const float* ebuf, float* ds, void* stream);
+                            const float* Wh, const float* a_pad, const float* Gp, const float* rowtab,
+                            const float* att_mask, const int32_t* perm_f,
+                            float* ebuf, float* dz_f, void* stream);
+int pygat_row_sum_dz(const pygat_graph* g, int H, const float* dz_f, float* ds, void* stream);
 int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm_t, int symmetric, int H, int Fo,
-                           const float* Gp, const float* ebuf, const float* a_pad,
+                           const float* Gp, const float* ebuf, const float* dz_f, const float* a_pad,
                            float* dWh, float* ds, float* dt, void* part, void* stream);
 /* da[H x 2F'] : da_src = sum_i ds_i Wh_i, da_dst = sum_j dt_j Wh_j (per head).
  * ws >= pygat_agrad_workspace_bytes(H, Fo). */

@@ -71,9 +71,9 @@ def _load():
     lib.pygat_gat_forward.argtypes = [C.POINTER(Graph), i, i, f, i, p, p, p, p, p, p, p, p, p, p, p]
     lib.pygat_head_mean.argtypes = [i, i, i, p, p, p, p]
     lib.pygat_gat_backward_prepare.argtypes = [i, i, i, i, i, p, p, p, p, p, p, p, p, p]
-    lib.pygat_gat_backward_edge.argtypes = [C.POINTER(Graph), i, i, f, p, p, p, p, p, p, p]
+    lib.pygat_gat_backward_edge.argtypes = [C.POINTER(Graph), i, i, f, p, p, p, p, p, p, p, p, p]
     lib.pygat_row_sum_dz.argtypes = [C.POINTER(Graph), i, p, p, p]
-    lib.pygat_gat_backward_col.argtypes = [C.POINTER(Graph), p, i, i, i, p, p, p, p, p, p, p, p]
+    lib.pygat_gat_backward_col.argtypes = [C.POINTER(Graph), p, i, i, i, p, p, p, p, p, p, p, p, p]
     lib.pygat_agrad_workspace_bytes.argtypes = [i, i]
     lib.pygat_agrad_workspace_bytes.restype = sz
     lib.pygat_a_grad.argtypes = [i, i, i, p, p, p, p, p, p]

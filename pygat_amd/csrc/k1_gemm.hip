@@ -236,6 +236,11 @@ static int launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
   return 0;
 }
 
+int try_gemm_smallk(int transB, int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                    const pygat_out_segments* out, int accumulate, hipStream_t st);
+int try_gemm_tn_stream(int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                       int max_splits, float* ws, hipStream_t st);
+
 }  // namespace pygat
 
 using namespace pygat;
@@ -259,6 +264,23 @@ extern "C" int pygat_gemm_f32(int transA, int transB, int M, int N, int64_t K, c
   PYGAT_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N), "gemm: leading dimension too small");
   if (split_k < 1) split_k = 1;
   PYGAT_REQUIRE(split_k == 1 || ws, "gemm: split_k > 1 needs a workspace");
+  hipStream_t st = (hipStream_t)stream;
+  if (!transA && split_k == 1) {  // tall-skinny, small K: B resident in LDS, A streamed through registers
+    int r = try_gemm_smallk(transB, M, N, K, A, lda, B, ldb, out, accumulate, st);
+    if (r < 0) return r;
+    if (r == 1) return PYGAT_OK;
+  }
+  if (transA && !transB && split_k > 1) {  // weight gradient: huge K, small M x N, no LDS
+    int r = try_gemm_tn_stream(M, N, K, A, lda, B, ldb, split_k, (float*)ws, st);
+    if (r < 0) return r;
+    if (r >= 1) {
+      int64_t tot = (int64_t)M * N;
+      hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, st, M, N, r,
+                         (const float*)ws, *out, accumulate);
+      PYGAT_CHECK_LAUNCH("gemm_splitk_reduce");
+      return PYGAT_OK;
+    }
+  }
   GemmArgs g;
   g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.out = *out;
   g.accumulate = accumulate;
@@ -268,7 +290,6 @@ extern "C" int pygat_gemm_f32(int transA, int transB, int M, int N, int64_t K, c
   g.ws = (splits > 1) ? (float*)ws : nullptr;
   g.a_vec = aligned16(A) && (lda % 4 == 0);
   g.b_vec = aligned16(B) && (ldb % 4 == 0);
-  hipStream_t st = (hipStream_t)stream;
   if (!transA && !transB) launch_gemm<false, false>(g, splits, st);
   else if (transA && !transB) launch_gemm<true, false>(g, splits, st);
   else if (!transA && transB) launch_gemm<false, true>(g, splits, st);

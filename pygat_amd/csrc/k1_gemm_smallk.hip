@@ -1,0 +1,334 @@
+// K1 fast path -- tall-skinny fp32 MFMA GEMM with a SMALL inner dimension (gfx950).
+//
+// C[M x N] = A[M x K] * op(B), K <= 256, M huge (one row per graph node): the projection
+// Wh = h W of the reference (layers.py:35,134, all heads and the s/t columns at once) and the
+// input gradient dX = dWh W^T.  These shapes are MFMA-bound in fp32 (157 TF peak is only
+// ~20 flop/B), so the structure removes everything but MFMAs from the steady state:
+//
+//   * op(B) (K x BN, <= 84 KB) is staged ONCE per work-group into LDS, k-major, and is then
+//     read-only: no barrier in the main loop, waves run free.
+//   * A never touches LDS: lane (i = l&31, h = l>>5) of a wave owns row i of the wave's 32-row
+//     tile and streams it in 32-float chunks straight into registers with 16-byte loads (the
+//     two half-waves fetch the same addresses and pick the even / odd k of each float4, which
+//     is exactly the A fragment of v_mfma_f32_32x32x2_f32: A[i][k = 2q + h]).
+//   * 8 waves per work-group (2 per SIMD) share the LDS image; work-groups are persistent and
+//     walk the row tiles with the next chunk prefetched during the current chunk's MFMAs.
+#include "common.h"
+
+namespace pygat {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct SmallKArgs {
+  int M, N, K;
+  const float* A;
+  int64_t lda;
+  const float* B;
+  int64_t ldb;
+  pygat_out_segments out;
+  int accumulate;
+  int tiles_m;  // 256-row tiles
+};
+
+template <bool TB, int NT>
+__global__ __launch_bounds__(512) void gemm_smallk_kernel(SmallKArgs g) {
+  constexpr int BN = 32 * NT;
+  constexpr int LDB = BN + 4;
+  extern __shared__ __attribute__((aligned(16))) float Bs[];  // [K][LDB]
+  const int n0 = blockIdx.y * BN;
+  // ---- stage op(B) once
+  if constexpr (!TB) {
+#pragma unroll 8
+    for (int idx = threadIdx.x; idx < g.K * BN; idx += 512) {
+      const int k = idx / BN, n = idx % BN;
+      Bs[k * LDB + n] = (n0 + n < g.N) ? g.B[(int64_t)k * g.ldb + n0 + n] : 0.f;
+    }
+  } else {
+#pragma unroll 8
+    for (int idx = threadIdx.x; idx < g.K * BN; idx += 512) {
+      const int n = idx / g.K, k = idx % g.K;
+      Bs[k * LDB + n] = (n0 + n < g.N) ? g.B[(int64_t)(n0 + n) * g.ldb + k] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int nchunks = g.K / 32;
+  if ((int)blockIdx.x >= g.tiles_m) return;
+  const int my_tiles = (g.tiles_m - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = my_tiles * nchunks;  // chunks this wave streams, tile after tile
+
+  // address of the wave's c-th chunk (clamped: every load below is unconditional, a conditionally
+  // defined register array ends up in scratch memory)
+  auto chunk_ptr = [&](int c) -> const float* {
+    if (c > total - 1) c = total - 1;
+    const int t = c / nchunks, kc = c - t * nchunks;
+    int64_t row = ((int64_t)blockIdx.x + (int64_t)t * gridDim.x) * 256 + 32 * w + fr;
+    if (row > g.M - 1) row = g.M - 1;
+    return g.A + row * g.lda + kc * 32;
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+#define PYGAT_LOAD8(R, P)                                                                     \
+  {                                                                                           \
+    const float* p__ = (P);                                                                   \
+    R##0 = ld4(p__); R##1 = ld4(p__ + 4); R##2 = ld4(p__ + 8); R##3 = ld4(p__ + 12);          \
+    R##4 = ld4(p__ + 16); R##5 = ld4(p__ + 20); R##6 = ld4(p__ + 24); R##7 = ld4(p__ + 28);   \
+  }
+#define PYGAT_BREAD(B0, B1, C)                                                                \
+  _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                         \
+    B0[nt] = bs[(4 * (C)) * LDB + 32 * nt];                                                   \
+    B1[nt] = bs[(4 * (C) + 2) * LDB + 32 * nt];                                               \
+  }
+// B fragments of float4 C+1 are read from LDS BEFORE the 2*NT MFMAs of float4 C are issued; the
+// sched_barriers keep hipcc from sinking the ds_reads back to their first use (it otherwise
+// serialises ds_read -> lgkmcnt(0) -> 2 MFMAs through one register pair).
+#define PYGAT_MMA4(V, C, BC0, BC1, BN0, BN1)                                                  \
+  {                                                                                           \
+    const float a0 = fh ? (V).y : (V).x; /* k = 4C + fh */                                    \
+    const float a1 = fh ? (V).w : (V).z; /* k = 4C + 2 + fh */                                \
+    if ((C) < 7) PYGAT_BREAD(BN0, BN1, (C) + 1)                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                         \
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, BC0[nt], acc[nt], 0, 0, 0);        \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                         \
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, BC1[nt], acc[nt], 0, 0, 0);        \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+  }
+#define PYGAT_STEP(R, CIDX)                                                                   \
+  {                                                                                           \
+    const int c__ = (CIDX);                                                                   \
+    const int t__ = c__ / nchunks, kc__ = c__ - t__ * nchunks;                                \
+    const float* bs = Bs + (kc__ * 32 + fh) * LDB + fr;                                       \
+    float bx0[NT], bx1[NT], by0[NT], by1[NT];                                                 \
+    PYGAT_BREAD(bx0, bx1, 0)                                                                  \
+    PYGAT_MMA4(R##0, 0, bx0, bx1, by0, by1) PYGAT_MMA4(R##1, 1, by0, by1, bx0, bx1)           \
+    PYGAT_MMA4(R##2, 2, bx0, bx1, by0, by1) PYGAT_MMA4(R##3, 3, by0, by1, bx0, bx1)           \
+    PYGAT_MMA4(R##4, 4, bx0, bx1, by0, by1) PYGAT_MMA4(R##5, 5, by0, by1, bx0, bx1)           \
+    PYGAT_MMA4(R##6, 6, bx0, bx1, by0, by1) PYGAT_MMA4(R##7, 7, by0, by1, bx0, bx1)           \
+    if (kc__ == nchunks - 1) store_tile(t__);                                                 \
+  }
+
+  // epilogue of one 32 x BN wave tile: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  auto store_tile = [&](int t) {
+    const int64_t row0 = ((int64_t)blockIdx.x + (int64_t)t * gridDim.x) * 256 + 32 * w;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = n0 + 32 * nt + fr;
+      if (col < g.N) {
+        int s = 0;
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+          if (q < g.out.nseg && col >= g.out.col_start[q]) s = q;
+        float* base = g.out.ptr[s] + (col - g.out.col_start[s]);
+        const int64_t ld = g.out.ld[s];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t orow = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+          if (orow < g.M) {
+            float* p = base + orow * ld;
+            if (g.accumulate) *p += acc[nt][r]; else *p = acc[nt][r];
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    }
+  };
+
+  float4 ra0, ra1, ra2, ra3, ra4, ra5, ra6, ra7;
+  float4 rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7;
+  PYGAT_LOAD8(ra, chunk_ptr(0))
+  for (int c = 0; c < total; c += 2) {
+    PYGAT_LOAD8(rb, chunk_ptr(c + 1))
+    PYGAT_STEP(ra, c)
+    PYGAT_LOAD8(ra, chunk_ptr(c + 2))
+    if (c + 1 < total) PYGAT_STEP(rb, c + 1)
+  }
+#undef PYGAT_LOAD8
+#undef PYGAT_BREAD
+#undef PYGAT_MMA4
+#undef PYGAT_STEP
+}
+
+template <bool TB>
+static hipError_t launch_smallk(const SmallKArgs& g, int NT, dim3 grid, size_t lds, hipStream_t st) {
+#define PYGAT_SMALLK_CASE(n)                                                                              \
+  case n: {                                                                                               \
+    static bool attr_set = false;                                                                         \
+    if (!attr_set) {                                                                                      \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_smallk_kernel<TB, n>),                \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
+      attr_set = true;                                                                                    \
+    }                                                                                                     \
+    hipLaunchKernelGGL((gemm_smallk_kernel<TB, n>), grid, dim3(512), lds, st, g);                         \
+  } break;
+  switch (NT) {
+    PYGAT_SMALLK_CASE(1)
+    PYGAT_SMALLK_CASE(2)
+    PYGAT_SMALLK_CASE(3)
+    PYGAT_SMALLK_CASE(4)
+    default: PYGAT_SMALLK_CASE(5)
+  }
+#undef PYGAT_SMALLK_CASE
+  return hipGetLastError();
+}
+
+// returns 1 if the fast path took the call, 0 if the shape does not qualify, <0 on launch error
+int try_gemm_smallk(int transB, int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                    const pygat_out_segments* out, int accumulate, hipStream_t st) {
+  if (K < 32 || K > 256 || (K % 32) != 0 || M < 8192) return 0;
+  if (!aligned16(A) || (lda % 4) != 0) return 0;
+  const int nt_needed = (int)cdiv(N, 32);
+  const int NT = nt_needed < 5 ? nt_needed : 5;
+  const size_t lds = (size_t)K * (32 * NT + 4) * sizeof(float);
+  if (lds > 150 * 1024) return 0;
+  SmallKArgs g;
+  g.M = M; g.N = N; g.K = (int)K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.out = *out; g.accumulate = accumulate;
+  g.tiles_m = (int)cdiv(M, 256);
+  const int tiles_n = (int)cdiv(N, 32 * NT);
+  int gx = 256 / tiles_n;
+  if (gx < 1) gx = 1;
+  if (gx > g.tiles_m) gx = g.tiles_m;
+  dim3 grid((unsigned)gx, (unsigned)tiles_n, 1);
+  hipError_t e = transB ? launch_smallk<true>(g, NT, grid, lds, st) : launch_smallk<false>(g, NT, grid, lds, st);
+  if (e != hipSuccess) {
+    set_error("gemm_smallk: %s", hipGetErrorString(e));
+    return PYGAT_EHIP;
+  }
+  return 1;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Weight-gradient fast path: C[M x N] = A^T B with A [K x M], B [K x N], K huge (one row per node),
+// M and N small: dW = X^T dWh (autograd of layers.py:35,134).  Both operands are k-strided, i.e. a
+// fragment of v_mfma_f32_32x32x2_f32 (lane (i = l&31, h = l>>5) -> A[k = 2q+h][m0+i], B[2q+h][n0+i])
+// is two coalesced 128-B segments of one wave-wide dword load: no LDS, no barrier.  Each wave owns a
+// 32 x (32*NT) block of C, the work-group a 128 x (32*NT) tile of one K slab; slabs go to the
+// split-K workspace and are summed in slab order by gemm_splitk_reduce_kernel.
+struct TnArgs {
+  int M, N;
+  int64_t K;
+  const float* A;
+  int64_t lda;
+  const float* B;
+  int64_t ldb;
+  int64_t k_per_split;
+  float* ws;  // [splits][M][N]
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void gemm_tn_stream_kernel(TnArgs g) {
+  constexpr int UK = 8;  // k2-steps in flight
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int m = blockIdx.y * 128 + 32 * w + fr;
+  const int n0 = blockIdx.z * 32 * NT;
+  const int64_t kbeg = (int64_t)blockIdx.x * g.k_per_split;
+  const int64_t kend = (kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K;
+  const float* ap = g.A + (m < g.M ? m : 0);
+  const float* bp[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + 32 * nt + fr;
+    bp[nt] = g.B + (n < g.N ? n : 0);
+  }
+  f32x16 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  // Lanes whose m / n fall outside C read a clamped (valid) column: their products only reach rows /
+  // columns of C that are never stored, so the steady state needs no masking at all -- a select on
+  // a loaded value makes hipcc branch around the load and wait vmcnt(0) after each one.
+  // double-buffered: the 8 k2-steps of block i+1 are in flight while block i's MFMAs issue
+#define PYGAT_TN_LOAD(AX, BX, KBASE)                                                          \
+  _Pragma("unroll") for (int u = 0; u < UK; ++u) {                                            \
+    const int64_t k = (KBASE) + 2 * u + fh;                                                   \
+    AX[u] = ap[k * g.lda];                                                                    \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) BX[u][nt] = bp[nt][k * g.ldb];          \
+  }
+#define PYGAT_TN_MMA(AX, BX)                                                                  \
+  _Pragma("unroll") for (int u = 0; u < UK; ++u)                                              \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                       \
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(AX[u], BX[u][nt], acc[nt], 0, 0, 0);
+  int64_t k0 = kbeg;
+  const int64_t nfull = (kend - kbeg) / (2 * UK);  // full blocks of 16 k rows
+  if (nfull > 0) {
+    float a0[UK], b0[UK][NT], a1[UK], b1[UK][NT];
+    PYGAT_TN_LOAD(a0, b0, k0)
+    for (int64_t i = 0; i < nfull; i += 2) {
+      // clamp the prefetch address to the last full block: loads stay unconditional
+      const int64_t kn1 = kbeg + ((i + 1 < nfull) ? i + 1 : nfull - 1) * 2 * UK;
+      PYGAT_TN_LOAD(a1, b1, kn1)
+      __builtin_amdgcn_sched_barrier(0);
+      PYGAT_TN_MMA(a0, b0)
+      __builtin_amdgcn_sched_barrier(0);
+      const int64_t kn2 = kbeg + ((i + 2 < nfull) ? i + 2 : nfull - 1) * 2 * UK;
+      PYGAT_TN_LOAD(a0, b0, kn2)
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 1 < nfull) PYGAT_TN_MMA(a1, b1)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    k0 = kbeg + nfull * 2 * UK;
+  }
+#undef PYGAT_TN_LOAD
+#undef PYGAT_TN_MMA
+  for (; k0 < kend; k0 += 2) {  // K tail of the last slab: rows past kend contribute a zero A operand
+    const int64_t k = k0 + fh;
+    const float keep = k < kend ? 1.f : 0.f;
+    const int64_t kk = k < kend ? k : kend - 1;
+    const float av = ap[kk * g.lda] * keep;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[nt][kk * g.ldb], acc[nt], 0, 0, 0);
+  }
+  float* base = g.ws + (int64_t)blockIdx.x * g.M * g.N;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = n0 + 32 * nt + fr;
+    if (col >= g.N) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = blockIdx.y * 128 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      if (row < g.M) base[(int64_t)row * g.N + col] = acc[nt][r];
+    }
+  }
+}
+
+// picks the slab count, launches; returns the number of slabs written to ws (>= 1), 0 if the shape
+// does not qualify, < 0 on error.  ws must hold max_splits * M * N floats.
+int try_gemm_tn_stream(int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                       int max_splits, float* ws, hipStream_t st) {
+  if (K < 4096 || (int64_t)M * N > 512 * 512 || max_splits < 1 || !ws) return 0;
+  const int nt_needed = (int)cdiv(N, 32);
+  const int NT = nt_needed < 4 ? nt_needed : 4;
+  const int tiles_m = (int)cdiv(M, 128), tiles_n = (int)cdiv(N, 32 * NT);
+  int splits = max_splits;
+  int64_t kps = cdiv(cdiv(K, splits), 16) * 16;
+  splits = (int)cdiv(K, kps);
+  TnArgs g;
+  g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.k_per_split = kps; g.ws = ws;
+  dim3 grid((unsigned)splits, (unsigned)tiles_m, (unsigned)tiles_n);
+  switch (NT) {
+    case 1: hipLaunchKernelGGL((gemm_tn_stream_kernel<1>), grid, dim3(256), 0, st, g); break;
+    case 2: hipLaunchKernelGGL((gemm_tn_stream_kernel<2>), grid, dim3(256), 0, st, g); break;
+    case 3: hipLaunchKernelGGL((gemm_tn_stream_kernel<3>), grid, dim3(256), 0, st, g); break;
+    default: hipLaunchKernelGGL((gemm_tn_stream_kernel<4>), grid, dim3(256), 0, st, g); break;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("gemm_tn_stream: %s", hipGetErrorString(e));
+    return PYGAT_EHIP;
+  }
+  return splits;
+}
+
+}  // namespace pygat

@@ -29,7 +29,7 @@ struct FwdArgs {
   int flags;
   const float* Wh;
   const float* s;
-  const float* t;
+  const float* a_pad;  // [H][2][Fp]; the a_dst halves give t_j = Wh_j . a_dst on the fly
   const float* sk;
   const float* mask;  // [nnz][H] attention dropout mask (pre-scaled) or nullptr
   float* out;
@@ -147,6 +147,13 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
   const int r_first = rc[e0].x;
   const bool head_partial = a.g.rowptr[r_first] < e0;
   int cur = r_first;
+  const int lph = a.rs.lph < 64 ? a.rs.lph : 64;
+  float4 adst[VEC];  // this lane's slice of a_dst (zero on padded / invalid chunks)
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    adst[v] = ld4(a.a_pad + (int64_t)lc.head[v] * 2 * a.rs.Fp + a.rs.Fp + (lc.cofs[v] & (a.rs.Fp - 1)));
+    if (!lc.valid[v]) adst[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   float m[VEC], z[VEC];
   float4 acc[VEC];
 #pragma unroll
@@ -164,9 +171,13 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
       for (int v = 0; v < VEC; ++v) {
         mk[u][v] = a.mask ? a.mask[((e + u < e1) ? e + u : e1 - 1) * H + lc.head[v]] : 1.f;
         sv[u][v] = a.s[(int64_t)p[u].x * H + lc.head[v]];
-        tv[u][v] = a.t[(int64_t)p[u].y * H + lc.head[v]];
         wv[u][v] = ld4(a.Wh + (int64_t)p[u].y * R + lc.cofs[v]);
       }
+    // t_j = Wh_j . a_dst per head, from the row just gathered (all lanes of the group are active here)
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) tv[u][v] = group_sum_rt(dot4(wv[u][v], adst[v]), lph);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (e + u < e1) {
@@ -287,20 +298,20 @@ extern "C" size_t pygat_partials_bytes(int64_t nnz, int slot_edges, int H, int F
 }
 
 extern "C" int pygat_gat_forward(const pygat_graph* g, int H, int Fo, float alpha, int flags, const float* Wh,
-                                 const float* s, const float* t, const float* sk, const float* att_mask,
+                                 const float* s, const float* a_pad, const float* sk, const float* att_mask,
                                  float* out, float* hattn, float* m, float* Z, void* part, void* stream) {
   FwdArgs a;
   int rc = check_graph(g, &a.g);
   if (rc) return rc;
   PYGAT_REQUIRE(make_row_shape(H, Fo, &a.rs), "gat_forward: unsupported H=%d F'=%d (need H*pad(F') <= 1024, F' <= 256)", H, Fo);
-  PYGAT_REQUIRE(Wh && s && t && part, "gat_forward: null Wh/s/t/part");
+  PYGAT_REQUIRE(Wh && s && a_pad && part, "gat_forward: null Wh/s/a_pad/part");
   PYGAT_REQUIRE(out || hattn, "gat_forward: need out and/or hattn");
   PYGAT_REQUIRE(!(flags & PYGAT_F_SKIP) || sk, "gat_forward: PYGAT_F_SKIP without sk");
   PYGAT_REQUIRE((m == nullptr) == (Z == nullptr), "gat_forward: m and Z must be given together");
-  PYGAT_REQUIRE(aligned16(Wh) && aligned16(part) && (!sk || aligned16(sk)) && (!hattn || aligned16(hattn)) &&
+  PYGAT_REQUIRE(aligned16(Wh) && aligned16(part) && aligned16(a_pad) && (!sk || aligned16(sk)) && (!hattn || aligned16(hattn)) &&
                     (!out || a.rs.Fo != a.rs.Fp || aligned16(out)),
                 "gat_forward: row tables must be 16-byte aligned");
-  a.alpha = alpha; a.flags = flags; a.Wh = Wh; a.s = s; a.t = t; a.sk = sk; a.mask = att_mask;
+  a.alpha = alpha; a.flags = flags; a.Wh = Wh; a.s = s; a.a_pad = a_pad; a.sk = sk; a.mask = att_mask;
   a.out = out; a.hattn = hattn; a.m = m; a.Z = Z; a.part = (float*)part;
   int lpr, vec;
   pick_lanes(a.rs, &lpr, &vec);

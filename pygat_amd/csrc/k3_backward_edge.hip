@@ -94,22 +94,73 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_kernel(PrepArgs a) {
   }
 }
 
+// Fast variant for the common layout (concat mode, F' == Fp, one chunk per lane): RB rows per
+// lane group with all loads issued up front (the kernel is a pure stream: 2 reads + 1 write).
+template <int LPR>
+__global__ __launch_bounds__(256) void gat_bwd_prepare_fast_kernel(PrepArgs a) {
+  constexpr int EPW = 64 / LPR;
+  constexpr int RB = 4;
+  const int lane = threadIdx.x & 63;
+  const int64_t i0 = (((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * EPW + lane / LPR) * RB;
+  if (i0 >= a.n) return;
+  const LaneCols<1> lc = lane_cols<LPR, 1>(a.rs);
+  const int H = a.rs.H, R = a.rs.R;
+  const int lph = a.rs.lph < 64 ? a.rs.lph : 64;
+  const int co = lc.cofs[0], h = lc.head[0];
+  const bool valid = lc.valid[0];
+  const bool lead = valid && (((co >> 2) & (a.rs.lph - 1)) == 0);
+  float4 g4[RB], y4[RB], k4[RB];
+  float sv[RB], mv[RB], zv[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int64_t i = (i0 + r < a.n) ? i0 + r : a.n - 1;
+    g4[r] = ld4(a.G + i * R + co);
+    y4[r] = ld4(a.y + i * R + co);
+    k4[r] = (a.flags & PYGAT_F_SKIP) ? ld4(a.sk + i * R + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    sv[r] = a.s[i * H + h]; mv[r] = a.m[i * H + h]; zv[r] = a.Z[i * H + h];
+  }
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int64_t i = i0 + r;
+    float gq[4] = {g4[r].x, g4[r].y, g4[r].z, g4[r].w};
+    float pq[4] = {y4[r].x, y4[r].y, y4[r].z, y4[r].w};
+    if (a.flags & PYGAT_F_ELU) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float o = pq[q];
+        const float d = o > 0.f ? 1.f : o + 1.f;
+        pq[q] = o > 0.f ? o : (d > 0.f ? log1pf(o) : 0.f);
+        gq[q] *= d;
+      }
+    }
+    float4 g = valid ? make_float4(gq[0], gq[1], gq[2], gq[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 hat = make_float4(pq[0] - k4[r].x, pq[1] - k4[r].y, pq[2] - k4[r].z, pq[3] - k4[r].w);
+    const float D = group_sum_rt(dot4(g, hat), lph);
+    if (i < a.n) {
+      if (valid) st4(a.Gp + i * R + co, g);
+      if (lead) st4(a.rowtab + (i * H + h) * 4, make_float4(sv[r], mv[r], 1.0f / zv[r], D));
+    }
+  }
+}
+
 struct EdgeArgs {
   GraphDev g;
   RowShape rs;
   float alpha;
   const float* Wh;
-  const float* t;
+  const float* a_pad;  // t_j = Wh_j . a_dst is recomputed from the gathered row
   const float* Gp;
   const float* rowtab;
   const float* mask;  // [nnz][H] attention dropout mask or nullptr
-  float* ebuf;
+  const int32_t* perm;  // nullptr, or the position of each forward edge in the transposed pattern
+  float* ebuf;          // [nnz][2][H], forward order (perm == nullptr) or transposed order
+  float* dzf;           // [nnz][H] in forward edge order
 };
 
 template <int LPR, int VEC>
 __global__ __launch_bounds__(256) void gat_bwd_edge_kernel(EdgeArgs a) {
   constexpr int EPW = 64 / LPR;
-  constexpr int U = 2;
+  constexpr int U = (VEC == 1) ? 4 : 2;
   const int lane = threadIdx.x & 63;
   const int64_t k = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * EPW + lane / LPR;
   const int64_t e0 = k * a.g.ts;
@@ -120,21 +171,29 @@ __global__ __launch_bounds__(256) void gat_bwd_edge_kernel(EdgeArgs a) {
   const int lph = a.rs.lph < 64 ? a.rs.lph : 64;
   const int2* __restrict__ rc = a.g.rc;
   bool lead[VEC];
+  float4 adst[VEC];
 #pragma unroll
-  for (int v = 0; v < VEC; ++v) lead[v] = lc.valid[v] && (((lc.cofs[v] >> 2) & (a.rs.lph - 1)) == 0);
+  for (int v = 0; v < VEC; ++v) {
+    lead[v] = lc.valid[v] && (((lc.cofs[v] >> 2) & (a.rs.lph - 1)) == 0);
+    adst[v] = ld4(a.a_pad + (int64_t)lc.head[v] * 2 * a.rs.Fp + a.rs.Fp + (lc.cofs[v] & (a.rs.Fp - 1)));
+    if (!lc.valid[v]) adst[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 
   for (int64_t e = e0; e < e1; e += U) {  // same trip count for every lane of the group
     int2 p[U];
+    int pe[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) p[u] = rc[(e + u < e1) ? e + u : e1 - 1];
-    float tv[U][VEC];
+    for (int u = 0; u < U; ++u) {
+      const int64_t ee = (e + u < e1) ? e + u : e1 - 1;
+      p[u] = rc[ee];
+      pe[u] = a.perm ? a.perm[ee] : (int)ee;
+    }
     float4 rt[U][VEC], wv[U][VEC], gv[U][VEC];
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         rt[u][v] = ld4(a.rowtab + ((int64_t)p[u].x * H + lc.head[v]) * 4);
-        tv[u][v] = a.t[(int64_t)p[u].y * H + lc.head[v]];
         wv[u][v] = ld4(a.Wh + (int64_t)p[u].y * R + lc.cofs[v]);
         gv[u][v] = ld4(a.Gp + (int64_t)p[u].x * R + lc.cofs[v]);
       }
@@ -144,7 +203,8 @@ __global__ __launch_bounds__(256) void gat_bwd_edge_kernel(EdgeArgs a) {
       for (int v = 0; v < VEC; ++v) {
         const float part = lc.valid[v] ? dot4(gv[u][v], wv[u][v]) : 0.f;
         const float dp = group_sum_rt(part, lph);
-        const float zz = rt[u][v].x + tv[u][v];
+        const float tj = group_sum_rt(dot4(wv[u][v], adst[v]), lph);
+        const float zz = rt[u][v].x + tj;
         const float ev = zz > 0.f ? zz : a.alpha * zz;
         const float al = __expf(ev - rt[u][v].y) * rt[u][v].z;
         if (lead[v] && e + u < e1) {
@@ -152,9 +212,10 @@ __global__ __launch_bounds__(256) void gat_bwd_edge_kernel(EdgeArgs a) {
           // needs the masked weight; the softmax Jacobian keeps the un-masked alpha
           const float mk = a.mask ? a.mask[(e + u) * H + lc.head[v]] : 1.f;
           const float dz = al * (mk * dp - rt[u][v].w) * (zz > 0.f ? 1.f : a.alpha);
-          float* eb = a.ebuf + (e + u) * 2 * H + lc.head[v];
+          float* eb = a.ebuf + (int64_t)pe[u] * 2 * H + lc.head[v];
           eb[0] = al * mk;
           eb[H] = dz;
+          if (a.perm) a.dzf[(e + u) * H + lc.head[v]] = dz;  // forward-order copy only when ebuf is scattered
         }
       }
   }
@@ -162,12 +223,12 @@ __global__ __launch_bounds__(256) void gat_bwd_edge_kernel(EdgeArgs a) {
 
 // fallback for structurally asymmetric patterns: ds_i = sum over row i of dz (one thread per (row, head))
 __global__ __launch_bounds__(256) void row_sum_dz_kernel(int n, int H, const int32_t* __restrict__ rowptr,
-                                                         const float* __restrict__ ebuf, float* __restrict__ ds) {
+                                                         const float* __restrict__ dzf, float* __restrict__ ds) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (int64_t)n * H) return;
   const int i = (int)(idx / H), h = (int)(idx % H);
   float acc = 0.f;
-  for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) acc += ebuf[k * 2 * H + H + h];
+  for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) acc += dzf[k * H + h];
   ds[idx] = acc;
 }
 
@@ -190,6 +251,21 @@ extern "C" int pygat_gat_backward_prepare(int n, int H, int Fo, int flags, int m
   a.Gp = Gp; a.rowtab = rowtab;
   int lpr, vec;
   pick_lanes(a.rs, &lpr, &vec);
+  if (!mean_mode && a.rs.Fo == a.rs.Fp && vec == 1) {
+    const unsigned fb = (unsigned)cdiv(cdiv(cdiv(n, 4), 64 / lpr), 4);
+    hipStream_t st = (hipStream_t)stream;
+    switch (lpr) {
+      case 1: hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<1>), dim3(fb), dim3(256), 0, st, a); break;
+      case 2: hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<2>), dim3(fb), dim3(256), 0, st, a); break;
+      case 4: hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<4>), dim3(fb), dim3(256), 0, st, a); break;
+      case 8: hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<8>), dim3(fb), dim3(256), 0, st, a); break;
+      case 16: hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<16>), dim3(fb), dim3(256), 0, st, a); break;
+      case 32: hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<32>), dim3(fb), dim3(256), 0, st, a); break;
+      default: hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<64>), dim3(fb), dim3(256), 0, st, a); break;
+    }
+    PYGAT_CHECK_LAUNCH("gat_backward_prepare");
+    return PYGAT_OK;
+  }
   const unsigned blocks = (unsigned)cdiv(cdiv(n, 64 / lpr), 4);
   PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_bwd_prepare_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0,
                                                     (hipStream_t)stream, a));
@@ -198,15 +274,16 @@ extern "C" int pygat_gat_backward_prepare(int n, int H, int Fo, int flags, int m
 }
 
 extern "C" int pygat_gat_backward_edge(const pygat_graph* g, int H, int Fo, float alpha, const float* Wh,
-                                       const float* t, const float* Gp, const float* rowtab,
-                                       const float* att_mask, float* ebuf, void* stream) {
+                                       const float* a_pad, const float* Gp, const float* rowtab,
+                                       const float* att_mask, const int32_t* perm_f, float* ebuf, float* dz_f,
+                                       void* stream) {
   EdgeArgs a;
   int rc = check_graph(g, &a.g);
   if (rc) return rc;
   PYGAT_REQUIRE(make_row_shape(H, Fo, &a.rs), "gat_backward_edge: unsupported H=%d F'=%d", H, Fo);
-  PYGAT_REQUIRE(Wh && t && Gp && rowtab && ebuf, "gat_backward_edge: null pointer");
-  PYGAT_REQUIRE(aligned16(Wh) && aligned16(Gp) && aligned16(rowtab), "gat_backward_edge: row tables must be 16-byte aligned");
-  a.alpha = alpha; a.Wh = Wh; a.t = t; a.Gp = Gp; a.rowtab = rowtab; a.mask = att_mask; a.ebuf = ebuf;
+  PYGAT_REQUIRE(Wh && a_pad && Gp && rowtab && ebuf && (dz_f || !perm_f), "gat_backward_edge: null pointer");
+  PYGAT_REQUIRE(aligned16(Wh) && aligned16(Gp) && aligned16(rowtab) && aligned16(a_pad), "gat_backward_edge: row tables must be 16-byte aligned");
+  a.alpha = alpha; a.Wh = Wh; a.a_pad = a_pad; a.Gp = Gp; a.rowtab = rowtab; a.mask = att_mask; a.perm = perm_f; a.ebuf = ebuf; a.dzf = dz_f;
   int lpr, vec;
   pick_lanes(a.rs, &lpr, &vec);
   const unsigned blocks = (unsigned)cdiv(cdiv(num_slots(a.g), 64 / lpr), 4);
@@ -216,13 +293,13 @@ extern "C" int pygat_gat_backward_edge(const pygat_graph* g, int H, int Fo, floa
   return PYGAT_OK;
 }
 
-extern "C" int pygat_row_sum_dz(const pygat_graph* g, int H, const float* ebuf, float* ds, void* stream) {
+extern "C" int pygat_row_sum_dz(const pygat_graph* g, int H, const float* dz_f, float* ds, void* stream) {
   GraphDev d;
   int rc = check_graph(g, &d);
   if (rc) return rc;
-  PYGAT_REQUIRE(H > 0 && ebuf && ds, "row_sum_dz: bad arguments");
+  PYGAT_REQUIRE(H > 0 && dz_f && ds, "row_sum_dz: bad arguments");
   hipLaunchKernelGGL(row_sum_dz_kernel, dim3((unsigned)cdiv((int64_t)d.n * H, 256)), dim3(256), 0, (hipStream_t)stream,
-                     d.n, H, d.rowptr, ebuf, ds);
+                     d.n, H, d.rowptr, dz_f, ds);
   PYGAT_CHECK_LAUNCH("row_sum_dz");
   return PYGAT_OK;
 }

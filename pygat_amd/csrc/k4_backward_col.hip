@@ -7,10 +7,10 @@
 //     dt_j  = sum_i dz_ij          (column sums of dz)
 //     ds_j  = sum_k dz_jk          (row sums of dz)
 // nnz split over the TRANSPOSED pattern: slot walks transposed edges (j <- i), gathers Gp_i (one
-// head-interleaved row, 16 B per lane) and the (alpha, dz) pair of the forward edge perm_t[k].
-// For a symmetric pattern the transposed CSR has the forward layout, so position k is also the
-// forward edge (j, col[k]) and ds_j is accumulated from ebuf[k] on the way -- no atomics, no
-// second pass.  Rows cut by a slot border go through `part` + a fix-up launch (fixed order).
+// head-interleaved row, 16 B per lane); the (alpha, dz) pairs are either gathered through perm_t
+// (wide rows) or were scattered by K3b into this order and stream in sequentially (narrow rows).  For a symmetric pattern the transposed CSR has the
+// forward layout, so position k is also the forward edge (j, col[k]) and ds_j is accumulated from
+// dz_f[k] on the way -- no atomics, no second pass.  Rows cut by a slot border go through `part` + a fix-up launch (fixed order).
 #include "attn_common.h"
 
 namespace pygat {
@@ -18,10 +18,11 @@ namespace pygat {
 struct ColArgs {
   GraphDev g;  // transposed pattern
   RowShape rs;
-  const int32_t* perm;
+  const int32_t* perm;  // nullptr: ebuf is in this (transposed) order; else forward edge of each edge here
   int symmetric;
   const float* Gp;
-  const float* ebuf;
+  const float* ebuf;  // [nnz][2][H] (alpha, dz)
+  const float* dzf;   // [nnz][H] dz in forward edge order (== this order's positions if symmetric)
   const float* a_pad;
   float* dWh;
   float* ds;
@@ -96,12 +97,12 @@ __global__ __launch_bounds__(256) void gat_bwd_col_kernel(ColArgs a) {
 
   for (int64_t e = e0; e < e1; e += U) {
     int2 p[U];
-    int pe[U];
+    int64_t pe[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t ee = (e + u < e1) ? e + u : e1 - 1;
       p[u] = rc[ee];
-      pe[u] = a.perm[ee];
+      pe[u] = a.perm ? (int64_t)a.perm[ee] : ee;
     }
     float al[U][VEC], dz[U][VEC], dzo[U][VEC];
     float4 gv[U][VEC];
@@ -109,11 +110,12 @@ __global__ __launch_bounds__(256) void gat_bwd_col_kernel(ColArgs a) {
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
-        const float* eb = a.ebuf + (int64_t)pe[u] * 2 * H + lc.head[v];
+        const int64_t ee = (e + u < e1) ? e + u : e1 - 1;
+        const float* eb = a.ebuf + pe[u] * 2 * H + lc.head[v];
         al[u][v] = eb[0];
         dz[u][v] = eb[H];
-        const int64_t ee = (e + u < e1) ? e + u : e1 - 1;
-        dzo[u][v] = a.symmetric ? a.ebuf[ee * 2 * H + H + lc.head[v]] : 0.f;
+        // ds_j: dz of the forward edge at this same position (symmetric patterns only)
+        dzo[u][v] = !a.symmetric ? 0.f : (a.perm ? a.ebuf[ee * 2 * H + H + lc.head[v]] : a.dzf[ee * H + lc.head[v]]);
         gv[u][v] = ld4(a.Gp + (int64_t)p[u].y * R + lc.cofs[v]);
       }
 #pragma unroll
@@ -184,16 +186,16 @@ __global__ __launch_bounds__(256) void gat_bwd_col_fixup_kernel(ColArgs a) {
 using namespace pygat;
 
 extern "C" int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm_t, int symmetric, int H, int Fo,
-                                      const float* Gp, const float* ebuf, const float* a_pad, float* dWh,
+                                      const float* Gp, const float* ebuf, const float* dz_f, const float* a_pad, float* dWh,
                                       float* ds, float* dt, void* part, void* stream) {
   ColArgs a;
   int rc = check_graph(gT, &a.g);
   if (rc) return rc;
   PYGAT_REQUIRE(make_row_shape(H, Fo, &a.rs), "gat_backward_col: unsupported H=%d F'=%d", H, Fo);
-  PYGAT_REQUIRE(perm_t && Gp && ebuf && ds && a_pad && dWh && dt && part, "gat_backward_col: null pointer");
+  PYGAT_REQUIRE(Gp && ebuf && (dz_f || perm_t || !symmetric) && ds && a_pad && dWh && dt && part, "gat_backward_col: null pointer");
   PYGAT_REQUIRE(aligned16(Gp) && aligned16(dWh) && aligned16(a_pad) && aligned16(part),
                 "gat_backward_col: row tables must be 16-byte aligned");
-  a.perm = perm_t; a.symmetric = symmetric; a.Gp = Gp; a.ebuf = ebuf; a.a_pad = a_pad; a.dWh = dWh; a.ds = ds;
+  a.perm = perm_t; a.symmetric = symmetric; a.Gp = Gp; a.ebuf = ebuf; a.dzf = dz_f; a.a_pad = a_pad; a.dWh = dWh; a.ds = ds;
   a.dt = dt; a.part = (float*)part;
   int lpr, vec;
   pick_lanes(a.rs, &lpr, &vec);

@@ -25,7 +25,7 @@ import torch
 
 from . import _lib
 from ._lib import lib, check, padded_width
-from .graph import CSRGraph
+from .graph import CSRGraph, slot_edges_for
 from .ops import _Level, _ptr, _span, _stream, gemm
 
 
@@ -51,6 +51,8 @@ class GATLevelDropoutFn(torch.autograd.Function):
         if skip:
             Wskip = Wskip.contiguous().float()
         L = _Level(x, H, Fo, skip)
+        L.ts = graph.slot_edges
+        L.ts_edge = slot_edges_for(L.R, graph.slot_edges)
         dev, f32 = x.device, torch.float32
         mask_x = mask_x.to(f32).contiguous(); mask_att = mask_att.to(f32).contiguous()
         # Wh mask in the padded head-interleaved layout [N, H, Fp]
@@ -78,10 +80,10 @@ class GATLevelDropoutFn(torch.autograd.Function):
             hattn = torch.empty(L.N, L.R, dtype=f32, device=dev) if not concat else None
             m = torch.empty(L.N, H, dtype=f32, device=dev); Z = torch.empty(L.N, H, dtype=f32, device=dev)
             out = torch.empty(L.N, H * Fo if concat else Fo, dtype=f32, device=dev)
-            part = torch.empty(lib.pygat_partials_bytes(graph.nnz, graph.slot_edges, H, L.Fp) // 4, dtype=f32, device=dev)
+            part = torch.empty(lib.pygat_partials_bytes(graph.nnz, L.ts, H, L.Fp) // 4, dtype=f32, device=dev)
             with _span("k2_forward"):
-                check(lib.pygat_gat_forward(graph.fwd.ref(), H, Fo, float(alpha), flags, Wh.data_ptr(), s.data_ptr(),
-                                            t.data_ptr(), _ptr(Sk), mask_att.data_ptr(),
+                check(lib.pygat_gat_forward(graph.fwd.ref(L.ts), H, Fo, float(alpha), flags, Wh.data_ptr(), s.data_ptr(),
+                                            a_pad.data_ptr(), _ptr(Sk), mask_att.data_ptr(),
                                             out.data_ptr() if concat else None, _ptr(hattn), m.data_ptr(), Z.data_ptr(),
                                             part.data_ptr(), st), "gat_forward")
             if not concat:
@@ -101,19 +103,23 @@ class GATLevelDropoutFn(torch.autograd.Function):
             Gp = torch.empty(L.N, L.R, dtype=f32, device=dev)
             rowtab = torch.empty(L.N, H, 4, dtype=f32, device=dev)
             ebuf = torch.empty(graph.nnz, 2, H, dtype=f32, device=dev)
+            scatter = L.scatter or not graph.symmetric   # asymmetric patterns need dz in forward order for ds
+            dzf = torch.empty(graph.nnz, H, dtype=f32, device=dev) if scatter else None
             ds = torch.empty(L.N, H, dtype=f32, device=dev); dt = torch.empty(L.N, H, dtype=f32, device=dev)
             dWh = torch.empty(L.N, L.R, dtype=f32, device=dev)
-            part = torch.empty(lib.pygat_partials_bytes(graph.nnz, graph.slot_edges, H, L.Fp) // 4, dtype=f32, device=dev)
+            part = torch.empty(lib.pygat_partials_bytes(graph.nnz, L.ts, H, L.Fp) // 4, dtype=f32, device=dev)
             check(lib.pygat_gat_backward_prepare(L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(), y.data_ptr(),
                                                  _ptr(Sk), s.data_ptr(), m.data_ptr(), Z.data_ptr(), Gp.data_ptr(),
                                                  rowtab.data_ptr(), st), "gat_backward_prepare")
-            check(lib.pygat_gat_backward_edge(graph.fwd.ref(), H, Fo, ctx.alpha, Wh.data_ptr(), t.data_ptr(), Gp.data_ptr(),
-                                              rowtab.data_ptr(), mask_att.data_ptr(), ebuf.data_ptr(), st),
+            check(lib.pygat_gat_backward_edge(graph.fwd.ref(L.ts_edge), H, Fo, ctx.alpha, Wh.data_ptr(), a_pad.data_ptr(),
+                                              Gp.data_ptr(), rowtab.data_ptr(), mask_att.data_ptr(),
+                                              graph.perm_f.data_ptr() if scatter else None, ebuf.data_ptr(), _ptr(dzf), st),
                   "gat_backward_edge")
             if not graph.symmetric:
-                check(lib.pygat_row_sum_dz(graph.fwd.ref(), H, ebuf.data_ptr(), ds.data_ptr(), st), "row_sum_dz")
-            check(lib.pygat_gat_backward_col(graph.bwd.ref(), graph.perm_t.data_ptr(), int(graph.symmetric), H, Fo,
-                                             Gp.data_ptr(), ebuf.data_ptr(), a_pad.data_ptr(), dWh.data_ptr(),
+                check(lib.pygat_row_sum_dz(graph.fwd.ref(L.ts), H, dzf.data_ptr(), ds.data_ptr(), st), "row_sum_dz")
+            check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), None if scatter else graph.perm_t.data_ptr(),
+                                                 int(graph.symmetric), H, Fo,
+                                             Gp.data_ptr(), ebuf.data_ptr(), _ptr(dzf), a_pad.data_ptr(), dWh.data_ptr(),
                                              ds.data_ptr(), dt.data_ptr(), part.data_ptr(), st), "gat_backward_col")
             da = torch.empty(H, 2 * Fo, dtype=f32, device=dev)
             ws = torch.empty(lib.pygat_agrad_workspace_bytes(H, Fo) // 4, dtype=f32, device=dev)

@@ -28,6 +28,19 @@ from ._lib import lib, check
 DEFAULT_SLOT_EDGES = 64   # edges per work slot of the nnz-split kernels (multiple of 4)
 
 
+def slot_edges_for(row_floats: int, base: int = DEFAULT_SLOT_EDGES) -> int:
+    """Slot length for a head-interleaved row of `row_floats` floats.  A wave carries 64/LPR slots
+    (LPR = lanes per row), so narrow rows (few heads per GPU) would put 1000+ edges on one wave and
+    leave the chip with ~1 wave per SIMD; keep a wave at <= 256 edges."""
+    nch = max(1, row_floats // 4)
+    lpr = 1
+    while lpr < nch and lpr < 64:
+        lpr <<= 1
+    epw = 64 // lpr
+    ts = min(base, max(8, 256 // epw))
+    return (ts // 4) * 4
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -48,9 +61,18 @@ class _Pattern:
             check(lib.pygat_edge_pairs(self.n, rowptr.data_ptr(), col.data_ptr(), self.edge_rc.data_ptr(), _stream()),
                   "edge_pairs")
         self.struct = _lib.Graph(self.n, self.nnz, _ptr(rowptr), _ptr(self.edge_rc), slot_edges)
+        self._alt = {}
 
-    def ref(self):
-        return C.byref(self.struct)
+    def ref(self, slot_edges: Optional[int] = None):
+        """pygat_graph* for a call; `slot_edges` overrides the slot length for this call only
+        (the edge arrays do not depend on it)."""
+        if slot_edges is None or slot_edges == self.slot_edges:
+            return C.byref(self.struct)
+        st = self._alt.get(slot_edges)
+        if st is None:
+            st = _lib.Graph(self.n, self.nnz, _ptr(self.rowptr), _ptr(self.edge_rc), slot_edges)
+            self._alt[slot_edges] = st
+        return C.byref(st)
 
 
 class CSRGraph:
@@ -86,7 +108,8 @@ class CSRGraph:
             raise ValueError("CSRGraph: some node has no neighbour (add self loops as utils.py:52 does)")
         self.symmetric = not asym
         if self.symmetric:
-            self.bwd, self.perm_t = self.fwd, perm
+            # the mirror permutation is an involution: it maps forward positions to transposed ones and back
+            self.bwd, self.perm_t, self.perm_f = self.fwd, perm, perm
         else:
             self._build_transpose()
 
@@ -100,7 +123,10 @@ class CSRGraph:
         rp_t = torch.zeros(self.n + 1, dtype=torch.int64, device=self.device)
         rp_t[1:] = torch.cumsum(cnt, 0)
         self.bwd = _Pattern(rp_t.to(torch.int32), src[order].to(torch.int32).contiguous(), self.slot_edges)
-        self.perm_t = order.to(torch.int32).contiguous()
+        self.perm_t = order.to(torch.int32).contiguous()          # transposed position -> forward edge
+        inv = torch.empty_like(order)
+        inv[order] = torch.arange(order.numel(), device=self.device)
+        self.perm_f = inv.to(torch.int32).contiguous()            # forward edge -> transposed position
 
     # ------------------------------------------------------------------ builders
     @staticmethod

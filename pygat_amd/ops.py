@@ -22,7 +22,7 @@ import torch
 
 from . import _lib
 from ._lib import lib, check, padded_width
-from .graph import CSRGraph
+from .graph import CSRGraph, slot_edges_for
 
 
 def _stream() -> int:
@@ -107,6 +107,10 @@ class _Level:
         if self.R > 1024:
             raise ValueError(f"pygat_amd: H*pad(F') = {self.R} > 1024 per call; shard the heads")
         self.ldw = -(-(self.R * (2 if skip else 1) + 2 * H) // 4) * 4
+        self.ts = 0        # slot length of K2 / K4 (rows cut by a slot border cost a partial record)
+        self.ts_edge = 0   # slot length of K3b (no reduction, no partials: shorter slots for narrow rows)
+        # (alpha, dz) hand-off K3b -> K4: scatter into transposed order for narrow rows, gather for wide ones
+        self.scatter = self.R <= 32
 
 
 class GATLevelFn(torch.autograd.Function):
@@ -127,6 +131,8 @@ class GATLevelFn(torch.autograd.Function):
         if skip:
             Wskip = Wskip.contiguous().float()
         L = _Level(x, H, Fo, skip)
+        L.ts = graph.slot_edges
+        L.ts_edge = slot_edges_for(L.R, graph.slot_edges)
         dev, f32 = x.device, torch.float32
         need_grad = any(ctx.needs_input_grad[:4])
         with torch.cuda.device(dev):
@@ -150,11 +156,11 @@ class GATLevelFn(torch.autograd.Function):
             m = torch.empty(L.N, H, dtype=f32, device=dev) if need_grad else None
             Z = torch.empty(L.N, H, dtype=f32, device=dev) if need_grad else None
             out = torch.empty(L.N, H * Fo if concat else Fo, dtype=f32, device=dev)
-            part = torch.empty(lib.pygat_partials_bytes(graph.nnz, graph.slot_edges, H, L.Fp) // 4, dtype=f32,
+            part = torch.empty(lib.pygat_partials_bytes(graph.nnz, L.ts, H, L.Fp) // 4, dtype=f32,
                                device=dev)
             with _span("k2_forward"):
-                check(lib.pygat_gat_forward(graph.fwd.ref(), H, Fo, float(alpha), flags, Wh.data_ptr(), s.data_ptr(),
-                                            t.data_ptr(), _ptr(Sk), None, out.data_ptr() if concat else None, _ptr(hattn),
+                check(lib.pygat_gat_forward(graph.fwd.ref(L.ts), H, Fo, float(alpha), flags, Wh.data_ptr(), s.data_ptr(),
+                                            a_pad.data_ptr(), _ptr(Sk), None, out.data_ptr() if concat else None, _ptr(hattn),
                                             _ptr(m), _ptr(Z), part.data_ptr(), st), "gat_forward")
             if not concat:
                 check(lib.pygat_head_mean(L.N, H, Fo, hattn.data_ptr(), _ptr(Sk), out.data_ptr(), st), "head_mean")
@@ -175,24 +181,28 @@ class GATLevelFn(torch.autograd.Function):
             Gp = torch.empty(L.N, L.R, dtype=f32, device=dev)
             rowtab = torch.empty(L.N, H, 4, dtype=f32, device=dev)
             ebuf = torch.empty(graph.nnz, 2, H, dtype=f32, device=dev)
+            scatter = L.scatter or not graph.symmetric   # asymmetric patterns need dz in forward order for ds
+            dzf = torch.empty(graph.nnz, H, dtype=f32, device=dev) if scatter else None
             ds = torch.empty(L.N, H, dtype=f32, device=dev)
             dt = torch.empty(L.N, H, dtype=f32, device=dev)
             dWh = torch.empty(L.N, L.R, dtype=f32, device=dev)
-            part = torch.empty(lib.pygat_partials_bytes(graph.nnz, graph.slot_edges, H, L.Fp) // 4, dtype=f32,
+            part = torch.empty(lib.pygat_partials_bytes(graph.nnz, L.ts, H, L.Fp) // 4, dtype=f32,
                                device=dev)
             with _span("k3a_prepare"):
                 check(lib.pygat_gat_backward_prepare(L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(),
                                                      y.data_ptr(), _ptr(Sk), s.data_ptr(), m.data_ptr(), Z.data_ptr(),
                                                      Gp.data_ptr(), rowtab.data_ptr(), st), "gat_backward_prepare")
             with _span("k3b_edge"):
-                check(lib.pygat_gat_backward_edge(graph.fwd.ref(), H, Fo, ctx.alpha, Wh.data_ptr(), t.data_ptr(),
-                                                  Gp.data_ptr(), rowtab.data_ptr(), None, ebuf.data_ptr(), st),
+                check(lib.pygat_gat_backward_edge(graph.fwd.ref(L.ts_edge), H, Fo, ctx.alpha, Wh.data_ptr(),
+                                                  a_pad.data_ptr(), Gp.data_ptr(), rowtab.data_ptr(), None,
+                                                  graph.perm_f.data_ptr() if scatter else None, ebuf.data_ptr(), _ptr(dzf), st),
                       "gat_backward_edge")
             if not graph.symmetric:
-                check(lib.pygat_row_sum_dz(graph.fwd.ref(), H, ebuf.data_ptr(), ds.data_ptr(), st), "row_sum_dz")
+                check(lib.pygat_row_sum_dz(graph.fwd.ref(L.ts), H, dzf.data_ptr(), ds.data_ptr(), st), "row_sum_dz")
             with _span("k4_backward_col"):
-                check(lib.pygat_gat_backward_col(graph.bwd.ref(), graph.perm_t.data_ptr(), int(graph.symmetric), H, Fo,
-                                                 Gp.data_ptr(), ebuf.data_ptr(), a_pad.data_ptr(), dWh.data_ptr(),
+                check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), None if scatter else graph.perm_t.data_ptr(),
+                                                 int(graph.symmetric), H, Fo,
+                                                 Gp.data_ptr(), ebuf.data_ptr(), _ptr(dzf), a_pad.data_ptr(), dWh.data_ptr(),
                                                  ds.data_ptr(), dt.data_ptr(), part.data_ptr(), st),
                       "gat_backward_col")
             # da

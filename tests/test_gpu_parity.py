@@ -70,6 +70,7 @@ def test_dense_to_csr_and_perm(pg):
     # mirror permutation: edge k=(i,j) -> position of (j,i)
     src = np.repeat(np.arange(N), np.diff(rowptr))
     perm = g.perm_t.cpu().numpy()
+    assert g.perm_f is g.perm_t                                   # involution for symmetric patterns
     assert np.array_equal(src[perm], col) and np.array_equal(col[perm], src)
     # "adj > 0" (dense layer) ignores negative entries, "adj != 0" (sparse layer) keeps them
     adj2 = adj.clone(); adj2[0, 1] = adj2[1, 0] = -1.0
@@ -96,8 +97,9 @@ def test_empty_row_rejected(pg):
         pg.CSRGraph(rowptr, col)
 
 
-def test_asymmetric_pattern_transpose(pg):
-    N, Fin, Fo, H = 64, 8, 8, 2
+@pytest.mark.parametrize("H,Fo", [(2, 8), (8, 16)])   # narrow rows: K3b scatters; wide rows: K4 gathers
+def test_asymmetric_pattern_transpose(pg, H, Fo):
+    N, Fin = 64, 8
     rng = np.random.default_rng(0)
     dense = (rng.random((N, N)) < 0.08) | np.eye(N, dtype=bool)
     rowptr = np.concatenate([[0], np.cumsum(dense.sum(1))]).astype(np.int32)
@@ -116,6 +118,10 @@ def test_asymmetric_pattern_transpose(pg):
     (False, False, 300, 80, 1433), (False, False, 1000, 144, 128), (False, False, 257, 272, 50),
     (True, False, 128, 128, 5000), (True, False, 1433, 64, 2708), (False, True, 999, 50, 1024),
     (False, True, 2708, 1433, 64), (False, False, 5, 3, 7),
+    # fast paths: small-K register-streamed A (M >= 8192, K % 32 == 0), weight-gradient stream (huge K)
+    (False, False, 10007, 144, 128), (False, True, 9000, 128, 128), (False, False, 8200, 40, 96),
+    (False, False, 8193, 300, 256), (False, True, 8192, 50, 64), (True, False, 128, 128, 20011),
+    (True, False, 200, 80, 5000), (True, False, 50, 1024, 4500),
 ])
 def test_gemm(pg, tA, tB, M, N, K):
     gen = torch.Generator().manual_seed(M * 7 + N)

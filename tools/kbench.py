@@ -53,13 +53,14 @@ def main():
     out = torch.empty(N, H * Fo, device=dev); hattn = torch.empty(N, R, device=dev)
     m = torch.empty(N, H, device=dev); Z = torch.empty(N, H, device=dev)
     Gp = torch.empty(N, R, device=dev); ebuf = torch.empty(E, 2, H, device=dev)
-    rowtab = torch.empty(N, H, 4, device=dev)
+    rowtab = torch.empty(N, H, 4, device=dev); dzf = torch.empty(E, H, device=dev)
     ds = torch.empty(N, H, device=dev); dt = torch.empty(N, H, device=dev); dWh = torch.empty(N, R, device=dev)
     part = torch.empty(max(1, lib.pygat_partials_bytes(E, args.ts, H, Fp) // 4), device=dev)
     P = lambda x: None if x is None else x.data_ptr()
+    scatter = R <= 32 or not graph.symmetric
 
     def k2(train=True):
-        check(lib.pygat_gat_forward(graph.fwd.ref(), H, Fo, 0.2, _lib.F_ELU, P(Wh), P(s), P(t), None, None, P(out),
+        check(lib.pygat_gat_forward(graph.fwd.ref(), H, Fo, 0.2, _lib.F_ELU, P(Wh), P(s), P(a_pad), None, None, P(out),
                                     None, P(m) if train else None, P(Z) if train else None, P(part), None))
 
     def k3a():
@@ -67,10 +68,12 @@ def main():
                                              P(rowtab), None))
 
     def k3b():
-        check(lib.pygat_gat_backward_edge(graph.fwd.ref(), H, Fo, 0.2, P(Wh), P(t), P(Gp), P(rowtab), None, P(ebuf), None))
+        check(lib.pygat_gat_backward_edge(graph.fwd.ref(), H, Fo, 0.2, P(Wh), P(a_pad), P(Gp), P(rowtab), None,
+                                          P(graph.perm_f) if scatter else None, P(ebuf), P(dzf), None))
 
     def k4():
-        check(lib.pygat_gat_backward_col(graph.bwd.ref(), P(graph.perm_t), int(graph.symmetric), H, Fo, P(Gp), P(ebuf),
+        check(lib.pygat_gat_backward_col(graph.bwd.ref(), None if scatter else P(graph.perm_t), int(graph.symmetric), H, Fo,
+                                         P(Gp), P(ebuf), P(dzf),
                                          P(a_pad), P(dWh), P(ds), P(dt), P(part), None))
 
     b_fwd = E * (4 + 4 * H + 4 * R) + N * (4 + 4 * H + 4 * R + 8 * H)

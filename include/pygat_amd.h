@@ -135,11 +135,19 @@ typedef struct {
   int64_t nnz;               /* edges */
   const int32_t* rowptr;     /* [n+1] */
   const int32_t* edge_rc;    /* [nnz][2]: (row i, column j) of every edge, CSR order (pygat_edge_pairs) */
-  int slot_edges;            /* edges per slot: multiple of 4, >= 4 */
+  int slot_edges;            /* nominal edges per slot: multiple of 4, >= 4 */
+  const int32_t* slot_begin; /* NULL: slot k = edges [k*slot_edges, (k+1)*slot_edges); else [n_slots+1]
+                                row-snapped borders from pygat_slot_bounds (fewer rows are cut) */
 } pygat_graph;
 
 /* edge_rc[k] = (i, col[k]) for rowptr[i] <= k < rowptr[i+1] */
 int pygat_edge_pairs(int n, const int32_t* rowptr, const int32_t* col, int32_t* edge_rc, void* stream);
+
+/* slot_begin[k] = k*slot_edges, moved forward to the next row start when that is less than
+ * slot_edges/2 edges away (so most slot borders fall between rows and only rows longer than
+ * slot_edges/2 are ever cut); slot_begin[n_slots] = nnz, n_slots = ceil(nnz / slot_edges). */
+int pygat_slot_bounds(int n, int64_t nnz, const int32_t* rowptr, const int32_t* edge_rc, int slot_edges,
+                      int32_t* slot_begin, void* stream);
 
 /* bytes of `part` workspace needed by forward / column backward for this graph and row width */
 size_t pygat_partials_bytes(int64_t nnz, int slot_edges, int H, int Fp);

@@ -23,7 +23,7 @@ SYMBOLS = [
     "pygat_exclusive_scan_i32", "pygat_dense_fill_cols", "pygat_csr_symmetric_perm",
     "pygat_gemm_workspace_bytes", "pygat_gemm_f32", "pygat_pack_params", "pygat_attn_scores",
     "pygat_unpack_wgrad",
-    "pygat_edge_pairs", "pygat_partials_bytes", "pygat_gat_forward", "pygat_head_mean",
+    "pygat_edge_pairs", "pygat_slot_bounds", "pygat_partials_bytes", "pygat_gat_forward", "pygat_head_mean",
     "pygat_gat_backward_prepare", "pygat_gat_backward_edge", "pygat_row_sum_dz", "pygat_gat_backward_col",
     "pygat_agrad_workspace_bytes", "pygat_a_grad",
 ]
@@ -36,7 +36,7 @@ class OutSegments(C.Structure):
 
 class Graph(C.Structure):
     _fields_ = [("n", C.c_int), ("nnz", C.c_int64), ("rowptr", C.c_void_p), ("edge_rc", C.c_void_p),
-                ("slot_edges", C.c_int)]
+                ("slot_edges", C.c_int), ("slot_begin", C.c_void_p)]
 
 
 def _load():
@@ -66,6 +66,7 @@ def _load():
     lib.pygat_unpack_wgrad.argtypes = [i, i, i, p, i64, i, p, p]
     lib.pygat_attn_scores.argtypes = [i, i, i, p, p, p, p, p]
     lib.pygat_edge_pairs.argtypes = [i, p, p, p, p]
+    lib.pygat_slot_bounds.argtypes = [i, i64, p, p, i, p, p]
     lib.pygat_partials_bytes.argtypes = [i64, i, i, i]
     lib.pygat_partials_bytes.restype = sz
     lib.pygat_gat_forward.argtypes = [C.POINTER(Graph), i, i, f, i, p, p, p, p, p, p, p, p, p, p, p]

@@ -16,6 +16,7 @@
 
 namespace pygat {
 
+constexpr int FIX_SCREEN = 8;  // slots screened per wave by the fix-up kernels (owned rows are merged serially)
 constexpr float NEG_BIG = -1.0e30f;  // running-max seed: exp(NEG_BIG - x) == 0, exp(NEG_BIG - NEG_BIG) == 1
 
 struct RowShape {
@@ -65,7 +66,8 @@ struct GraphDev {  // device view of pygat_graph
   int64_t nnz;
   const int32_t* rowptr;
   const int2* rc;   // (row, col) per edge
-  int ts;           // edges per slot
+  int ts;           // nominal edges per slot
+  const int32_t* sb;  // row-snapped slot borders [nslots+1] or nullptr (uniform slots)
 };
 
 static inline int check_graph(const pygat_graph* g, GraphDev* d) {
@@ -82,13 +84,33 @@ static inline int check_graph(const pygat_graph* g, GraphDev* d) {
     return PYGAT_EINVAL;
   }
   d->n = g->n; d->nnz = g->nnz; d->rowptr = g->rowptr; d->rc = reinterpret_cast<const int2*>(g->edge_rc);
-  d->ts = g->slot_edges;
+  d->ts = g->slot_edges; d->sb = g->slot_begin;
   return PYGAT_OK;
 }
 
+#ifdef __HIPCC__
+__host__ __device__
+#endif
 static inline int64_t num_slots(const GraphDev& g) { return (g.nnz + g.ts - 1) / g.ts; }
 
 #ifdef __HIPCC__
+// edge range of slot k
+__device__ __forceinline__ void slot_range(const GraphDev& g, int64_t k, int64_t* e0, int64_t* e1) {
+  if (g.sb) {
+    *e0 = g.sb[k];
+    *e1 = g.sb[k + 1];
+  } else {
+    *e0 = k * g.ts;
+    *e1 = (*e0 + g.ts < g.nnz) ? *e0 + g.ts : g.nnz;
+  }
+}
+// slot that contains edge position pos
+__device__ __forceinline__ int64_t slot_of(const GraphDev& g, int64_t pos) {
+  int64_t k = pos / g.ts;
+  if (g.sb && pos < g.sb[k]) --k;
+  return k;
+}
+
 template <int VEC>
 struct LaneCols {
   int cofs[VEC];   // float offset of the lane's chunk inside a padded row (clamped when invalid)

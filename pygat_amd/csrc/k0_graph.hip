@@ -146,6 +146,24 @@ __global__ __launch_bounds__(256) void csr_symmetric_perm_kernel(int n, const in
   }
 }
 
+// ---- row-snapped slot borders for the nnz-split kernels ---------------------------
+__global__ __launch_bounds__(256) void slot_bounds_kernel(int64_t nnz, int ts, int64_t nslots,
+                                                          const int32_t* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ edge_rc,
+                                                          int32_t* __restrict__ sb) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k > nslots) return;
+  if (k == nslots) { sb[k] = (int32_t)nnz; return; }
+  const int64_t pos = k * ts;
+  const int r = edge_rc[2 * pos];        // row that contains edge `pos`
+  int64_t b = pos;
+  if (rowptr[r] != pos) {                // inside a row: move to its end if that is close
+    const int64_t nxt = rowptr[r + 1];
+    if (nxt - pos < ts / 2 && nxt < nnz) b = nxt;
+  }
+  sb[k] = (int32_t)b;
+}
+
 }  // namespace pygat
 
 using namespace pygat;
@@ -191,5 +209,16 @@ extern "C" int pygat_csr_symmetric_perm(int n, const int32_t* rowptr, const int3
   hipLaunchKernelGGL(csr_symmetric_perm_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream,
                      n, rowptr, col, perm, flags);
   PYGAT_CHECK_LAUNCH("csr_symmetric_perm");
+  return PYGAT_OK;
+}
+
+extern "C" int pygat_slot_bounds(int n, int64_t nnz, const int32_t* rowptr, const int32_t* edge_rc, int slot_edges,
+                                 int32_t* slot_begin, void* stream) {
+  PYGAT_REQUIRE(n > 0 && nnz > 0 && rowptr && edge_rc && slot_begin && slot_edges >= 4 && (slot_edges & 3) == 0,
+                "slot_bounds: bad arguments");
+  const int64_t nslots = cdiv(nnz, slot_edges);
+  hipLaunchKernelGGL(slot_bounds_kernel, dim3((unsigned)cdiv(nslots + 1, 256)), dim3(256), 0, (hipStream_t)stream, nnz,
+                     slot_edges, nslots, rowptr, edge_rc, slot_begin);
+  PYGAT_CHECK_LAUNCH("slot_bounds");
   return PYGAT_OK;
 }

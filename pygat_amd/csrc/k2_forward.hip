@@ -137,9 +137,9 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
   constexpr int U = (VEC == 1) ? 4 : 2;
   const int lane = threadIdx.x & 63;
   const int64_t k = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * EPW + lane / LPR;  // slot id
-  const int64_t e0 = k * a.g.ts;
-  if (e0 >= a.g.nnz) return;  // lane groups are independent: no cross-lane op below
-  const int64_t e1 = (e0 + a.g.ts < a.g.nnz) ? e0 + a.g.ts : a.g.nnz;
+  if (k >= num_slots(a.g)) return;  // lane groups are independent: no cross-lane op below
+  int64_t e0, e1;
+  slot_range(a.g, k, &e0, &e1);
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
   const int H = a.rs.H, R = a.rs.R;
   const int2* __restrict__ rc = a.g.rc;
@@ -196,58 +196,103 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
   fwd_flush<VEC>(a, lc, k, cur, cur == r_first && head_partial, tail_partial, m, z, acc);
 }
 
-// One wave per slot k: if the last row of slot k starts inside it and continues beyond, this
-// wave owns that row and merges its pieces in slot order: tail(k), head(k+1), ..., head(k_e).
-// The wave's EPW lane groups take the pieces round-robin and are merged with shuffles.
+// Fix-up of the rows cut by a slot border.  A work-group screens FIX_SCREEN consecutive slots: slot k
+// OWNS a cut row if its last row starts inside k and continues beyond.  Every owned row is merged in
+// turn: its pieces tail(k), head(k+1), ..., head(k_e) are dealt round-robin to the 4 waves x EPW lane
+// groups (PF pieces in flight each -- the chain of a 26k-edge row has 400+ pieces), combined inside a
+// wave with shuffles and across waves through LDS, always in the same order (reproducible).
 template <int LPR, int VEC>
 __global__ __launch_bounds__(256) void gat_fwd_fixup_kernel(FwdArgs a) {
   constexpr int EPW = 64 / LPR;
-  const int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t e0 = k * a.g.ts;
-  if (e0 >= a.g.nnz) return;
-  const int64_t e1 = (e0 + a.g.ts < a.g.nnz) ? e0 + a.g.ts : a.g.nnz;
-  const int r = a.g.rc[e1 - 1].x;
-  const int64_t row_end = a.g.rowptr[r + 1];
-  if (row_end <= e1) return;                 // the slot's last row ends here: nothing to merge
-  if ((int64_t)a.g.rowptr[r] < e0) return;   // the row began in an earlier slot: not the owner
-  const int64_t k_e = (row_end - 1) / a.g.ts;
-  const int npieces = (int)(k_e - k) + 1;
+  constexpr int PF = (VEC == 1) ? 4 : 2;
+  extern __shared__ __attribute__((aligned(16))) float fix_sm[];  // [4][R + 2H]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t kbase = (int64_t)blockIdx.x * FIX_SCREEN;
+  const int64_t nslots = num_slots(a.g);
+  int my_r = 0, my_end = 0;
+  bool owner = false;
+  if (lane < FIX_SCREEN && kbase + lane < nslots) {
+    int64_t e0, e1;
+    slot_range(a.g, kbase + lane, &e0, &e1);
+    my_r = a.g.rc[e1 - 1].x;
+    my_end = a.g.rowptr[my_r + 1];
+    owner = (int64_t)my_end > e1 && (int64_t)a.g.rowptr[my_r] >= e0;
+  }
+  unsigned long long todo = __ballot(owner);  // identical in the 4 waves
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
-  const int slot = (threadIdx.x & 63) / LPR;
+  const int slot = lane / LPR;
   const int64_t PS = a.rs.R + 2 * a.rs.H;
-  float m[VEC], z[VEC];
-  float4 acc[VEC];
+  while (todo) {
+    const int src = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int64_t k = kbase + src;
+    const int r = __shfl(my_r, src);
+    const int64_t row_end = __shfl(my_end, src);
+    const int64_t k_e = slot_of(a.g, row_end - 1);
+    const int npieces = (int)(k_e - k) + 1;
+    const bool wide = npieces > EPW * PF;  // more pieces than one wave takes in a single round
+    float m[VEC], z[VEC];
+    float4 acc[VEC];
 #pragma unroll
-  for (int v = 0; v < VEC; ++v) { m[v] = NEG_BIG; z[v] = 0.f; acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); }
-  for (int q = slot; q < npieces; q += 2 * EPW) {
-    const int q2 = q + EPW;
-    const float* p1 = a.part + (q == 0 ? 2 * k + 1 : 2 * (k + q)) * PS;
-    const float* p2 = a.part + 2 * (k + (q2 < npieces ? q2 : q)) * PS;
-    float m1[VEC], z1[VEC], m2[VEC], z2[VEC];
-    float4 a1[VEC], a2[VEC];
+    for (int v = 0; v < VEC; ++v) { m[v] = NEG_BIG; z[v] = 0.f; acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    if (wide || w == 0) {
+      const int nw = wide ? 4 : 1;
+      for (int q = (wide ? w : 0) * EPW * PF + slot; q < npieces; q += nw * EPW * PF) {
+        float mp[PF][VEC], zp[PF][VEC];
+        float4 ap[PF][VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      m1[v] = p1[a.rs.R + lc.head[v]]; z1[v] = p1[a.rs.R + a.rs.H + lc.head[v]]; a1[v] = ld4(p1 + lc.cofs[v]);
-      m2[v] = p2[a.rs.R + lc.head[v]]; z2[v] = p2[a.rs.R + a.rs.H + lc.head[v]]; a2[v] = ld4(p2 + lc.cofs[v]);
+        for (int f = 0; f < PF; ++f) {
+          const int qq = q + f * EPW;
+          const int qc = qq < npieces ? qq : q;
+          const float* p = a.part + (qc == 0 ? 2 * k + 1 : 2 * (k + qc)) * PS;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            mp[f][v] = p[a.rs.R + lc.head[v]]; zp[f][v] = p[a.rs.R + a.rs.H + lc.head[v]]; ap[f][v] = ld4(p + lc.cofs[v]);
+          }
+        }
+#pragma unroll
+        for (int f = 0; f < PF; ++f)
+          if (q + f * EPW < npieces) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) merge_state(m[v], z[v], acc[v], mp[f][v], zp[f][v], ap[f][v]);
+          }
+      }
+#pragma unroll
+      for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          float mo = __shfl_xor(m[v], off), zo = __shfl_xor(z[v], off);
+          float4 ao;
+          ao.x = __shfl_xor(acc[v].x, off); ao.y = __shfl_xor(acc[v].y, off);
+          ao.z = __shfl_xor(acc[v].z, off); ao.w = __shfl_xor(acc[v].w, off);
+          merge_state(m[v], z[v], acc[v], mo, zo, ao);
+        }
+      }
     }
+    if (wide) {  // wave partials -> LDS -> wave 0 (uniform branch: `wide` is the same in all waves)
+      if (slot == 0) {
+        float* p = fix_sm + w * PS;
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      merge_state(m[v], z[v], acc[v], m1[v], z1[v], a1[v]);
-      if (q2 < npieces) merge_state(m[v], z[v], acc[v], m2[v], z2[v], a2[v]);
+        for (int v = 0; v < VEC; ++v)
+          if (lc.valid[v]) {
+            st4(p + lc.cofs[v], acc[v]);
+            if (((lc.cofs[v] >> 2) & (a.rs.lph - 1)) == 0) { p[a.rs.R + lc.head[v]] = m[v]; p[a.rs.R + a.rs.H + lc.head[v]] = z[v]; }
+          }
+      }
+      __syncthreads();
+      if (w == 0 && slot == 0) {
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) {
+          const float* p = fix_sm + ww * PS;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v)
+            merge_state(m[v], z[v], acc[v], p[a.rs.R + lc.head[v]], p[a.rs.R + a.rs.H + lc.head[v]], ld4(p + lc.cofs[v]));
+        }
+      }
+      __syncthreads();
     }
+    if (w == 0 && slot == 0) fwd_finish<VEC>(a, lc, r, m, z, acc);
   }
-#pragma unroll
-  for (int off = LPR; off < 64; off <<= 1) {
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      float mo = __shfl_xor(m[v], off), zo = __shfl_xor(z[v], off);
-      float4 ao;
-      ao.x = __shfl_xor(acc[v].x, off); ao.y = __shfl_xor(acc[v].y, off);
-      ao.z = __shfl_xor(acc[v].z, off); ao.w = __shfl_xor(acc[v].w, off);
-      merge_state(m[v], z[v], acc[v], mo, zo, ao);
-    }
-  }
-  if (slot == 0) fwd_finish<VEC>(a, lc, r, m, z, acc);
 }
 
 // models.py:34 -- mean over heads of (hattn [+ sk]); one thread per output element
@@ -321,9 +366,10 @@ extern "C" int pygat_gat_forward(const pygat_graph* g, int H, int Fo, float alph
   PYGAT_DISPATCH_LANES(lpr, vec,
                        hipLaunchKernelGGL((gat_fwd_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0, st, a));
   PYGAT_CHECK_LAUNCH("gat_forward");
-  const unsigned fb = (unsigned)cdiv(nslots, 4);
+  const unsigned fb = (unsigned)cdiv(nslots, FIX_SCREEN);
+  const size_t fix_lds = 4 * (size_t)(a.rs.R + 2 * a.rs.H) * sizeof(float);
   PYGAT_DISPATCH_LANES(lpr, vec,
-                       hipLaunchKernelGGL((gat_fwd_fixup_kernel<LPR, VEC>), dim3(fb), dim3(256), 0, st, a));
+                       hipLaunchKernelGGL((gat_fwd_fixup_kernel<LPR, VEC>), dim3(fb), dim3(256), fix_lds, st, a));
   PYGAT_CHECK_LAUNCH("gat_forward_fixup");
   return PYGAT_OK;
 }

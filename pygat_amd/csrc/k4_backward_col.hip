@@ -81,9 +81,9 @@ __global__ __launch_bounds__(256) void gat_bwd_col_kernel(ColArgs a) {
   constexpr int U = (VEC == 1) ? 4 : 2;
   const int lane = threadIdx.x & 63;
   const int64_t k = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * EPW + lane / LPR;
-  const int64_t e0 = k * a.g.ts;
-  if (e0 >= a.g.nnz) return;
-  const int64_t e1 = (e0 + a.g.ts < a.g.nnz) ? e0 + a.g.ts : a.g.nnz;
+  if (k >= num_slots(a.g)) return;
+  int64_t e0, e1;
+  slot_range(a.g, k, &e0, &e1);
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
   const int H = a.rs.H, R = a.rs.R;
   const int2* __restrict__ rc = a.g.rc;
@@ -141,44 +141,104 @@ __global__ __launch_bounds__(256) void gat_bwd_col_kernel(ColArgs a) {
   col_flush<VEC>(a, lc, k, cur, cur == r_first && head_partial, tail_partial, acc, dt, ds);
 }
 
-// owner = slot where the cut row starts; sums tail(k), head(k+1), ..., head(k_e) in that order
+// Fix-up of cut rows (same scheme as gat_fwd_fixup_kernel): a work-group screens FIX_SCREEN slots, the
+// owner slot of a cut row is the one where the row starts; its pieces tail(k), head(k+1), ..., head(k_e)
+// are summed by the 4 waves x EPW lane groups and combined through LDS in a fixed order.
 template <int LPR, int VEC>
 __global__ __launch_bounds__(256) void gat_bwd_col_fixup_kernel(ColArgs a) {
   constexpr int EPW = 64 / LPR;
-  const int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t e0 = k * a.g.ts;
-  if (e0 >= a.g.nnz) return;
-  const int64_t e1 = (e0 + a.g.ts < a.g.nnz) ? e0 + a.g.ts : a.g.nnz;
-  const int r = a.g.rc[e1 - 1].x;
-  const int64_t row_end = a.g.rowptr[r + 1];
-  if (row_end <= e1) return;
-  if ((int64_t)a.g.rowptr[r] < e0) return;
-  const int64_t k_e = (row_end - 1) / a.g.ts;
-  const int npieces = (int)(k_e - k) + 1;
+  constexpr int PF = (VEC == 1) ? 4 : 2;
+  extern __shared__ __attribute__((aligned(16))) float fix_sm[];  // [4][R + 2H]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t kbase = (int64_t)blockIdx.x * FIX_SCREEN;
+  const int64_t nslots = num_slots(a.g);
+  int my_r = 0, my_end = 0;
+  bool owner = false;
+  if (lane < FIX_SCREEN && kbase + lane < nslots) {
+    int64_t e0, e1;
+    slot_range(a.g, kbase + lane, &e0, &e1);
+    my_r = a.g.rc[e1 - 1].x;
+    my_end = a.g.rowptr[my_r + 1];
+    owner = (int64_t)my_end > e1 && (int64_t)a.g.rowptr[my_r] >= e0;
+  }
+  unsigned long long todo = __ballot(owner);
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
-  const int slot = (threadIdx.x & 63) / LPR;
+  const int slot = lane / LPR;
   const int64_t PS = a.rs.R + 2 * a.rs.H;
-  float4 acc[VEC];
-  float dt[VEC], ds[VEC];
+  while (todo) {
+    const int src = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int64_t k = kbase + src;
+    const int r = __shfl(my_r, src);
+    const int64_t row_end = __shfl(my_end, src);
+    const int64_t k_e = slot_of(a.g, row_end - 1);
+    const int npieces = (int)(k_e - k) + 1;
+    const bool wide = npieces > EPW * PF;
+    float4 acc[VEC];
+    float dt[VEC], ds[VEC];
 #pragma unroll
-  for (int v = 0; v < VEC; ++v) { acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); dt[v] = 0.f; ds[v] = 0.f; }
-  for (int q = slot; q < npieces; q += EPW) {
-    const float* p = a.part + (q == 0 ? 2 * k + 1 : 2 * (k + q)) * PS;
+    for (int v = 0; v < VEC; ++v) { acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); dt[v] = 0.f; ds[v] = 0.f; }
+    if (wide || w == 0) {
+      const int nw = wide ? 4 : 1;
+      for (int q = (wide ? w : 0) * EPW * PF + slot; q < npieces; q += nw * EPW * PF) {
+        float4 xp[PF][VEC];
+        float tp[PF][VEC], sp[PF][VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      const float4 x = ld4(p + lc.cofs[v]);
-      acc[v].x += x.x; acc[v].y += x.y; acc[v].z += x.z; acc[v].w += x.w;
-      dt[v] += p[a.rs.R + lc.head[v]];
-      ds[v] += p[a.rs.R + a.rs.H + lc.head[v]];
+        for (int f = 0; f < PF; ++f) {
+          const int qq = q + f * EPW;
+          const int qc = qq < npieces ? qq : q;
+          const float* p = a.part + (qc == 0 ? 2 * k + 1 : 2 * (k + qc)) * PS;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            xp[f][v] = ld4(p + lc.cofs[v]); tp[f][v] = p[a.rs.R + lc.head[v]]; sp[f][v] = p[a.rs.R + a.rs.H + lc.head[v]];
+          }
+        }
+#pragma unroll
+        for (int f = 0; f < PF; ++f)
+          if (q + f * EPW < npieces) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+              acc[v].x += xp[f][v].x; acc[v].y += xp[f][v].y; acc[v].z += xp[f][v].z; acc[v].w += xp[f][v].w;
+              dt[v] += tp[f][v];
+              ds[v] += sp[f][v];
+            }
+          }
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        acc[v] = slot_sum4<LPR>(acc[v]);
+        dt[v] = slot_sum<LPR>(dt[v]);
+        ds[v] = slot_sum<LPR>(ds[v]);
+      }
     }
-  }
+    if (wide) {
+      if (slot == 0) {
+        float* p = fix_sm + w * PS;
 #pragma unroll
-  for (int v = 0; v < VEC; ++v) {
-    acc[v] = slot_sum4<LPR>(acc[v]);
-    dt[v] = slot_sum<LPR>(dt[v]);
-    ds[v] = slot_sum<LPR>(ds[v]);
+        for (int v = 0; v < VEC; ++v)
+          if (lc.valid[v]) {
+            st4(p + lc.cofs[v], acc[v]);
+            if (((lc.cofs[v] >> 2) & (a.rs.lph - 1)) == 0) { p[a.rs.R + lc.head[v]] = dt[v]; p[a.rs.R + a.rs.H + lc.head[v]] = ds[v]; }
+          }
+      }
+      __syncthreads();
+      if (w == 0 && slot == 0) {
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) {
+          const float* p = fix_sm + ww * PS;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            const float4 x = ld4(p + lc.cofs[v]);
+            acc[v].x += x.x; acc[v].y += x.y; acc[v].z += x.z; acc[v].w += x.w;
+            dt[v] += p[a.rs.R + lc.head[v]];
+            ds[v] += p[a.rs.R + a.rs.H + lc.head[v]];
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (w == 0 && slot == 0) col_finish<VEC>(a, lc, r, acc, dt, ds);
   }
-  if (slot == 0) col_finish<VEC>(a, lc, r, acc, dt, ds);
 }
 
 }  // namespace pygat
@@ -205,8 +265,9 @@ extern "C" int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm
   PYGAT_DISPATCH_LANES(lpr, vec,
                        hipLaunchKernelGGL((gat_bwd_col_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0, st, a));
   PYGAT_CHECK_LAUNCH("gat_backward_col");
+  const size_t fix_lds = 4 * (size_t)(a.rs.R + 2 * a.rs.H) * sizeof(float);
   PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_bwd_col_fixup_kernel<LPR, VEC>),
-                                                    dim3((unsigned)cdiv(nslots, 4)), dim3(256), 0, st, a));
+                                                    dim3((unsigned)cdiv(nslots, FIX_SCREEN)), dim3(256), fix_lds, st, a));
   PYGAT_CHECK_LAUNCH("gat_backward_col_fixup");
   return PYGAT_OK;
 }

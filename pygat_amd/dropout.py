@@ -111,7 +111,7 @@ class GATLevelDropoutFn(torch.autograd.Function):
             check(lib.pygat_gat_backward_prepare(L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(), y.data_ptr(),
                                                  _ptr(Sk), s.data_ptr(), m.data_ptr(), Z.data_ptr(), Gp.data_ptr(),
                                                  rowtab.data_ptr(), st), "gat_backward_prepare")
-            check(lib.pygat_gat_backward_edge(graph.fwd.ref(L.ts_edge), H, Fo, ctx.alpha, Wh.data_ptr(), a_pad.data_ptr(),
+            check(lib.pygat_gat_backward_edge(graph.fwd.ref(L.ts_edge, snapped=False), H, Fo, ctx.alpha, Wh.data_ptr(), a_pad.data_ptr(),
                                               Gp.data_ptr(), rowtab.data_ptr(), mask_att.data_ptr(),
                                               graph.perm_f.data_ptr() if scatter else None, ebuf.data_ptr(), _ptr(dzf), st),
                   "gat_backward_edge")

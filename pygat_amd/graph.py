@@ -60,19 +60,27 @@ class _Pattern:
         with torch.cuda.device(rowptr.device):
             check(lib.pygat_edge_pairs(self.n, rowptr.data_ptr(), col.data_ptr(), self.edge_rc.data_ptr(), _stream()),
                   "edge_pairs")
-        self.struct = _lib.Graph(self.n, self.nnz, _ptr(rowptr), _ptr(self.edge_rc), slot_edges)
-        self._alt = {}
+        self._alt = {}          # (slot_edges, snapped) -> (struct, slot_begin tensor)
+        self.struct = self._make(slot_edges, True)
 
-    def ref(self, slot_edges: Optional[int] = None):
-        """pygat_graph* for a call; `slot_edges` overrides the slot length for this call only
-        (the edge arrays do not depend on it)."""
-        if slot_edges is None or slot_edges == self.slot_edges:
-            return C.byref(self.struct)
-        st = self._alt.get(slot_edges)
-        if st is None:
-            st = _lib.Graph(self.n, self.nnz, _ptr(self.rowptr), _ptr(self.edge_rc), slot_edges)
-            self._alt[slot_edges] = st
-        return C.byref(st)
+    def _make(self, slot_edges: int, snapped: bool):
+        key = (slot_edges, snapped)
+        if key not in self._alt:
+            sb = None
+            if snapped:   # row-snapped slot borders (K2 / K4: fewer cut rows, fewer partial records)
+                nslots = -(-self.nnz // slot_edges)
+                sb = torch.empty(nslots + 1, dtype=torch.int32, device=self.rowptr.device)
+                with torch.cuda.device(self.rowptr.device):
+                    check(lib.pygat_slot_bounds(self.n, self.nnz, self.rowptr.data_ptr(), self.edge_rc.data_ptr(),
+                                                slot_edges, sb.data_ptr(), _stream()), "slot_bounds")
+            st = _lib.Graph(self.n, self.nnz, _ptr(self.rowptr), _ptr(self.edge_rc), slot_edges, _ptr(sb))
+            self._alt[key] = (st, sb)
+        return self._alt[key][0]
+
+    def ref(self, slot_edges: Optional[int] = None, snapped: bool = True):
+        """pygat_graph* for a call.  `slot_edges` overrides the slot length for this call only (the edge
+        arrays do not depend on it); `snapped=False` gives uniform slots (K3b has no row reduction)."""
+        return C.byref(self._make(slot_edges or self.slot_edges, snapped))
 
 
 class CSRGraph:

@@ -87,7 +87,8 @@ def gemm(transA: bool, transB: bool, M: int, N: int, K: int, A: torch.Tensor, ld
         nt = -(-N // 32)
         bn = 32 * (nt if nt <= 8 else 4)
         tiles = -(-M // 128) * -(-N // bn)
-        split_k = max(1, min(512 // tiles, K // 256)) if tiles < 256 else 1
+        # one work-group per CU: on the weight-gradient shape (huge K) more slabs only add partial-sum traffic
+        split_k = max(1, min(256 // tiles, K // 256)) if tiles < 256 else 1
     ws = None
     if split_k > 1:
         ws = torch.empty(lib.pygat_gemm_workspace_bytes(M, N, split_k) // 4, dtype=torch.float32, device=A.device)
@@ -193,7 +194,7 @@ class GATLevelFn(torch.autograd.Function):
                                                      y.data_ptr(), _ptr(Sk), s.data_ptr(), m.data_ptr(), Z.data_ptr(),
                                                      Gp.data_ptr(), rowtab.data_ptr(), st), "gat_backward_prepare")
             with _span("k3b_edge"):
-                check(lib.pygat_gat_backward_edge(graph.fwd.ref(L.ts_edge), H, Fo, ctx.alpha, Wh.data_ptr(),
+                check(lib.pygat_gat_backward_edge(graph.fwd.ref(L.ts_edge, snapped=False), H, Fo, ctx.alpha, Wh.data_ptr(),
                                                   a_pad.data_ptr(), Gp.data_ptr(), rowtab.data_ptr(), None,
                                                   graph.perm_f.data_ptr() if scatter else None, ebuf.data_ptr(), _ptr(dzf), st),
                       "gat_backward_edge")

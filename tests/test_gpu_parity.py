@@ -121,7 +121,7 @@ def test_asymmetric_pattern_transpose(pg, H, Fo):
     # fast paths: small-K register-streamed A (M >= 8192, K % 32 == 0), weight-gradient stream (huge K)
     (False, False, 10007, 144, 128), (False, True, 9000, 128, 128), (False, False, 8200, 40, 96),
     (False, False, 8193, 300, 256), (False, True, 8192, 50, 64), (True, False, 128, 128, 20011),
-    (True, False, 200, 80, 5000), (True, False, 50, 1024, 4500),
+    (True, False, 200, 80, 5000), (True, False, 50, 1024, 4500), (True, False, 256, 132, 9001),
 ])
 def test_gemm(pg, tA, tB, M, N, K):
     gen = torch.Generator().manual_seed(M * 7 + N)

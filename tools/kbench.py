@@ -68,7 +68,7 @@ def main():
                                              P(rowtab), None))
 
     def k3b():
-        check(lib.pygat_gat_backward_edge(graph.fwd.ref(), H, Fo, 0.2, P(Wh), P(a_pad), P(Gp), P(rowtab), None,
+        check(lib.pygat_gat_backward_edge(graph.fwd.ref(snapped=False), H, Fo, 0.2, P(Wh), P(a_pad), P(Gp), P(rowtab), None,
                                           P(graph.perm_f) if scatter else None, P(ebuf), P(dzf), None))
 
     def k4():

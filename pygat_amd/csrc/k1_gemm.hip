@@ -202,20 +202,40 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   }
 }
 
-// deterministic slab-order reduction of split-K partials, routed to the segments
-__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(int M, int N, int splits,
+// deterministic reduction of split-K partials, routed to the segments.  A 512-thread work-group owns
+// 64 consecutive output elements: wave q sums slabs q, q+8, ... in order (256-B coalesced reads,
+// unrolled so several are in flight), then the 8 partial sums are added in wave order -- the same
+// association on every run.
+__global__ __launch_bounds__(512) void gemm_splitk_reduce_kernel(int M, int N, int splits,
                                                                  const float* __restrict__ ws,
                                                                  pygat_out_segments out, int accumulate) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (int64_t)M * N) return;
-  int row = (int)(i / N), col = (int)(i % N);
+  const int64_t tot = (int64_t)M * N;
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
   float v = 0.f;
-  for (int z = 0; z < splits; ++z) v += ws[(int64_t)z * M * N + i];
-  int s = 0;
-  for (int q = 1; q < out.nseg; ++q)
-    if (col >= out.col_start[q]) s = q;
-  float* p = out.ptr[s] + (int64_t)row * out.ld[s] + (col - out.col_start[s]);
-  if (accumulate) *p += v; else *p = v;
+  if (i < tot) {
+    int z = q;
+    for (; z + 24 < splits; z += 32) {
+      const float x0 = ws[(int64_t)z * tot + i], x1 = ws[(int64_t)(z + 8) * tot + i];
+      const float x2 = ws[(int64_t)(z + 16) * tot + i], x3 = ws[(int64_t)(z + 24) * tot + i];
+      v += x0; v += x1; v += x2; v += x3;
+    }
+    for (; z < splits; z += 8) v += ws[(int64_t)z * tot + i];
+  }
+  __shared__ float sm[8][64];
+  sm[q][lane] = v;
+  __syncthreads();
+  if (q == 0 && i < tot) {
+    float acc = 0.f;
+#pragma unroll
+    for (int z = 0; z < 8; ++z) acc += sm[z][lane];
+    const int row = (int)(i / N), col = (int)(i % N);
+    int s = 0;
+    for (int k = 1; k < out.nseg; ++k)
+      if (col >= out.col_start[k]) s = k;
+    float* p = out.ptr[s] + (int64_t)row * out.ld[s] + (col - out.col_start[s]);
+    if (accumulate) *p += acc; else *p = acc;
+  }
 }
 
 template <bool TA, bool TB>
@@ -275,7 +295,7 @@ extern "C" int pygat_gemm_f32(int transA, int transB, int M, int N, int64_t K, c
     if (r < 0) return r;
     if (r >= 1) {
       int64_t tot = (int64_t)M * N;
-      hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, st, M, N, r,
+      hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)cdiv(tot, 64)), dim3(512), 0, st, M, N, r,
                          (const float*)ws, *out, accumulate);
       PYGAT_CHECK_LAUNCH("gemm_splitk_reduce");
       return PYGAT_OK;
@@ -297,7 +317,7 @@ extern "C" int pygat_gemm_f32(int transA, int transB, int M, int N, int64_t K, c
   PYGAT_CHECK_LAUNCH("gemm_f32");
   if (splits > 1) {
     int64_t tot = (int64_t)M * N;
-    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, st, M, N, splits,
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)cdiv(tot, 64)), dim3(512), 0, st, M, N, splits,
                        (const float*)ws, *out, accumulate);
     PYGAT_CHECK_LAUNCH("gemm_splitk_reduce");
   }

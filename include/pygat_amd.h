@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PYGAT_ABI_VERSION 2
+#define PYGAT_ABI_VERSION 3
 
 enum {
   PYGAT_OK = 0,
@@ -168,34 +168,32 @@ int pygat_head_mean(int n, int H, int Fo, const float* hattn, const float* sk,
 /* ------------------------------------------------ K3/K4: backward, no N x N, no atomics
  * Replaces SpecialSpmmFunction.backward (layers.py:81-90) and the autograd of
  * layers.py:141-170.
- *   K3a prepare (per row):  Gp_i = G_i * ELU'(.), D_i = Gp_i . hattn_i, rowtab_i = (s_i, m_i, 1/Z_i, D_i)
+ *   K3a prepare (per row):  Gp_i = G_i * ELU'(.), D_i = Gp_i . hattn_i,
+ *        GR_i = [ Gp_i (R floats) | (s_i, m_i, 1/Z_i, D_i) per head (4H floats) ]   -> GR [n x (R+4H)]
  *        mean_mode 0: G is [n x H*F'] and y is the forward OUTPUT out [n x H*F'] (hattn is
  *                     recovered from it: out > 0 ? out : log1p(out), minus sk);
  *        mean_mode 1: G is [n x F'] (every head receives G/H, models.py:34), y is hattn [n x R].
- *   K3b edge pass (nnz split, no reduction): alpha_ij, dz_ij = alpha_ij (Gp_i.Wh_j - D_i) LeakyReLU'(s_i+t_j)
- *        -> ebuf [nnz][2][H] (alpha then dz per edge); dz_f [nnz][H] = dz in forward order, written
- *           only when ebuf is scattered (it then feeds the row sums ds; may be NULL otherwise).
- *           ebuf order: perm_f == NULL: forward edge order, K4 then gathers it through perm_t;
- *           perm_f != NULL: scattered to the TRANSPOSED position perm_f[k] of each edge, K4 then
- *           streams it (perm_t == NULL).  Gather wins for wide rows, scatter for narrow ones
- *           (few heads per GPU), where a second random sector per edge in K4 costs the most.
- *   K4 column pass over the transposed pattern gT:
- *        dWh_j = sum_i alpha_ij Gp_i + ds_j a_src + dt_j a_dst, dt_j = sum_i dz_ij, ds_j = sum_k dz_jk.
- *        symmetric != 0: gT has the forward pattern's layout, so ds_j is summed from dz_f at gT's own
- *        edge positions and written to ds; symmetric == 0: ds must already hold pygat_row_sum_dz(dz_f).
+ *   K3b row pass (nnz split over the forward pattern g): per edge (i,j)
+ *        alpha_ij = exp(LeakyReLU(s_i + t_j) - m_i)/Z_i, dz_ij = alpha_ij (mask_ij Gp_i.Wh_j - D_i) LeakyReLU'(.)
+ *        ds_i = sum_j dz_ij            (GR_i row-local, Wh_j gathered; the layers.py:85 entry, per edge)
+ *   K4 column pass (nnz split over the TRANSPOSED pattern gT, any pattern, symmetric or not):
+ *        alpha_ij, dz_ij recomputed (GR_i gathered as one contiguous row, Wh_j row-local)
+ *        dWh_j = sum_i alpha_ij mask_ij Gp_i + ds_j a_src + dt_j a_dst,  dt_j = sum_i dz_ij
+ * Nothing per-edge is stored between the passes.  att_mask [nnz x H] (forward edge order) or NULL;
+ * perm_t[k] = forward edge of gT's edge k, needed only to index att_mask (may be NULL without mask).
+ * part: >= pygat_partials_bytes for both passes.
  */
 int pygat_gat_backward_prepare(int n, int H, int Fo, int flags, int mean_mode,
                                const float* G, const float* y, const float* sk,
                                const float* s, const float* m, const float* Z,
-                               float* Gp, float* rowtab, void* stream);
-int pygat_gat_backward_edge(const pygat_graph* g, int H, int Fo, float alpha,
-                            const float* Wh, const float* a_pad, const float* Gp, const float* rowtab,
-                            const float* att_mask, const int32_t* perm_f,
-                            float* ebuf, float* dz_f, void* stream);
-int pygat_row_sum_dz(const pygat_graph* g, int H, const float* dz_f, float* ds, void* stream);
-int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm_t, int symmetric, int H, int Fo,
-                           const float* Gp, const float* ebuf, const float* dz_f, const float* a_pad,
-                           float* dWh, float* ds, float* dt, void* part, void* stream);
+                               float* GR, void* stream);
+int pygat_gat_backward_row(const pygat_graph* g, int H, int Fo, float alpha,
+                           const float* Wh, const float* a_pad, const float* GR,
+                           const float* att_mask, float* ds, void* part, void* stream);
+int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm_t, int H, int Fo, float alpha,
+                           const float* Wh, const float* a_pad, const float* GR,
+                           const float* att_mask, const float* ds,
+                           float* dWh, float* dt, void* part, void* stream);
 /* da[H x 2F'] : da_src = sum_i ds_i Wh_i, da_dst = sum_j dt_j Wh_j (per head).
  * ws >= pygat_agrad_workspace_bytes(H, Fo). */
 size_t pygat_agrad_workspace_bytes(int H, int Fo);

@@ -1,15 +1,18 @@
-// K3 -- backward, row-side quantities and the per-edge pass (gfx950, wave64).
+// K3 -- backward, row side (gfx950, wave64).
 //
 // Replaces SpecialSpmmFunction.backward's grad_values (reference layers.py:84-87), which the
 // reference obtains from a DENSE N x N product `grad_output.matmul(b.t())` gathered at the edges,
 // and the ATen autograd of layers.py:144-170 (LeakyReLU, exp, row normalisation, ELU).
 //
-//   K3a (one lane group per row)   Gp_i = G_i * ELU'(pre_i),  D_i = Gp_i . hattn_i  (= sum_j alpha_ij dp_ij)
-//                                  rowtab_i = (s_i, m_i, 1/Z_i, D_i) per head
-//   K3b (nnz split, no reduction)  dp_ij = Gp_i . Wh_j        (the (i,j) entry of layers.py:85)
-//                                  alpha_ij = exp(e_ij - m_i) / Z_i
-//                                  dz_ij = alpha_ij (dp_ij - D_i) * LeakyReLU'(s_i + t_j)
-//                                  ebuf[k] = (alpha, dz) per head for edge k
+//   K3a (one lane group per row)  Gp_i = G_i * ELU'(pre_i),  D_i = Gp_i . hattn_i  (= sum_j alpha_ij dp_ij)
+//                                 GR_i = [ Gp_i (R floats) | (s_i, m_i, 1/Z_i, D_i) per head (4H floats) ]
+//   K3b (nnz split over CSR rows) dp_ij = Gp_i . Wh_j   (the (i,j) entry of layers.py:85)
+//                                 alpha_ij = exp(e_ij - m_i) / Z_i,  e_ij = LeakyReLU(s_i + t_j), t_j = Wh_j . a_dst
+//                                 dz_ij = alpha_ij (mask_ij dp_ij - D_i) * LeakyReLU'(s_i + t_j)
+//                                 ds_i  = sum_j dz_ij
+// Nothing per-edge is stored: the column pass K4 recomputes alpha and dz from the same two tables
+// (GR gathered, Wh row-local there), which costs two dot products per edge but removes the
+// [nnz x 2H] hand-off buffer, its scattered re-read and the edge permutation from the hot path.
 // In concat mode hattn is not stored by the forward: it is recovered from the output,
 // pre = out > 0 ? out : log1p(out), hattn = pre - sk, ELU'(pre) = out > 0 ? 1 : out + 1.
 #include "attn_common.h"
@@ -26,8 +29,7 @@ struct PrepArgs {
   const float* s;
   const float* m;
   const float* Z;
-  float* Gp;
-  float* rowtab;    // [n][H][4]
+  float* GR;        // [n][R + 4H]
 };
 
 template <int LPR, int VEC>
@@ -38,6 +40,7 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_kernel(PrepArgs a) {
   if (i >= a.n) return;  // whole lane groups leave together: the DPP sums below stay inside a group
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
   const int H = a.rs.H, R = a.rs.R, Fo = a.rs.Fo, Fp = a.rs.Fp;
+  const int64_t RW = R + 4 * H;
   const int lph = a.rs.lph < 64 ? a.rs.lph : 64;
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
@@ -84,12 +87,12 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_kernel(PrepArgs a) {
           hat.x -= k4.x; hat.y -= k4.y; hat.z -= k4.z; hat.w -= k4.w;
         }
       }
-      st4(a.Gp + i * R + co, g4);
+      st4(a.GR + i * RW + co, g4);
     }
     const float D = group_sum_rt(dot4(g4, hat), lph);
     if (lc.valid[v] && ((co >> 2) & (a.rs.lph - 1)) == 0) {
       const int64_t q = i * H + h;
-      st4(a.rowtab + q * 4, make_float4(a.s[q], a.m[q], 1.0f / a.Z[q], D));
+      st4(a.GR + i * RW + R + 4 * h, make_float4(a.s[q], a.m[q], 1.0f / a.Z[q], D));
     }
   }
 }
@@ -105,6 +108,7 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_fast_kernel(PrepArgs a) {
   if (i0 >= a.n) return;
   const LaneCols<1> lc = lane_cols<LPR, 1>(a.rs);
   const int H = a.rs.H, R = a.rs.R;
+  const int64_t RW = R + 4 * H;
   const int lph = a.rs.lph < 64 ? a.rs.lph : 64;
   const int co = lc.cofs[0], h = lc.head[0];
   const bool valid = lc.valid[0];
@@ -137,99 +141,125 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_fast_kernel(PrepArgs a) {
     float4 hat = make_float4(pq[0] - k4[r].x, pq[1] - k4[r].y, pq[2] - k4[r].z, pq[3] - k4[r].w);
     const float D = group_sum_rt(dot4(g, hat), lph);
     if (i < a.n) {
-      if (valid) st4(a.Gp + i * R + co, g);
-      if (lead) st4(a.rowtab + (i * H + h) * 4, make_float4(sv[r], mv[r], 1.0f / zv[r], D));
+      if (valid) st4(a.GR + i * RW + co, g);
+      if (lead) st4(a.GR + i * RW + R + 4 * h, make_float4(sv[r], mv[r], 1.0f / zv[r], D));
     }
   }
 }
 
-struct EdgeArgs {
+// ------------------------------------------------------------------ K3b: ds_i = sum_j dz_ij
+struct RowArgs {
   GraphDev g;
   RowShape rs;
   float alpha;
   const float* Wh;
   const float* a_pad;  // t_j = Wh_j . a_dst is recomputed from the gathered row
-  const float* Gp;
-  const float* rowtab;
-  const float* mask;  // [nnz][H] attention dropout mask or nullptr
-  const int32_t* perm;  // nullptr, or the position of each forward edge in the transposed pattern
-  float* ebuf;          // [nnz][2][H], forward order (perm == nullptr) or transposed order
-  float* dzf;           // [nnz][H] in forward edge order
+  const float* GR;
+  const float* mask;   // [nnz][H] attention dropout mask (forward edge order) or nullptr
+  float* ds;           // [n][H]
+  float* part;         // [2 * nslots][H]
 };
 
+template <int VEC>
+__device__ __forceinline__ void row_flush(const RowArgs& a, const LaneCols<VEC>& lc, int64_t k, int i,
+                                          bool is_head, bool is_tail, const float (&acc)[VEC]) {
+  float* dst = (is_head || is_tail) ? a.part + (2 * k + (is_head ? 0 : 1)) * (int64_t)a.rs.H
+                                    : a.ds + (int64_t)i * a.rs.H;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v)
+    if (lc.valid[v] && (((lc.cofs[v] >> 2) & (a.rs.lph - 1)) == 0)) dst[lc.head[v]] = acc[v];
+}
+
 template <int LPR, int VEC>
-__global__ __launch_bounds__(256) void gat_bwd_edge_kernel(EdgeArgs a) {
+__global__ __launch_bounds__(256) void gat_bwd_row_kernel(RowArgs a) {
   constexpr int EPW = 64 / LPR;
   constexpr int U = (VEC == 1) ? 4 : 2;
   const int lane = threadIdx.x & 63;
   const int64_t k = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * EPW + lane / LPR;
-  const int64_t e0 = k * a.g.ts;
-  if (e0 >= a.g.nnz) return;
-  const int64_t e1 = (e0 + a.g.ts < a.g.nnz) ? e0 + a.g.ts : a.g.nnz;
+  if (k >= num_slots(a.g)) return;
+  int64_t e0, e1;
+  slot_range(a.g, k, &e0, &e1);
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
   const int H = a.rs.H, R = a.rs.R;
+  const int64_t RW = R + 4 * H;
   const int lph = a.rs.lph < 64 ? a.rs.lph : 64;
   const int2* __restrict__ rc = a.g.rc;
-  bool lead[VEC];
   float4 adst[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
-    lead[v] = lc.valid[v] && (((lc.cofs[v] >> 2) & (a.rs.lph - 1)) == 0);
     adst[v] = ld4(a.a_pad + (int64_t)lc.head[v] * 2 * a.rs.Fp + a.rs.Fp + (lc.cofs[v] & (a.rs.Fp - 1)));
     if (!lc.valid[v]) adst[v] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  const int r_first = rc[e0].x;
+  const bool head_partial = a.g.rowptr[r_first] < e0;
+  int cur = r_first;
+  float acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
 
-  for (int64_t e = e0; e < e1; e += U) {  // same trip count for every lane of the group
+  for (int64_t e = e0; e < e1; e += U) {
     int2 p[U];
-    int pe[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t ee = (e + u < e1) ? e + u : e1 - 1;
-      p[u] = rc[ee];
-      pe[u] = a.perm ? a.perm[ee] : (int)ee;
-    }
+    for (int u = 0; u < U; ++u) p[u] = rc[(e + u < e1) ? e + u : e1 - 1];
     float4 rt[U][VEC], wv[U][VEC], gv[U][VEC];
+    float mk[U][VEC];
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
-        rt[u][v] = ld4(a.rowtab + ((int64_t)p[u].x * H + lc.head[v]) * 4);
+        const float* gr = a.GR + (int64_t)p[u].x * RW;
+        gv[u][v] = ld4(gr + lc.cofs[v]);
+        rt[u][v] = ld4(gr + R + 4 * lc.head[v]);
         wv[u][v] = ld4(a.Wh + (int64_t)p[u].y * R + lc.cofs[v]);
-        gv[u][v] = ld4(a.Gp + (int64_t)p[u].x * R + lc.cofs[v]);
+        mk[u][v] = a.mask ? a.mask[((e + u < e1) ? e + u : e1 - 1) * H + lc.head[v]] : 1.f;
       }
+    // all lanes of the group are active here: the per-head DPP sums are safe
+    float dz[U][VEC];
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
-        const float part = lc.valid[v] ? dot4(gv[u][v], wv[u][v]) : 0.f;
-        const float dp = group_sum_rt(part, lph);
+        const float dp = group_sum_rt(lc.valid[v] ? dot4(gv[u][v], wv[u][v]) : 0.f, lph);
         const float tj = group_sum_rt(dot4(wv[u][v], adst[v]), lph);
         const float zz = rt[u][v].x + tj;
         const float ev = zz > 0.f ? zz : a.alpha * zz;
         const float al = __expf(ev - rt[u][v].y) * rt[u][v].z;
-        if (lead[v] && e + u < e1) {
-          // with attention dropout the aggregated weight is alpha*mask: d(alpha) = mask*dp, and K4
-          // needs the masked weight; the softmax Jacobian keeps the un-masked alpha
-          const float mk = a.mask ? a.mask[(e + u) * H + lc.head[v]] : 1.f;
-          const float dz = al * (mk * dp - rt[u][v].w) * (zz > 0.f ? 1.f : a.alpha);
-          float* eb = a.ebuf + (int64_t)pe[u] * 2 * H + lc.head[v];
-          eb[0] = al * mk;
-          eb[H] = dz;
-          if (a.perm) a.dzf[(e + u) * H + lc.head[v]] = dz;  // forward-order copy only when ebuf is scattered
-        }
+        dz[u][v] = al * (mk[u][v] * dp - rt[u][v].w) * (zz > 0.f ? 1.f : a.alpha);
       }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (e + u < e1) {
+        if (p[u].x != cur) {
+          row_flush<VEC>(a, lc, k, cur, cur == r_first && head_partial, false, acc);
+          cur = p[u].x;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += dz[u][v];
+      }
+    }
   }
+  const bool tail_partial = a.g.rowptr[cur + 1] > e1;
+  row_flush<VEC>(a, lc, k, cur, cur == r_first && head_partial, tail_partial, acc);
 }
 
-// fallback for structurally asymmetric patterns: ds_i = sum over row i of dz (one thread per (row, head))
-__global__ __launch_bounds__(256) void row_sum_dz_kernel(int n, int H, const int32_t* __restrict__ rowptr,
-                                                         const float* __restrict__ dzf, float* __restrict__ ds) {
+// cut rows: one thread per (slot, head) screens ownership and sums the pieces in slot order
+__global__ __launch_bounds__(256) void gat_bwd_row_fixup_kernel(RowArgs a) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)n * H) return;
-  const int i = (int)(idx / H), h = (int)(idx % H);
-  float acc = 0.f;
-  for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) acc += dzf[k * H + h];
-  ds[idx] = acc;
+  const int H = a.rs.H;
+  const int64_t k = idx / H;
+  const int h = (int)(idx % H);
+  if (k >= num_slots(a.g)) return;
+  int64_t e0, e1;
+  slot_range(a.g, k, &e0, &e1);
+  const int r = a.g.rc[e1 - 1].x;
+  const int64_t row_end = a.g.rowptr[r + 1];
+  if (row_end <= e1 || (int64_t)a.g.rowptr[r] < e0) return;
+  const int64_t k_e = slot_of(a.g, row_end - 1);
+  float acc = a.part[(2 * k + 1) * H + h];
+  for (int64_t kk = k + 1; kk <= k_e; ++kk) acc += a.part[(2 * kk) * H + h];
+  a.ds[(int64_t)r * H + h] = acc;
 }
 
 }  // namespace pygat
@@ -238,17 +268,17 @@ using namespace pygat;
 
 extern "C" int pygat_gat_backward_prepare(int n, int H, int Fo, int flags, int mean_mode, const float* G,
                                           const float* y, const float* sk, const float* s, const float* m,
-                                          const float* Z, float* Gp, float* rowtab, void* stream) {
+                                          const float* Z, float* GR, void* stream) {
   PrepArgs a;
   PYGAT_REQUIRE(make_row_shape(H, Fo, &a.rs), "gat_backward_prepare: unsupported H=%d F'=%d", H, Fo);
-  PYGAT_REQUIRE(n > 0 && G && y && s && m && Z && Gp && rowtab, "gat_backward_prepare: null pointer");
+  PYGAT_REQUIRE(n > 0 && G && y && s && m && Z && GR, "gat_backward_prepare: null pointer");
   PYGAT_REQUIRE(!(flags & PYGAT_F_SKIP) || sk, "gat_backward_prepare: PYGAT_F_SKIP without sk");
   PYGAT_REQUIRE(!(mean_mode && (flags & PYGAT_F_ELU)), "gat_backward_prepare: the head mean never carries an ELU (models.py:23)");
-  PYGAT_REQUIRE(aligned16(Gp) && aligned16(rowtab) && (!sk || aligned16(sk)) &&
+  PYGAT_REQUIRE(aligned16(GR) && (!sk || aligned16(sk)) &&
                     (mean_mode ? aligned16(y) : (a.rs.Fo != a.rs.Fp || (aligned16(G) && aligned16(y)))),
                 "gat_backward_prepare: row tables must be 16-byte aligned");
   a.n = n; a.flags = flags; a.mean_mode = mean_mode; a.G = G; a.y = y; a.sk = sk; a.s = s; a.m = m; a.Z = Z;
-  a.Gp = Gp; a.rowtab = rowtab;
+  a.GR = GR;
   int lpr, vec;
   pick_lanes(a.rs, &lpr, &vec);
   if (!mean_mode && a.rs.Fo == a.rs.Fp && vec == 1) {
@@ -273,33 +303,24 @@ extern "C" int pygat_gat_backward_prepare(int n, int H, int Fo, int flags, int m
   return PYGAT_OK;
 }
 
-extern "C" int pygat_gat_backward_edge(const pygat_graph* g, int H, int Fo, float alpha, const float* Wh,
-                                       const float* a_pad, const float* Gp, const float* rowtab,
-                                       const float* att_mask, const int32_t* perm_f, float* ebuf, float* dz_f,
-                                       void* stream) {
-  EdgeArgs a;
+extern "C" int pygat_gat_backward_row(const pygat_graph* g, int H, int Fo, float alpha, const float* Wh,
+                                      const float* a_pad, const float* GR, const float* att_mask, float* ds,
+                                      void* part, void* stream) {
+  RowArgs a;
   int rc = check_graph(g, &a.g);
   if (rc) return rc;
-  PYGAT_REQUIRE(make_row_shape(H, Fo, &a.rs), "gat_backward_edge: unsupported H=%d F'=%d", H, Fo);
-  PYGAT_REQUIRE(Wh && a_pad && Gp && rowtab && ebuf && (dz_f || !perm_f), "gat_backward_edge: null pointer");
-  PYGAT_REQUIRE(aligned16(Wh) && aligned16(Gp) && aligned16(rowtab) && aligned16(a_pad), "gat_backward_edge: row tables must be 16-byte aligned");
-  a.alpha = alpha; a.Wh = Wh; a.a_pad = a_pad; a.Gp = Gp; a.rowtab = rowtab; a.mask = att_mask; a.perm = perm_f; a.ebuf = ebuf; a.dzf = dz_f;
+  PYGAT_REQUIRE(make_row_shape(H, Fo, &a.rs), "gat_backward_row: unsupported H=%d F'=%d", H, Fo);
+  PYGAT_REQUIRE(Wh && a_pad && GR && ds && part, "gat_backward_row: null pointer");
+  PYGAT_REQUIRE(aligned16(Wh) && aligned16(GR) && aligned16(a_pad), "gat_backward_row: row tables must be 16-byte aligned");
+  a.alpha = alpha; a.Wh = Wh; a.a_pad = a_pad; a.GR = GR; a.mask = att_mask; a.ds = ds; a.part = (float*)part;
   int lpr, vec;
   pick_lanes(a.rs, &lpr, &vec);
-  const unsigned blocks = (unsigned)cdiv(cdiv(num_slots(a.g), 64 / lpr), 4);
-  PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_bwd_edge_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0,
-                                                    (hipStream_t)stream, a));
-  PYGAT_CHECK_LAUNCH("gat_backward_edge");
-  return PYGAT_OK;
-}
-
-extern "C" int pygat_row_sum_dz(const pygat_graph* g, int H, const float* dz_f, float* ds, void* stream) {
-  GraphDev d;
-  int rc = check_graph(g, &d);
-  if (rc) return rc;
-  PYGAT_REQUIRE(H > 0 && dz_f && ds, "row_sum_dz: bad arguments");
-  hipLaunchKernelGGL(row_sum_dz_kernel, dim3((unsigned)cdiv((int64_t)d.n * H, 256)), dim3(256), 0, (hipStream_t)stream,
-                     d.n, H, d.rowptr, dz_f, ds);
-  PYGAT_CHECK_LAUNCH("row_sum_dz");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nslots = num_slots(a.g);
+  const unsigned blocks = (unsigned)cdiv(cdiv(nslots, 64 / lpr), 4);
+  PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_bwd_row_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0, st, a));
+  PYGAT_CHECK_LAUNCH("gat_backward_row");
+  hipLaunchKernelGGL(gat_bwd_row_fixup_kernel, dim3((unsigned)cdiv(nslots * H, 256)), dim3(256), 0, st, a);
+  PYGAT_CHECK_LAUNCH("gat_backward_row_fixup");
   return PYGAT_OK;
 }

@@ -1,45 +1,43 @@
-// K4 -- backward, column pass: dWh, dt, ds (gfx950, wave64).
+// K4 -- backward, column pass: dWh, dt (gfx950, wave64).
 //
 // Replaces `grad_b = a.t().matmul(grad_output)` of SpecialSpmmFunction.backward (reference
 // layers.py:89) -- the transposed SpMM -- plus the autograd of the two a-halves matmuls
 // (layers.py:60-61):
-//     dWh_j = sum_i alpha_ij Gp_i + ds_j a_src + dt_j a_dst
-//     dt_j  = sum_i dz_ij          (column sums of dz)
-//     ds_j  = sum_k dz_jk          (row sums of dz)
-// nnz split over the TRANSPOSED pattern: slot walks transposed edges (j <- i), gathers Gp_i (one
-// head-interleaved row, 16 B per lane); the (alpha, dz) pairs are either gathered through perm_t
-// (wide rows) or were scattered by K3b into this order and stream in sequentially (narrow rows).  For a symmetric pattern the transposed CSR has the
-// forward layout, so position k is also the forward edge (j, col[k]) and ds_j is accumulated from
-// dz_f[k] on the way -- no atomics, no second pass.  Rows cut by a slot border go through `part` + a fix-up launch (fixed order).
+//     dWh_j = sum_i alpha~_ij Gp_i + ds_j a_src + dt_j a_dst        alpha~ = alpha * dropout mask
+//     dt_j  = sum_i dz_ij                                            (column sums of dz)
+// nnz split over the TRANSPOSED pattern: a slot walks transposed edges (j <- i) and gathers ONE
+// contiguous row per edge, GR_i = [Gp_i | (s_i, m_i, 1/Z_i, D_i) per head]; with the row-local Wh_j
+// (and t_j = Wh_j . a_dst) it recomputes alpha_ij and dz_ij in registers instead of reading a
+// per-edge buffer through the edge permutation.  ds comes from K3b.  Rows cut by a slot border go
+// through `part` + a fix-up launch (fixed order).  No atomics.
 #include "attn_common.h"
 
 namespace pygat {
 
 struct ColArgs {
-  GraphDev g;  // transposed pattern
+  GraphDev g;  // transposed pattern: rc[k] = (j, i) for the forward edge (i, j)
   RowShape rs;
-  const int32_t* perm;  // nullptr: ebuf is in this (transposed) order; else forward edge of each edge here
-  int symmetric;
-  const float* Gp;
-  const float* ebuf;  // [nnz][2][H] (alpha, dz)
-  const float* dzf;   // [nnz][H] dz in forward edge order (== this order's positions if symmetric)
+  float alpha;
+  const int32_t* perm;  // transposed position -> forward edge (only to index the dropout mask)
+  const float* mask;    // [nnz][H] attention dropout mask in FORWARD edge order, or nullptr
+  const float* Wh;
+  const float* GR;
   const float* a_pad;
+  const float* ds;
   float* dWh;
-  float* ds;
   float* dt;
-  float* part;  // [2 * nslots][R + 2H]: acc[R], dt[H], ds[H]
+  float* part;  // [2 * nslots][R + 2H]: acc[R], dt[H]
 };
 
 template <int VEC>
 __device__ __forceinline__ void col_finish(const ColArgs& a, const LaneCols<VEC>& lc, int j,
-                                           const float4 (&acc)[VEC], const float (&dt)[VEC],
-                                           const float (&ds)[VEC]) {
+                                           const float4 (&acc)[VEC], const float (&dt)[VEC]) {
   const int H = a.rs.H, R = a.rs.R, Fp = a.rs.Fp;
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
     if (!lc.valid[v]) continue;
     const int co = lc.cofs[v], h = lc.head[v], f0 = co & (Fp - 1);
-    const float dsj = a.symmetric ? ds[v] : a.ds[(int64_t)j * H + h];
+    const float dsj = a.ds[(int64_t)j * H + h];
     const float4 as = ld4(a.a_pad + (int64_t)h * 2 * Fp + f0);
     const float4 ad = ld4(a.a_pad + (int64_t)h * 2 * Fp + Fp + f0);
     float4 o;
@@ -48,30 +46,24 @@ __device__ __forceinline__ void col_finish(const ColArgs& a, const LaneCols<VEC>
     o.z = acc[v].z + dsj * as.z + dt[v] * ad.z;
     o.w = acc[v].w + dsj * as.w + dt[v] * ad.w;
     st4(a.dWh + (int64_t)j * R + co, o);
-    if (((co >> 2) & (a.rs.lph - 1)) == 0) {
-      a.dt[(int64_t)j * H + h] = dt[v];
-      if (a.symmetric) a.ds[(int64_t)j * H + h] = ds[v];
-    }
+    if (((co >> 2) & (a.rs.lph - 1)) == 0) a.dt[(int64_t)j * H + h] = dt[v];
   }
 }
 
 template <int VEC>
 __device__ __forceinline__ void col_flush(const ColArgs& a, const LaneCols<VEC>& lc, int64_t k, int j,
                                           bool is_head, bool is_tail, const float4 (&acc)[VEC],
-                                          const float (&dt)[VEC], const float (&ds)[VEC]) {
+                                          const float (&dt)[VEC]) {
   if (is_head || is_tail) {
     float* p = a.part + (2 * k + (is_head ? 0 : 1)) * (int64_t)(a.rs.R + 2 * a.rs.H);
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       if (!lc.valid[v]) continue;
       st4(p + lc.cofs[v], acc[v]);
-      if (((lc.cofs[v] >> 2) & (a.rs.lph - 1)) == 0) {
-        p[a.rs.R + lc.head[v]] = dt[v];
-        p[a.rs.R + a.rs.H + lc.head[v]] = ds[v];
-      }
+      if (((lc.cofs[v] >> 2) & (a.rs.lph - 1)) == 0) p[a.rs.R + lc.head[v]] = dt[v];
     }
   } else {
-    col_finish<VEC>(a, lc, j, acc, dt, ds);
+    col_finish<VEC>(a, lc, j, acc, dt);
   }
 }
 
@@ -86,59 +78,73 @@ __global__ __launch_bounds__(256) void gat_bwd_col_kernel(ColArgs a) {
   slot_range(a.g, k, &e0, &e1);
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
   const int H = a.rs.H, R = a.rs.R;
+  const int64_t RW = R + 4 * H;
+  const int lph = a.rs.lph < 64 ? a.rs.lph : 64;
   const int2* __restrict__ rc = a.g.rc;
+  float4 adst[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    adst[v] = ld4(a.a_pad + (int64_t)lc.head[v] * 2 * a.rs.Fp + a.rs.Fp + (lc.cofs[v] & (a.rs.Fp - 1)));
+    if (!lc.valid[v]) adst[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   const int r_first = rc[e0].x;
   const bool head_partial = a.g.rowptr[r_first] < e0;
   int cur = r_first;
   float4 acc[VEC];
-  float dt[VEC], ds[VEC];
+  float dt[VEC];
 #pragma unroll
-  for (int v = 0; v < VEC; ++v) { acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); dt[v] = 0.f; ds[v] = 0.f; }
+  for (int v = 0; v < VEC; ++v) { acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); dt[v] = 0.f; }
 
   for (int64_t e = e0; e < e1; e += U) {
-    int2 p[U];
-    int64_t pe[U];
+    int2 p[U];  // (j, i): j = this (transposed) row, i = the forward row that attends to j
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t ee = (e + u < e1) ? e + u : e1 - 1;
-      p[u] = rc[ee];
-      pe[u] = a.perm ? (int64_t)a.perm[ee] : ee;
-    }
-    float al[U][VEC], dz[U][VEC], dzo[U][VEC];
-    float4 gv[U][VEC];
+    for (int u = 0; u < U; ++u) p[u] = rc[(e + u < e1) ? e + u : e1 - 1];
+    float4 rt[U][VEC], gv[U][VEC], wv[U][VEC];
+    float mk[U][VEC];
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
-        const int64_t ee = (e + u < e1) ? e + u : e1 - 1;
-        const float* eb = a.ebuf + pe[u] * 2 * H + lc.head[v];
-        al[u][v] = eb[0];
-        dz[u][v] = eb[H];
-        // ds_j: dz of the forward edge at this same position (symmetric patterns only)
-        dzo[u][v] = !a.symmetric ? 0.f : (a.perm ? a.ebuf[ee * 2 * H + H + lc.head[v]] : a.dzf[ee * H + lc.head[v]]);
-        gv[u][v] = ld4(a.Gp + (int64_t)p[u].y * R + lc.cofs[v]);
+        const float* gr = a.GR + (int64_t)p[u].y * RW;           // gathered: one contiguous row
+        gv[u][v] = ld4(gr + lc.cofs[v]);
+        rt[u][v] = ld4(gr + R + 4 * lc.head[v]);
+        wv[u][v] = ld4(a.Wh + (int64_t)p[u].x * R + lc.cofs[v]);  // row-local (L1 after the first edge)
+        mk[u][v] = 1.f;
+        if (a.mask) mk[u][v] = a.mask[(int64_t)a.perm[(e + u < e1) ? e + u : e1 - 1] * H + lc.head[v]];
+      }
+    float al[U][VEC], dz[U][VEC];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const float dp = group_sum_rt(lc.valid[v] ? dot4(gv[u][v], wv[u][v]) : 0.f, lph);
+        const float tj = group_sum_rt(dot4(wv[u][v], adst[v]), lph);
+        const float zz = rt[u][v].x + tj;
+        const float ev = zz > 0.f ? zz : a.alpha * zz;
+        const float a0 = __expf(ev - rt[u][v].y) * rt[u][v].z;
+        dz[u][v] = a0 * (mk[u][v] * dp - rt[u][v].w) * (zz > 0.f ? 1.f : a.alpha);
+        al[u][v] = a0 * mk[u][v];
       }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (e + u < e1) {
         if (p[u].x != cur) {
-          col_flush<VEC>(a, lc, k, cur, cur == r_first && head_partial, false, acc, dt, ds);
+          col_flush<VEC>(a, lc, k, cur, cur == r_first && head_partial, false, acc, dt);
           cur = p[u].x;
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) { acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); dt[v] = 0.f; ds[v] = 0.f; }
+          for (int v = 0; v < VEC; ++v) { acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); dt[v] = 0.f; }
         }
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           acc[v].x = fmaf(al[u][v], gv[u][v].x, acc[v].x); acc[v].y = fmaf(al[u][v], gv[u][v].y, acc[v].y);
           acc[v].z = fmaf(al[u][v], gv[u][v].z, acc[v].z); acc[v].w = fmaf(al[u][v], gv[u][v].w, acc[v].w);
           dt[v] += dz[u][v];
-          ds[v] += dzo[u][v];
         }
       }
     }
   }
   const bool tail_partial = a.g.rowptr[cur + 1] > e1;
-  col_flush<VEC>(a, lc, k, cur, cur == r_first && head_partial, tail_partial, acc, dt, ds);
+  col_flush<VEC>(a, lc, k, cur, cur == r_first && head_partial, tail_partial, acc, dt);
 }
 
 // Fix-up of cut rows (same scheme as gat_fwd_fixup_kernel): a work-group screens FIX_SCREEN slots, the
@@ -175,14 +181,14 @@ __global__ __launch_bounds__(256) void gat_bwd_col_fixup_kernel(ColArgs a) {
     const int npieces = (int)(k_e - k) + 1;
     const bool wide = npieces > EPW * PF;
     float4 acc[VEC];
-    float dt[VEC], ds[VEC];
+    float dt[VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) { acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); dt[v] = 0.f; ds[v] = 0.f; }
+    for (int v = 0; v < VEC; ++v) { acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); dt[v] = 0.f; }
     if (wide || w == 0) {
       const int nw = wide ? 4 : 1;
       for (int q = (wide ? w : 0) * EPW * PF + slot; q < npieces; q += nw * EPW * PF) {
         float4 xp[PF][VEC];
-        float tp[PF][VEC], sp[PF][VEC];
+        float tp[PF][VEC];
 #pragma unroll
         for (int f = 0; f < PF; ++f) {
           const int qq = q + f * EPW;
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(256) void gat_bwd_col_fixup_kernel(ColArgs a) {
           const float* p = a.part + (qc == 0 ? 2 * k + 1 : 2 * (k + qc)) * PS;
 #pragma unroll
           for (int v = 0; v < VEC; ++v) {
-            xp[f][v] = ld4(p + lc.cofs[v]); tp[f][v] = p[a.rs.R + lc.head[v]]; sp[f][v] = p[a.rs.R + a.rs.H + lc.head[v]];
+            xp[f][v] = ld4(p + lc.cofs[v]); tp[f][v] = p[a.rs.R + lc.head[v]];
           }
         }
 #pragma unroll
@@ -200,7 +206,6 @@ __global__ __launch_bounds__(256) void gat_bwd_col_fixup_kernel(ColArgs a) {
             for (int v = 0; v < VEC; ++v) {
               acc[v].x += xp[f][v].x; acc[v].y += xp[f][v].y; acc[v].z += xp[f][v].z; acc[v].w += xp[f][v].w;
               dt[v] += tp[f][v];
-              ds[v] += sp[f][v];
             }
           }
       }
@@ -208,7 +213,6 @@ __global__ __launch_bounds__(256) void gat_bwd_col_fixup_kernel(ColArgs a) {
       for (int v = 0; v < VEC; ++v) {
         acc[v] = slot_sum4<LPR>(acc[v]);
         dt[v] = slot_sum<LPR>(dt[v]);
-        ds[v] = slot_sum<LPR>(ds[v]);
       }
     }
     if (wide) {
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(256) void gat_bwd_col_fixup_kernel(ColArgs a) {
         for (int v = 0; v < VEC; ++v)
           if (lc.valid[v]) {
             st4(p + lc.cofs[v], acc[v]);
-            if (((lc.cofs[v] >> 2) & (a.rs.lph - 1)) == 0) { p[a.rs.R + lc.head[v]] = dt[v]; p[a.rs.R + a.rs.H + lc.head[v]] = ds[v]; }
+            if (((lc.cofs[v] >> 2) & (a.rs.lph - 1)) == 0) p[a.rs.R + lc.head[v]] = dt[v];
           }
       }
       __syncthreads();
@@ -231,13 +235,12 @@ __global__ __launch_bounds__(256) void gat_bwd_col_fixup_kernel(ColArgs a) {
             const float4 x = ld4(p + lc.cofs[v]);
             acc[v].x += x.x; acc[v].y += x.y; acc[v].z += x.z; acc[v].w += x.w;
             dt[v] += p[a.rs.R + lc.head[v]];
-            ds[v] += p[a.rs.R + a.rs.H + lc.head[v]];
           }
         }
       }
       __syncthreads();
     }
-    if (w == 0 && slot == 0) col_finish<VEC>(a, lc, r, acc, dt, ds);
+    if (w == 0 && slot == 0) col_finish<VEC>(a, lc, r, acc, dt);
   }
 }
 
@@ -245,18 +248,20 @@ __global__ __launch_bounds__(256) void gat_bwd_col_fixup_kernel(ColArgs a) {
 
 using namespace pygat;
 
-extern "C" int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm_t, int symmetric, int H, int Fo,
-                                      const float* Gp, const float* ebuf, const float* dz_f, const float* a_pad, float* dWh,
-                                      float* ds, float* dt, void* part, void* stream) {
+extern "C" int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm_t, int H, int Fo, float alpha,
+                                      const float* Wh, const float* a_pad, const float* GR,
+                                      const float* att_mask, const float* ds, float* dWh, float* dt, void* part,
+                                      void* stream) {
   ColArgs a;
   int rc = check_graph(gT, &a.g);
   if (rc) return rc;
   PYGAT_REQUIRE(make_row_shape(H, Fo, &a.rs), "gat_backward_col: unsupported H=%d F'=%d", H, Fo);
-  PYGAT_REQUIRE(Gp && ebuf && (dz_f || perm_t || !symmetric) && ds && a_pad && dWh && dt && part, "gat_backward_col: null pointer");
-  PYGAT_REQUIRE(aligned16(Gp) && aligned16(dWh) && aligned16(a_pad) && aligned16(part),
+  PYGAT_REQUIRE(Wh && a_pad && GR && ds && dWh && dt && part, "gat_backward_col: null pointer");
+  PYGAT_REQUIRE(!att_mask || perm_t, "gat_backward_col: an attention mask needs perm_t (mask is in forward edge order)");
+  PYGAT_REQUIRE(aligned16(Wh) && aligned16(GR) && aligned16(dWh) && aligned16(a_pad) && aligned16(part),
                 "gat_backward_col: row tables must be 16-byte aligned");
-  a.perm = perm_t; a.symmetric = symmetric; a.Gp = Gp; a.ebuf = ebuf; a.dzf = dz_f; a.a_pad = a_pad; a.dWh = dWh; a.ds = ds;
-  a.dt = dt; a.part = (float*)part;
+  a.alpha = alpha; a.perm = perm_t; a.mask = att_mask; a.Wh = Wh; a.GR = GR; a.a_pad = a_pad; a.ds = ds;
+  a.dWh = dWh; a.dt = dt; a.part = (float*)part;
   int lpr, vec;
   pick_lanes(a.rs, &lpr, &vec);
   hipStream_t st = (hipStream_t)stream;

@@ -52,7 +52,6 @@ class GATLevelDropoutFn(torch.autograd.Function):
             Wskip = Wskip.contiguous().float()
         L = _Level(x, H, Fo, skip)
         L.ts = graph.slot_edges
-        L.ts_edge = slot_edges_for(L.R, graph.slot_edges)
         dev, f32 = x.device, torch.float32
         mask_x = mask_x.to(f32).contiguous(); mask_att = mask_att.to(f32).contiguous()
         # Wh mask in the padded head-interleaved layout [N, H, Fp]
@@ -100,27 +99,22 @@ class GATLevelDropoutFn(torch.autograd.Function):
         G = G.contiguous().float()
         with torch.cuda.device(dev):
             st = _stream()
-            Gp = torch.empty(L.N, L.R, dtype=f32, device=dev)
-            rowtab = torch.empty(L.N, H, 4, dtype=f32, device=dev)
-            ebuf = torch.empty(graph.nnz, 2, H, dtype=f32, device=dev)
-            scatter = L.scatter or not graph.symmetric   # asymmetric patterns need dz in forward order for ds
-            dzf = torch.empty(graph.nnz, H, dtype=f32, device=dev) if scatter else None
+            RW = L.R + 4 * H
+            GR = torch.empty(L.N, RW, dtype=f32, device=dev)
+            Gp = GR[:, :L.R]
             ds = torch.empty(L.N, H, dtype=f32, device=dev); dt = torch.empty(L.N, H, dtype=f32, device=dev)
             dWh = torch.empty(L.N, L.R, dtype=f32, device=dev)
             part = torch.empty(lib.pygat_partials_bytes(graph.nnz, L.ts, H, L.Fp) // 4, dtype=f32, device=dev)
             check(lib.pygat_gat_backward_prepare(L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(), y.data_ptr(),
-                                                 _ptr(Sk), s.data_ptr(), m.data_ptr(), Z.data_ptr(), Gp.data_ptr(),
-                                                 rowtab.data_ptr(), st), "gat_backward_prepare")
-            check(lib.pygat_gat_backward_edge(graph.fwd.ref(L.ts_edge, snapped=False), H, Fo, ctx.alpha, Wh.data_ptr(), a_pad.data_ptr(),
-                                              Gp.data_ptr(), rowtab.data_ptr(), mask_att.data_ptr(),
-                                              graph.perm_f.data_ptr() if scatter else None, ebuf.data_ptr(), _ptr(dzf), st),
-                  "gat_backward_edge")
-            if not graph.symmetric:
-                check(lib.pygat_row_sum_dz(graph.fwd.ref(L.ts), H, dzf.data_ptr(), ds.data_ptr(), st), "row_sum_dz")
-            check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), None if scatter else graph.perm_t.data_ptr(),
-                                                 int(graph.symmetric), H, Fo,
-                                             Gp.data_ptr(), ebuf.data_ptr(), _ptr(dzf), a_pad.data_ptr(), dWh.data_ptr(),
-                                             ds.data_ptr(), dt.data_ptr(), part.data_ptr(), st), "gat_backward_col")
+                                                 _ptr(Sk), s.data_ptr(), m.data_ptr(), Z.data_ptr(), GR.data_ptr(), st),
+                  "gat_backward_prepare")
+            check(lib.pygat_gat_backward_row(graph.fwd.ref(L.ts), H, Fo, ctx.alpha, Wh.data_ptr(), a_pad.data_ptr(),
+                                             GR.data_ptr(), mask_att.data_ptr(), ds.data_ptr(), part.data_ptr(), st),
+                  "gat_backward_row")
+            check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), graph.perm_t.data_ptr(), H, Fo, ctx.alpha,
+                                             Wh.data_ptr(), a_pad.data_ptr(), GR.data_ptr(), mask_att.data_ptr(),
+                                             ds.data_ptr(), dWh.data_ptr(), dt.data_ptr(), part.data_ptr(), st),
+                  "gat_backward_col")
             da = torch.empty(H, 2 * Fo, dtype=f32, device=dev)
             ws = torch.empty(lib.pygat_agrad_workspace_bytes(H, Fo) // 4, dtype=f32, device=dev)
             check(lib.pygat_a_grad(L.N, H, Fo, Wh.data_ptr(), ds.data_ptr(), dt.data_ptr(), da.data_ptr(), ws.data_ptr(), st),
@@ -136,12 +130,12 @@ class GATLevelDropoutFn(torch.autograd.Function):
                 c0 = h * L.Fp
                 gemm(True, False, L.Fin, L.Fp, L.N, xh, L.Fin, dWh[:, c0:], L.R, [(L.Fp, dWc[:, c0:], L.R)])
                 if L.skip:
-                    gemm(True, False, L.Fin, L.Fp, L.N, xh, L.Fin, Gp[:, c0:], L.R, [(L.Fp, dSc[:, c0:], L.R)])
+                    gemm(True, False, L.Fin, L.Fp, L.N, xh, L.Fin, Gp[:, c0:], RW, [(L.Fp, dSc[:, c0:], L.R)])
                 if need_dx:
                     gemm(False, True, L.N, L.Fin, L.Fp, dWh[:, c0:], L.R, Wcat[:, c0:], L.ldw, [(L.Fin, dxh, L.Fin)],
                          split_k=1)
                     if L.skip:
-                        gemm(False, True, L.N, L.Fin, L.Fp, Gp[:, c0:], L.R, Wcat[:, L.R + c0:], L.ldw,
+                        gemm(False, True, L.N, L.Fin, L.Fp, Gp[:, c0:], RW, Wcat[:, L.R + c0:], L.ldw,
                              [(L.Fin, dxh, L.Fin)], accumulate=True, split_k=1)
                     dx.addcmul_(dxh, mask_x[h])    # back through the per-head input dropout
             dW = torch.empty(H, L.Fin, Fo, dtype=f32, device=dev)

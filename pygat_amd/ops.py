@@ -108,10 +108,7 @@ class _Level:
         if self.R > 1024:
             raise ValueError(f"pygat_amd: H*pad(F') = {self.R} > 1024 per call; shard the heads")
         self.ldw = -(-(self.R * (2 if skip else 1) + 2 * H) // 4) * 4
-        self.ts = 0        # slot length of K2 / K4 (rows cut by a slot border cost a partial record)
-        self.ts_edge = 0   # slot length of K3b (no reduction, no partials: shorter slots for narrow rows)
-        # (alpha, dz) hand-off K3b -> K4: scatter into transposed order for narrow rows, gather for wide ones
-        self.scatter = self.R <= 32
+        self.ts = 0        # slot length of the nnz-split kernels (rows cut by a slot border cost a partial record)
 
 
 class GATLevelFn(torch.autograd.Function):
@@ -133,7 +130,6 @@ class GATLevelFn(torch.autograd.Function):
             Wskip = Wskip.contiguous().float()
         L = _Level(x, H, Fo, skip)
         L.ts = graph.slot_edges
-        L.ts_edge = slot_edges_for(L.R, graph.slot_edges)
         dev, f32 = x.device, torch.float32
         need_grad = any(ctx.needs_input_grad[:4])
         with torch.cuda.device(dev):
@@ -179,11 +175,9 @@ class GATLevelFn(torch.autograd.Function):
         G = G.contiguous().float()
         with torch.cuda.device(dev):
             st = _stream()
-            Gp = torch.empty(L.N, L.R, dtype=f32, device=dev)
-            rowtab = torch.empty(L.N, H, 4, dtype=f32, device=dev)
-            ebuf = torch.empty(graph.nnz, 2, H, dtype=f32, device=dev)
-            scatter = L.scatter or not graph.symmetric   # asymmetric patterns need dz in forward order for ds
-            dzf = torch.empty(graph.nnz, H, dtype=f32, device=dev) if scatter else None
+            RW = L.R + 4 * H
+            GR = torch.empty(L.N, RW, dtype=f32, device=dev)      # [Gp | (s, m, 1/Z, D) per head]
+            Gp = GR[:, :L.R]                                      # view, row stride RW
             ds = torch.empty(L.N, H, dtype=f32, device=dev)
             dt = torch.empty(L.N, H, dtype=f32, device=dev)
             dWh = torch.empty(L.N, L.R, dtype=f32, device=dev)
@@ -192,19 +186,15 @@ class GATLevelFn(torch.autograd.Function):
             with _span("k3a_prepare"):
                 check(lib.pygat_gat_backward_prepare(L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(),
                                                      y.data_ptr(), _ptr(Sk), s.data_ptr(), m.data_ptr(), Z.data_ptr(),
-                                                     Gp.data_ptr(), rowtab.data_ptr(), st), "gat_backward_prepare")
-            with _span("k3b_edge"):
-                check(lib.pygat_gat_backward_edge(graph.fwd.ref(L.ts_edge, snapped=False), H, Fo, ctx.alpha, Wh.data_ptr(),
-                                                  a_pad.data_ptr(), Gp.data_ptr(), rowtab.data_ptr(), None,
-                                                  graph.perm_f.data_ptr() if scatter else None, ebuf.data_ptr(), _ptr(dzf), st),
-                      "gat_backward_edge")
-            if not graph.symmetric:
-                check(lib.pygat_row_sum_dz(graph.fwd.ref(L.ts), H, dzf.data_ptr(), ds.data_ptr(), st), "row_sum_dz")
+                                                     GR.data_ptr(), st), "gat_backward_prepare")
+            with _span("k3b_row"):
+                check(lib.pygat_gat_backward_row(graph.fwd.ref(L.ts), H, Fo, ctx.alpha, Wh.data_ptr(),
+                                                 a_pad.data_ptr(), GR.data_ptr(), None, ds.data_ptr(),
+                                                 part.data_ptr(), st), "gat_backward_row")
             with _span("k4_backward_col"):
-                check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), None if scatter else graph.perm_t.data_ptr(),
-                                                 int(graph.symmetric), H, Fo,
-                                                 Gp.data_ptr(), ebuf.data_ptr(), _ptr(dzf), a_pad.data_ptr(), dWh.data_ptr(),
-                                                 ds.data_ptr(), dt.data_ptr(), part.data_ptr(), st),
+                check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), None, H, Fo, ctx.alpha, Wh.data_ptr(),
+                                                 a_pad.data_ptr(), GR.data_ptr(), None, ds.data_ptr(),
+                                                 dWh.data_ptr(), dt.data_ptr(), part.data_ptr(), st),
                       "gat_backward_col")
             # da
             da = torch.empty(H, 2 * Fo, dtype=f32, device=dev)
@@ -222,7 +212,7 @@ class GATLevelFn(torch.autograd.Function):
                 check(lib.pygat_unpack_wgrad(H, L.Fin, Fo, dWc.data_ptr(), L.R, 0, dW.data_ptr(), st), "unpack")
             if L.skip and ctx.needs_input_grad[3]:
                 dSc = torch.empty(L.Fin, L.R, dtype=f32, device=dev)
-                gemm(True, False, L.Fin, L.R, L.N, x, L.Fin, Gp, L.R, [(L.R, dSc, L.R)])
+                gemm(True, False, L.Fin, L.R, L.N, x, L.Fin, Gp, RW, [(L.R, dSc, L.R)])
                 dWs = torch.empty(H, L.Fin, Fo, dtype=f32, device=dev)
                 check(lib.pygat_unpack_wgrad(H, L.Fin, Fo, dSc.data_ptr(), L.R, 0, dWs.data_ptr(), st), "unpack")
             # dx = dWh Wcat[:, :R]^T (+ Gp Wcat[:, R:2R]^T)
@@ -231,7 +221,7 @@ class GATLevelFn(torch.autograd.Function):
                 with _span("k5_xgrad"):
                     gemm(False, True, L.N, L.Fin, L.R, dWh, L.R, Wcat, L.ldw, [(L.Fin, dx, L.Fin)])
                     if L.skip:
-                        gemm(False, True, L.N, L.Fin, L.R, Gp, L.R, Wcat[:, L.R:], L.ldw, [(L.Fin, dx, L.Fin)],
+                        gemm(False, True, L.N, L.Fin, L.R, Gp, RW, Wcat[:, L.R:], L.ldw, [(L.Fin, dx, L.Fin)],
                              accumulate=True, split_k=1)
         return dx, dW, (da if ctx.needs_input_grad[2] else None), dWs, None, None, None
 

@@ -52,36 +52,32 @@ def main():
     a_pad = torch.randn(H, 2, Fp, generator=g2, device=dev)
     out = torch.empty(N, H * Fo, device=dev); hattn = torch.empty(N, R, device=dev)
     m = torch.empty(N, H, device=dev); Z = torch.empty(N, H, device=dev)
-    Gp = torch.empty(N, R, device=dev); ebuf = torch.empty(E, 2, H, device=dev)
-    rowtab = torch.empty(N, H, 4, device=dev); dzf = torch.empty(E, H, device=dev)
     ds = torch.empty(N, H, device=dev); dt = torch.empty(N, H, device=dev); dWh = torch.empty(N, R, device=dev)
     part = torch.empty(max(1, lib.pygat_partials_bytes(E, args.ts, H, Fp) // 4), device=dev)
     P = lambda x: None if x is None else x.data_ptr()
-    scatter = R <= 32 or not graph.symmetric
 
     def k2(train=True):
         check(lib.pygat_gat_forward(graph.fwd.ref(), H, Fo, 0.2, _lib.F_ELU, P(Wh), P(s), P(a_pad), None, None, P(out),
                                     None, P(m) if train else None, P(Z) if train else None, P(part), None))
 
+    GR = torch.empty(N, R + 4 * H, device=dev)
+
     def k3a():
-        check(lib.pygat_gat_backward_prepare(N, H, Fo, _lib.F_ELU, 0, P(G), P(out), None, P(s), P(m), P(Z), P(Gp),
-                                             P(rowtab), None))
+        check(lib.pygat_gat_backward_prepare(N, H, Fo, _lib.F_ELU, 0, P(G), P(out), None, P(s), P(m), P(Z), P(GR), None))
 
     def k3b():
-        check(lib.pygat_gat_backward_edge(graph.fwd.ref(snapped=False), H, Fo, 0.2, P(Wh), P(a_pad), P(Gp), P(rowtab), None,
-                                          P(graph.perm_f) if scatter else None, P(ebuf), P(dzf), None))
+        check(lib.pygat_gat_backward_row(graph.fwd.ref(), H, Fo, 0.2, P(Wh), P(a_pad), P(GR), None, P(ds), P(part), None))
 
     def k4():
-        check(lib.pygat_gat_backward_col(graph.bwd.ref(), None if scatter else P(graph.perm_t), int(graph.symmetric), H, Fo,
-                                         P(Gp), P(ebuf), P(dzf),
-                                         P(a_pad), P(dWh), P(ds), P(dt), P(part), None))
+        check(lib.pygat_gat_backward_col(graph.bwd.ref(), None, H, Fo, 0.2, P(Wh), P(a_pad), P(GR), None, P(ds),
+                                         P(dWh), P(dt), P(part), None))
 
     b_fwd = E * (4 + 4 * H + 4 * R) + N * (4 + 4 * H + 4 * R + 8 * H)
     b_k3a = N * (12 * R + 12 * H + 16 * H)
     b_k3 = E * (4 + 4 * R + 8 * H) + N * (4 + 8 * R + 16 * H)
     b_k4 = E * (8 + 4 * R + 8 * H) + N * (4 + 8 * R + 8 * H)
     runs = [("k2_train", lambda: k2(True), b_fwd), ("k2_eval", lambda: k2(False), b_fwd - N * 8 * H),
-            ("k3a_prep", k3a, b_k3a), ("k3b_edge", k3b, b_k3 - b_k3a), ("k4_col", k4, b_k4)]
+            ("k3a_prep", k3a, b_k3a), ("k3b_row", k3b, b_k3 - b_k3a), ("k4_col", k4, b_k4)]
     if args.only:
         runs = [r for r in runs if r[0] in args.only.split(",")]
     deg = (rowptr[1:] - rowptr[:-1])

@@ -159,6 +159,15 @@ def main():
         b_fwd = E * (4 + 4 * h_loc + 4 * R) + N * (4 + 4 * h_loc + 4 * R + 8 * h_loc)
         k2 = kt.get("k2_forward", float("nan"))
         achieved = b_fwd / (k2 * 1e-3) / 1e9
+        # HBM traffic of K2 from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+        # runs of this same command; FETCH_SIZE doubled as the gfx950 guide prescribes): main + fix-up launch.
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_k2_latest.json")))
+            if pmc.get("workload_edges") == E and pmc.get("heads_per_gpu") == h_loc:
+                traffic = pmc["k2_hbm_traffic_bytes"]
+        except Exception:
+            traffic = None
         line = {
             "metric": "GAT-layer fwd+bwd edges/sec", "value": E / (ms * 1e-3), "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -171,7 +180,7 @@ def main():
                        "parallelism": f"head-parallel x{world}" if world > 1 else "single GPU",
                        "heads_per_gpu": h_loc},
             "roofline": {"kernel": "k2_forward (gat_fwd_kernel + combine)", "bound": "hbm", "achieved": achieved,
-                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "algorithmic_bytes": b_fwd, "avg_ms": k2},
             "kernels_ms": kt,
         }

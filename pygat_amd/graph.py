@@ -164,6 +164,20 @@ class CSRGraph:
         return CSRGraph(rowptr, col, slot_edges)
 
     @staticmethod
+    def block_diag(graphs: "list[CSRGraph]") -> "CSRGraph":
+        """Batch of graphs as one block-diagonal pattern (replaces torch.block_diag of the dense
+        adjacencies in the reference's PPI collate, load_data_ppi.py:71-88): CSR concatenation with
+        row and column offsets, no N x N tensor."""
+        rps, cols, noff, eoff = [], [], 0, 0
+        for g in graphs:
+            rp = g.fwd.rowptr.long()
+            rps.append(rp[(1 if rps else 0):] + eoff)
+            cols.append(g.fwd.col.long() + noff)
+            noff += g.n
+            eoff += g.nnz
+        return CSRGraph(torch.cat(rps).to(torch.int32), torch.cat(cols).to(torch.int32), graphs[0].slot_edges)
+
+    @staticmethod
     def from_edge_index(row: torch.Tensor, col: torch.Tensor, n: int,
                         slot_edges: int = DEFAULT_SLOT_EDGES) -> "CSRGraph":
         """COO (row=i, col=j), duplicates removed, rows sorted."""

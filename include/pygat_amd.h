@@ -200,6 +200,28 @@ size_t pygat_agrad_workspace_bytes(int H, int Fo);
 int pygat_a_grad(int n, int H, int Fo, const float* Wh, const float* ds, const float* dt,
                  float* da, void* ws, void* stream);
 
+/* ------------------------------------------------ GATv2 (next row of the scope table)
+ * The reference's SpGraphAttentionLayerV2 (layers.py:258-313): per head
+ *   e_ij = a . LeakyReLU(Whi_i + Whj_j), alpha = row softmax, h'_i = sum_j alpha_ij Whi_j  (Whi is aggregated,
+ *   layers.py:296).  WW [n x 2R] holds [Whi | Whj] rows (one projection GEMM with W[:Fin] and W[Fin:]),
+ *   a2 [H x Fp] the zero-padded attention vectors.  Same outputs / flags / part as pygat_gat_forward.
+ * (GraphAttentionLayerV2, layers.py:204-230, broadcasts one logit per ROW and is therefore a neighbour mean:
+ *  it maps onto pygat_gat_forward with s = 0 and a = 0.)
+ */
+int pygat_gatv2_forward(const pygat_graph* g, int H, int Fo, float alpha, int flags,
+                        const float* WW, const float* a2, const float* sk, const float* att_mask,
+                        float* out, float* hattn, float* m, float* Z, void* part, void* stream);
+/* GRW [n x (2R+4H)] = [Gp | (., m, 1/Z, D) per head | Whi]; G, y, sk, mean_mode as pygat_gat_backward_prepare. */
+int pygat_gatv2_backward_prepare(int n, int H, int Fo, int flags, int mean_mode,
+                                 const float* G, const float* y, const float* sk,
+                                 const float* m, const float* Z, const float* WW, float* GRW, void* stream);
+/* Row pass over g + column pass over gT (perm_t only indexes att_mask, may be NULL without one):
+ *   dWW [n x 2R] = [dWhi | dWhj], da [H x F'];  dwhi_row [n x R] is scratch.  ws >= pygat_gatv2_workspace_bytes. */
+size_t pygat_gatv2_workspace_bytes(int64_t nnz, int slot_edges, int H, int Fo);
+int pygat_gatv2_backward(const pygat_graph* g, const pygat_graph* gT, const int32_t* perm_t, int H, int Fo,
+                         float alpha, const float* WW, const float* a2, const float* GRW,
+                         const float* att_mask, float* dwhi_row, float* dWW, float* da, void* ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

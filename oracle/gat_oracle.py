@@ -11,6 +11,8 @@ imported in the build container: `layers.py:5` imports `torch_scatter`
 which is not installed and stays absent.  This file is therefore a restatement,
 in our own words, of the algorithm as read from the reference source:
 
+  GATv2 variants      layers.py:179-232 (dense V2, incl. its row-broadcast of the
+                      logits = neighbour mean), layers.py:234-316 (sparse V2)
   dense formulation   layers.py:32-64   (GraphAttentionLayer.forward and
                                          _prepare_attentional_mechanism_input)
   sparse formulation  layers.py:125-173 (SpGraphAttentionLayer.forward) with
@@ -104,6 +106,82 @@ def sparse_head_forward(h, rowptr, col, W, a, alpha, concat, W_skip=None,
     if W_skip is not None:                       # layers.py:165-166
         hp = hp + h @ W_skip
     return F.elu(hp) if concat else hp           # layers.py:168-173
+
+
+# --------------------------------------------------------------------------
+# GATv2 variants as the reference WRITES them -- layers.py:179-232 (dense), 234-316 (sparse)
+# --------------------------------------------------------------------------
+def dense_head_forward_v2(h, adj, W, a, alpha, concat, W_skip=None,
+                          mask_x=None, mask_wh1=None, mask_wh2=None, mask_att=None):
+    """GraphAttentionLayerV2.forward.  W [2Fin,F] (layers.py:192), a [F,1] (layers.py:194).
+    NOTE (faithful to the reference): e is [N,1] (layers.py:214) and broadcasts
+    along each ROW in torch.where (layers.py:217), so every neighbour of i gets the same logit and
+    the softmax is uniform: the layer is a neighbour-MEAN of Wh2."""
+    Fin = W.shape[0] // 2
+    if mask_x is not None:                       # layers.py:206
+        h = h * mask_x
+    Wh1 = h @ W[:Fin]                            # layers.py:208
+    Wh2 = h @ W[Fin:]                            # layers.py:209
+    if mask_wh1 is not None:                     # layers.py:211-212
+        Wh1 = Wh1 * mask_wh1
+    if mask_wh2 is not None:
+        Wh2 = Wh2 * mask_wh2
+    e = F.leaky_relu(Wh1 + Wh2, alpha) @ a.reshape(-1, 1)          # layers.py:213-215 -> [N,1]
+    att = torch.where(adj > 0, e, torch.full_like(adj, -9e15))      # layers.py:217-218 (row broadcast)
+    att = torch.softmax(att, dim=1)              # layers.py:219
+    if mask_att is not None:                     # layers.py:220
+        att = att * mask_att
+    hp = att @ Wh2                               # layers.py:221
+    if W_skip is not None:                       # layers.py:224-225
+        hp = hp + h @ W_skip
+    return F.elu(hp) if concat else hp           # layers.py:227-230
+
+
+def sparse_head_forward_v2(h, rowptr, col, W, a, alpha, concat, W_skip=None,
+                           mask_x=None, mask_whi=None, mask_whj=None, mask_edge=None):
+    """SpGraphAttentionLayerV2.forward.  W [2Fin,F] (layers.py:246), a [1,F] (layers.py:249).
+    Scores e_ij = a . LeakyReLU(Whi_i + Whj_j) (layers.py:280-283); NOTE the aggregation gathers
+    Whi at the neighbour, `special_spmm(edge, edge_e, ., Whi)` (layers.py:296), not Whj."""
+    N = h.shape[0]
+    Fin = W.shape[0] // 2
+    rowptr = torch.as_tensor(rowptr, dtype=torch.int64)
+    col = torch.as_tensor(col, dtype=torch.int64)
+    src = torch.repeat_interleave(torch.arange(N), rowptr[1:] - rowptr[:-1])
+    if mask_x is not None:                       # layers.py:266
+        h = h * mask_x
+    Whi = h @ W[:Fin]                            # layers.py:268
+    Whj = h @ W[Fin:]                            # layers.py:269
+    if mask_whi is not None:                     # layers.py:271-272
+        Whi = Whi * mask_whi
+    if mask_whj is not None:
+        Whj = Whj * mask_whj
+    edge_h = Whi[src] + Whj[col]                 # layers.py:280
+    edge_e = F.leaky_relu(edge_h, alpha) @ a.reshape(-1)           # layers.py:283
+    m = torch.full((N,), -float("inf"), dtype=h.dtype).scatter_reduce(
+        0, src, edge_e.detach(), "amax", include_self=True)        # layers.py:285 scatter_max
+    p = torch.exp(edge_e - m[src])               # layers.py:286
+    Z = torch.zeros(N, dtype=h.dtype).index_add(0, src, p)         # layers.py:290
+    if mask_edge is not None:                    # layers.py:293
+        p = p * mask_edge
+    hp = torch.zeros(N, Whi.shape[1], dtype=h.dtype).index_add(0, src, p[:, None] * Whi[col])  # layers.py:296
+    hp = hp / Z[:, None]                         # layers.py:300
+    if W_skip is not None:                       # layers.py:305-306
+        hp = hp + h @ W_skip
+    return F.elu(hp) if concat else hp           # layers.py:308-313
+
+
+def level_forward_v2(x, graph, Ws, As, alpha, concat, W_skips=None, formulation="sparse"):
+    """All heads of a V2 level (models.py:29-35).  Ws [H,2Fin,F], As [H,F]."""
+    outs = []
+    for hd in range(Ws.shape[0]):
+        sk = None if W_skips is None else W_skips[hd]
+        if formulation == "dense":
+            outs.append(dense_head_forward_v2(x, graph, Ws[hd], As[hd], alpha, concat, sk))
+        else:
+            outs.append(sparse_head_forward_v2(x, graph[0], graph[1], Ws[hd], As[hd], alpha, concat, sk))
+    if concat:
+        return torch.cat(outs, dim=1)
+    return torch.mean(torch.stack(outs, dim=1), dim=1)
 
 
 # --------------------------------------------------------------------------

@@ -26,6 +26,7 @@ SYMBOLS = [
     "pygat_edge_pairs", "pygat_slot_bounds", "pygat_partials_bytes", "pygat_gat_forward", "pygat_head_mean",
     "pygat_gat_backward_prepare", "pygat_gat_backward_row", "pygat_gat_backward_col",
     "pygat_agrad_workspace_bytes", "pygat_a_grad",
+    "pygat_gatv2_forward", "pygat_gatv2_backward_prepare", "pygat_gatv2_workspace_bytes", "pygat_gatv2_backward",
 ]
 
 
@@ -77,6 +78,11 @@ def _load():
     lib.pygat_agrad_workspace_bytes.argtypes = [i, i]
     lib.pygat_agrad_workspace_bytes.restype = sz
     lib.pygat_a_grad.argtypes = [i, i, i, p, p, p, p, p, p]
+    lib.pygat_gatv2_forward.argtypes = [C.POINTER(Graph), i, i, f, i, p, p, p, p, p, p, p, p, p, p]
+    lib.pygat_gatv2_backward_prepare.argtypes = [i, i, i, i, i, p, p, p, p, p, p, p, p]
+    lib.pygat_gatv2_workspace_bytes.argtypes = [i64, i, i, i]
+    lib.pygat_gatv2_workspace_bytes.restype = sz
+    lib.pygat_gatv2_backward.argtypes = [C.POINTER(Graph), C.POINTER(Graph), p, i, i, f, p, p, p, p, p, p, p, p, p]
     for s in SYMBOLS:
         fn = getattr(lib, s)
         if fn.restype is C.c_int or s in ("pygat_abi_version", "pygat_padded_width", "pygat_device_count"):

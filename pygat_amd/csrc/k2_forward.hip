@@ -27,9 +27,10 @@ struct FwdArgs {
   RowShape rs;
   float alpha;
   int flags;
-  const float* Wh;
+  const float* Wh;     // gathered table; GATv2: [Whi | Whj] rows of 2R floats
+  int64_t ldwh;        // its row stride in floats (R, or 2R for GATv2)
   const float* s;
-  const float* a_pad;  // [H][2][Fp]; the a_dst halves give t_j = Wh_j . a_dst on the fly
+  const float* a_pad;  // [H][2][Fp]; the a_dst halves give t_j = Wh_j . a_dst on the fly (GATv2: a [H][Fp])
   const float* sk;
   const float* mask;  // [nnz][H] attention dropout mask (pre-scaled) or nullptr
   float* out;
@@ -131,7 +132,9 @@ __device__ __forceinline__ void fwd_flush(const FwdArgs& a, const LaneCols<VEC>&
   }
 }
 
-template <int LPR, int VEC>
+// V2 = the reference's SpGraphAttentionLayerV2 scoring (layers.py:280-283): e_ij = a . LeakyReLU(Whi_i +
+// Whj_j) per head, aggregation of Whi_j (layers.py:296); the gathered row is [Whi_j | Whj_j].
+template <int LPR, int VEC, bool V2>
 __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
   constexpr int EPW = 64 / LPR;
   constexpr int U = (VEC == 1) ? 4 : 2;
@@ -151,9 +154,11 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
   float4 adst[VEC];  // this lane's slice of a_dst (zero on padded / invalid chunks)
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
-    adst[v] = ld4(a.a_pad + (int64_t)lc.head[v] * 2 * a.rs.Fp + a.rs.Fp + (lc.cofs[v] & (a.rs.Fp - 1)));
+    adst[v] = V2 ? ld4(a.a_pad + (int64_t)lc.head[v] * a.rs.Fp + (lc.cofs[v] & (a.rs.Fp - 1)))
+                 : ld4(a.a_pad + (int64_t)lc.head[v] * 2 * a.rs.Fp + a.rs.Fp + (lc.cofs[v] & (a.rs.Fp - 1)));
     if (!lc.valid[v]) adst[v] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  const int64_t ldw = a.ldwh;
   float m[VEC], z[VEC];
   float4 acc[VEC];
 #pragma unroll
@@ -170,14 +175,26 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         mk[u][v] = a.mask ? a.mask[((e + u < e1) ? e + u : e1 - 1) * H + lc.head[v]] : 1.f;
-        sv[u][v] = a.s[(int64_t)p[u].x * H + lc.head[v]];
-        wv[u][v] = ld4(a.Wh + (int64_t)p[u].y * R + lc.cofs[v]);
+        wv[u][v] = ld4(a.Wh + (int64_t)p[u].y * ldw + lc.cofs[v]);
+        if constexpr (V2) {
+          const float4 wi = ld4(a.Wh + (int64_t)p[u].x * ldw + lc.cofs[v]);      // Whi_i (row-local)
+          const float4 wj = ld4(a.Wh + (int64_t)p[u].y * ldw + R + lc.cofs[v]);  // Whj_j (same gathered row)
+          const float4 hh = make_float4(wi.x + wj.x, wi.y + wj.y, wi.z + wj.z, wi.w + wj.w);
+          const float4 ll = make_float4(lrelu(hh.x, a.alpha), lrelu(hh.y, a.alpha), lrelu(hh.z, a.alpha), lrelu(hh.w, a.alpha));
+          sv[u][v] = dot4(ll, adst[v]);   // partial of e_ij over this lane's 4 features
+        } else {
+          sv[u][v] = a.s[(int64_t)p[u].x * H + lc.head[v]];
+        }
       }
-    // t_j = Wh_j . a_dst per head, from the row just gathered (all lanes of the group are active here)
+    // per-head sums over the lanes of a head (all lanes of the group are active here):
+    // V1: t_j = Wh_j . a_dst from the row just gathered; V2: the logit e_ij itself
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) tv[u][v] = group_sum_rt(dot4(wv[u][v], adst[v]), lph);
+      for (int v = 0; v < VEC; ++v) {
+        if constexpr (V2) { tv[u][v] = group_sum_rt(sv[u][v], lph); }
+        else { tv[u][v] = group_sum_rt(dot4(wv[u][v], adst[v]), lph); }
+      }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (e + u < e1) {
@@ -188,7 +205,8 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
           for (int v = 0; v < VEC; ++v) { m[v] = NEG_BIG; z[v] = 0.f; acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); }
         }
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) fold_edge(m[v], z[v], acc[v], lrelu(sv[u][v] + tv[u][v], a.alpha), wv[u][v], mk[u][v]);
+        for (int v = 0; v < VEC; ++v)
+          fold_edge(m[v], z[v], acc[v], V2 ? tv[u][v] : lrelu(sv[u][v] + tv[u][v], a.alpha), wv[u][v], mk[u][v]);
       }
     }
   }
@@ -342,29 +360,35 @@ extern "C" size_t pygat_partials_bytes(int64_t nnz, int slot_edges, int H, int F
   return (size_t)(2 * nslots) * (size_t)(H * Fp + 2 * H) * sizeof(float);
 }
 
-extern "C" int pygat_gat_forward(const pygat_graph* g, int H, int Fo, float alpha, int flags, const float* Wh,
-                                 const float* s, const float* a_pad, const float* sk, const float* att_mask,
-                                 float* out, float* hattn, float* m, float* Z, void* part, void* stream) {
+static int launch_forward(const pygat_graph* g, int H, int Fo, float alpha, int flags, const float* Wh, int v2,
+                          const float* s, const float* a_pad, const float* sk, const float* att_mask, float* out,
+                          float* hattn, float* m, float* Z, void* part, void* stream) {
   FwdArgs a;
   int rc = check_graph(g, &a.g);
   if (rc) return rc;
   PYGAT_REQUIRE(make_row_shape(H, Fo, &a.rs), "gat_forward: unsupported H=%d F'=%d (need H*pad(F') <= 1024, F' <= 256)", H, Fo);
-  PYGAT_REQUIRE(Wh && s && a_pad && part, "gat_forward: null Wh/s/a_pad/part");
+  PYGAT_REQUIRE(Wh && (s || v2) && a_pad && part, "gat_forward: null Wh/s/a_pad/part");
   PYGAT_REQUIRE(out || hattn, "gat_forward: need out and/or hattn");
   PYGAT_REQUIRE(!(flags & PYGAT_F_SKIP) || sk, "gat_forward: PYGAT_F_SKIP without sk");
   PYGAT_REQUIRE((m == nullptr) == (Z == nullptr), "gat_forward: m and Z must be given together");
   PYGAT_REQUIRE(aligned16(Wh) && aligned16(part) && aligned16(a_pad) && (!sk || aligned16(sk)) && (!hattn || aligned16(hattn)) &&
                     (!out || a.rs.Fo != a.rs.Fp || aligned16(out)),
                 "gat_forward: row tables must be 16-byte aligned");
-  a.alpha = alpha; a.flags = flags; a.Wh = Wh; a.s = s; a.a_pad = a_pad; a.sk = sk; a.mask = att_mask;
+  a.alpha = alpha; a.flags = flags; a.Wh = Wh; a.ldwh = v2 ? 2 * (int64_t)a.rs.R : a.rs.R; a.s = s; a.a_pad = a_pad;
+  a.sk = sk; a.mask = att_mask;
   a.out = out; a.hattn = hattn; a.m = m; a.Z = Z; a.part = (float*)part;
   int lpr, vec;
   pick_lanes(a.rs, &lpr, &vec);
   hipStream_t st = (hipStream_t)stream;
   const int64_t nslots = num_slots(a.g);
   const unsigned blocks = (unsigned)cdiv(cdiv(nslots, 64 / lpr), 4);
-  PYGAT_DISPATCH_LANES(lpr, vec,
-                       hipLaunchKernelGGL((gat_fwd_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0, st, a));
+  if (v2) {
+    PYGAT_DISPATCH_LANES(lpr, vec,
+                         hipLaunchKernelGGL((gat_fwd_kernel<LPR, VEC, true>), dim3(blocks), dim3(256), 0, st, a));
+  } else {
+    PYGAT_DISPATCH_LANES(lpr, vec,
+                         hipLaunchKernelGGL((gat_fwd_kernel<LPR, VEC, false>), dim3(blocks), dim3(256), 0, st, a));
+  }
   PYGAT_CHECK_LAUNCH("gat_forward");
   const unsigned fb = (unsigned)cdiv(nslots, FIX_SCREEN);
   const size_t fix_lds = 4 * (size_t)(a.rs.R + 2 * a.rs.H) * sizeof(float);
@@ -372,6 +396,18 @@ extern "C" int pygat_gat_forward(const pygat_graph* g, int H, int Fo, float alph
                        hipLaunchKernelGGL((gat_fwd_fixup_kernel<LPR, VEC>), dim3(fb), dim3(256), fix_lds, st, a));
   PYGAT_CHECK_LAUNCH("gat_forward_fixup");
   return PYGAT_OK;
+}
+
+extern "C" int pygat_gat_forward(const pygat_graph* g, int H, int Fo, float alpha, int flags, const float* Wh,
+                                 const float* s, const float* a_pad, const float* sk, const float* att_mask,
+                                 float* out, float* hattn, float* m, float* Z, void* part, void* stream) {
+  return launch_forward(g, H, Fo, alpha, flags, Wh, 0, s, a_pad, sk, att_mask, out, hattn, m, Z, part, stream);
+}
+
+extern "C" int pygat_gatv2_forward(const pygat_graph* g, int H, int Fo, float alpha, int flags, const float* WW,
+                                   const float* a2, const float* sk, const float* att_mask, float* out,
+                                   float* hattn, float* m, float* Z, void* part, void* stream) {
+  return launch_forward(g, H, Fo, alpha, flags, WW, 1, nullptr, a2, sk, att_mask, out, hattn, m, Z, part, stream);
 }
 
 extern "C" int pygat_head_mean(int n, int H, int Fo, const float* hattn, const float* sk, float* out,

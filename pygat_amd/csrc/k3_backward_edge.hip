@@ -29,7 +29,10 @@ struct PrepArgs {
   const float* s;
   const float* m;
   const float* Z;
-  float* GR;        // [n][R + 4H]
+  float* GR;        // [n][ldgr]: Gp (R) | rowtab (4H) [| copy of Whi (R), GATv2]
+  int64_t ldgr;
+  const float* whi; // GATv2: table whose first R floats per row are copied behind the rowtab, else nullptr
+  int64_t ld_whi;
 };
 
 template <int LPR, int VEC>
@@ -40,7 +43,7 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_kernel(PrepArgs a) {
   if (i >= a.n) return;  // whole lane groups leave together: the DPP sums below stay inside a group
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
   const int H = a.rs.H, R = a.rs.R, Fo = a.rs.Fo, Fp = a.rs.Fp;
-  const int64_t RW = R + 4 * H;
+  const int64_t RW = a.ldgr;
   const int lph = a.rs.lph < 64 ? a.rs.lph : 64;
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
@@ -88,6 +91,7 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_kernel(PrepArgs a) {
         }
       }
       st4(a.GR + i * RW + co, g4);
+      if (a.whi) st4(a.GR + i * RW + R + 4 * H + co, ld4(a.whi + i * a.ld_whi + co));
     }
     const float D = group_sum_rt(dot4(g4, hat), lph);
     if (lc.valid[v] && ((co >> 2) & (a.rs.lph - 1)) == 0) {
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_fast_kernel(PrepArgs a) {
   if (i0 >= a.n) return;
   const LaneCols<1> lc = lane_cols<LPR, 1>(a.rs);
   const int H = a.rs.H, R = a.rs.R;
-  const int64_t RW = R + 4 * H;
+  const int64_t RW = a.ldgr;
   const int lph = a.rs.lph < 64 ? a.rs.lph : 64;
   const int co = lc.cofs[0], h = lc.head[0];
   const bool valid = lc.valid[0];
@@ -141,7 +145,10 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_fast_kernel(PrepArgs a) {
     float4 hat = make_float4(pq[0] - k4[r].x, pq[1] - k4[r].y, pq[2] - k4[r].z, pq[3] - k4[r].w);
     const float D = group_sum_rt(dot4(g, hat), lph);
     if (i < a.n) {
-      if (valid) st4(a.GR + i * RW + co, g);
+      if (valid) {
+        st4(a.GR + i * RW + co, g);
+        if (a.whi) st4(a.GR + i * RW + R + 4 * H + co, ld4(a.whi + i * a.ld_whi + co));
+      }
       if (lead) st4(a.GR + i * RW + R + 4 * h, make_float4(sv[r], mv[r], 1.0f / zv[r], D));
     }
   }
@@ -266,9 +273,29 @@ __global__ __launch_bounds__(256) void gat_bwd_row_fixup_kernel(RowArgs a) {
 
 using namespace pygat;
 
+static int launch_prepare(int n, int H, int Fo, int flags, int mean_mode, const float* G, const float* y,
+                          const float* sk, const float* s, const float* m, const float* Z, float* GR,
+                          const float* whi, int64_t ld_whi, void* stream);
+
 extern "C" int pygat_gat_backward_prepare(int n, int H, int Fo, int flags, int mean_mode, const float* G,
                                           const float* y, const float* sk, const float* s, const float* m,
                                           const float* Z, float* GR, void* stream) {
+  return launch_prepare(n, H, Fo, flags, mean_mode, G, y, sk, s, m, Z, GR, nullptr, 0, stream);
+}
+
+/* GATv2: GRW [n x (2R + 4H)] = [Gp | (., m, 1/Z, D) | Whi], Whi copied from WW [n x 2R] */
+extern "C" int pygat_gatv2_backward_prepare(int n, int H, int Fo, int flags, int mean_mode, const float* G,
+                                            const float* y, const float* sk, const float* m, const float* Z,
+                                            const float* WW, float* GRW, void* stream) {
+  if (!WW) { pygat::set_error("gatv2_backward_prepare: null WW"); return PYGAT_EINVAL; }
+  int Fp = pygat::padded_width(Fo);
+  return launch_prepare(n, H, Fo, flags, mean_mode, G, y, sk, m /* s slot unused in V2 */, m, Z, GRW, WW,
+                        2 * (int64_t)H * Fp, stream);
+}
+
+static int launch_prepare(int n, int H, int Fo, int flags, int mean_mode, const float* G, const float* y,
+                          const float* sk, const float* s, const float* m, const float* Z, float* GR,
+                          const float* whi, int64_t ld_whi, void* stream) {
   PrepArgs a;
   PYGAT_REQUIRE(make_row_shape(H, Fo, &a.rs), "gat_backward_prepare: unsupported H=%d F'=%d", H, Fo);
   PYGAT_REQUIRE(n > 0 && G && y && s && m && Z && GR, "gat_backward_prepare: null pointer");
@@ -278,7 +305,8 @@ extern "C" int pygat_gat_backward_prepare(int n, int H, int Fo, int flags, int m
                     (mean_mode ? aligned16(y) : (a.rs.Fo != a.rs.Fp || (aligned16(G) && aligned16(y)))),
                 "gat_backward_prepare: row tables must be 16-byte aligned");
   a.n = n; a.flags = flags; a.mean_mode = mean_mode; a.G = G; a.y = y; a.sk = sk; a.s = s; a.m = m; a.Z = Z;
-  a.GR = GR;
+  a.GR = GR; a.whi = whi; a.ld_whi = ld_whi;
+  a.ldgr = (int64_t)a.rs.R * (whi ? 2 : 1) + 4 * a.rs.H;
   int lpr, vec;
   pick_lanes(a.rs, &lpr, &vec);
   if (!mean_mode && a.rs.Fo == a.rs.Fp && vec == 1) {

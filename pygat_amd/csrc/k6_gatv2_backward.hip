@@ -1,0 +1,299 @@
+// K6 -- backward of the reference's sparse GATv2 layer (SpGraphAttentionLayerV2, layers.py:258-313).
+//
+//   e_ij = a . LeakyReLU(Whi_i + Whj_j)  per head          (layers.py:280-283)
+//   alpha_ij = softmax_j e_ij,  h'_i = sum_j alpha~_ij Whi_j (layers.py:285-300; note Whi, not Whj, is aggregated)
+// With Gp, D as in K3a:  dp_ij = Gp_i . Whi_j,  de_ij = alpha_ij (mask_ij dp_ij - D_i),
+//   q_ij = de_ij * a (.) LeakyReLU'(Whi_i + Whj_j)          (an F'-vector per edge, never stored)
+//   dWhi_i += sum_j q_ij (row sums)     dWhj_j += sum_i q_ij (column sums)     dWhi_j += sum_i alpha~_ij Gp_i
+//   da = sum_ij de_ij LeakyReLU(Whi_i + Whj_j)
+// Same nnz-split structure as K3b/K4: the row pass walks the forward pattern (GRW_i row-local,
+// WW_j = [Whi_j | Whj_j] gathered), the column pass the transposed pattern (GRW_i = [Gp | m,1/Z,D | Whi]
+// gathered as one contiguous row, WW_j row-local); both recompute e, alpha and de per edge.
+#include "attn_common.h"
+
+namespace pygat {
+
+struct V2Args {
+  GraphDev g;
+  RowShape rs;
+  float alpha;
+  const int32_t* perm;  // column pass only: transposed position -> forward edge (mask index)
+  const float* mask;    // [nnz][H] forward order or nullptr
+  const float* WW;      // [n][2R]
+  const float* GRW;     // [n][2R + 4H]
+  const float* a2;      // [H][Fp]
+  const float* dwhi_row;  // column pass: row-side part of dWhi to add in
+  float* out;           // row pass: dWhi_row [n][R]; column pass: dWW [n][2R]
+  float* part;          // [2 * nslots][R] (row) / [2 * nslots][2R] (col)
+  float* da_part;       // row pass: [blocks][R]
+};
+
+__device__ __forceinline__ float lrelu2(float z, float alpha) { return z > 0.f ? z : alpha * z; }
+
+// per-edge recomputation shared by both passes
+struct EdgeOut { float al, de; float4 q, l; };
+__device__ __forceinline__ EdgeOut v2_edge(float4 wi_i, float4 wi_j, float4 wj_j, float4 gp, float4 rt, float4 a4,
+                                           float mk, float alpha, bool valid, int lph) {
+  const float4 h = make_float4(wi_i.x + wj_j.x, wi_i.y + wj_j.y, wi_i.z + wj_j.z, wi_i.w + wj_j.w);
+  EdgeOut o;
+  o.l = make_float4(lrelu2(h.x, alpha), lrelu2(h.y, alpha), lrelu2(h.z, alpha), lrelu2(h.w, alpha));
+  const float e = group_sum_rt(dot4(o.l, a4), lph);          // a4 is zero on padded / invalid chunks
+  const float dp = group_sum_rt(valid ? dot4(gp, wi_j) : 0.f, lph);
+  const float a0 = __expf(e - rt.y) * rt.z;
+  o.de = a0 * (mk * dp - rt.w);
+  o.al = a0 * mk;
+  o.q = make_float4(o.de * a4.x * (h.x > 0.f ? 1.f : alpha), o.de * a4.y * (h.y > 0.f ? 1.f : alpha),
+                    o.de * a4.z * (h.z > 0.f ? 1.f : alpha), o.de * a4.w * (h.w > 0.f ? 1.f : alpha));
+  return o;
+}
+
+// ---------------------------------------------------------------------------- row pass
+template <int LPR, int VEC>
+__global__ __launch_bounds__(256) void gat2_bwd_row_kernel(V2Args a) {
+  constexpr int EPW = 64 / LPR;
+  constexpr int U = 2;
+  __shared__ __attribute__((aligned(16))) float sm_da[4][1024];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t k = ((int64_t)blockIdx.x * 4 + w) * EPW + lane / LPR;
+  const bool active = k < num_slots(a.g);   // no early return: every lane joins the da reduction below
+  const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
+  const int H = a.rs.H, R = a.rs.R;
+  const int64_t LW = 2 * (int64_t)R, LG = 2 * (int64_t)R + 4 * H;
+  const int lph = a.rs.lph < 64 ? a.rs.lph : 64;
+  float4 a4[VEC], dacc[VEC], acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    a4[v] = ld4(a.a2 + (int64_t)lc.head[v] * a.rs.Fp + (lc.cofs[v] & (a.rs.Fp - 1)));
+    if (!lc.valid[v]) a4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    dacc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (active) {
+    int64_t e0, e1;
+    slot_range(a.g, k, &e0, &e1);
+    const int2* __restrict__ rc = a.g.rc;
+    const int r_first = rc[e0].x;
+    const bool head_partial = a.g.rowptr[r_first] < e0;
+    int cur = r_first;
+    auto flush = [&](int i, bool is_head, bool is_tail) {
+      float* dst = (is_head || is_tail) ? a.part + (2 * k + (is_head ? 0 : 1)) * (int64_t)R : a.out + (int64_t)i * R;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v)
+        if (lc.valid[v]) st4(dst + lc.cofs[v], acc[v]);
+    };
+    for (int64_t e = e0; e < e1; e += U) {
+      int2 p[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) p[u] = rc[(e + u < e1) ? e + u : e1 - 1];
+      EdgeOut eo[U][VEC];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const float* gi = a.GRW + (int64_t)p[u].x * LG;   // row-local
+          const float* wj = a.WW + (int64_t)p[u].y * LW;    // gathered
+          const float mk = a.mask ? a.mask[((e + u < e1) ? e + u : e1 - 1) * H + lc.head[v]] : 1.f;
+          eo[u][v] = v2_edge(ld4(gi + R + 4 * H + lc.cofs[v]), ld4(wj + lc.cofs[v]), ld4(wj + R + lc.cofs[v]),
+                             ld4(gi + lc.cofs[v]), ld4(gi + R + 4 * lc.head[v]), a4[v], mk, a.alpha, lc.valid[v], lph);
+        }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (e + u < e1) {
+          if (p[u].x != cur) {
+            flush(cur, cur == r_first && head_partial, false);
+            cur = p[u].x;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            acc[v].x += eo[u][v].q.x; acc[v].y += eo[u][v].q.y; acc[v].z += eo[u][v].q.z; acc[v].w += eo[u][v].q.w;
+            dacc[v].x = fmaf(eo[u][v].de, eo[u][v].l.x, dacc[v].x); dacc[v].y = fmaf(eo[u][v].de, eo[u][v].l.y, dacc[v].y);
+            dacc[v].z = fmaf(eo[u][v].de, eo[u][v].l.z, dacc[v].z); dacc[v].w = fmaf(eo[u][v].de, eo[u][v].l.w, dacc[v].w);
+          }
+        }
+      }
+    }
+    flush(cur, cur == r_first && head_partial, a.g.rowptr[cur + 1] > e1);
+  }
+  // da: lane groups -> wave (shuffles) -> work-group (LDS) -> one record per work-group, fixed order
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) dacc[v] = slot_sum4<LPR>(dacc[v]);
+  if (lane / LPR == 0)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+      if (lc.valid[v]) st4(&sm_da[w][lc.cofs[v]], dacc[v]);
+  __syncthreads();
+  for (int c = threadIdx.x; c < R; c += 256)
+    a.da_part[(int64_t)blockIdx.x * R + c] = sm_da[0][c] + sm_da[1][c] + sm_da[2][c] + sm_da[3][c];
+}
+
+// sums the R-float pieces of the rows cut by a slot border (thread per (slot, float))
+__global__ __launch_bounds__(256) void gat2_rowsum_fixup_kernel(V2Args a, int width, float* dst, int64_t ld_dst,
+                                                                 const float* add, int col_finish) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t k = idx / width;
+  const int c = (int)(idx % width);
+  if (k >= num_slots(a.g)) return;
+  int64_t e0, e1;
+  slot_range(a.g, k, &e0, &e1);
+  const int r = a.g.rc[e1 - 1].x;
+  const int64_t row_end = a.g.rowptr[r + 1];
+  if (row_end <= e1 || (int64_t)a.g.rowptr[r] < e0) return;
+  const int64_t k_e = slot_of(a.g, row_end - 1);
+  float acc = a.part[(2 * k + 1) * (int64_t)width + c];
+  for (int64_t kk = k + 1; kk <= k_e; ++kk) acc += a.part[(2 * kk) * (int64_t)width + c];
+  if (col_finish && c < a.rs.R) acc += add[(int64_t)r * a.rs.R + c];   // column pass: + row-side part of dWhi
+  dst[(int64_t)r * ld_dst + c] = acc;
+}
+
+__global__ __launch_bounds__(256) void gat2_da_final_kernel(RowShape rs, int nblocks, const float* __restrict__ da_part,
+                                                            float* __restrict__ da) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // over H * Fo
+  if (idx >= rs.H * rs.Fo) return;
+  const int h = idx / rs.Fo, f = idx % rs.Fo;
+  float acc = 0.f;
+  for (int b = 0; b < nblocks; ++b) acc += da_part[(int64_t)b * rs.R + h * rs.Fp + f];
+  da[idx] = acc;
+}
+
+// ------------------------------------------------------------------------- column pass
+template <int LPR, int VEC>
+__global__ __launch_bounds__(256) void gat2_bwd_col_kernel(V2Args a) {
+  constexpr int EPW = 64 / LPR;
+  constexpr int U = 2;
+  const int lane = threadIdx.x & 63;
+  const int64_t k = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * EPW + lane / LPR;
+  if (k >= num_slots(a.g)) return;
+  int64_t e0, e1;
+  slot_range(a.g, k, &e0, &e1);
+  const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
+  const int H = a.rs.H, R = a.rs.R;
+  const int64_t LW = 2 * (int64_t)R, LG = 2 * (int64_t)R + 4 * H;
+  const int lph = a.rs.lph < 64 ? a.rs.lph : 64;
+  const int2* __restrict__ rc = a.g.rc;
+  float4 a4[VEC], accA[VEC], accJ[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    a4[v] = ld4(a.a2 + (int64_t)lc.head[v] * a.rs.Fp + (lc.cofs[v] & (a.rs.Fp - 1)));
+    if (!lc.valid[v]) a4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    accA[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    accJ[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int r_first = rc[e0].x;
+  const bool head_partial = a.g.rowptr[r_first] < e0;
+  int cur = r_first;
+  auto flush = [&](int j, bool is_head, bool is_tail) {
+    if (is_head || is_tail) {
+      float* dst = a.part + (2 * k + (is_head ? 0 : 1)) * LW;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v)
+        if (lc.valid[v]) { st4(dst + lc.cofs[v], accA[v]); st4(dst + R + lc.cofs[v], accJ[v]); }
+    } else {
+      float* dst = a.out + (int64_t)j * LW;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v)
+        if (lc.valid[v]) {
+          const float4 r4 = ld4(a.dwhi_row + (int64_t)j * R + lc.cofs[v]);
+          st4(dst + lc.cofs[v], make_float4(accA[v].x + r4.x, accA[v].y + r4.y, accA[v].z + r4.z, accA[v].w + r4.w));
+          st4(dst + R + lc.cofs[v], accJ[v]);
+        }
+    }
+  };
+  for (int64_t e = e0; e < e1; e += U) {
+    int2 p[U];  // (j, i)
+#pragma unroll
+    for (int u = 0; u < U; ++u) p[u] = rc[(e + u < e1) ? e + u : e1 - 1];
+    EdgeOut eo[U][VEC];
+    float4 gv[U][VEC];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const float* gi = a.GRW + (int64_t)p[u].y * LG;   // gathered: [Gp_i | rowtab_i | Whi_i]
+        const float* wj = a.WW + (int64_t)p[u].x * LW;    // row-local: [Whi_j | Whj_j]
+        float mk = 1.f;
+        if (a.mask) mk = a.mask[(int64_t)a.perm[(e + u < e1) ? e + u : e1 - 1] * H + lc.head[v]];
+        gv[u][v] = ld4(gi + lc.cofs[v]);
+        eo[u][v] = v2_edge(ld4(gi + R + 4 * H + lc.cofs[v]), ld4(wj + lc.cofs[v]), ld4(wj + R + lc.cofs[v]), gv[u][v],
+                           ld4(gi + R + 4 * lc.head[v]), a4[v], mk, a.alpha, lc.valid[v], lph);
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (e + u < e1) {
+        if (p[u].x != cur) {
+          flush(cur, cur == r_first && head_partial, false);
+          cur = p[u].x;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) { accA[v] = make_float4(0.f, 0.f, 0.f, 0.f); accJ[v] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const float al = eo[u][v].al;
+          accA[v].x = fmaf(al, gv[u][v].x, accA[v].x); accA[v].y = fmaf(al, gv[u][v].y, accA[v].y);
+          accA[v].z = fmaf(al, gv[u][v].z, accA[v].z); accA[v].w = fmaf(al, gv[u][v].w, accA[v].w);
+          accJ[v].x += eo[u][v].q.x; accJ[v].y += eo[u][v].q.y; accJ[v].z += eo[u][v].q.z; accJ[v].w += eo[u][v].q.w;
+        }
+      }
+    }
+  }
+  flush(cur, cur == r_first && head_partial, a.g.rowptr[cur + 1] > e1);
+}
+
+}  // namespace pygat
+
+using namespace pygat;
+
+extern "C" size_t pygat_gatv2_workspace_bytes(int64_t nnz, int slot_edges, int H, int Fo) {
+  const int Fp = padded_width(Fo);
+  if (nnz <= 0 || slot_edges <= 0 || Fp == 0) return 0;
+  const int64_t nslots = (nnz + slot_edges - 1) / slot_edges;
+  const int64_t R = (int64_t)H * Fp;
+  // partial records of the column pass (2R floats each) + one da record per row-pass work-group
+  return (size_t)(2 * nslots * 2 * R + (nslots / 4 + 2) * R) * sizeof(float);
+}
+
+extern "C" int pygat_gatv2_backward(const pygat_graph* g, const pygat_graph* gT, const int32_t* perm_t, int H, int Fo,
+                                    float alpha, const float* WW, const float* a2, const float* GRW,
+                                    const float* att_mask, float* dwhi_row, float* dWW, float* da, void* ws,
+                                    void* stream) {
+  V2Args a;
+  int rc = check_graph(g, &a.g);
+  if (rc) return rc;
+  PYGAT_REQUIRE(make_row_shape(H, Fo, &a.rs), "gatv2_backward: unsupported H=%d F'=%d", H, Fo);
+  PYGAT_REQUIRE(a.rs.R <= 1024, "gatv2_backward: row too wide");
+  PYGAT_REQUIRE(WW && a2 && GRW && dwhi_row && dWW && da && ws, "gatv2_backward: null pointer");
+  PYGAT_REQUIRE(!att_mask || perm_t, "gatv2_backward: an attention mask needs perm_t");
+  PYGAT_REQUIRE(aligned16(WW) && aligned16(a2) && aligned16(GRW) && aligned16(dwhi_row) && aligned16(dWW) && aligned16(ws),
+                "gatv2_backward: row tables must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int R = a.rs.R;
+  a.alpha = alpha; a.perm = nullptr; a.mask = att_mask; a.WW = WW; a.GRW = GRW; a.a2 = a2; a.dwhi_row = nullptr;
+  int lpr, vec;
+  pick_lanes(a.rs, &lpr, &vec);
+  const int64_t nslots = num_slots(a.g);
+  const unsigned blocks = (unsigned)cdiv(cdiv(nslots, 64 / lpr), 4);
+  float* part = (float*)ws;
+  float* da_part = part + 2 * nslots * 2 * (int64_t)R;
+  // row pass: dWhi_row, da
+  a.out = dwhi_row; a.part = part; a.da_part = da_part;
+  PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat2_bwd_row_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0, st, a));
+  PYGAT_CHECK_LAUNCH("gatv2_backward_row");
+  hipLaunchKernelGGL(gat2_rowsum_fixup_kernel, dim3((unsigned)cdiv(nslots * R, 256)), dim3(256), 0, st, a, R, dwhi_row,
+                     (int64_t)R, (const float*)nullptr, 0);
+  hipLaunchKernelGGL(gat2_da_final_kernel, dim3((unsigned)cdiv(a.rs.H * a.rs.Fo, 256)), dim3(256), 0, st, a.rs, (int)blocks,
+                     (const float*)da_part, da);
+  PYGAT_CHECK_LAUNCH("gatv2_backward_row_fixup");
+  // column pass over the transposed pattern: dWW = [dWhi | dWhj]
+  V2Args b = a;
+  rc = check_graph(gT, &b.g);
+  if (rc) return rc;
+  PYGAT_REQUIRE(b.g.nnz == a.g.nnz && b.g.ts == a.g.ts, "gatv2_backward: g and gT differ in size / slot length");
+  b.perm = perm_t; b.dwhi_row = dwhi_row; b.out = dWW; b.part = part;
+  PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat2_bwd_col_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0, st, b));
+  PYGAT_CHECK_LAUNCH("gatv2_backward_col");
+  hipLaunchKernelGGL(gat2_rowsum_fixup_kernel, dim3((unsigned)cdiv(nslots * 2 * R, 256)), dim3(256), 0, st, b, 2 * R, dWW,
+                     2 * (int64_t)R, (const float*)dwhi_row, 1);
+  PYGAT_CHECK_LAUNCH("gatv2_backward_col_fixup");
+  return PYGAT_OK;
+}

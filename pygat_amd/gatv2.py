@@ -1,0 +1,186 @@
+"""GATv2 layers of the reference (layers.py:179-316), on the same HIP machinery.
+
+`SpGraphAttentionLayerV2` (layers.py:234-316): e_ij = a . LeakyReLU(W_l h_i + W_r h_j), softmax over
+the row, aggregation of the LEFT projection at the neighbour (`special_spmm(..., Whi)`, layers.py:296).
+One projection GEMM yields [Whi | Whj] rows; K2 (V2 variant) gathers one such row per edge; the
+backward recomputes everything per edge in a row pass and a column pass (csrc/k6_gatv2_backward.hip).
+
+`GraphAttentionLayerV2` (layers.py:179-232): as written, the logit is ONE value per node broadcast
+along its row (layers.py:214-217), so attention is uniform and the layer is the neighbour mean of
+`h W[Fin:]`; `a` and `W[:Fin]` receive exactly-zero gradients.  Reproduced as is.
+"""
+from __future__ import annotations
+
+import ctypes as C  # noqa: F401
+from typing import Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import lib, check
+from .graph import CSRGraph, as_graph
+from .ops import _Level, _ptr, _stream, gemm, gat_level
+
+
+class GATv2LevelFn(torch.autograd.Function):
+    """forward(x, W[H,2Fin,F'], a[H,F'], Wskip[H,Fin,F']|None, graph, alpha, concat)."""
+
+    @staticmethod
+    def forward(ctx, x, W, a, Wskip, graph: CSRGraph, alpha: float, concat: bool):
+        if not x.is_cuda:
+            raise RuntimeError("pygat_amd: inputs must be on the GPU; the hot path has no CPU fallback")
+        x = x.contiguous().float(); W = W.contiguous().float(); a = a.contiguous().float()
+        H, Fin2, Fo = W.shape
+        Fin = Fin2 // 2
+        if x.shape[1] != Fin or a.shape != (H, Fo):
+            raise ValueError(f"shape mismatch: x {tuple(x.shape)}, W {tuple(W.shape)}, a {tuple(a.shape)}")
+        skip = Wskip is not None
+        L = _Level(x, H, Fo, skip)
+        L.ts = graph.slot_edges
+        if 2 * L.R > 2048:
+            raise ValueError("pygat_amd: GATv2 row too wide; shard the heads")
+        dev, f32 = x.device, torch.float32
+        R, Fp = L.R, L.Fp
+        # operand of the projection: columns [Wi heads | Wj heads | skip heads], heads padded to Fp
+        ncols = 2 * R + (R if skip else 0)
+        Wcat = torch.zeros(Fin, ncols, dtype=f32, device=dev)
+        Wv = Wcat.view(Fin, ncols // Fp, Fp)
+        Wv[:, 0:H, :Fo] = W[:, :Fin, :].permute(1, 0, 2)
+        Wv[:, H:2 * H, :Fo] = W[:, Fin:, :].permute(1, 0, 2)
+        if skip:
+            Wv[:, 2 * H:3 * H, :Fo] = Wskip.contiguous().float().permute(1, 0, 2)
+        a2 = torch.zeros(H, Fp, dtype=f32, device=dev)
+        a2[:, :Fo] = a
+        need_grad = any(ctx.needs_input_grad[:4])
+        with torch.cuda.device(dev):
+            st = _stream()
+            WW = torch.empty(L.N, 2 * R, dtype=f32, device=dev)
+            Sk = torch.empty(L.N, R, dtype=f32, device=dev) if skip else None
+            segs = [(2 * R, WW, 2 * R)] + ([(R, Sk, R)] if skip else [])
+            gemm(False, False, L.N, ncols, Fin, x, Fin, Wcat, ncols, segs)
+            flags = (_lib.F_ELU if concat else 0) | (_lib.F_SKIP if skip else 0)
+            hattn = torch.empty(L.N, R, dtype=f32, device=dev) if not concat else None
+            m = torch.empty(L.N, H, dtype=f32, device=dev) if need_grad else None
+            Z = torch.empty(L.N, H, dtype=f32, device=dev) if need_grad else None
+            out = torch.empty(L.N, H * Fo if concat else Fo, dtype=f32, device=dev)
+            part = torch.empty(lib.pygat_partials_bytes(graph.nnz, L.ts, H, Fp) // 4, dtype=f32, device=dev)
+            check(lib.pygat_gatv2_forward(graph.fwd.ref(L.ts), H, Fo, float(alpha), flags, WW.data_ptr(), a2.data_ptr(),
+                                          _ptr(Sk), None, out.data_ptr() if concat else None, _ptr(hattn), _ptr(m),
+                                          _ptr(Z), part.data_ptr(), st), "gatv2_forward")
+            if not concat:
+                check(lib.pygat_head_mean(L.N, H, Fo, hattn.data_ptr(), _ptr(Sk), out.data_ptr(), st), "head_mean")
+        if need_grad:
+            ctx.save_for_backward(x, Wcat, a2, WW, Sk, out if concat else hattn, m, Z)
+            ctx.graph, ctx.L, ctx.alpha, ctx.concat, ctx.flags, ctx.Fin = graph, L, float(alpha), concat, flags, Fin
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        x, Wcat, a2, WW, Sk, y, m, Z = ctx.saved_tensors
+        graph, L, H, Fo, Fin = ctx.graph, ctx.L, ctx.L.H, ctx.L.Fo, ctx.Fin
+        R, Fp = L.R, L.Fp
+        dev, f32 = x.device, torch.float32
+        G = G.contiguous().float()
+        with torch.cuda.device(dev):
+            st = _stream()
+            LG = 2 * R + 4 * H
+            GRW = torch.empty(L.N, LG, dtype=f32, device=dev)
+            Gp = GRW[:, :R]
+            check(lib.pygat_gatv2_backward_prepare(L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(), y.data_ptr(),
+                                                   _ptr(Sk), m.data_ptr(), Z.data_ptr(), WW.data_ptr(), GRW.data_ptr(), st),
+                  "gatv2_backward_prepare")
+            dwr = torch.empty(L.N, R, dtype=f32, device=dev)
+            dWW = torch.empty(L.N, 2 * R, dtype=f32, device=dev)
+            da_p = torch.empty(H, Fo, dtype=f32, device=dev)
+            ws = torch.empty(lib.pygat_gatv2_workspace_bytes(graph.nnz, L.ts, H, Fo) // 4 + 4, dtype=f32, device=dev)
+            check(lib.pygat_gatv2_backward(graph.fwd.ref(L.ts), graph.bwd.ref(L.ts), None, H, Fo, ctx.alpha, WW.data_ptr(),
+                                           a2.data_ptr(), GRW.data_ptr(), None, dwr.data_ptr(), dWW.data_ptr(),
+                                           da_p.data_ptr(), ws.data_ptr(), st), "gatv2_backward")
+            ncols = Wcat.shape[1]
+            dW = dWs = dx = None
+            # dWcat[:, :2R] = x^T dWW ; skip columns = x^T Gp
+            dWc = torch.empty(Fin, 2 * R, dtype=f32, device=dev)
+            gemm(True, False, Fin, 2 * R, L.N, x, Fin, dWW, 2 * R, [(2 * R, dWc, 2 * R)])
+            dv = dWc.view(Fin, 2 * H, Fp)
+            dW = torch.cat([dv[:, 0:H, :Fo].permute(1, 0, 2), dv[:, H:2 * H, :Fo].permute(1, 0, 2)], dim=1).contiguous()
+            if L.skip:
+                dSc = torch.empty(Fin, R, dtype=f32, device=dev)
+                gemm(True, False, Fin, R, L.N, x, Fin, Gp, LG, [(R, dSc, R)])
+                dWs = dSc.view(Fin, H, Fp)[:, :, :Fo].permute(1, 0, 2).contiguous()
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty(L.N, Fin, dtype=f32, device=dev)
+                gemm(False, True, L.N, Fin, 2 * R, dWW, 2 * R, Wcat, ncols, [(Fin, dx, Fin)], split_k=1)
+                if L.skip:
+                    gemm(False, True, L.N, Fin, R, Gp, LG, Wcat[:, 2 * R:], ncols, [(Fin, dx, Fin)], accumulate=True,
+                         split_k=1)
+        return dx, dW, da_p, dWs, None, None, None
+
+
+def gatv2_level(x, graph: CSRGraph, Ws: Sequence[torch.Tensor], As: Sequence[torch.Tensor],
+                Wskips: Optional[Sequence[torch.Tensor]], alpha: float, concat: bool) -> torch.Tensor:
+    """All heads of one SpGraphAttentionLayerV2 level.  Ws: H tensors [2Fin,F']; As: H tensors of F' elements."""
+    W = torch.stack(list(Ws), 0)
+    a = torch.stack([q.reshape(-1) for q in As], 0)
+    Wskip = torch.stack(list(Wskips), 0) if Wskips is not None else None
+    return GATv2LevelFn.apply(x, W, a, Wskip, graph, alpha, concat)
+
+
+class _V2Base(nn.Module):
+    def __init__(self, in_features, out_features, dropout, alpha, concat=True, skip_connection=False):
+        super().__init__()
+        self.dropout, self.in_features, self.out_features = dropout, in_features, out_features
+        self.alpha, self.concat, self.skip_connection = alpha, concat, skip_connection
+
+    def _check_dropout(self):
+        if self.training and self.dropout > 0.0:
+            raise NotImplementedError("pygat_amd: train-mode dropout is implemented for the GAT (v1) layers only; "
+                                      "use dropout=0 or eval() with the GATv2 layers")
+
+    def __repr__(self):  # layers.py:231-232,315-316
+        return self.__class__.__name__ + ' (' + str(self.in_features) + ' -> ' + str(self.out_features) + ')'
+
+
+class SpGraphAttentionLayerV2(_V2Base):
+    """Same constructor / parameters / initialisers as reference layers.py:239-256."""
+    pattern_mode = "nonzero"
+
+    def __init__(self, in_features, out_features, dropout, alpha, concat=True, skip_connection=False):
+        super().__init__(in_features, out_features, dropout, alpha, concat, skip_connection)
+        self.W = nn.Parameter(torch.empty(size=(2 * in_features, out_features)))
+        nn.init.xavier_normal_(self.W.data, gain=1.414)
+        self.a = nn.Parameter(torch.zeros(size=(1, out_features)))
+        nn.init.xavier_normal_(self.a.data, gain=1.414)
+        if self.skip_connection:
+            self.skip_projection = nn.Parameter(torch.empty(size=(in_features, out_features)))
+            nn.init.xavier_uniform_(self.skip_projection.data, gain=1.414)
+
+    def forward(self, input, adj):
+        self._check_dropout()
+        return gatv2_level(input, as_graph(adj, self.pattern_mode), [self.W], [self.a],
+                           [self.skip_projection] if self.skip_connection else None, self.alpha, self.concat)
+
+
+class GraphAttentionLayerV2(_V2Base):
+    """Same constructor / parameters / initialisers as reference layers.py:183-202; same function as
+    the reference computes (neighbour mean of h W[Fin:], see module docstring)."""
+    pattern_mode = "positive"
+
+    def __init__(self, in_features, out_features, dropout, alpha, concat=True, skip_connection=False):
+        super().__init__(in_features, out_features, dropout, alpha, concat, skip_connection)
+        self.W = nn.Parameter(torch.empty(size=(2 * in_features, out_features)))
+        nn.init.xavier_uniform_(self.W.data, gain=1.414)
+        self.a = nn.Parameter(torch.empty(size=(out_features, 1)))
+        nn.init.xavier_uniform_(self.a.data, gain=1.414)
+        if self.skip_connection:
+            self.skip_projection = nn.Parameter(torch.empty(size=(in_features, out_features)))
+            nn.init.xavier_uniform_(self.skip_projection.data, gain=1.414)
+
+    def forward(self, h, adj):
+        self._check_dropout()
+        Fo = self.out_features
+        zero_a = torch.zeros(2 * Fo, 1, dtype=self.W.dtype, device=self.W.device)   # uniform attention
+        out = gat_level(h, as_graph(adj, self.pattern_mode), [self.W[self.in_features:]], [zero_a],
+                        [self.skip_projection] if self.skip_connection else None, self.alpha, self.concat)
+        # the reference's autograd gives a and W[:Fin] exactly-zero gradients (not None): keep them in the graph
+        return out + 0.0 * (self.a.sum() + self.W[:self.in_features].sum())

@@ -46,12 +46,26 @@ class GAT(nn.Module):
                 self.gat_layers[i].append(layer)
                 self.add_module('attention_layer_{}_head_{}'.format(i + 1, j + 1), layer)
         self.pattern_mode = getattr(layer_type, "pattern_mode", "nonzero")
+        from .gatv2 import SpGraphAttentionLayerV2
+        self._kind = ("v1" if issubclass(layer_type, (GraphAttentionLayer, SpGraphAttentionLayer))
+                      else "v2sp" if issubclass(layer_type, SpGraphAttentionLayerV2) else "other")
 
     def forward(self, x, adj):
         graph = as_graph(adj, self.pattern_mode)
         nl = len(self.gat_layers)
         for i, heads in enumerate(self.gat_layers):
             concat = i < nl - 1
+            if self._kind == "other":   # e.g. GraphAttentionLayerV2: one head per call, as the reference does
+                ys = [att(x, graph) for att in heads]
+                x = torch.cat(ys, dim=1) if concat else torch.mean(torch.stack(ys, dim=1), dim=1)
+                continue
+            if self._kind == "v2sp":
+                from .gatv2 import gatv2_level
+                for att in heads:
+                    att._check_dropout()
+                x = gatv2_level(x, graph, [h.W for h in heads], [h.a for h in heads],
+                                [h.skip_projection for h in heads] if self.skip_connection else None, self.alpha, concat)
+                continue
             Ws = [h.W for h in heads]
             As = [h.a for h in heads]
             Sk = [h.skip_projection for h in heads] if self.skip_connection else None

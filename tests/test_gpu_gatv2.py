@@ -1,0 +1,91 @@
+"""GATv2 layers (reference layers.py:179-316) on the HIP path vs the oracle (fp64 autograd)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gat_oracle as O
+from test_gpu_parity import close, pg  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def v2params(H, Fin, Fo, skip, seed):
+    g = torch.Generator().manual_seed(seed)
+    W = torch.randn(H, 2 * Fin, Fo, generator=g, dtype=torch.float64) * (1.414 * (2.0 / (2 * Fin + Fo)) ** 0.5)
+    a = torch.randn(H, Fo, generator=g, dtype=torch.float64) * (1.414 * (2.0 / (1 + Fo)) ** 0.5)
+    Sk = torch.randn(H, Fin, Fo, generator=g, dtype=torch.float64) * 0.3 if skip else None
+    return W, a, Sk
+
+
+@pytest.mark.parametrize("H,Fin,Fo,skip,concat", [(8, 16, 8, False, True), (1, 12, 7, False, False), (4, 10, 16, True, True),
+                                                 (2, 20, 64, True, False), (3, 9, 4, False, True), (4, 8, 128, False, True)])
+@pytest.mark.parametrize("slot", [64, 8])
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_sparse_v2_level(pg, H, Fin, Fo, skip, concat, slot, symmetric):  # noqa: F811
+    N = 90
+    if symmetric:
+        rowptr, col = O.random_symmetric_csr(N, 5, 7 + H, hub=(4, 60))
+    else:
+        rng = np.random.default_rng(H)
+        dense = (rng.random((N, N)) < 0.06) | np.eye(N, dtype=bool)
+        rowptr = np.concatenate([[0], np.cumsum(dense.sum(1))]).astype(np.int32)
+        col = np.nonzero(dense)[1].astype(np.int32)
+    W, a, Sk = v2params(H, Fin, Fo, skip, 3 + Fo)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(N, Fin, dtype=torch.float64, generator=gen)
+    G = torch.randn(N, H * Fo if concat else Fo, dtype=torch.float64, generator=gen)
+    leaves = [t.clone().requires_grad_(True) for t in (x, W, a)] + ([Sk.clone().requires_grad_(True)] if skip else [])
+    y = O.level_forward_v2(leaves[0], (rowptr, col), leaves[1], leaves[2], 0.2, concat, leaves[3] if skip else None)
+    gr = torch.autograd.grad(y, leaves, G)
+    dev = "cuda:0"
+    g = pg.CSRGraph(torch.as_tensor(rowptr, device=dev), torch.as_tensor(col, device=dev), slot_edges=slot)
+    xd = x.float().to(dev).requires_grad_(True)
+    Wd = W.float().to(dev).requires_grad_(True)
+    ad = a.float().to(dev).requires_grad_(True)
+    Sd = Sk.float().to(dev).requires_grad_(True) if skip else None
+    out = pg.GATv2LevelFn.apply(xd, Wd, ad, Sd, g, 0.2, concat)
+    out.backward(G.float().to(dev))
+    close(out, y.detach().numpy(), "out")
+    close(xd.grad, gr[0].numpy(), "dX"); close(Wd.grad, gr[1].numpy(), "dW"); close(ad.grad, gr[2].numpy(), "da")
+    if skip:
+        close(Sd.grad, gr[3].numpy(), "dW_skip")
+
+
+def test_v2_dropin_layers_and_model(pg, topologies):  # noqa: F811
+    rowptr, col = topologies["cora"]
+    N, Fin, Fo = len(rowptr) - 1, 32, 8
+    adj = O.dense_from_csr(rowptr, col, N)
+    x = torch.randn(N, Fin, generator=torch.Generator().manual_seed(1))
+    # dense V2: the reference's row-broadcast logits = neighbour mean of h W[Fin:]
+    torch.manual_seed(2)
+    d = pg.GraphAttentionLayerV2(Fin, Fo, 0.0, 0.2, concat=True, skip_connection=True).cuda()
+    yd = d(x.cuda(), adj.cuda())
+    ref = O.dense_head_forward_v2(x.double(), adj.double(), d.W.detach().double().cpu(), d.a.detach().double().cpu(), 0.2,
+                                  True, d.skip_projection.detach().double().cpu())
+    close(yd, ref.numpy(), "dense V2")
+    yd.sum().backward()
+    assert d.a.grad is not None and float(d.a.grad.abs().max()) == 0.0
+    assert float(d.W.grad[:Fin].abs().max()) == 0.0 and float(d.W.grad[Fin:].abs().max()) > 0.0
+    # sparse V2 single layer
+    torch.manual_seed(3)
+    s = pg.SpGraphAttentionLayerV2(Fin, Fo, 0.0, 0.2, concat=False).cuda()
+    ys = s(x.cuda(), adj.cuda())
+    ref = O.sparse_head_forward_v2(x.double(), rowptr, col, s.W.detach().double().cpu(), s.a.detach().double().cpu(), 0.2, False)
+    close(ys, ref.numpy(), "sparse V2")
+    # model: --model GATv2_sparse (train.py:117), 8 heads then 1
+    torch.manual_seed(4)
+    m = pg.GAT([Fin, 8, 7], [8, 1], 2, 0.0, 0.2, pg.SpGraphAttentionLayerV2).cuda()
+    sd = m.state_dict()
+    assert tuple(sd["attention_layer_1_head_1.W"].shape) == (2 * Fin, 8) and tuple(sd["attention_layer_1_head_1.a"].shape) == (1, 8)
+    y = m(x.cuda(), adj.cuda())
+    h = O.level_forward_v2(x.double(), (rowptr, col),
+                           torch.stack([sd[f"attention_layer_1_head_{j}.W"].double().cpu() for j in range(1, 9)]),
+                           torch.stack([sd[f"attention_layer_1_head_{j}.a"].double().cpu().reshape(-1) for j in range(1, 9)]),
+                           0.2, True)
+    ref = O.level_forward_v2(h, (rowptr, col), sd["attention_layer_2_head_1.W"].double().cpu()[None],
+                             sd["attention_layer_2_head_1.a"].double().cpu().reshape(1, -1), 0.2, False)
+    close(y, ref.numpy(), "GATv2_sparse model")
+    y.sum().backward()
+    assert all(p.grad is not None for p in m.parameters())
+    with pytest.raises(NotImplementedError):
+        pg.SpGraphAttentionLayerV2(Fin, Fo, 0.5, 0.2).cuda().train()(x.cuda(), adj.cuda())

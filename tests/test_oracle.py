@@ -100,3 +100,31 @@ def test_real_topologies_fp32_vs_fp64(topologies):
     y64 = O.level_forward(x, (rowptr, col), W, a, 0.2, True)
     y32 = O.level_forward(x.float(), (rowptr, col), W.float(), a.float(), 0.2, True)
     assert (y64 - y32.double()).abs().max() < 1e-5
+
+
+def test_dense_v2_is_a_neighbour_mean():
+    """layers.py:214-219: e is [N,1] and broadcasts along rows -> uniform attention;
+    so dense V2 == mean of Wh2 over the neighbours, and a / W[:Fin] get exactly-zero gradients."""
+    N, Fin, Fo = 30, 6, 4
+    rowptr, col = O.random_symmetric_csr(N, 4, 31)
+    adj = O.dense_from_csr(rowptr, col, N, torch.float64)
+    gen = torch.Generator().manual_seed(32)
+    x = torch.randn(N, Fin, dtype=torch.float64, generator=gen)
+    W = torch.randn(2 * Fin, Fo, dtype=torch.float64, generator=gen).requires_grad_()
+    a = torch.randn(Fo, 1, dtype=torch.float64, generator=gen).requires_grad_()
+    y = O.dense_head_forward_v2(x, adj, W, a, 0.2, False)
+    deg = adj.sum(1, keepdim=True)
+    assert torch.allclose(y, (adj @ (x @ W[Fin:])) / deg, atol=1e-12)
+    y.sum().backward()
+    assert a.grad.abs().max() < 1e-12 and W.grad[:Fin].abs().max() < 1e-12 and W.grad[Fin:].abs().max() > 1e-3
+
+
+def test_sparse_v2_gradcheck():
+    N, Fin, Fo = 10, 4, 4
+    rowptr, col = O.random_symmetric_csr(N, 3, 41)
+    gen = torch.Generator().manual_seed(42)
+    x = torch.randn(N, Fin, dtype=torch.float64, generator=gen).requires_grad_()
+    W = (torch.randn(2 * Fin, Fo, dtype=torch.float64, generator=gen) * 0.5).requires_grad_()
+    a = torch.randn(1, Fo, dtype=torch.float64, generator=gen).requires_grad_()
+    f = lambda x_, W_, a_: O.sparse_head_forward_v2(x_, rowptr, col, W_, a_, 0.2, True)  # noqa: E731
+    assert torch.autograd.gradcheck(f, (x, W, a), eps=1e-6, atol=1e-6)

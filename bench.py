@@ -179,7 +179,7 @@ def main():
                        "nodes": N, "edges": E, "fin": Fin, "heads": H, "f_out": Fo,
                        "parallelism": f"head-parallel x{world}" if world > 1 else "single GPU",
                        "heads_per_gpu": h_loc},
-            "roofline": {"kernel": "k2_forward (gat_fwd_kernel + combine)", "bound": "hbm", "achieved": achieved,
+            "roofline": {"kernel": "k2_forward (gat_fwd_kernel + gat_fwd_fixup_kernel)", "bound": "hbm", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "algorithmic_bytes": b_fwd, "avg_ms": k2},
             "kernels_ms": kt,

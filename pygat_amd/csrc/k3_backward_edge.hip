@@ -200,9 +200,11 @@ __global__ __launch_bounds__(256) void gat_bwd_row_kernel(RowArgs a) {
   const int r_first = rc[e0].x;
   const bool head_partial = a.g.rowptr[r_first] < e0;
   int cur = r_first;
+  int rprev = -1;
+  float4 gcur[VEC], rtcur[VEC];
   float acc[VEC];
 #pragma unroll
-  for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+  for (int v = 0; v < VEC; ++v) { acc[v] = 0.f; gcur[v] = make_float4(0.f, 0.f, 0.f, 0.f); rtcur[v] = gcur[v]; }
 
   for (int64_t e = e0; e < e1; e += U) {
     int2 p[U];
@@ -210,16 +212,33 @@ __global__ __launch_bounds__(256) void gat_bwd_row_kernel(RowArgs a) {
     for (int u = 0; u < U; ++u) p[u] = rc[(e + u < e1) ? e + u : e1 - 1];
     float4 rt[U][VEC], wv[U][VEC], gv[U][VEC];
     float mk[U][VEC];
+    // the gathers first; the row-local GR_i chunk is only re-fetched when the row id changes inside the
+    // batch (edge-weighted, most consecutive edges share their row: the kernel is load-issue bound)
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
-        const float* gr = a.GR + (int64_t)p[u].x * RW;
-        gv[u][v] = ld4(gr + lc.cofs[v]);
-        rt[u][v] = ld4(gr + R + 4 * lc.head[v]);
         wv[u][v] = ld4(a.Wh + (int64_t)p[u].y * R + lc.cofs[v]);
         mk[u][v] = a.mask ? a.mask[((e + u < e1) ? e + u : e1 - 1) * H + lc.head[v]] : 1.f;
       }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int prev = (u == 0) ? rprev : p[u - 1].x;
+      if (p[u].x != prev) {
+        const float* gr = a.GR + (int64_t)p[u].x * RW;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { gv[u][v] = ld4(gr + lc.cofs[v]); rt[u][v] = ld4(gr + R + 4 * lc.head[v]); }
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          gv[u][v] = (u == 0) ? gcur[v] : gv[u > 0 ? u - 1 : 0][v];
+          rt[u][v] = (u == 0) ? rtcur[v] : rt[u > 0 ? u - 1 : 0][v];
+        }
+      }
+    }
+    rprev = p[U - 1].x;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { gcur[v] = gv[U - 1][v]; rtcur[v] = rt[U - 1][v]; }
     // all lanes of the group are active here: the per-head DPP sums are safe
     float dz[U][VEC];
 #pragma unroll

@@ -132,15 +132,18 @@ int gat_oracle_level(int64_t N, int64_t E, const int32_t* rowptr, const int32_t*
         al[k] = ev;
         if (ev > m) m = ev;
       }
-      float Z = 0.f;
-      for (int k = b; k < e; ++k) { al[k] = expf(al[k] - m); Z += al[k]; }
+      /* row sums in double: a hub row has 10^4+ terms and fp32 running sums would make the ORACLE the
+         less accurate side of the comparison */
+      double Zd = 0.0;
+      for (int k = b; k < e; ++k) { al[k] = expf(al[k] - m); Zd += al[k]; }
+      const float Z = (float)Zd;
       float* hr = hp + i * F;
-      for (int f = 0; f < F; ++f) hr[f] = 0.f;
-      for (int k = b; k < e; ++k) {
-        const float* wj = Wh + (int64_t)col[k] * F;
-        for (int f = 0; f < F; ++f) hr[f] += al[k] * wj[f];
+      for (int f = 0; f < F; ++f) {
+        double acc = 0.0;
+        for (int k = b; k < e; ++k) acc += (double)al[k] * Wh[(int64_t)col[k] * F + f];
+        hr[f] = (float)acc;
       }
-      float D = 0.f;
+      double D = 0.0;
       for (int f = 0; f < F; ++f) {
         hr[f] /= Z;
         float g, o;
@@ -153,34 +156,33 @@ int gat_oracle_level(int64_t N, int64_t E, const int32_t* rowptr, const int32_t*
           g = G[i * OC + f] / (float)H;
         }
         Gp[i * F + f] = g;
-        D += g * hr[f];
+        D += (double)g * hr[f];
       }
-      float dsi = 0.f;
+      double dsi = 0.0;
       for (int k = b; k < e; ++k) {
         const float* wj = Wh + (int64_t)col[k] * F;
         float dp = 0.f;
         for (int f = 0; f < F; ++f) dp += Gp[i * F + f] * wj[f];
         al[k] /= Z;
         float z = s[i] + t[col[k]];
-        dz[k] = al[k] * (dp - D) * (z > 0.f ? 1.f : alpha);
+        dz[k] = al[k] * (dp - (float)D) * (z > 0.f ? 1.f : alpha);
         dsi += dz[k];
       }
-      ds[i] = dsi;
+      ds[i] = (float)dsi;
     }
     /* column pass over the transposed pattern */
 #pragma omp parallel for schedule(dynamic, 256)
     for (int64_t j = 0; j < N; ++j) {
       float* dr = dWh + j * F;
-      for (int f = 0; f < F; ++f) dr[f] = 0.f;
-      float dtj = 0.f;
-      for (int k = rowptr_t[j]; k < rowptr_t[j + 1]; ++k) {
-        const int pe = perm_t[k];
-        const float* gi = Gp + (int64_t)col_t[k] * F;
-        for (int f = 0; f < F; ++f) dr[f] += al[pe] * gi[f];
-        dtj += dz[pe];
-      }
+      double dtd = 0.0;
+      for (int k = rowptr_t[j]; k < rowptr_t[j + 1]; ++k) dtd += dz[perm_t[k]];
+      const float dtj = (float)dtd;
       dt[j] = dtj;
-      for (int f = 0; f < F; ++f) dr[f] += ds[j] * as[f] + dtj * ad[f];
+      for (int f = 0; f < F; ++f) {
+        double acc = 0.0;
+        for (int k = rowptr_t[j]; k < rowptr_t[j + 1]; ++k) acc += (double)al[perm_t[k]] * Gp[(int64_t)col_t[k] * F + f];
+        dr[f] = (float)acc + ds[j] * as[f] + dtj * ad[f];
+      }
     }
     /* da */
     for (int f = 0; f < F; ++f) {

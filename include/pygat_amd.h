@@ -138,6 +138,11 @@ typedef struct {
   int slot_edges;            /* nominal edges per slot: multiple of 4, >= 4 */
   const int32_t* slot_begin; /* NULL: slot k = edges [k*slot_edges, (k+1)*slot_edges); else [n_slots+1]
                                 row-snapped borders from pygat_slot_bounds (fewer rows are cut) */
+  const int32_t* cut_rows;   /* NULL, or [n_cut][3] = (first slot k, row, number of pieces) of every row that a
+                                slot border cuts, sorted by pieces descending: lets the fix-up launches go
+                                straight to the cut rows instead of screening every slot */
+  int n_cut;
+  int n_cut_wide;            /* leading entries with more than 32 pieces (merged by a whole work-group) */
 } pygat_graph;
 
 /* edge_rc[k] = (i, col[k]) for rowptr[i] <= k < rowptr[i+1] */

@@ -16,6 +16,7 @@
 
 namespace pygat {
 
+constexpr int FIX_WIDE = 32;   // cut rows with more pieces are merged by a whole work-group
 constexpr int FIX_SCREEN = 8;  // slots screened per wave by the fix-up kernels (owned rows are merged serially)
 constexpr float NEG_BIG = -1.0e30f;  // running-max seed: exp(NEG_BIG - x) == 0, exp(NEG_BIG - NEG_BIG) == 1
 
@@ -68,6 +69,8 @@ struct GraphDev {  // device view of pygat_graph
   const int2* rc;   // (row, col) per edge
   int ts;           // nominal edges per slot
   const int32_t* sb;  // row-snapped slot borders [nslots+1] or nullptr (uniform slots)
+  const int32_t* cut;  // [n_cut][3] (slot, row, pieces) or nullptr
+  int n_cut, n_cut_wide;
 };
 
 static inline int check_graph(const pygat_graph* g, GraphDev* d) {
@@ -85,6 +88,11 @@ static inline int check_graph(const pygat_graph* g, GraphDev* d) {
   }
   d->n = g->n; d->nnz = g->nnz; d->rowptr = g->rowptr; d->rc = reinterpret_cast<const int2*>(g->edge_rc);
   d->ts = g->slot_edges; d->sb = g->slot_begin;
+  d->cut = g->cut_rows; d->n_cut = g->cut_rows ? g->n_cut : 0; d->n_cut_wide = g->cut_rows ? g->n_cut_wide : 0;
+  if (d->n_cut < 0 || d->n_cut_wide < 0 || d->n_cut_wide > d->n_cut) {
+    set_error("graph: bad cut-row list (n_cut=%d n_cut_wide=%d)", g->n_cut, g->n_cut_wide);
+    return PYGAT_EINVAL;
+  }
   return PYGAT_OK;
 }
 

@@ -313,6 +313,88 @@ __global__ __launch_bounds__(256) void gat_fwd_fixup_kernel(FwdArgs a) {
   }
 }
 
+// list-driven variant: entry q of g.cut = (owner slot k, row, pieces); the first n_cut_wide entries (long
+// chains) get a whole work-group each, the others one wave each.
+template <int LPR, int VEC>
+__global__ __launch_bounds__(256) void gat_fwd_fixup_list_kernel(FwdArgs a) {
+  constexpr int EPW = 64 / LPR;
+  constexpr int PF = (VEC == 1) ? 4 : 2;
+  extern __shared__ __attribute__((aligned(16))) float fix_sm[];  // [4][R + 2H]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const bool wide = (int)blockIdx.x < a.g.n_cut_wide;
+  const int q0 = wide ? (int)blockIdx.x : a.g.n_cut_wide + ((int)blockIdx.x - a.g.n_cut_wide) * 4 + w;
+  if (q0 >= a.g.n_cut) return;
+  const int64_t k = a.g.cut[3 * q0];
+  const int r = a.g.cut[3 * q0 + 1];
+  const int npieces = a.g.cut[3 * q0 + 2];
+  const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
+  const int slot = lane / LPR;
+  const int64_t PS = a.rs.R + 2 * a.rs.H;
+  const int wsel = wide ? w : 0;   // wave index inside the merge; a lone wave plays wave 0
+  float m[VEC], z[VEC];
+  float4 acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { m[v] = NEG_BIG; z[v] = 0.f; acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); }
+  {
+    const int nw = wide ? 4 : 1;
+    for (int q = (wide ? w : 0) * EPW * PF + slot; q < npieces; q += nw * EPW * PF) {
+      float mp[PF][VEC], zp[PF][VEC];
+      float4 ap[PF][VEC];
+#pragma unroll
+      for (int f = 0; f < PF; ++f) {
+        const int qq = q + f * EPW;
+        const int qc = qq < npieces ? qq : q;
+        const float* p = a.part + (qc == 0 ? 2 * k + 1 : 2 * (k + qc)) * PS;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          mp[f][v] = p[a.rs.R + lc.head[v]]; zp[f][v] = p[a.rs.R + a.rs.H + lc.head[v]]; ap[f][v] = ld4(p + lc.cofs[v]);
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < PF; ++f)
+        if (q + f * EPW < npieces) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) merge_state(m[v], z[v], acc[v], mp[f][v], zp[f][v], ap[f][v]);
+        }
+    }
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        float mo = __shfl_xor(m[v], off), zo = __shfl_xor(z[v], off);
+        float4 ao;
+        ao.x = __shfl_xor(acc[v].x, off); ao.y = __shfl_xor(acc[v].y, off);
+        ao.z = __shfl_xor(acc[v].z, off); ao.w = __shfl_xor(acc[v].w, off);
+        merge_state(m[v], z[v], acc[v], mo, zo, ao);
+      }
+    }
+  }
+  if (wide) {  // wave partials -> LDS -> wave 0 (uniform branch: `wide` is the same in all waves)
+    if (slot == 0) {
+      float* p = fix_sm + w * PS;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v)
+        if (lc.valid[v]) {
+          st4(p + lc.cofs[v], acc[v]);
+          if (((lc.cofs[v] >> 2) & (a.rs.lph - 1)) == 0) { p[a.rs.R + lc.head[v]] = m[v]; p[a.rs.R + a.rs.H + lc.head[v]] = z[v]; }
+        }
+    }
+    __syncthreads();
+    if (wsel == 0 && slot == 0) {
+#pragma unroll
+      for (int ww = 1; ww < 4; ++ww) {
+        const float* p = fix_sm + ww * PS;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+          merge_state(m[v], z[v], acc[v], p[a.rs.R + lc.head[v]], p[a.rs.R + a.rs.H + lc.head[v]], ld4(p + lc.cofs[v]));
+      }
+    }
+    __syncthreads();
+  }
+  if (wsel == 0 && slot == 0) fwd_finish<VEC>(a, lc, r, m, z, acc);
+}
+
+
 // models.py:34 -- mean over heads of (hattn [+ sk]); one thread per output element
 __global__ __launch_bounds__(256) void head_mean_kernel(int n, int H, int Fo, int Fp,
                                                         const float* __restrict__ hattn,
@@ -390,10 +472,18 @@ static int launch_forward(const pygat_graph* g, int H, int Fo, float alpha, int 
                          hipLaunchKernelGGL((gat_fwd_kernel<LPR, VEC, false>), dim3(blocks), dim3(256), 0, st, a));
   }
   PYGAT_CHECK_LAUNCH("gat_forward");
-  const unsigned fb = (unsigned)cdiv(nslots, FIX_SCREEN);
   const size_t fix_lds = 4 * (size_t)(a.rs.R + 2 * a.rs.H) * sizeof(float);
-  PYGAT_DISPATCH_LANES(lpr, vec,
-                       hipLaunchKernelGGL((gat_fwd_fixup_kernel<LPR, VEC>), dim3(fb), dim3(256), fix_lds, st, a));
+  if (a.g.cut) {  // the caller listed the cut rows: go straight to them
+    if (a.g.n_cut > 0) {
+      const unsigned fb = (unsigned)(a.g.n_cut_wide + cdiv(a.g.n_cut - a.g.n_cut_wide, 4));
+      PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_fwd_fixup_list_kernel<LPR, VEC>), dim3(fb), dim3(256),
+                                                        fix_lds, st, a));
+    }
+  } else {
+    const unsigned fb = (unsigned)cdiv(nslots, FIX_SCREEN);
+    PYGAT_DISPATCH_LANES(lpr, vec,
+                         hipLaunchKernelGGL((gat_fwd_fixup_kernel<LPR, VEC>), dim3(fb), dim3(256), fix_lds, st, a));
+  }
   PYGAT_CHECK_LAUNCH("gat_forward_fixup");
   return PYGAT_OK;
 }

@@ -244,6 +244,88 @@ __global__ __launch_bounds__(256) void gat_bwd_col_fixup_kernel(ColArgs a) {
   }
 }
 
+// list-driven variant: entry q of g.cut = (owner slot k, row, pieces); the first n_cut_wide entries (long
+// chains) get a whole work-group each, the others one wave each.
+template <int LPR, int VEC>
+__global__ __launch_bounds__(256) void gat_bwd_col_fixup_list_kernel(ColArgs a) {
+  constexpr int EPW = 64 / LPR;
+  constexpr int PF = (VEC == 1) ? 4 : 2;
+  extern __shared__ __attribute__((aligned(16))) float fix_sm[];  // [4][R + 2H]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const bool wide = (int)blockIdx.x < a.g.n_cut_wide;
+  const int q0 = wide ? (int)blockIdx.x : a.g.n_cut_wide + ((int)blockIdx.x - a.g.n_cut_wide) * 4 + w;
+  if (q0 >= a.g.n_cut) return;
+  const int64_t k = a.g.cut[3 * q0];
+  const int r = a.g.cut[3 * q0 + 1];
+  const int npieces = a.g.cut[3 * q0 + 2];
+  const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
+  const int slot = lane / LPR;
+  const int64_t PS = a.rs.R + 2 * a.rs.H;
+  const int wsel = wide ? w : 0;   // wave index inside the merge; a lone wave plays wave 0
+  float4 acc[VEC];
+  float dt[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); dt[v] = 0.f; }
+  {
+    const int nw = wide ? 4 : 1;
+    for (int q = (wide ? w : 0) * EPW * PF + slot; q < npieces; q += nw * EPW * PF) {
+      float4 xp[PF][VEC];
+      float tp[PF][VEC];
+#pragma unroll
+      for (int f = 0; f < PF; ++f) {
+        const int qq = q + f * EPW;
+        const int qc = qq < npieces ? qq : q;
+        const float* p = a.part + (qc == 0 ? 2 * k + 1 : 2 * (k + qc)) * PS;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          xp[f][v] = ld4(p + lc.cofs[v]); tp[f][v] = p[a.rs.R + lc.head[v]];
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < PF; ++f)
+        if (q + f * EPW < npieces) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            acc[v].x += xp[f][v].x; acc[v].y += xp[f][v].y; acc[v].z += xp[f][v].z; acc[v].w += xp[f][v].w;
+            dt[v] += tp[f][v];
+          }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      acc[v] = slot_sum4<LPR>(acc[v]);
+      dt[v] = slot_sum<LPR>(dt[v]);
+    }
+  }
+  if (wide) {
+    if (slot == 0) {
+      float* p = fix_sm + w * PS;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v)
+        if (lc.valid[v]) {
+          st4(p + lc.cofs[v], acc[v]);
+          if (((lc.cofs[v] >> 2) & (a.rs.lph - 1)) == 0) p[a.rs.R + lc.head[v]] = dt[v];
+        }
+    }
+    __syncthreads();
+    if (wsel == 0 && slot == 0) {
+#pragma unroll
+      for (int ww = 1; ww < 4; ++ww) {
+        const float* p = fix_sm + ww * PS;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const float4 x = ld4(p + lc.cofs[v]);
+          acc[v].x += x.x; acc[v].y += x.y; acc[v].z += x.z; acc[v].w += x.w;
+          dt[v] += p[a.rs.R + lc.head[v]];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (wsel == 0 && slot == 0) col_finish<VEC>(a, lc, r, acc, dt);
+}
+
+
 }  // namespace pygat
 
 using namespace pygat;
@@ -271,8 +353,16 @@ extern "C" int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm
                        hipLaunchKernelGGL((gat_bwd_col_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0, st, a));
   PYGAT_CHECK_LAUNCH("gat_backward_col");
   const size_t fix_lds = 4 * (size_t)(a.rs.R + 2 * a.rs.H) * sizeof(float);
-  PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_bwd_col_fixup_kernel<LPR, VEC>),
-                                                    dim3((unsigned)cdiv(nslots, FIX_SCREEN)), dim3(256), fix_lds, st, a));
+  if (a.g.cut) {
+    if (a.g.n_cut > 0) {
+      const unsigned fb = (unsigned)(a.g.n_cut_wide + cdiv(a.g.n_cut - a.g.n_cut_wide, 4));
+      PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_bwd_col_fixup_list_kernel<LPR, VEC>), dim3(fb), dim3(256),
+                                                        fix_lds, st, a));
+    }
+  } else {
+    PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_bwd_col_fixup_kernel<LPR, VEC>),
+                                                      dim3((unsigned)cdiv(nslots, FIX_SCREEN)), dim3(256), fix_lds, st, a));
+  }
   PYGAT_CHECK_LAUNCH("gat_backward_col_fixup");
   return PYGAT_OK;
 }

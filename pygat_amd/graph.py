@@ -73,8 +73,23 @@ class _Pattern:
                 with torch.cuda.device(self.rowptr.device):
                     check(lib.pygat_slot_bounds(self.n, self.nnz, self.rowptr.data_ptr(), self.edge_rc.data_ptr(),
                                                 slot_edges, sb.data_ptr(), _stream()), "slot_bounds")
-            st = _lib.Graph(self.n, self.nnz, _ptr(self.rowptr), _ptr(self.edge_rc), slot_edges, _ptr(sb))
-            self._alt[key] = (st, sb)
+            cut, n_cut, n_wide = None, 0, 0
+            if snapped:   # rows cut by a slot border: (owner slot, row, pieces), longest chains first
+                sbl = sb.long()
+                e0, e1 = sbl[:-1], sbl[1:]
+                r_last = self.edge_rc[e1 - 1, 0].long()
+                rp = self.rowptr.long()
+                row_end = rp[r_last + 1]
+                k = torch.nonzero((row_end > e1) & (rp[r_last] >= e0)).flatten()
+                if k.numel():
+                    k_e = torch.searchsorted(sbl, row_end[k] - 1, right=True) - 1
+                    pieces = k_e - k + 1
+                    order = torch.argsort(pieces, descending=True, stable=True)
+                    cut = torch.stack([k, r_last[k], pieces], 1)[order].to(torch.int32).contiguous()
+                    n_cut, n_wide = int(k.numel()), int((pieces > 32).sum().item())
+            st = _lib.Graph(self.n, self.nnz, _ptr(self.rowptr), _ptr(self.edge_rc), slot_edges, _ptr(sb), _ptr(cut),
+                            n_cut, n_wide)
+            self._alt[key] = (st, sb, cut)
         return self._alt[key][0]
 
     def ref(self, slot_edges: Optional[int] = None, snapped: bool = True):

@@ -46,10 +46,10 @@ def test_argument_validation_returns_einval(lib):
     assert L.pygat_dense_row_counts(None, 4, 4, 0, None, None) == -1
     assert b"bad arguments" in L.pygat_last_error()
     assert L.pygat_gemm_f32(0, 0, 4, 4, 4, None, 4, None, 4, None, 0, 1, None, None) == -1
-    g = lib.Graph(0, 0, None, None, 64, None)
+    g = lib.Graph(0, 0, None, None, 64, None, None, 0, 0)
     assert L.pygat_gat_forward(C.byref(g), 8, 16, 0.2, 1, None, None, None, None, None, None, None, None, None, None, None) == -1
     assert b"graph" in L.pygat_last_error()
-    g2 = lib.Graph(4, 4, 1, 1, 6, None)             # slot_edges not a multiple of 4
+    g2 = lib.Graph(4, 4, 1, 1, 6, None, None, 0, 0)             # slot_edges not a multiple of 4
     assert L.pygat_gat_forward(C.byref(g2), 8, 16, 0.2, 1, None, None, None, None, None, None, None, None, None, None, None) == -1
     assert b"slot_edges" in L.pygat_last_error()
     with pytest.raises(ValueError):

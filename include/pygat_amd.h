@@ -111,7 +111,12 @@ int pygat_gemm_f32(int transA, int transB, int M, int N, int64_t K,
 int pygat_pack_params(int H, int Fin, int Fo, const float* W, const float* a,
                       const float* w_skip, float* Wcat, int64_t ldw, float* a_pad,
                       void* stream);
-/* s[n x H], t[n x H] from an (already masked) Wh table: s_ih = Wh_ih . a_src_h, t_ih = Wh_ih . a_dst_h
+/* Projection of one level in one GEMM: [Wh | Sk | s] = X * Wcat[:, :R (+R) + H]; the H columns behind the
+ * heads are W_h a_src_h (pygat_pack_params), so s_i = Wh_i . a_src (layers.py:60) comes out of the same pass.
+ * Sk may be NULL (no skip).  split_k / ws as pygat_gemm_f32. */
+int pygat_project(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const float* Wcat, int64_t ldw,
+                  float* Wh, float* Sk, float* s, int split_k, void* ws, void* stream);
+/* s[n x H], t[n x H] (t may be NULL) from an (already masked) Wh table: s_ih = Wh_ih . a_src_h, t_ih = Wh_ih . a_dst_h
  * (layers.py:60-61 after the Wh dropout of layers.py:37,136).  a_pad as written by pygat_pack_params. */
 int pygat_attn_scores(int n, int H, int Fo, const float* Wh, const float* a_pad,
                       float* s, float* t, void* stream);

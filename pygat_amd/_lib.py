@@ -21,7 +21,7 @@ SYMBOLS = [
     "pygat_abi_version", "pygat_last_error", "pygat_padded_width", "pygat_device_count",
     "pygat_device_name", "pygat_dense_row_counts", "pygat_scan_workspace_bytes",
     "pygat_exclusive_scan_i32", "pygat_dense_fill_cols", "pygat_csr_symmetric_perm",
-    "pygat_gemm_workspace_bytes", "pygat_gemm_f32", "pygat_pack_params", "pygat_attn_scores",
+    "pygat_gemm_workspace_bytes", "pygat_gemm_f32", "pygat_pack_params", "pygat_project", "pygat_attn_scores",
     "pygat_unpack_wgrad",
     "pygat_edge_pairs", "pygat_slot_bounds", "pygat_partials_bytes", "pygat_gat_forward", "pygat_head_mean",
     "pygat_gat_backward_prepare", "pygat_gat_backward_row", "pygat_gat_backward_col",
@@ -67,6 +67,7 @@ def _load():
     lib.pygat_pack_params.argtypes = [i, i, i, p, p, p, p, i64, p, p]
     lib.pygat_unpack_wgrad.argtypes = [i, i, i, p, i64, i, p, p]
     lib.pygat_attn_scores.argtypes = [i, i, i, p, p, p, p, p]
+    lib.pygat_project.argtypes = [i, i, i, i, p, i64, p, i64, p, p, p, i, p, p]
     lib.pygat_edge_pairs.argtypes = [i, p, p, p, p]
     lib.pygat_slot_bounds.argtypes = [i, i64, p, p, i, p, p]
     lib.pygat_partials_bytes.argtypes = [i64, i, i, i]

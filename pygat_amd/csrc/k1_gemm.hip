@@ -323,3 +323,23 @@ extern "C" int pygat_gemm_f32(int transA, int transB, int M, int N, int64_t K, c
   }
   return PYGAT_OK;
 }
+
+// Projection of one level in one GEMM: [Wh | Sk | s] = X * Wcat[:, :R (+R) + H] -- the H columns behind the
+// heads are W_h a_src_h (written by pygat_pack_params), so s_i = Wh_i . a_src (layers.py:60) falls out of
+// the same MFMA pass.  (Computing s in the GEMM epilogue from the accumulators instead was tried: the
+// 64 cross-lane reductions per wave tile cost more than the fifth 32-column MFMA block they save.)
+extern "C" int pygat_project(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const float* Wcat, int64_t ldw,
+                             float* Wh, float* Sk, float* s, int split_k, void* ws, void* stream) {
+  const int Fp = padded_width(Fo);
+  PYGAT_REQUIRE(n > 0 && Fin > 0 && H > 0 && Fp > 0 && X && Wcat && Wh && s, "project: bad arguments");
+  const int R = H * Fp, nw = R * (Sk ? 2 : 1), ncols = nw + H;
+  PYGAT_REQUIRE(ldw >= nw + 2 * H && ldx >= Fin, "project: leading dimension too small");
+  pygat_out_segments seg;
+  int k = 0;
+  seg.col_start[0] = 0; seg.ptr[k] = Wh; seg.ld[k] = R; ++k;
+  if (Sk) { seg.col_start[k] = R; seg.ptr[k] = Sk; seg.ld[k] = R; ++k; }
+  seg.col_start[k] = nw; seg.ptr[k] = s; seg.ld[k] = H; ++k;
+  seg.col_start[k] = ncols;
+  seg.nseg = k;
+  return pygat_gemm_f32(0, 0, n, ncols, Fin, X, ldx, Wcat, ldw, &seg, 0, split_k, ws, stream);
+}

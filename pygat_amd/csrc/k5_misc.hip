@@ -12,7 +12,7 @@ namespace pygat {
 // da_src[h][f] = sum_i ds[i][h] Wh[i][h*Fp+f], da_dst likewise with dt (layers.py:60-61 autograd).
 constexpr int AG_BLOCKS = 1024;
 
-__global__ __launch_bounds__(256) void a_grad_partial_kernel(int n, RowShape rs, const float* __restrict__ Wh,
+__global__ __launch_bounds__(256) void a_grad_partial_kernel(int n, int nblocks, RowShape rs, const float* __restrict__ Wh,
                                                              const float* __restrict__ ds,
                                                              const float* __restrict__ dt,
                                                              float* __restrict__ ws) {
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void a_grad_partial_kernel(int n, RowShape rs,
   const int c = threadIdx.x % tpr, rg = threadIdx.x / tpr;
   const bool valid = c < rs.NCH;
   const int co = valid ? 4 * c : 0, h = co >> rs.fp_shift;
-  const int64_t rows_per_block = cdiv(n, AG_BLOCKS);
+  const int64_t rows_per_block = cdiv(n, nblocks);
   const int64_t r0 = blockIdx.x * rows_per_block;
   const int64_t r1 = (r0 + rows_per_block < n) ? r0 + rows_per_block : n;
   float4 as = make_float4(0.f, 0.f, 0.f, 0.f), ad = as;
@@ -66,14 +66,24 @@ __global__ __launch_bounds__(256) void a_grad_partial_kernel(int n, RowShape rs,
   }
 }
 
-__global__ __launch_bounds__(256) void a_grad_final_kernel(RowShape rs, const float* __restrict__ ws,
+__global__ __launch_bounds__(256) void a_grad_final_kernel(RowShape rs, int nblocks, const float* __restrict__ ws,
                                                            float* __restrict__ da) {
   const int idx = blockIdx.x * 256 + threadIdx.x;  // over H * 2 * Fo
   if (idx >= rs.H * 2 * rs.Fo) return;
   const int h = idx / (2 * rs.Fo), r = idx % (2 * rs.Fo);
   const int which = r / rs.Fo, f = r % rs.Fo;
   float acc = 0.f;
-  for (int b = 0; b < AG_BLOCKS; ++b) acc += ws[(int64_t)b * 2 * rs.R + which * rs.R + h * rs.Fp + f];
+  const float* p = ws + which * rs.R + h * rs.Fp + f;
+  const int64_t st = 2 * (int64_t)rs.R;
+  int b = 0;
+  for (; b + 8 <= nblocks; b += 8) {  // 8 loads in flight, added in slab order
+    float x[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) x[q] = p[(b + q) * st];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc += x[q];
+  }
+  for (; b < nblocks; ++b) acc += p[b * st];
   da[idx] = acc;
 }
 
@@ -93,7 +103,7 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(int n, int H, int Fp, 
     y += dot4(w4, d4);
   }
   s[idx] = x;
-  t[idx] = y;
+  if (t) t[idx] = y;
 }
 
 // ------------------------------------------------------------- parameter packing
@@ -154,8 +164,11 @@ extern "C" int pygat_a_grad(int n, int H, int Fo, const float* Wh, const float* 
   PYGAT_REQUIRE(make_row_shape(H, Fo, &rs), "a_grad: unsupported H=%d F'=%d", H, Fo);
   PYGAT_REQUIRE(n > 0 && Wh && ds && dt && da && ws && aligned16(Wh) && aligned16(ws), "a_grad: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(a_grad_partial_kernel, dim3(AG_BLOCKS), dim3(256), 0, st, n, rs, Wh, ds, dt, (float*)ws);
-  hipLaunchKernelGGL(a_grad_final_kernel, dim3((unsigned)cdiv(rs.H * 2 * rs.Fo, 256)), dim3(256), 0, st, rs,
+  // one slab of >= 256 rows per work-group, at most AG_BLOCKS slabs (small graphs: few, short reductions)
+  int nblocks = (int)cdiv(n, 256);
+  if (nblocks > AG_BLOCKS) nblocks = AG_BLOCKS;
+  hipLaunchKernelGGL(a_grad_partial_kernel, dim3(nblocks), dim3(256), 0, st, n, nblocks, rs, Wh, ds, dt, (float*)ws);
+  hipLaunchKernelGGL(a_grad_final_kernel, dim3((unsigned)cdiv(rs.H * 2 * rs.Fo, 256)), dim3(256), 0, st, rs, nblocks,
                      (const float*)ws, da);
   PYGAT_CHECK_LAUNCH("a_grad");
   return PYGAT_OK;
@@ -164,7 +177,7 @@ extern "C" int pygat_a_grad(int n, int H, int Fo, const float* Wh, const float* 
 extern "C" int pygat_attn_scores(int n, int H, int Fo, const float* Wh, const float* a_pad, float* s, float* t,
                                  void* stream) {
   int Fp = padded_width(Fo);
-  PYGAT_REQUIRE(n > 0 && H > 0 && Fp > 0 && Wh && a_pad && s && t && aligned16(Wh) && aligned16(a_pad),
+  PYGAT_REQUIRE(n > 0 && H > 0 && Fp > 0 && Wh && a_pad && s && aligned16(Wh) && aligned16(a_pad),
                 "attn_scores: bad arguments");
   hipLaunchKernelGGL(attn_scores_kernel, dim3((unsigned)cdiv((int64_t)n * H, 256)), dim3(256), 0, (hipStream_t)stream, n,
                      H, Fp, Wh, a_pad, s, t);

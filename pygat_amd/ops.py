@@ -142,11 +142,14 @@ class GATLevelFn(torch.autograd.Function):
             Wh = torch.empty(L.N, L.R, dtype=f32, device=dev)
             Sk = torch.empty(L.N, L.R, dtype=f32, device=dev) if skip else None
             s = torch.empty(L.N, H, dtype=f32, device=dev)
-            t = torch.empty(L.N, H, dtype=f32, device=dev)
-            segs = [(L.R, Wh, L.R)] + ([(L.R, Sk, L.R)] if skip else []) + [(H, s, H), (H, t, H)]
-            ncols = L.R * (2 if skip else 1) + 2 * H
+            ncols = L.R * (2 if skip else 1) + H
+            tiles = -(-L.N // 128) * -(-ncols // 128)
+            split_k = max(1, min(256 // tiles, Fin // 256)) if tiles < 256 else 1
+            ws = torch.empty(lib.pygat_gemm_workspace_bytes(L.N, ncols, split_k) // 4, dtype=f32, device=dev) \
+                if split_k > 1 else None
             with _span("k1_project"):
-                gemm(False, False, L.N, ncols, Fin, x, Fin, Wcat, L.ldw, segs)
+                check(lib.pygat_project(L.N, Fin, H, Fo, x.data_ptr(), Fin, Wcat.data_ptr(), L.ldw, Wh.data_ptr(),
+                                        _ptr(Sk), s.data_ptr(), split_k, _ptr(ws), st), "project")
             # K2
             flags = (_lib.F_ELU if concat else 0) | (_lib.F_SKIP if skip else 0)
             hattn = torch.empty(L.N, L.R, dtype=f32, device=dev) if not concat else None
@@ -163,13 +166,13 @@ class GATLevelFn(torch.autograd.Function):
                 check(lib.pygat_head_mean(L.N, H, Fo, hattn.data_ptr(), _ptr(Sk), out.data_ptr(), st), "head_mean")
         if need_grad:
             # concat: the backward recovers hattn from `out` (no second [N,R] table is written)
-            ctx.save_for_backward(x, Wcat, a_pad, Wh, s, t, Sk, out if concat else hattn, m, Z)
+            ctx.save_for_backward(x, Wcat, a_pad, Wh, s, Sk, out if concat else hattn, m, Z)
             ctx.graph, ctx.L, ctx.alpha, ctx.concat, ctx.flags = graph, L, float(alpha), concat, flags
         return out
 
     @staticmethod
     def backward(ctx, G):
-        x, Wcat, a_pad, Wh, s, t, Sk, y, m, Z = ctx.saved_tensors
+        x, Wcat, a_pad, Wh, s, Sk, y, m, Z = ctx.saved_tensors
         graph, L, H, Fo = ctx.graph, ctx.L, ctx.L.H, ctx.L.Fo
         dev, f32 = x.device, torch.float32
         G = G.contiguous().float()
@@ -231,6 +234,15 @@ def gat_level(x: torch.Tensor, graph: CSRGraph, Ws: Sequence[torch.Tensor], As: 
     """All heads of one level. Ws: H tensors [Fin,F']; As: H tensors with 2F' elements
     ([2F',1] as in GraphAttentionLayer, layers.py:23, or [1,2F'] as in SpGraphAttentionLayer,
     layers.py:114); Wskips: H tensors [Fin,F'] or None."""
+    H, Fp = len(Ws), padded_width(Ws[0].shape[1])
+    gmax = max(1, 1024 // Fp)          # a kernel call takes rows of at most 1024 floats (H*pad(F'))
+    if H > gmax:                       # more heads than one call holds: head groups, then cat / weighted mean
+        outs = []
+        for s0 in range(0, H, gmax):
+            s1 = min(H, s0 + gmax)
+            o = gat_level(x, graph, Ws[s0:s1], As[s0:s1], None if Wskips is None else Wskips[s0:s1], alpha, concat)
+            outs.append(o if concat else o * ((s1 - s0) / H))
+        return torch.cat(outs, dim=1) if concat else torch.stack(outs, 0).sum(0)
     W = torch.stack(list(Ws), 0)
     a = torch.stack([p.reshape(-1) for p in As], 0)
     Wskip = torch.stack(list(Wskips), 0) if Wskips is not None else None

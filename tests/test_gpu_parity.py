@@ -293,3 +293,48 @@ def test_single_layer_dropin_matches_oracle_head(pg):
             close(y, ref.numpy(), f"{cls.__name__} concat={concat}")
             y.sum().backward()
             assert layer.W.grad is not None and layer.a.grad.shape == layer.a.shape
+
+
+def test_more_heads_than_one_call_holds(pg):
+    """8 heads x 256 = 2048 floats per node row: gat_level splits into head groups (cat / weighted mean)."""
+    N, Fin, Fo, H = 40, 6, 256, 8
+    rowptr, col = O.random_symmetric_csr(N, 4, 17)
+    W, a, _ = params(H, Fin, Fo, False, 18)
+    x = torch.randn(N, Fin, dtype=torch.float64, generator=torch.Generator().manual_seed(19))
+    g = pg.CSRGraph(torch.as_tensor(rowptr).cuda(), torch.as_tensor(col).cuda())
+    for concat in (True, False):
+        ref = O.level_forward(x, (rowptr, col), W, a, 0.2, concat)
+        with torch.no_grad():
+            y = pg.gat_level(x.float().cuda(), g, list(W.float().cuda()), list(a.float().cuda()), None, 0.2, concat)
+        close(y, ref.numpy(), f"concat={concat}")
+
+
+@pytest.mark.parametrize("H,Fo,skip", [(8, 16, False), (2, 64, False), (1, 128, False), (8, 16, True), (16, 8, False), (3, 32, False)])
+def test_project(pg, H, Fo, skip):
+    """pygat_project (tall-skinny fast path: n >= 8192, Fin % 32 == 0): Wh, Sk and s_i = Wh_i . a_src against fp64."""
+    from pygat_amd._lib import lib, check
+    n, Fin = 8200, 64
+    Fp = pg.padded_width(Fo); R = H * Fp
+    gen = torch.Generator().manual_seed(H * 100 + Fo)
+    X = torch.randn(n, Fin, generator=gen); W = torch.randn(H, Fin, Fo, generator=gen) * 0.3
+    a = torch.randn(H, 2 * Fo, generator=gen) * 0.5
+    Ws = torch.randn(H, Fin, Fo, generator=gen) * 0.3 if skip else None
+    dev = "cuda"
+    ldw = -(-(R * (2 if skip else 1) + 2 * H) // 4) * 4
+    Wcat = torch.empty(Fin, ldw, device=dev); a_pad = torch.empty(H, 2, Fp, device=dev)
+    Wd, ad = W.to(dev).contiguous(), a.to(dev).contiguous()
+    Wsd = Ws.to(dev).contiguous() if skip else None
+    check(lib.pygat_pack_params(H, Fin, Fo, Wd.data_ptr(), ad.data_ptr(), Wsd.data_ptr() if skip else None, Wcat.data_ptr(),
+                                ldw, a_pad.data_ptr(), None))
+    Xd = X.to(dev); Wh = torch.full((n, R), float("nan"), device=dev); s = torch.full((n, H), float("nan"), device=dev)
+    Sk = torch.full((n, R), float("nan"), device=dev) if skip else None
+    check(lib.pygat_project(n, Fin, H, Fo, Xd.data_ptr(), Fin, Wcat.data_ptr(), ldw, Wh.data_ptr(),
+                            Sk.data_ptr() if skip else None, s.data_ptr(), 1, None, None))
+    torch.cuda.synchronize()
+    ref_wh = torch.einsum("nk,hkf->nhf", X.double(), W.double())
+    close(Wh.view(n, H, Fp)[:, :, :Fo], ref_wh.numpy(), "Wh", 1e-5)
+    close(s, torch.einsum("nhf,hf->nh", ref_wh, a[:, :Fo].double()).numpy(), "s", 1e-5)
+    if skip:
+        close(Sk.view(n, H, Fp)[:, :, :Fo], torch.einsum("nk,hkf->nhf", X.double(), Ws.double()).numpy(), "Sk", 1e-5)
+    if Fp > Fo:
+        assert bool((Wh.view(n, H, Fp)[:, :, Fo:] == 0).all())

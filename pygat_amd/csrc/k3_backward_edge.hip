@@ -288,6 +288,25 @@ __global__ __launch_bounds__(256) void gat_bwd_row_fixup_kernel(RowArgs a) {
   a.ds[(int64_t)r * H + h] = acc;
 }
 
+// list-driven variant: one wave per cut row; lane l sums pieces l, l+64, ... of each head, then a fixed
+// butterfly adds the 64 partial sums (a 26k-edge row has 400+ pieces: a single thread would walk them serially)
+__global__ __launch_bounds__(256) void gat_bwd_row_fixup_list_kernel(RowArgs a) {
+  const int q0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q0 >= a.g.n_cut) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t k = a.g.cut[3 * q0];
+  const int r = a.g.cut[3 * q0 + 1];
+  const int npieces = a.g.cut[3 * q0 + 2];
+  const int H = a.rs.H;
+  for (int h = 0; h < H; ++h) {
+    float acc = 0.f;
+    for (int q = lane; q < npieces; q += 64) acc += a.part[(q == 0 ? 2 * k + 1 : 2 * (k + q)) * (int64_t)H + h];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) a.ds[(int64_t)r * H + h] = acc;
+  }
+}
+
 }  // namespace pygat
 
 using namespace pygat;
@@ -367,7 +386,12 @@ extern "C" int pygat_gat_backward_row(const pygat_graph* g, int H, int Fo, float
   const unsigned blocks = (unsigned)cdiv(cdiv(nslots, 64 / lpr), 4);
   PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_bwd_row_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0, st, a));
   PYGAT_CHECK_LAUNCH("gat_backward_row");
-  hipLaunchKernelGGL(gat_bwd_row_fixup_kernel, dim3((unsigned)cdiv(nslots * H, 256)), dim3(256), 0, st, a);
+  if (a.g.cut) {
+    if (a.g.n_cut > 0)
+      hipLaunchKernelGGL(gat_bwd_row_fixup_list_kernel, dim3((unsigned)cdiv(a.g.n_cut, 4)), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(gat_bwd_row_fixup_kernel, dim3((unsigned)cdiv(nslots * H, 256)), dim3(256), 0, st, a);
+  }
   PYGAT_CHECK_LAUNCH("gat_backward_row_fixup");
   return PYGAT_OK;
 }

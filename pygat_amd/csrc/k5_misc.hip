@@ -66,25 +66,29 @@ __global__ __launch_bounds__(256) void a_grad_partial_kernel(int n, int nblocks,
   }
 }
 
+// 8 lanes share one output: lane q sums slabs q, q+8, ... (8 loads in flight each), then a fixed butterfly
 __global__ __launch_bounds__(256) void a_grad_final_kernel(RowShape rs, int nblocks, const float* __restrict__ ws,
                                                            float* __restrict__ da) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;  // over H * 2 * Fo
-  if (idx >= rs.H * 2 * rs.Fo) return;
-  const int h = idx / (2 * rs.Fo), r = idx % (2 * rs.Fo);
+  const int idx = (blockIdx.x * 256 + threadIdx.x) >> 3;  // over H * 2 * Fo
+  const int q = threadIdx.x & 7;
+  const bool ok = idx < rs.H * 2 * rs.Fo;
+  const int ii = ok ? idx : 0;
+  const int h = ii / (2 * rs.Fo), r = ii % (2 * rs.Fo);
   const int which = r / rs.Fo, f = r % rs.Fo;
-  float acc = 0.f;
   const float* p = ws + which * rs.R + h * rs.Fp + f;
   const int64_t st = 2 * (int64_t)rs.R;
-  int b = 0;
-  for (; b + 8 <= nblocks; b += 8) {  // 8 loads in flight, added in slab order
+  float acc = 0.f;
+  int b = q;
+  for (; b + 56 < nblocks; b += 64) {
     float x[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) x[q] = p[(b + q) * st];
+    for (int u = 0; u < 8; ++u) x[u] = p[(b + 8 * u) * st];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc += x[q];
+    for (int u = 0; u < 8; ++u) acc += x[u];
   }
-  for (; b < nblocks; ++b) acc += p[b * st];
-  da[idx] = acc;
+  for (; b < nblocks; b += 8) acc += p[b * st];
+  acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+  if (ok && q == 0) da[idx] = acc;
 }
 
 // s, t from a (masked) Wh table: one thread per (node, head)
@@ -168,7 +172,7 @@ extern "C" int pygat_a_grad(int n, int H, int Fo, const float* Wh, const float* 
   int nblocks = (int)cdiv(n, 256);
   if (nblocks > AG_BLOCKS) nblocks = AG_BLOCKS;
   hipLaunchKernelGGL(a_grad_partial_kernel, dim3(nblocks), dim3(256), 0, st, n, nblocks, rs, Wh, ds, dt, (float*)ws);
-  hipLaunchKernelGGL(a_grad_final_kernel, dim3((unsigned)cdiv(rs.H * 2 * rs.Fo, 256)), dim3(256), 0, st, rs, nblocks,
+  hipLaunchKernelGGL(a_grad_final_kernel, dim3((unsigned)cdiv(rs.H * 2 * rs.Fo * 8, 256)), dim3(256), 0, st, rs, nblocks,
                      (const float*)ws, da);
   PYGAT_CHECK_LAUNCH("a_grad");
   return PYGAT_OK;

@@ -51,7 +51,7 @@ class GATLevelDropoutFn(torch.autograd.Function):
         if skip:
             Wskip = Wskip.contiguous().float()
         L = _Level(x, H, Fo, skip)
-        L.ts = graph.slot_edges
+        L.ts = slot_edges_for(L.R, graph.slot_edges)
         dev, f32 = x.device, torch.float32
         mask_x = mask_x.to(f32).contiguous(); mask_att = mask_att.to(f32).contiguous()
         # Wh mask in the padded head-interleaved layout [N, H, Fp]

@@ -129,7 +129,7 @@ class GATLevelFn(torch.autograd.Function):
         if skip:
             Wskip = Wskip.contiguous().float()
         L = _Level(x, H, Fo, skip)
-        L.ts = graph.slot_edges
+        L.ts = slot_edges_for(L.R, graph.slot_edges)
         dev, f32 = x.device, torch.float32
         need_grad = any(ctx.needs_input_grad[:4])
         with torch.cuda.device(dev):

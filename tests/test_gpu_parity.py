@@ -338,3 +338,35 @@ def test_project(pg, H, Fo, skip):
         close(Sk.view(n, H, Fp)[:, :, :Fo], torch.einsum("nk,hkf->nhf", X.double(), Ws.double()).numpy(), "Sk", 1e-5)
     if Fp > Fo:
         assert bool((Wh.view(n, H, Fp)[:, :, Fo:] == 0).all())
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_level(pg, seed):
+    """Random shapes / patterns / slot lengths (fixed seeds): forward + all gradients vs the fp64 oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.integers(1, 400))
+    H = int(rng.choice([1, 2, 3, 4, 6, 8]))
+    Fo = int(rng.choice([1, 3, 4, 5, 8, 16, 17, 32, 64, 100]))
+    while H * pg.padded_width(Fo) > 1024:
+        H = max(1, H // 2)
+    Fin = int(rng.integers(1, 70))
+    skip, concat = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    slot = int(rng.choice([4, 8, 16, 64]))
+    if rng.integers(0, 2):
+        rowptr, col = O.random_symmetric_csr(N, float(rng.uniform(0.5, 12)), seed, hub=(0, int(rng.integers(1, N + 1))))
+    else:  # asymmetric, still with self loops (no empty row)
+        dense = (rng.random((N, N)) < rng.uniform(0.01, 0.3)) | np.eye(N, dtype=bool)
+        rowptr = np.concatenate([[0], np.cumsum(dense.sum(1))]).astype(np.int32)
+        col = np.nonzero(dense)[1].astype(np.int32)
+    W, a, Sk = params(H, Fin, Fo, skip, seed)
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Fin, dtype=torch.float64, generator=gen)
+    G = torch.randn(N, H * Fo if concat else Fo, dtype=torch.float64, generator=gen)
+    ref = O.csr_layer_fwd_bwd(x.numpy(), rowptr, col, W.numpy(), a.numpy(), 0.2, concat, G.numpy(),
+                              None if Sk is None else Sk.numpy())
+    out, dx, dW, da, dS = run_level(pg, x, rowptr, col, W, a, Sk, concat, G, slot=slot)
+    tag = f"N={N} H={H} Fo={Fo} Fin={Fin} skip={skip} concat={concat} slot={slot} E={len(col)}"
+    close(out, ref["out"], "out " + tag); close(dx, ref["dX"], "dX " + tag)
+    close(dW, ref["dW"], "dW " + tag); close(da, ref["da"], "da " + tag)
+    if skip:
+        close(dS, ref["dW_skip"], "dW_skip " + tag)

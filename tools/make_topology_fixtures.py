@@ -11,6 +11,7 @@ the D^-1/2 (A+I) D^-1/2 values of utils.py:73-79 are not kept.
             utils.py:25-26) is unknown: ids are ranked in ascending order here.
   citeseer  citeseer_dgl/adj_sparse.npz (utils.py:45), COO, self loops included
   pubmed    pubmed_dgl/adj_sparse.npz   (utils.py:45)
+  labels    {citeseer,pubmed}_dgl/labels.pt, idx_{train,val,test}.pt (utils.py:40-43) -> *_labels.npz
 
 Output: rowptr int32 [N+1], col int32 [E] (sorted within a row).
 """
@@ -47,6 +48,14 @@ def main():
         print(f"{name}: N={len(rowptr)-1} E={len(col)} deg min/med/mean/max = "
               f"{deg.min()}/{int(np.median(deg))}/{deg.mean():.2f}/{deg.max()}")
         np.savez_compressed(os.path.join(OUT, f"{name}_csr.npz"), rowptr=rowptr, col=col)
+    # labels and splits of the DGL dumps (utils.py:40-43); weights_only=True executes nothing from the files
+    import torch
+    for name in ("citeseer", "pubmed"):
+        d = f"{REF}/{name}_dgl"
+        ld = lambda f: torch.load(f"{d}/{f}.pt", weights_only=True).numpy()  # noqa: E731
+        np.savez_compressed(os.path.join(OUT, f"{name}_labels.npz"), labels=ld("labels").astype(np.int16),
+                            idx_train=ld("idx_train").astype(np.int32), idx_val=ld("idx_val").astype(np.int32),
+                            idx_test=ld("idx_test").astype(np.int32))
     # PPI: per-graph node counts are all that survives offline (graph JSONs are missing blobs)
     counts = {}
     for split in ("train", "valid", "test"):

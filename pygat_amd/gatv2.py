@@ -24,10 +24,14 @@ from .ops import _Level, _ptr, _stream, gemm, gat_level
 
 
 class GATv2LevelFn(torch.autograd.Function):
-    """forward(x, W[H,2Fin,F'], a[H,F'], Wskip[H,Fin,F']|None, graph, alpha, concat)."""
+    """forward(x, W[H,2Fin,F'], a[H,F'], Wskip[H,Fin,F']|None, graph, alpha, concat, masks|None).
+
+    masks (train-mode dropout, layers.py:266,271-272,293): dict of pre-scaled keep masks
+    {"x": [H,N,Fin], "whi": [H,N,F'], "whj": [H,N,F'], "att": [E,H]}; each head draws its own input mask
+    (models.py:32), so the projection then runs per head on the masked input."""
 
     @staticmethod
-    def forward(ctx, x, W, a, Wskip, graph: CSRGraph, alpha: float, concat: bool):
+    def forward(ctx, x, W, a, Wskip, graph: CSRGraph, alpha: float, concat: bool, masks=None):
         if not x.is_cuda:
             raise RuntimeError("pygat_amd: inputs must be on the GPU; the hot path has no CPU fallback")
         x = x.contiguous().float(); W = W.contiguous().float(); a = a.contiguous().float()
@@ -57,8 +61,26 @@ class GATv2LevelFn(torch.autograd.Function):
             st = _stream()
             WW = torch.empty(L.N, 2 * R, dtype=f32, device=dev)
             Sk = torch.empty(L.N, R, dtype=f32, device=dev) if skip else None
-            segs = [(2 * R, WW, 2 * R)] + ([(R, Sk, R)] if skip else [])
-            gemm(False, False, L.N, ncols, Fin, x, Fin, Wcat, ncols, segs)
+            mask_x = mww = matt = None
+            if masks is None:
+                segs = [(2 * R, WW, 2 * R)] + ([(R, Sk, R)] if skip else [])
+                gemm(False, False, L.N, ncols, Fin, x, Fin, Wcat, ncols, segs)
+            else:
+                mask_x = masks["x"].to(f32).contiguous()
+                matt = masks["att"].to(f32).contiguous()
+                mww = torch.zeros(L.N, 2 * H, Fp, dtype=f32, device=dev)      # [Whi | Whj] mask, padded layout
+                mww[:, :H, :Fo] = masks["whi"].to(f32).permute(1, 0, 2)
+                mww[:, H:, :Fo] = masks["whj"].to(f32).permute(1, 0, 2)
+                for h in range(H):
+                    xh = x * mask_x[h]
+                    c0 = h * Fp
+                    gemm(False, False, L.N, Fp, Fin, xh, Fin, Wcat[:, c0:], ncols, [(Fp, WW[:, c0:], 2 * R)])
+                    gemm(False, False, L.N, Fp, Fin, xh, Fin, Wcat[:, R + c0:], ncols, [(Fp, WW[:, R + c0:], 2 * R)])
+                    if skip:
+                        gemm(False, False, L.N, Fp, Fin, xh, Fin, Wcat[:, 2 * R + c0:], ncols, [(Fp, Sk[:, c0:], R)])
+                WW.mul_(mww.view(L.N, 2 * R))
+                need_grad = True
+                m = Z = None
             flags = (_lib.F_ELU if concat else 0) | (_lib.F_SKIP if skip else 0)
             hattn = torch.empty(L.N, R, dtype=f32, device=dev) if not concat else None
             m = torch.empty(L.N, H, dtype=f32, device=dev) if need_grad else None
@@ -66,18 +88,18 @@ class GATv2LevelFn(torch.autograd.Function):
             out = torch.empty(L.N, H * Fo if concat else Fo, dtype=f32, device=dev)
             part = torch.empty(lib.pygat_partials_bytes(graph.nnz, L.ts, H, Fp) // 4, dtype=f32, device=dev)
             check(lib.pygat_gatv2_forward(graph.fwd.ref(L.ts), H, Fo, float(alpha), flags, WW.data_ptr(), a2.data_ptr(),
-                                          _ptr(Sk), None, out.data_ptr() if concat else None, _ptr(hattn), _ptr(m),
+                                          _ptr(Sk), _ptr(matt), out.data_ptr() if concat else None, _ptr(hattn), _ptr(m),
                                           _ptr(Z), part.data_ptr(), st), "gatv2_forward")
             if not concat:
                 check(lib.pygat_head_mean(L.N, H, Fo, hattn.data_ptr(), _ptr(Sk), out.data_ptr(), st), "head_mean")
         if need_grad:
-            ctx.save_for_backward(x, Wcat, a2, WW, Sk, out if concat else hattn, m, Z)
+            ctx.save_for_backward(x, Wcat, a2, WW, Sk, out if concat else hattn, m, Z, mask_x, mww, matt)
             ctx.graph, ctx.L, ctx.alpha, ctx.concat, ctx.flags, ctx.Fin = graph, L, float(alpha), concat, flags, Fin
         return out
 
     @staticmethod
     def backward(ctx, G):
-        x, Wcat, a2, WW, Sk, y, m, Z = ctx.saved_tensors
+        x, Wcat, a2, WW, Sk, y, m, Z, mask_x, mww, matt = ctx.saved_tensors
         graph, L, H, Fo, Fin = ctx.graph, ctx.L, ctx.L.H, ctx.L.Fo, ctx.Fin
         R, Fp = L.R, L.Fp
         dev, f32 = x.device, torch.float32
@@ -94,11 +116,39 @@ class GATv2LevelFn(torch.autograd.Function):
             dWW = torch.empty(L.N, 2 * R, dtype=f32, device=dev)
             da_p = torch.empty(H, Fo, dtype=f32, device=dev)
             ws = torch.empty(lib.pygat_gatv2_workspace_bytes(graph.nnz, L.ts, H, Fo) // 4 + 4, dtype=f32, device=dev)
-            check(lib.pygat_gatv2_backward(graph.fwd.ref(L.ts), graph.bwd.ref(L.ts), None, H, Fo, ctx.alpha, WW.data_ptr(),
-                                           a2.data_ptr(), GRW.data_ptr(), None, dwr.data_ptr(), dWW.data_ptr(),
-                                           da_p.data_ptr(), ws.data_ptr(), st), "gatv2_backward")
+            check(lib.pygat_gatv2_backward(graph.fwd.ref(L.ts), graph.bwd.ref(L.ts),
+                                           graph.perm_t.data_ptr() if matt is not None else None, H, Fo, ctx.alpha,
+                                           WW.data_ptr(), a2.data_ptr(), GRW.data_ptr(), _ptr(matt), dwr.data_ptr(),
+                                           dWW.data_ptr(), da_p.data_ptr(), ws.data_ptr(), st), "gatv2_backward")
             ncols = Wcat.shape[1]
             dW = dWs = dx = None
+            if mask_x is not None:   # dropout: back through the Whi/Whj masks, then per head through its input mask
+                dWW.mul_(mww.view(L.N, 2 * R))
+                dWc = torch.zeros(Fin, 2 * R, dtype=f32, device=dev)
+                dSc = torch.zeros(Fin, R, dtype=f32, device=dev) if L.skip else None
+                need_dx = ctx.needs_input_grad[0]
+                dx = torch.zeros(L.N, Fin, dtype=f32, device=dev) if need_dx else None
+                dxh = torch.empty(L.N, Fin, dtype=f32, device=dev) if need_dx else None
+                for h in range(H):
+                    xh = x * mask_x[h]
+                    c0 = h * Fp
+                    for blk in (0, R):
+                        gemm(True, False, Fin, Fp, L.N, xh, Fin, dWW[:, blk + c0:], 2 * R, [(Fp, dWc[:, blk + c0:], 2 * R)])
+                    if L.skip:
+                        gemm(True, False, Fin, Fp, L.N, xh, Fin, Gp[:, c0:], LG, [(Fp, dSc[:, c0:], R)])
+                    if need_dx:
+                        gemm(False, True, L.N, Fin, Fp, dWW[:, c0:], 2 * R, Wcat[:, c0:], ncols, [(Fin, dxh, Fin)], split_k=1)
+                        gemm(False, True, L.N, Fin, Fp, dWW[:, R + c0:], 2 * R, Wcat[:, R + c0:], ncols, [(Fin, dxh, Fin)],
+                             accumulate=True, split_k=1)
+                        if L.skip:
+                            gemm(False, True, L.N, Fin, Fp, Gp[:, c0:], LG, Wcat[:, 2 * R + c0:], ncols, [(Fin, dxh, Fin)],
+                                 accumulate=True, split_k=1)
+                        dx.addcmul_(dxh, mask_x[h])
+                dv = dWc.view(Fin, 2 * H, Fp)
+                dW = torch.cat([dv[:, 0:H, :Fo].permute(1, 0, 2), dv[:, H:2 * H, :Fo].permute(1, 0, 2)], dim=1).contiguous()
+                if L.skip:
+                    dWs = dSc.view(Fin, H, Fp)[:, :, :Fo].permute(1, 0, 2).contiguous()
+                return dx, dW, da_p, dWs, None, None, None, None
             # dWcat[:, :2R] = x^T dWW ; skip columns = x^T Gp
             dWc = torch.empty(Fin, 2 * R, dtype=f32, device=dev)
             gemm(True, False, Fin, 2 * R, L.N, x, Fin, dWW, 2 * R, [(2 * R, dWc, 2 * R)])
@@ -114,16 +164,29 @@ class GATv2LevelFn(torch.autograd.Function):
                 if L.skip:
                     gemm(False, True, L.N, Fin, R, Gp, LG, Wcat[:, 2 * R:], ncols, [(Fin, dx, Fin)], accumulate=True,
                          split_k=1)
-        return dx, dW, da_p, dWs, None, None, None
+        return dx, dW, da_p, dWs, None, None, None, None
+
+
+def draw_masks_v2(p: float, H: int, N: int, Fin: int, Fo: int, E: int, device, generator=None):
+    keep = 1.0 - p
+
+    def mk(*shape):
+        return (torch.rand(*shape, device=device, generator=generator) < keep).to(torch.float32) / keep
+    return {"x": mk(H, N, Fin), "whi": mk(H, N, Fo), "whj": mk(H, N, Fo), "att": mk(E, H)}
 
 
 def gatv2_level(x, graph: CSRGraph, Ws: Sequence[torch.Tensor], As: Sequence[torch.Tensor],
-                Wskips: Optional[Sequence[torch.Tensor]], alpha: float, concat: bool) -> torch.Tensor:
-    """All heads of one SpGraphAttentionLayerV2 level.  Ws: H tensors [2Fin,F']; As: H tensors of F' elements."""
+                Wskips: Optional[Sequence[torch.Tensor]], alpha: float, concat: bool, dropout: float = 0.0,
+                masks: Optional[dict] = None) -> torch.Tensor:
+    """All heads of one SpGraphAttentionLayerV2 level.  Ws: H tensors [2Fin,F']; As: H tensors of F' elements.
+    dropout > 0 (training): per-head masks are drawn here unless given (`masks`, tests)."""
     W = torch.stack(list(Ws), 0)
     a = torch.stack([q.reshape(-1) for q in As], 0)
     Wskip = torch.stack(list(Wskips), 0) if Wskips is not None else None
-    return GATv2LevelFn.apply(x, W, a, Wskip, graph, alpha, concat)
+    if masks is None and dropout > 0.0:
+        H, Fin2, Fo = W.shape
+        masks = draw_masks_v2(dropout, H, x.shape[0], Fin2 // 2, Fo, graph.nnz, x.device)
+    return GATv2LevelFn.apply(x, W, a, Wskip, graph, alpha, concat, masks)
 
 
 class _V2Base(nn.Module):
@@ -134,8 +197,8 @@ class _V2Base(nn.Module):
 
     def _check_dropout(self):
         if self.training and self.dropout > 0.0:
-            raise NotImplementedError("pygat_amd: train-mode dropout is implemented for the GAT (v1) layers only; "
-                                      "use dropout=0 or eval() with the GATv2 layers")
+            raise NotImplementedError("pygat_amd: train-mode dropout is not implemented for GraphAttentionLayerV2 "
+                                      "(the dense V2 layer); use SpGraphAttentionLayerV2, dropout=0 or eval()")
 
     def __repr__(self):  # layers.py:231-232,315-316
         return self.__class__.__name__ + ' (' + str(self.in_features) + ' -> ' + str(self.out_features) + ')'
@@ -155,10 +218,13 @@ class SpGraphAttentionLayerV2(_V2Base):
             self.skip_projection = nn.Parameter(torch.empty(size=(in_features, out_features)))
             nn.init.xavier_uniform_(self.skip_projection.data, gain=1.414)
 
+    def _check_dropout(self):   # the sparse V2 layer supports train-mode dropout
+        return None
+
     def forward(self, input, adj):
-        self._check_dropout()
         return gatv2_level(input, as_graph(adj, self.pattern_mode), [self.W], [self.a],
-                           [self.skip_projection] if self.skip_connection else None, self.alpha, self.concat)
+                           [self.skip_projection] if self.skip_connection else None, self.alpha, self.concat,
+                           self.dropout if self.training else 0.0)
 
 
 class GraphAttentionLayerV2(_V2Base):

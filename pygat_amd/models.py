@@ -61,10 +61,9 @@ class GAT(nn.Module):
                 continue
             if self._kind == "v2sp":
                 from .gatv2 import gatv2_level
-                for att in heads:
-                    att._check_dropout()
                 x = gatv2_level(x, graph, [h.W for h in heads], [h.a for h in heads],
-                                [h.skip_projection for h in heads] if self.skip_connection else None, self.alpha, concat)
+                                [h.skip_projection for h in heads] if self.skip_connection else None, self.alpha, concat,
+                                self.dropout if self.training else 0.0)
                 continue
             Ws = [h.W for h in heads]
             As = [h.a for h in heads]

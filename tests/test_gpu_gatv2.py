@@ -88,4 +88,47 @@ def test_v2_dropin_layers_and_model(pg, topologies):  # noqa: F811
     y.sum().backward()
     assert all(p.grad is not None for p in m.parameters())
     with pytest.raises(NotImplementedError):
-        pg.SpGraphAttentionLayerV2(Fin, Fo, 0.5, 0.2).cuda().train()(x.cuda(), adj.cuda())
+        pg.GraphAttentionLayerV2(Fin, Fo, 0.5, 0.2).cuda().train()(x.cuda(), adj.cuda())
+    # train-mode dropout of the sparse V2 layer: runs, differs between calls, has gradients
+    m.dropout = 0.6
+    for lay in m.modules():
+        if hasattr(lay, "dropout"):
+            lay.dropout = 0.6
+    m.train()
+    y1, y2 = m(x.cuda(), adj.cuda()), m(x.cuda(), adj.cuda())
+    assert torch.isfinite(y1).all() and not torch.equal(y1, y2)
+    y1.sum().backward()
+
+
+@pytest.mark.parametrize("H,Fin,Fo,skip,concat", [(3, 10, 8, False, True), (2, 7, 5, True, False)])
+def test_sparse_v2_dropout_explicit_masks(pg, H, Fin, Fo, skip, concat):  # noqa: F811
+    """layers.py:266,271-272,293 with given masks: HIP path vs fp64 autograd through the oracle."""
+    from pygat_amd.gatv2 import gatv2_level
+    N, p = 60, 0.5
+    rowptr, col = O.random_symmetric_csr(N, 5, 3, hub=(2, 40))
+    E = len(col)
+    W, a, Sk = v2params(H, Fin, Fo, skip, 4)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(N, Fin, dtype=torch.float64, generator=gen)
+    G = torch.randn(N, H * Fo if concat else Fo, dtype=torch.float64, generator=gen)
+    keep = lambda *s: (torch.rand(*s, generator=gen) >= p).double() / (1 - p)  # noqa: E731
+    mx, mi, mj, matt = keep(H, N, Fin), keep(H, N, Fo), keep(H, N, Fo), keep(E, H)
+    leaves = [t.clone().requires_grad_(True) for t in (x, W, a)] + ([Sk.clone().requires_grad_(True)] if skip else [])
+    outs = [O.sparse_head_forward_v2(leaves[0], rowptr, col, leaves[1][h], leaves[2][h], 0.2, concat,
+                                     leaves[3][h] if skip else None, mx[h], mi[h], mj[h], matt[:, h]) for h in range(H)]
+    y = torch.cat(outs, 1) if concat else torch.mean(torch.stack(outs, 1), 1)
+    gr = torch.autograd.grad(y, leaves, G)
+    dev = "cuda:0"
+    g = pg.CSRGraph(torch.as_tensor(rowptr, device=dev), torch.as_tensor(col, device=dev), slot_edges=16)
+    xd = x.float().to(dev).requires_grad_(True)
+    Ws = [W[h].float().to(dev).requires_grad_(True) for h in range(H)]
+    As = [a[h].float().to(dev).reshape(1, -1).requires_grad_(True) for h in range(H)]
+    Ss = [Sk[h].float().to(dev).requires_grad_(True) for h in range(H)] if skip else None
+    masks = dict(x=mx.float().to(dev), whi=mi.float().to(dev), whj=mj.float().to(dev), att=matt.float().to(dev))
+    out = gatv2_level(xd, g, Ws, As, Ss, 0.2, concat, p, masks=masks)
+    out.backward(G.float().to(dev))
+    close(out, y.detach().numpy(), "out"); close(xd.grad, gr[0].numpy(), "dX")
+    close(torch.stack([w.grad for w in Ws]), gr[1].numpy(), "dW")
+    close(torch.stack([w.grad.reshape(-1) for w in As]), gr[2].numpy(), "da")
+    if skip:
+        close(torch.stack([w.grad for w in Ss]), gr[3].numpy(), "dW_skip")

@@ -195,7 +195,8 @@ int try_gemm_smallk(int transB, int M, int N, int64_t K, const float* A, int64_t
   if (K < 32 || K > 256 || (K % 32) != 0 || M < 8192) return 0;
   if (!aligned16(A) || (lda % 4) != 0) return 0;
   const int nt_needed = (int)cdiv(N, 32);
-  const int NT = nt_needed < 5 ? nt_needed : 5;
+  // up to 160 columns in one tile; wider outputs in balanced 128-column tiles
+  const int NT = nt_needed <= 5 ? nt_needed : 4;
   const size_t lds = (size_t)K * (32 * NT + 4) * sizeof(float);
   if (lds > 150 * 1024) return 0;
   SmallKArgs g;

@@ -51,7 +51,7 @@ __device__ __forceinline__ EdgeOut v2_edge(float4 wi_i, float4 wi_j, float4 wj_j
 template <int LPR, int VEC>
 __global__ __launch_bounds__(256) void gat2_bwd_row_kernel(V2Args a) {
   constexpr int EPW = 64 / LPR;
-  constexpr int U = 2;
+  constexpr int U = (VEC == 1) ? 4 : 2;
   __shared__ __attribute__((aligned(16))) float sm_da[4][1024];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t k = ((int64_t)blockIdx.x * 4 + w) * EPW + lane / LPR;
@@ -145,6 +145,44 @@ __global__ __launch_bounds__(256) void gat2_rowsum_fixup_kernel(V2Args a, int wi
   for (int64_t kk = k + 1; kk <= k_e; ++kk) acc += a.part[(2 * kk) * (int64_t)width + c];
   if (col_finish && c < a.rs.R) acc += add[(int64_t)r * a.rs.R + c];   // column pass: + row-side part of dWhi
   dst[(int64_t)r * ld_dst + c] = acc;
+}
+
+// stage 1 of the da reduction: DA_STAGE work-groups, each sums every DA_STAGE-th record (coalesced R-float rows)
+constexpr int DA_STAGE = 128;
+// list-driven variant: one work-group per cut row; thread c sums float c of its pieces, 4 in flight
+__global__ __launch_bounds__(256) void gat2_rowsum_fixup_list_kernel(V2Args a, int width, float* dst, int64_t ld_dst,
+                                                                      const float* add, int col_finish) {
+  const int q0 = blockIdx.x;
+  const int64_t k = a.g.cut[3 * q0];
+  const int r = a.g.cut[3 * q0 + 1];
+  const int npieces = a.g.cut[3 * q0 + 2];
+  for (int c = threadIdx.x; c < width; c += 256) {
+    float acc = a.part[(2 * k + 1) * (int64_t)width + c];
+    int q = 1;
+    for (; q + 3 < npieces; q += 4) {
+      const float x0 = a.part[(2 * (k + q)) * (int64_t)width + c], x1 = a.part[(2 * (k + q + 1)) * (int64_t)width + c];
+      const float x2 = a.part[(2 * (k + q + 2)) * (int64_t)width + c], x3 = a.part[(2 * (k + q + 3)) * (int64_t)width + c];
+      acc += x0; acc += x1; acc += x2; acc += x3;
+    }
+    for (; q < npieces; ++q) acc += a.part[(2 * (k + q)) * (int64_t)width + c];
+    if (col_finish && c < a.rs.R) acc += add[(int64_t)r * a.rs.R + c];
+    dst[(int64_t)r * ld_dst + c] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void gat2_da_stage_kernel(int R, int nrec, const float* __restrict__ da_part,
+                                                            float* __restrict__ out2) {
+  for (int c = threadIdx.x; c < R; c += 256) {
+    float acc = 0.f;
+    int b = blockIdx.x;
+    for (; b + 3 * DA_STAGE < nrec; b += 4 * DA_STAGE) {
+      const float x0 = da_part[(int64_t)b * R + c], x1 = da_part[(int64_t)(b + DA_STAGE) * R + c];
+      const float x2 = da_part[(int64_t)(b + 2 * DA_STAGE) * R + c], x3 = da_part[(int64_t)(b + 3 * DA_STAGE) * R + c];
+      acc += x0; acc += x1; acc += x2; acc += x3;
+    }
+    for (; b < nrec; b += DA_STAGE) acc += da_part[(int64_t)b * R + c];
+    out2[(int64_t)blockIdx.x * R + c] = acc;
+  }
 }
 
 __global__ __launch_bounds__(256) void gat2_da_final_kernel(RowShape rs, int nblocks, const float* __restrict__ da_part,
@@ -250,7 +288,7 @@ extern "C" size_t pygat_gatv2_workspace_bytes(int64_t nnz, int slot_edges, int H
   const int64_t nslots = (nnz + slot_edges - 1) / slot_edges;
   const int64_t R = (int64_t)H * Fp;
   // partial records of the column pass (2R floats each) + one da record per row-pass work-group
-  return (size_t)(2 * nslots * 2 * R + (nslots / 4 + 2) * R) * sizeof(float);
+  return (size_t)(2 * nslots * 2 * R + (nslots / 4 + 2) * R + DA_STAGE * R) * sizeof(float);
 }
 
 extern "C" int pygat_gatv2_backward(const pygat_graph* g, const pygat_graph* gT, const int32_t* perm_t, int H, int Fo,
@@ -279,10 +317,18 @@ extern "C" int pygat_gatv2_backward(const pygat_graph* g, const pygat_graph* gT,
   a.out = dwhi_row; a.part = part; a.da_part = da_part;
   PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat2_bwd_row_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0, st, a));
   PYGAT_CHECK_LAUNCH("gatv2_backward_row");
-  hipLaunchKernelGGL(gat2_rowsum_fixup_kernel, dim3((unsigned)cdiv(nslots * R, 256)), dim3(256), 0, st, a, R, dwhi_row,
-                     (int64_t)R, (const float*)nullptr, 0);
-  hipLaunchKernelGGL(gat2_da_final_kernel, dim3((unsigned)cdiv(a.rs.H * a.rs.Fo, 256)), dim3(256), 0, st, a.rs, (int)blocks,
-                     (const float*)da_part, da);
+  if (a.g.cut) {
+    if (a.g.n_cut > 0)
+      hipLaunchKernelGGL(gat2_rowsum_fixup_list_kernel, dim3((unsigned)a.g.n_cut), dim3(256), 0, st, a, R, dwhi_row, (int64_t)R,
+                         (const float*)nullptr, 0);
+  } else {
+    hipLaunchKernelGGL(gat2_rowsum_fixup_kernel, dim3((unsigned)cdiv(nslots * R, 256)), dim3(256), 0, st, a, R, dwhi_row,
+                       (int64_t)R, (const float*)nullptr, 0);
+  }
+  float* da_stage = da_part + (nslots / 4 + 2) * (int64_t)R;
+  hipLaunchKernelGGL(gat2_da_stage_kernel, dim3(DA_STAGE), dim3(256), 0, st, R, (int)blocks, (const float*)da_part, da_stage);
+  hipLaunchKernelGGL(gat2_da_final_kernel, dim3((unsigned)cdiv(a.rs.H * a.rs.Fo, 256)), dim3(256), 0, st, a.rs, DA_STAGE,
+                     (const float*)da_stage, da);
   PYGAT_CHECK_LAUNCH("gatv2_backward_row_fixup");
   // column pass over the transposed pattern: dWW = [dWhi | dWhj]
   V2Args b = a;
@@ -292,8 +338,14 @@ extern "C" int pygat_gatv2_backward(const pygat_graph* g, const pygat_graph* gT,
   b.perm = perm_t; b.dwhi_row = dwhi_row; b.out = dWW; b.part = part;
   PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat2_bwd_col_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0, st, b));
   PYGAT_CHECK_LAUNCH("gatv2_backward_col");
-  hipLaunchKernelGGL(gat2_rowsum_fixup_kernel, dim3((unsigned)cdiv(nslots * 2 * R, 256)), dim3(256), 0, st, b, 2 * R, dWW,
-                     2 * (int64_t)R, (const float*)dwhi_row, 1);
+  if (b.g.cut) {
+    if (b.g.n_cut > 0)
+      hipLaunchKernelGGL(gat2_rowsum_fixup_list_kernel, dim3((unsigned)b.g.n_cut), dim3(256), 0, st, b, 2 * R, dWW,
+                         2 * (int64_t)R, (const float*)dwhi_row, 1);
+  } else {
+    hipLaunchKernelGGL(gat2_rowsum_fixup_kernel, dim3((unsigned)cdiv(nslots * 2 * R, 256)), dim3(256), 0, st, b, 2 * R, dWW,
+                       2 * (int64_t)R, (const float*)dwhi_row, 1);
+  }
   PYGAT_CHECK_LAUNCH("gatv2_backward_col_fixup");
   return PYGAT_OK;
 }

@@ -1,16 +1,15 @@
 """Drop-in for the reference's `models.GAT` (models.py:7-35), fused per level.
 
-Same constructor, same registered sub-modules and therefore the same
-`state_dict` keys `attention_layer_{L}_head_{H}.{W,a,skip_projection}`
-(models.py:27).  forward(x, adj) runs ONE fused call per level for all heads
-(the reference runs the heads one after another in a Python list
-comprehension, models.py:32,34):
+Same constructor keywords; the per-head sub-modules are registered under the reference's names, so
+`state_dict` keys are `attention_layer_{L}_head_{H}.{W,a,skip_projection}` (models.py:27).  forward(x,
+adj) issues ONE fused call per level for all its heads (the reference walks the heads in a Python
+list comprehension, models.py:32,34):
 
     hidden level : cat(heads, dim=1)            -> written in place by K2
     last level   : mean(stack(heads, 1), 1)     -> head-mean kernel
 
-With `torch.distributed` initialised and `head_parallel=True` the heads of each
-level are sharded over the ranks (pygat_amd.dist).
+With `torch.distributed` initialised and `head_parallel=True` the heads of each level are sharded over
+the ranks (pygat_amd.dist).
 """
 from __future__ import annotations
 
@@ -26,25 +25,18 @@ class GAT(nn.Module):
     def __init__(self, nfeat, nheads, nlayers, dropout, alpha, layer_type=GraphAttentionLayer,
                  skip_connection=False, head_parallel=False):
         super().__init__()
-        self.dropout = dropout
-        self.alpha = alpha
-        self.skip_connection = skip_connection
-        self.head_parallel = head_parallel
-        nheads = [1] + list(nheads)
-        self.gat_layers = []
-        for i in range(nlayers):
-            self.gat_layers.append([])
-            for j in range(nheads[i + 1]):
-                layer = layer_type(
-                    in_features=nfeat[i] * nheads[i],
-                    out_features=nfeat[i + 1],
-                    dropout=dropout,
-                    alpha=alpha,
-                    concat=True if i < nlayers - 1 else False,
-                    skip_connection=skip_connection,
-                )
-                self.gat_layers[i].append(layer)
-                self.add_module('attention_layer_{}_head_{}'.format(i + 1, j + 1), layer)
+        self.dropout, self.alpha = dropout, alpha
+        self.skip_connection, self.head_parallel = skip_connection, head_parallel
+        widths = [1] + list(nheads)          # heads feeding level i (the input counts as one head)
+        self.gat_layers = []                 # plain lists like the reference: registration is by name below
+        for lvl in range(nlayers):
+            last = lvl == nlayers - 1
+            row = [layer_type(in_features=nfeat[lvl] * widths[lvl], out_features=nfeat[lvl + 1], dropout=dropout,
+                              alpha=alpha, concat=not last, skip_connection=skip_connection)
+                   for _ in range(widths[lvl + 1])]
+            for hd, layer in enumerate(row, start=1):
+                self.add_module(f"attention_layer_{lvl + 1}_head_{hd}", layer)
+            self.gat_layers.append(row)
         self.pattern_mode = getattr(layer_type, "pattern_mode", "nonzero")
         from .gatv2 import SpGraphAttentionLayerV2
         self._kind = ("v1" if issubclass(layer_type, (GraphAttentionLayer, SpGraphAttentionLayer))
@@ -52,29 +44,24 @@ class GAT(nn.Module):
 
     def forward(self, x, adj):
         graph = as_graph(adj, self.pattern_mode)
-        nl = len(self.gat_layers)
-        for i, heads in enumerate(self.gat_layers):
-            concat = i < nl - 1
+        p_drop = self.dropout if self.training else 0.0
+        for lvl, heads in enumerate(self.gat_layers):
+            concat = lvl < len(self.gat_layers) - 1
             if self._kind == "other":   # e.g. GraphAttentionLayerV2: one head per call, as the reference does
                 ys = [att(x, graph) for att in heads]
                 x = torch.cat(ys, dim=1) if concat else torch.mean(torch.stack(ys, dim=1), dim=1)
                 continue
+            Ws, As = [h.W for h in heads], [h.a for h in heads]
+            Sk = [h.skip_projection for h in heads] if self.skip_connection else None
             if self._kind == "v2sp":
                 from .gatv2 import gatv2_level
-                x = gatv2_level(x, graph, [h.W for h in heads], [h.a for h in heads],
-                                [h.skip_projection for h in heads] if self.skip_connection else None, self.alpha, concat,
-                                self.dropout if self.training else 0.0)
-                continue
-            Ws = [h.W for h in heads]
-            As = [h.a for h in heads]
-            Sk = [h.skip_projection for h in heads] if self.skip_connection else None
-            if self.head_parallel:
+                x = gatv2_level(x, graph, Ws, As, Sk, self.alpha, concat, p_drop)
+            elif self.head_parallel:
                 from .dist import gat_level_head_parallel
-                x = gat_level_head_parallel(x, graph, Ws, As, Sk, self.alpha, concat,
-                                            self.dropout if self.training else 0.0)
-            elif self.training and self.dropout > 0.0:
+                x = gat_level_head_parallel(x, graph, Ws, As, Sk, self.alpha, concat, p_drop)
+            elif p_drop > 0.0:
                 from .dropout import gat_level_dropout
-                x = gat_level_dropout(x, graph, Ws, As, Sk, self.alpha, concat, self.dropout, head_mean=not concat)
+                x = gat_level_dropout(x, graph, Ws, As, Sk, self.alpha, concat, p_drop)
             else:
                 x = gat_level(x, graph, Ws, As, Sk, self.alpha, concat)
         return x

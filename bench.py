@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--dx", action="store_true", help="also back-propagate into the input features")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--verify", action="store_true", help="check the gathered sharded output against the unsharded level")
     return ap.parse_args()
 
 
@@ -75,13 +76,21 @@ def main():
         if rank == 0:
             print(f"bench: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # BENCH_BACKEND=gloo is a rehearsal aid only: several ranks may then share one card (local_rank modulo the
+    # device count) to exercise the N>1 code path on a 1-GPU box; the driver's runs use RCCL ("nccl").
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import pygat_amd as pg
     from pygat_amd import ops
@@ -150,6 +159,15 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ms = dt / args.steps * 1e3
+    if args.verify and rank == 0:
+        # the gathered concat output of the sharded run against the unsharded level on this rank
+        full = step()
+        ref = pg.GATLevelFn.apply(X.detach(), W, a, None, graph, 0.2, True)
+        err = float((full - ref).abs().max())
+        print(f"bench --verify: max |sharded - unsharded| = {err:.3e} over {tuple(ref.shape)}", file=sys.stderr)
+        assert err < 1e-5, err
+    if args.verify and rank != 0 and use_pg:
+        step()
 
     if rank == 0:
         kt = {k: float(np.mean(v)) for k, v in timer.times_ms().items()}

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PYGAT_ABI_VERSION 3
+#define PYGAT_ABI_VERSION 4
 
 enum {
   PYGAT_OK = 0,
@@ -162,6 +162,15 @@ int pygat_slot_bounds(int n, int64_t nnz, const int32_t* rowptr, const int32_t* 
 /* bytes of `part` workspace needed by forward / column backward for this graph and row width */
 size_t pygat_partials_bytes(int64_t nnz, int slot_edges, int H, int Fp);
 
+/* Heads per backward kernel pass ("head window").  The attention entry points take the level's
+ * full-width tables.  The forward walks rows of up to 1024 floats per pass; the two backward passes of
+ * a LARGE graph (gathered table beyond the 256 MiB Infinity Cache) with rows wider than 512 floats walk
+ * the heads in windows of at most 256 floats (one 16-byte chunk per lane of a wave64): window w covers
+ * heads [w*hg, min(H, (w+1)*hg)), hg = pygat_head_group(n, H, F').  Callers only need it to find Gp
+ * inside GR (see K3a below).  Returns H when the backward takes the whole row in one pass, 0 on bad
+ * arguments. */
+int pygat_head_group(int n, int H, int Fo);
+
 /* Wh [n x R], s,t [n x H], sk [n x R] or NULL.
  * out [n x H*F'] compact (may be NULL), hattn [n x R] padded (may be NULL; needed for the
  * head mean), m,Z [n x H] (may be NULL together in eval).  */
@@ -180,6 +189,9 @@ int pygat_head_mean(int n, int H, int Fo, const float* hattn, const float* sk,
  * layers.py:141-170.
  *   K3a prepare (per row):  Gp_i = G_i * ELU'(.), D_i = Gp_i . hattn_i,
  *        GR_i = [ Gp_i (R floats) | (s_i, m_i, 1/Z_i, D_i) per head (4H floats) ]   -> GR [n x (R+4H)]
+ *        With more than one head window (pygat_head_group(n,H,F') < H) the row is laid out window by
+ *        window, each [ Gp of its heads | their 4-float records ], window w starting at float
+ *        w*hg*(Fp+4): head h's Gp slice is at  (h/hg)*hg*(Fp+4) + (h%hg)*Fp.
  *        mean_mode 0: G is [n x H*F'] and y is the forward OUTPUT out [n x H*F'] (hattn is
  *                     recovered from it: out > 0 ? out : log1p(out), minus sk);
  *        mean_mode 1: G is [n x F'] (every head receives G/H, models.py:34), y is hattn [n x R].

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpygat_amd.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 F_ELU = 1
 F_SKIP = 2
 
@@ -23,7 +23,7 @@ SYMBOLS = [
     "pygat_exclusive_scan_i32", "pygat_dense_fill_cols", "pygat_csr_symmetric_perm",
     "pygat_gemm_workspace_bytes", "pygat_gemm_f32", "pygat_pack_params", "pygat_project", "pygat_attn_scores",
     "pygat_unpack_wgrad",
-    "pygat_edge_pairs", "pygat_slot_bounds", "pygat_partials_bytes", "pygat_gat_forward", "pygat_head_mean",
+    "pygat_edge_pairs", "pygat_slot_bounds", "pygat_partials_bytes", "pygat_head_group", "pygat_gat_forward", "pygat_head_mean",
     "pygat_gat_backward_prepare", "pygat_gat_backward_row", "pygat_gat_backward_col",
     "pygat_agrad_workspace_bytes", "pygat_a_grad",
     "pygat_gatv2_forward", "pygat_gatv2_backward_prepare", "pygat_gatv2_workspace_bytes", "pygat_gatv2_backward",
@@ -72,6 +72,8 @@ def _load():
     lib.pygat_slot_bounds.argtypes = [i, i64, p, p, i, p, p]
     lib.pygat_partials_bytes.argtypes = [i64, i, i, i]
     lib.pygat_partials_bytes.restype = sz
+    lib.pygat_head_group.argtypes = [i, i, i]
+    lib.pygat_head_group.restype = i
     lib.pygat_gat_forward.argtypes = [C.POINTER(Graph), i, i, f, i, p, p, p, p, p, p, p, p, p, p, p]
     lib.pygat_head_mean.argtypes = [i, i, i, p, p, p, p]
     lib.pygat_gat_backward_prepare.argtypes = [i, i, i, i, i, p, p, p, p, p, p, p, p]

@@ -21,9 +21,15 @@ constexpr int FIX_SCREEN = 8;  // slots screened per wave by the fix-up kernels 
 constexpr float NEG_BIG = -1.0e30f;  // running-max seed: exp(NEG_BIG - x) == 0, exp(NEG_BIG - NEG_BIG) == 1
 
 struct RowShape {
-  int H, Fo, Fp, R, NCH;  // heads, true width, padded width, H*Fp, R/4
+  int H, Fo, Fp, R, NCH;  // heads of THIS kernel pass, true width, padded width, H*Fp, R/4
   int fp_shift;           // log2(Fp)
   int lph;                // lanes per head = Fp/4 (power of two, may exceed 64 only if Fp > 256: rejected)
+  // A pass may cover a WINDOW of the level's heads (see head_group): the per-node tables keep the
+  // level's full width, so rows are addressed with the level's strides and pointers pre-offset to the window.
+  int Htot;               // heads of the level (mean mode divides by it)
+  int64_t ldr;            // row stride of the R-wide tables (Wh, Sk, hattn, dWh) = Htot*Fp
+  int64_t ldh;            // row stride of the per-head tables (s, m, Z, ds, dt, attention mask) = Htot
+  int64_t ldo;            // row stride of out / G = Htot*Fo
 };
 
 static inline bool make_row_shape(int H, int Fo, RowShape* rs) {
@@ -31,8 +37,43 @@ static inline bool make_row_shape(int H, int Fo, RowShape* rs) {
   if (H <= 0 || Fp == 0) return false;
   rs->H = H; rs->Fo = Fo; rs->Fp = Fp; rs->R = H * Fp; rs->NCH = rs->R / 4;
   rs->fp_shift = ilog2(Fp); rs->lph = Fp / 4;
+  rs->Htot = H; rs->ldr = rs->R; rs->ldh = H; rs->ldo = (int64_t)H * Fo;
   return rs->NCH <= 256;  // VEC <= 4
 }
+
+// Heads per kernel pass ("head window").
+// A pass takes rows of at most 1024 floats (VEC <= 4 chunks of 16 B per lane); wider levels are walked
+// window by window.  That is the only reason to window the forward: measured on MI355X (RMAT 1M/10.8M,
+// 8 heads x 128) K2 is fastest on the full 4-KB rows (9.1 ms; 9.7 ms as 4 windows of 1 KB, whose
+// gathers hit only a quarter of each row and load the HBM channels unevenly).
+static inline int head_group_fwd(int H, int Fp) {
+  if (H * Fp <= 1024) return H;
+  const int g = 1024 / Fp;
+  return g < 1 ? 1 : g;
+}
+// The two backward passes hold two gathered/row-local rows per edge: at VEC >= 3 they need 170-250
+// VGPRs, run 2 waves per SIMD and stop covering the HBM latency (same workload: K3b 11.0 -> 8.5 ms,
+// K4 11.6 -> 9.9 ms as windows of 256 floats = one chunk per lane).  Windows cost extra launches, so
+// they are used only where the gathered table is far beyond the caches (small graphs are launch-bound:
+// a PPI-sized epoch went 4.4 -> 5.9 ms with them) and rows are wider than 512 floats (neutral there).
+// PYGAT_BWD_WINDOW_BYTES overrides the table-size threshold (tests set 0 to window tiny graphs).
+static inline int head_group_bwd(int64_t n, int H, int Fp) {
+  const int64_t R = (int64_t)H * Fp;
+  int64_t min_bytes = (int64_t)256 << 20;
+  if (const char* e = getenv("PYGAT_BWD_WINDOW_BYTES")) min_bytes = strtoll(e, nullptr, 10);
+  if (R <= 512 || n * R * 4 < min_bytes) return head_group_fwd(H, Fp);
+  const int g = 256 / Fp;
+  return g < 1 ? 1 : g;
+}
+
+// shape of the window [h0, h0+hc) of a level with Htot heads
+static inline bool make_window_shape(int Htot, int Fo, int hc, RowShape* rs) {
+  if (!make_row_shape(hc, Fo, rs)) return false;
+  rs->Htot = Htot; rs->ldr = (int64_t)Htot * rs->Fp; rs->ldh = Htot; rs->ldo = (int64_t)Htot * Fo;
+  return true;
+}
+// column offset of a window inside a GR row [Gp(window) | rowtab(window)] ... : h0 * (Fp + 4)
+static inline int64_t gr_window_offset(int h0, int Fp) { return (int64_t)h0 * (Fp + 4); }
 
 // (LPR, VEC) for a row shape
 static inline void pick_lanes(const RowShape& rs, int* lpr, int* vec) {

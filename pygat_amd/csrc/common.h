@@ -1,5 +1,6 @@
 // Shared host/device helpers for the gfx950 GAT kernels (not part of the C ABI).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

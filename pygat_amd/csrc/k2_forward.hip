@@ -78,26 +78,27 @@ template <int VEC>
 __device__ __forceinline__ void fwd_finish(const FwdArgs& a, const LaneCols<VEC>& lc, int i,
                                            const float (&m)[VEC], const float (&z)[VEC],
                                            const float4 (&acc)[VEC]) {
-  const int H = a.rs.H, R = a.rs.R, Fo = a.rs.Fo, Fp = a.rs.Fp;
+  const int Fo = a.rs.Fo, Fp = a.rs.Fp;
+  const int64_t ldr = a.rs.ldr, ldh = a.rs.ldh, ldo = a.rs.ldo;
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
     if (!lc.valid[v]) continue;
     const int co = lc.cofs[v], h = lc.head[v];
     const float rz = 1.0f / z[v];
     float4 hat = make_float4(acc[v].x * rz, acc[v].y * rz, acc[v].z * rz, acc[v].w * rz);
-    if (a.hattn) st4(a.hattn + (int64_t)i * R + co, hat);
+    if (a.hattn) st4(a.hattn + (int64_t)i * ldr + co, hat);
     if (a.out) {
       float4 pre = hat;
       if (a.flags & PYGAT_F_SKIP) {
-        float4 k4 = ld4(a.sk + (int64_t)i * R + co);
+        float4 k4 = ld4(a.sk + (int64_t)i * ldr + co);
         pre.x += k4.x; pre.y += k4.y; pre.z += k4.z; pre.w += k4.w;
       }
       if (a.flags & PYGAT_F_ELU) { pre.x = elu1(pre.x); pre.y = elu1(pre.y); pre.z = elu1(pre.z); pre.w = elu1(pre.w); }
       if (Fo == Fp) {
-        st4(a.out + (int64_t)i * R + co, pre);
+        st4(a.out + (int64_t)i * ldo + co, pre);
       } else {
         const int f0 = co & (Fp - 1);
-        float* o = a.out + (int64_t)i * H * Fo + (int64_t)h * Fo + f0;
+        float* o = a.out + (int64_t)i * ldo + (int64_t)h * Fo + f0;
         if (f0 + 0 < Fo) o[0] = pre.x;
         if (f0 + 1 < Fo) o[1] = pre.y;
         if (f0 + 2 < Fo) o[2] = pre.z;
@@ -105,8 +106,8 @@ __device__ __forceinline__ void fwd_finish(const FwdArgs& a, const LaneCols<VEC>
       }
     }
     if (a.m && ((co >> 2) & (a.rs.lph - 1)) == 0) {
-      a.m[(int64_t)i * H + h] = m[v];
-      a.Z[(int64_t)i * H + h] = z[v];
+      a.m[(int64_t)i * ldh + h] = m[v];
+      a.Z[(int64_t)i * ldh + h] = z[v];
     }
   }
 }
@@ -144,7 +145,8 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
   int64_t e0, e1;
   slot_range(a.g, k, &e0, &e1);
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
-  const int H = a.rs.H, R = a.rs.R;
+  const int R = a.rs.R;
+  const int64_t ldh = a.rs.ldh;
   const int2* __restrict__ rc = a.g.rc;
 
   const int r_first = rc[e0].x;
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
-        mk[u][v] = a.mask ? a.mask[((e + u < e1) ? e + u : e1 - 1) * H + lc.head[v]] : 1.f;
+        mk[u][v] = a.mask ? a.mask[((e + u < e1) ? e + u : e1 - 1) * ldh + lc.head[v]] : 1.f;
         wv[u][v] = ld4(a.Wh + (int64_t)p[u].y * ldw + lc.cofs[v]);
         if constexpr (V2) {
           const float4 wi = ld4(a.Wh + (int64_t)p[u].x * ldw + lc.cofs[v]);      // Whi_i (row-local)
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
           const float4 ll = make_float4(lrelu(hh.x, a.alpha), lrelu(hh.y, a.alpha), lrelu(hh.z, a.alpha), lrelu(hh.w, a.alpha));
           sv[u][v] = dot4(ll, adst[v]);   // partial of e_ij over this lane's 4 features
         } else {
-          sv[u][v] = a.s[(int64_t)p[u].x * H + lc.head[v]];
+          sv[u][v] = a.s[(int64_t)p[u].x * ldh + lc.head[v]];
         }
       }
     // per-head sums over the lanes of a head (all lanes of the group are active here):
@@ -448,44 +450,65 @@ static int launch_forward(const pygat_graph* g, int H, int Fo, float alpha, int 
   FwdArgs a;
   int rc = check_graph(g, &a.g);
   if (rc) return rc;
-  PYGAT_REQUIRE(make_row_shape(H, Fo, &a.rs), "gat_forward: unsupported H=%d F'=%d (need H*pad(F') <= 1024, F' <= 256)", H, Fo);
+  const int Fp = padded_width(Fo);
+  PYGAT_REQUIRE(H > 0 && Fp > 0, "gat_forward: unsupported H=%d F'=%d", H, Fo);
   PYGAT_REQUIRE(Wh && (s || v2) && a_pad && part, "gat_forward: null Wh/s/a_pad/part");
   PYGAT_REQUIRE(out || hattn, "gat_forward: need out and/or hattn");
   PYGAT_REQUIRE(!(flags & PYGAT_F_SKIP) || sk, "gat_forward: PYGAT_F_SKIP without sk");
   PYGAT_REQUIRE((m == nullptr) == (Z == nullptr), "gat_forward: m and Z must be given together");
   PYGAT_REQUIRE(aligned16(Wh) && aligned16(part) && aligned16(a_pad) && (!sk || aligned16(sk)) && (!hattn || aligned16(hattn)) &&
-                    (!out || a.rs.Fo != a.rs.Fp || aligned16(out)),
+                    (!out || Fo != Fp || aligned16(out)),
                 "gat_forward: row tables must be 16-byte aligned");
-  a.alpha = alpha; a.flags = flags; a.Wh = Wh; a.ldwh = v2 ? 2 * (int64_t)a.rs.R : a.rs.R; a.s = s; a.a_pad = a_pad;
-  a.sk = sk; a.mask = att_mask;
-  a.out = out; a.hattn = hattn; a.m = m; a.Z = Z; a.part = (float*)part;
-  int lpr, vec;
-  pick_lanes(a.rs, &lpr, &vec);
   hipStream_t st = (hipStream_t)stream;
   const int64_t nslots = num_slots(a.g);
-  const unsigned blocks = (unsigned)cdiv(cdiv(nslots, 64 / lpr), 4);
-  if (v2) {
-    PYGAT_DISPATCH_LANES(lpr, vec,
-                         hipLaunchKernelGGL((gat_fwd_kernel<LPR, VEC, true>), dim3(blocks), dim3(256), 0, st, a));
-  } else {
-    PYGAT_DISPATCH_LANES(lpr, vec,
-                         hipLaunchKernelGGL((gat_fwd_kernel<LPR, VEC, false>), dim3(blocks), dim3(256), 0, st, a));
-  }
-  PYGAT_CHECK_LAUNCH("gat_forward");
-  const size_t fix_lds = 4 * (size_t)(a.rs.R + 2 * a.rs.H) * sizeof(float);
-  if (a.g.cut) {  // the caller listed the cut rows: go straight to them
-    if (a.g.n_cut > 0) {
-      const unsigned fb = (unsigned)(a.g.n_cut_wide + cdiv(a.g.n_cut - a.g.n_cut_wide, 4));
-      PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_fwd_fixup_list_kernel<LPR, VEC>), dim3(fb), dim3(256),
-                                                        fix_lds, st, a));
+  // GATv2 gathers [Whi|Whj] rows and is not windowed
+  const int hg = v2 ? H : head_group_fwd(H, Fp);
+  for (int h0 = 0; h0 < H; h0 += hg) {
+    const int hc = (H - h0 < hg) ? H - h0 : hg;
+    PYGAT_REQUIRE(make_window_shape(H, Fo, hc, &a.rs),
+                  "gat_forward: unsupported H=%d F'=%d (a pass takes rows of at most 1024 floats)", hc, Fo);
+    a.alpha = alpha; a.flags = flags;
+    a.Wh = Wh + (int64_t)h0 * Fp; a.ldwh = v2 ? 2 * a.rs.ldr : a.rs.ldr;
+    a.s = s ? s + h0 : nullptr;
+    a.a_pad = a_pad + (int64_t)h0 * (v2 ? 1 : 2) * Fp;
+    a.sk = sk ? sk + (int64_t)h0 * Fp : nullptr;
+    a.mask = att_mask ? att_mask + h0 : nullptr;
+    a.out = out ? out + (int64_t)h0 * Fo : nullptr;
+    a.hattn = hattn ? hattn + (int64_t)h0 * Fp : nullptr;
+    a.m = m ? m + h0 : nullptr; a.Z = Z ? Z + h0 : nullptr;
+    a.part = (float*)part;   // reused by the windows: the launches are ordered on the stream
+    int lpr, vec;
+    pick_lanes(a.rs, &lpr, &vec);
+    const unsigned blocks = (unsigned)cdiv(cdiv(nslots, 64 / lpr), 4);
+    if (v2) {
+      PYGAT_DISPATCH_LANES(lpr, vec,
+                           hipLaunchKernelGGL((gat_fwd_kernel<LPR, VEC, true>), dim3(blocks), dim3(256), 0, st, a));
+    } else {
+      PYGAT_DISPATCH_LANES(lpr, vec,
+                           hipLaunchKernelGGL((gat_fwd_kernel<LPR, VEC, false>), dim3(blocks), dim3(256), 0, st, a));
     }
-  } else {
-    const unsigned fb = (unsigned)cdiv(nslots, FIX_SCREEN);
-    PYGAT_DISPATCH_LANES(lpr, vec,
-                         hipLaunchKernelGGL((gat_fwd_fixup_kernel<LPR, VEC>), dim3(fb), dim3(256), fix_lds, st, a));
+    PYGAT_CHECK_LAUNCH("gat_forward");
+    const size_t fix_lds = 4 * (size_t)(a.rs.R + 2 * a.rs.H) * sizeof(float);
+    if (a.g.cut) {  // the caller listed the cut rows: go straight to them
+      if (a.g.n_cut > 0) {
+        const unsigned fb = (unsigned)(a.g.n_cut_wide + cdiv(a.g.n_cut - a.g.n_cut_wide, 4));
+        PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_fwd_fixup_list_kernel<LPR, VEC>), dim3(fb), dim3(256),
+                                                          fix_lds, st, a));
+      }
+    } else {
+      const unsigned fb = (unsigned)cdiv(nslots, FIX_SCREEN);
+      PYGAT_DISPATCH_LANES(lpr, vec,
+                           hipLaunchKernelGGL((gat_fwd_fixup_kernel<LPR, VEC>), dim3(fb), dim3(256), fix_lds, st, a));
+    }
+    PYGAT_CHECK_LAUNCH("gat_forward_fixup");
   }
-  PYGAT_CHECK_LAUNCH("gat_forward_fixup");
   return PYGAT_OK;
+}
+
+extern "C" int pygat_head_group(int n, int H, int Fo) {
+  const int Fp = padded_width(Fo);
+  if (n <= 0 || H <= 0 || Fp <= 0) return 0;
+  return head_group_bwd(n, H, Fp);
 }
 
 extern "C" int pygat_gat_forward(const pygat_graph* g, int H, int Fo, float alpha, int flags, const float* Wh,

@@ -29,11 +29,24 @@ struct PrepArgs {
   const float* s;
   const float* m;
   const float* Z;
-  float* GR;        // [n][ldgr]: Gp (R) | rowtab (4H) [| copy of Whi (R), GATv2]
+  float* GR;        // [n][ldgr]: per backward head window [Gp | 4-float records]  [| copy of Whi (R), GATv2]
   int64_t ldgr;
+  int h0p;          // first head (of the level) covered by this pass
+  int gr_hg;        // heads per backward window: fixes where a head's Gp and record live inside a GR row
   const float* whi; // GATv2: table whose first R floats per row are copied behind the rowtab, else nullptr
   int64_t ld_whi;
 };
+
+// float offsets inside a GR row (include/pygat_amd.h, K3a): window w0 = first head of the backward window
+__device__ __forceinline__ int64_t gr_gp_off(const PrepArgs& a, int co, int h) {
+  const int gh = a.h0p + h;
+  return (int64_t)a.h0p * a.rs.Fp + co + 4 * ((gh / a.gr_hg) * a.gr_hg);
+}
+__device__ __forceinline__ int64_t gr_rt_off(const PrepArgs& a, int h) {
+  const int gh = a.h0p + h, w0 = (gh / a.gr_hg) * a.gr_hg;
+  const int hcw = (a.rs.Htot - w0 < a.gr_hg) ? a.rs.Htot - w0 : a.gr_hg;
+  return (int64_t)w0 * (a.rs.Fp + 4) + (int64_t)hcw * a.rs.Fp + 4 * (gh - w0);
+}
 
 template <int LPR, int VEC>
 __global__ __launch_bounds__(256) void gat_bwd_prepare_kernel(PrepArgs a) {
@@ -43,7 +56,7 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_kernel(PrepArgs a) {
   if (i >= a.n) return;  // whole lane groups leave together: the DPP sums below stay inside a group
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
   const int H = a.rs.H, R = a.rs.R, Fo = a.rs.Fo, Fp = a.rs.Fp;
-  const int64_t RW = a.ldgr;
+  const int64_t RW = a.ldgr, ldr = a.rs.ldr, ldh = a.rs.ldh, ldo = a.rs.ldo;
   const int lph = a.rs.lph < 64 ? a.rs.lph : 64;
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
@@ -51,9 +64,9 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_kernel(PrepArgs a) {
     float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f), hat = g4;
     if (lc.valid[v]) {
       if (a.mean_mode) {
-        hat = ld4(a.y + i * R + co);
+        hat = ld4(a.y + i * ldr + co);
         const float* gr = a.G + i * Fo + f0;
-        const float inv = 1.0f / (float)H;
+        const float inv = 1.0f / (float)a.rs.Htot;
         if (f0 + 0 < Fo) g4.x = gr[0] * inv;
         if (f0 + 1 < Fo) g4.y = gr[1] * inv;
         if (f0 + 2 < Fo) g4.z = gr[2] * inv;
@@ -61,10 +74,10 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_kernel(PrepArgs a) {
       } else {
         float4 y4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (Fo == Fp) {
-          g4 = ld4(a.G + i * R + co);
-          y4 = ld4(a.y + i * R + co);
+          g4 = ld4(a.G + i * ldo + co);
+          y4 = ld4(a.y + i * ldo + co);
         } else {
-          const int64_t o = i * H * Fo + (int64_t)h * Fo + f0;
+          const int64_t o = i * ldo + (int64_t)h * Fo + f0;
           if (f0 + 0 < Fo) { g4.x = a.G[o + 0]; y4.x = a.y[o + 0]; }
           if (f0 + 1 < Fo) { g4.y = a.G[o + 1]; y4.y = a.y[o + 1]; }
           if (f0 + 2 < Fo) { g4.z = a.G[o + 2]; y4.z = a.y[o + 2]; }
@@ -86,17 +99,17 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_kernel(PrepArgs a) {
           hat = make_float4(pq[0], pq[1], pq[2], pq[3]);
         }
         if (a.flags & PYGAT_F_SKIP) {
-          const float4 k4 = ld4(a.sk + i * R + co);
+          const float4 k4 = ld4(a.sk + i * ldr + co);
           hat.x -= k4.x; hat.y -= k4.y; hat.z -= k4.z; hat.w -= k4.w;
         }
       }
-      st4(a.GR + i * RW + co, g4);
+      st4(a.GR + i * RW + gr_gp_off(a, co, h), g4);
       if (a.whi) st4(a.GR + i * RW + R + 4 * H + co, ld4(a.whi + i * a.ld_whi + co));
     }
     const float D = group_sum_rt(dot4(g4, hat), lph);
     if (lc.valid[v] && ((co >> 2) & (a.rs.lph - 1)) == 0) {
-      const int64_t q = i * H + h;
-      st4(a.GR + i * RW + R + 4 * h, make_float4(a.s[q], a.m[q], 1.0f / a.Z[q], D));
+      const int64_t q = i * ldh + h;
+      st4(a.GR + i * RW + gr_rt_off(a, h), make_float4(a.s[q], a.m[q], 1.0f / a.Z[q], D));
     }
   }
 }
@@ -112,20 +125,21 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_fast_kernel(PrepArgs a) {
   if (i0 >= a.n) return;
   const LaneCols<1> lc = lane_cols<LPR, 1>(a.rs);
   const int H = a.rs.H, R = a.rs.R;
-  const int64_t RW = a.ldgr;
+  const int64_t RW = a.ldgr, ldr = a.rs.ldr, ldh = a.rs.ldh, ldo = a.rs.ldo;
   const int lph = a.rs.lph < 64 ? a.rs.lph : 64;
   const int co = lc.cofs[0], h = lc.head[0];
   const bool valid = lc.valid[0];
   const bool lead = valid && (((co >> 2) & (a.rs.lph - 1)) == 0);
+  const int64_t gp_off = gr_gp_off(a, co, h), rt_off = gr_rt_off(a, h);
   float4 g4[RB], y4[RB], k4[RB];
   float sv[RB], mv[RB], zv[RB];
 #pragma unroll
   for (int r = 0; r < RB; ++r) {
     const int64_t i = (i0 + r < a.n) ? i0 + r : a.n - 1;
-    g4[r] = ld4(a.G + i * R + co);
-    y4[r] = ld4(a.y + i * R + co);
-    k4[r] = (a.flags & PYGAT_F_SKIP) ? ld4(a.sk + i * R + co) : make_float4(0.f, 0.f, 0.f, 0.f);
-    sv[r] = a.s[i * H + h]; mv[r] = a.m[i * H + h]; zv[r] = a.Z[i * H + h];
+    g4[r] = ld4(a.G + i * ldo + co);
+    y4[r] = ld4(a.y + i * ldo + co);
+    k4[r] = (a.flags & PYGAT_F_SKIP) ? ld4(a.sk + i * ldr + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    sv[r] = a.s[i * ldh + h]; mv[r] = a.m[i * ldh + h]; zv[r] = a.Z[i * ldh + h];
   }
 #pragma unroll
   for (int r = 0; r < RB; ++r) {
@@ -146,10 +160,10 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_fast_kernel(PrepArgs a) {
     const float D = group_sum_rt(dot4(g, hat), lph);
     if (i < a.n) {
       if (valid) {
-        st4(a.GR + i * RW + co, g);
+        st4(a.GR + i * RW + gp_off, g);
         if (a.whi) st4(a.GR + i * RW + R + 4 * H + co, ld4(a.whi + i * a.ld_whi + co));
       }
-      if (lead) st4(a.GR + i * RW + R + 4 * h, make_float4(sv[r], mv[r], 1.0f / zv[r], D));
+      if (lead) st4(a.GR + i * RW + rt_off, make_float4(sv[r], mv[r], 1.0f / zv[r], D));
     }
   }
 }
@@ -162,8 +176,9 @@ struct RowArgs {
   const float* Wh;
   const float* a_pad;  // t_j = Wh_j . a_dst is recomputed from the gathered row
   const float* GR;
-  const float* mask;   // [nnz][H] attention dropout mask (forward edge order) or nullptr
-  float* ds;           // [n][H]
+  int64_t ldgr;        // row stride of GR
+  const float* mask;   // [nnz][Htot] attention dropout mask (forward edge order) or nullptr
+  float* ds;           // [n][Htot]
   float* part;         // [2 * nslots][H]
 };
 
@@ -171,7 +186,7 @@ template <int VEC>
 __device__ __forceinline__ void row_flush(const RowArgs& a, const LaneCols<VEC>& lc, int64_t k, int i,
                                           bool is_head, bool is_tail, const float (&acc)[VEC]) {
   float* dst = (is_head || is_tail) ? a.part + (2 * k + (is_head ? 0 : 1)) * (int64_t)a.rs.H
-                                    : a.ds + (int64_t)i * a.rs.H;
+                                    : a.ds + (int64_t)i * a.rs.ldh;
 #pragma unroll
   for (int v = 0; v < VEC; ++v)
     if (lc.valid[v] && (((lc.cofs[v] >> 2) & (a.rs.lph - 1)) == 0)) dst[lc.head[v]] = acc[v];
@@ -187,8 +202,8 @@ __global__ __launch_bounds__(256) void gat_bwd_row_kernel(RowArgs a) {
   int64_t e0, e1;
   slot_range(a.g, k, &e0, &e1);
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
-  const int H = a.rs.H, R = a.rs.R;
-  const int64_t RW = R + 4 * H;
+  const int R = a.rs.R;
+  const int64_t RW = a.ldgr, ldr = a.rs.ldr, ldh = a.rs.ldh;
   const int lph = a.rs.lph < 64 ? a.rs.lph : 64;
   const int2* __restrict__ rc = a.g.rc;
   float4 adst[VEC];
@@ -218,8 +233,8 @@ __global__ __launch_bounds__(256) void gat_bwd_row_kernel(RowArgs a) {
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
-        wv[u][v] = ld4(a.Wh + (int64_t)p[u].y * R + lc.cofs[v]);
-        mk[u][v] = a.mask ? a.mask[((e + u < e1) ? e + u : e1 - 1) * H + lc.head[v]] : 1.f;
+        wv[u][v] = ld4(a.Wh + (int64_t)p[u].y * ldr + lc.cofs[v]);
+        mk[u][v] = a.mask ? a.mask[((e + u < e1) ? e + u : e1 - 1) * ldh + lc.head[v]] : 1.f;
       }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -285,7 +300,7 @@ __global__ __launch_bounds__(256) void gat_bwd_row_fixup_kernel(RowArgs a) {
   const int64_t k_e = slot_of(a.g, row_end - 1);
   float acc = a.part[(2 * k + 1) * H + h];
   for (int64_t kk = k + 1; kk <= k_e; ++kk) acc += a.part[(2 * kk) * H + h];
-  a.ds[(int64_t)r * H + h] = acc;
+  a.ds[(int64_t)r * a.rs.ldh + h] = acc;
 }
 
 // list-driven variant: one wave per cut row; lane l sums pieces l, l+64, ... of each head, then a fixed
@@ -303,7 +318,7 @@ __global__ __launch_bounds__(256) void gat_bwd_row_fixup_list_kernel(RowArgs a) 
     for (int q = lane; q < npieces; q += 64) acc += a.part[(q == 0 ? 2 * k + 1 : 2 * (k + q)) * (int64_t)H + h];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-    if (lane == 0) a.ds[(int64_t)r * H + h] = acc;
+    if (lane == 0) a.ds[(int64_t)r * a.rs.ldh + h] = acc;
   }
 }
 
@@ -335,37 +350,48 @@ static int launch_prepare(int n, int H, int Fo, int flags, int mean_mode, const 
                           const float* sk, const float* s, const float* m, const float* Z, float* GR,
                           const float* whi, int64_t ld_whi, void* stream) {
   PrepArgs a;
-  PYGAT_REQUIRE(make_row_shape(H, Fo, &a.rs), "gat_backward_prepare: unsupported H=%d F'=%d", H, Fo);
+  const int Fp = padded_width(Fo);
+  PYGAT_REQUIRE(H > 0 && Fp > 0, "gat_backward_prepare: unsupported H=%d F'=%d", H, Fo);
   PYGAT_REQUIRE(n > 0 && G && y && s && m && Z && GR, "gat_backward_prepare: null pointer");
   PYGAT_REQUIRE(!(flags & PYGAT_F_SKIP) || sk, "gat_backward_prepare: PYGAT_F_SKIP without sk");
   PYGAT_REQUIRE(!(mean_mode && (flags & PYGAT_F_ELU)), "gat_backward_prepare: the head mean never carries an ELU (models.py:23)");
   PYGAT_REQUIRE(aligned16(GR) && (!sk || aligned16(sk)) &&
-                    (mean_mode ? aligned16(y) : (a.rs.Fo != a.rs.Fp || (aligned16(G) && aligned16(y)))),
+                    (mean_mode ? aligned16(y) : (Fo != Fp || (aligned16(G) && aligned16(y)))),
                 "gat_backward_prepare: row tables must be 16-byte aligned");
-  a.n = n; a.flags = flags; a.mean_mode = mean_mode; a.G = G; a.y = y; a.sk = sk; a.s = s; a.m = m; a.Z = Z;
-  a.GR = GR; a.whi = whi; a.ld_whi = ld_whi;
-  a.ldgr = (int64_t)a.rs.R * (whi ? 2 : 1) + 4 * a.rs.H;
-  int lpr, vec;
-  pick_lanes(a.rs, &lpr, &vec);
-  if (!mean_mode && a.rs.Fo == a.rs.Fp && vec == 1) {
-    const unsigned fb = (unsigned)cdiv(cdiv(cdiv(n, 4), 64 / lpr), 4);
-    hipStream_t st = (hipStream_t)stream;
-    switch (lpr) {
-      case 1: hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<1>), dim3(fb), dim3(256), 0, st, a); break;
-      case 2: hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<2>), dim3(fb), dim3(256), 0, st, a); break;
-      case 4: hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<4>), dim3(fb), dim3(256), 0, st, a); break;
-      case 8: hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<8>), dim3(fb), dim3(256), 0, st, a); break;
-      case 16: hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<16>), dim3(fb), dim3(256), 0, st, a); break;
-      case 32: hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<32>), dim3(fb), dim3(256), 0, st, a); break;
-      default: hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<64>), dim3(fb), dim3(256), 0, st, a); break;
+  hipStream_t st = (hipStream_t)stream;
+  const int hg = whi ? H : head_group_fwd(H, Fp);   // kernel passes (GATv2 is not windowed)
+  for (int h0 = 0; h0 < H; h0 += hg) {
+    const int hc = (H - h0 < hg) ? H - h0 : hg;
+    PYGAT_REQUIRE(make_window_shape(H, Fo, hc, &a.rs), "gat_backward_prepare: unsupported H=%d F'=%d", hc, Fo);
+    a.n = n; a.flags = flags; a.mean_mode = mean_mode;
+    // mean mode: G is [n, F'] (shared by the heads), y = hattn [n, R]; concat: G and y = out are [n, H*F']
+    a.G = mean_mode ? G : G + (int64_t)h0 * Fo;
+    a.y = mean_mode ? y + (int64_t)h0 * Fp : y + (int64_t)h0 * Fo;
+    a.sk = sk ? sk + (int64_t)h0 * Fp : nullptr;
+    a.s = s + h0; a.m = m + h0; a.Z = Z + h0;
+    a.ldgr = (int64_t)H * Fp * (whi ? 2 : 1) + 4 * H;
+    a.GR = GR; a.h0p = h0; a.gr_hg = whi ? H : head_group_bwd(n, H, Fp);
+    a.whi = whi; a.ld_whi = ld_whi;
+    int lpr, vec;
+    pick_lanes(a.rs, &lpr, &vec);
+    if (!mean_mode && a.rs.Fo == a.rs.Fp && vec == 1) {
+      const unsigned fb = (unsigned)cdiv(cdiv(cdiv(n, 4), 64 / lpr), 4);
+      switch (lpr) {
+        case 1: hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<1>), dim3(fb), dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<2>), dim3(fb), dim3(256), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<4>), dim3(fb), dim3(256), 0, st, a); break;
+        case 8: hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<8>), dim3(fb), dim3(256), 0, st, a); break;
+        case 16: hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<16>), dim3(fb), dim3(256), 0, st, a); break;
+        case 32: hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<32>), dim3(fb), dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<64>), dim3(fb), dim3(256), 0, st, a); break;
+      }
+    } else {
+      const unsigned blocks = (unsigned)cdiv(cdiv(n, 64 / lpr), 4);
+      PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_bwd_prepare_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0,
+                                                        st, a));
     }
     PYGAT_CHECK_LAUNCH("gat_backward_prepare");
-    return PYGAT_OK;
   }
-  const unsigned blocks = (unsigned)cdiv(cdiv(n, 64 / lpr), 4);
-  PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_bwd_prepare_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0,
-                                                    (hipStream_t)stream, a));
-  PYGAT_CHECK_LAUNCH("gat_backward_prepare");
   return PYGAT_OK;
 }
 
@@ -375,23 +401,31 @@ extern "C" int pygat_gat_backward_row(const pygat_graph* g, int H, int Fo, float
   RowArgs a;
   int rc = check_graph(g, &a.g);
   if (rc) return rc;
-  PYGAT_REQUIRE(make_row_shape(H, Fo, &a.rs), "gat_backward_row: unsupported H=%d F'=%d", H, Fo);
+  const int Fp = padded_width(Fo);
+  PYGAT_REQUIRE(H > 0 && Fp > 0, "gat_backward_row: unsupported H=%d F'=%d", H, Fo);
   PYGAT_REQUIRE(Wh && a_pad && GR && ds && part, "gat_backward_row: null pointer");
   PYGAT_REQUIRE(aligned16(Wh) && aligned16(GR) && aligned16(a_pad), "gat_backward_row: row tables must be 16-byte aligned");
-  a.alpha = alpha; a.Wh = Wh; a.a_pad = a_pad; a.GR = GR; a.mask = att_mask; a.ds = ds; a.part = (float*)part;
-  int lpr, vec;
-  pick_lanes(a.rs, &lpr, &vec);
   hipStream_t st = (hipStream_t)stream;
   const int64_t nslots = num_slots(a.g);
-  const unsigned blocks = (unsigned)cdiv(cdiv(nslots, 64 / lpr), 4);
-  PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_bwd_row_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0, st, a));
-  PYGAT_CHECK_LAUNCH("gat_backward_row");
-  if (a.g.cut) {
-    if (a.g.n_cut > 0)
-      hipLaunchKernelGGL(gat_bwd_row_fixup_list_kernel, dim3((unsigned)cdiv(a.g.n_cut, 4)), dim3(256), 0, st, a);
-  } else {
-    hipLaunchKernelGGL(gat_bwd_row_fixup_kernel, dim3((unsigned)cdiv(nslots * H, 256)), dim3(256), 0, st, a);
+  const int hg = head_group_bwd(a.g.n, H, Fp);
+  for (int h0 = 0; h0 < H; h0 += hg) {
+    const int hc = (H - h0 < hg) ? H - h0 : hg;
+    PYGAT_REQUIRE(make_window_shape(H, Fo, hc, &a.rs), "gat_backward_row: unsupported H=%d F'=%d", hc, Fo);
+    a.alpha = alpha; a.Wh = Wh + (int64_t)h0 * Fp; a.a_pad = a_pad + (int64_t)h0 * 2 * Fp;
+    a.GR = GR + gr_window_offset(h0, Fp); a.ldgr = (int64_t)H * Fp + 4 * H;
+    a.mask = att_mask ? att_mask + h0 : nullptr; a.ds = ds + h0; a.part = (float*)part;
+    int lpr, vec;
+    pick_lanes(a.rs, &lpr, &vec);
+    const unsigned blocks = (unsigned)cdiv(cdiv(nslots, 64 / lpr), 4);
+    PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_bwd_row_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0, st, a));
+    PYGAT_CHECK_LAUNCH("gat_backward_row");
+    if (a.g.cut) {
+      if (a.g.n_cut > 0)
+        hipLaunchKernelGGL(gat_bwd_row_fixup_list_kernel, dim3((unsigned)cdiv(a.g.n_cut, 4)), dim3(256), 0, st, a);
+    } else {
+      hipLaunchKernelGGL(gat_bwd_row_fixup_kernel, dim3((unsigned)cdiv(nslots * hc, 256)), dim3(256), 0, st, a);
+    }
+    PYGAT_CHECK_LAUNCH("gat_backward_row_fixup");
   }
-  PYGAT_CHECK_LAUNCH("gat_backward_row_fixup");
   return PYGAT_OK;
 }

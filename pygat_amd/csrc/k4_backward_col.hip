@@ -22,6 +22,7 @@ struct ColArgs {
   const float* mask;    // [nnz][H] attention dropout mask in FORWARD edge order, or nullptr
   const float* Wh;
   const float* GR;
+  int64_t ldgr;         // row stride of GR
   const float* a_pad;
   const float* ds;
   float* dWh;
@@ -32,12 +33,13 @@ struct ColArgs {
 template <int VEC>
 __device__ __forceinline__ void col_finish(const ColArgs& a, const LaneCols<VEC>& lc, int j,
                                            const float4 (&acc)[VEC], const float (&dt)[VEC]) {
-  const int H = a.rs.H, R = a.rs.R, Fp = a.rs.Fp;
+  const int Fp = a.rs.Fp;
+  const int64_t ldr = a.rs.ldr, ldh = a.rs.ldh;
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
     if (!lc.valid[v]) continue;
     const int co = lc.cofs[v], h = lc.head[v], f0 = co & (Fp - 1);
-    const float dsj = a.ds[(int64_t)j * H + h];
+    const float dsj = a.ds[(int64_t)j * ldh + h];
     const float4 as = ld4(a.a_pad + (int64_t)h * 2 * Fp + f0);
     const float4 ad = ld4(a.a_pad + (int64_t)h * 2 * Fp + Fp + f0);
     float4 o;
@@ -45,8 +47,8 @@ __device__ __forceinline__ void col_finish(const ColArgs& a, const LaneCols<VEC>
     o.y = acc[v].y + dsj * as.y + dt[v] * ad.y;
     o.z = acc[v].z + dsj * as.z + dt[v] * ad.z;
     o.w = acc[v].w + dsj * as.w + dt[v] * ad.w;
-    st4(a.dWh + (int64_t)j * R + co, o);
-    if (((co >> 2) & (a.rs.lph - 1)) == 0) a.dt[(int64_t)j * H + h] = dt[v];
+    st4(a.dWh + (int64_t)j * ldr + co, o);
+    if (((co >> 2) & (a.rs.lph - 1)) == 0) a.dt[(int64_t)j * ldh + h] = dt[v];
   }
 }
 
@@ -77,8 +79,8 @@ __global__ __launch_bounds__(256) void gat_bwd_col_kernel(ColArgs a) {
   int64_t e0, e1;
   slot_range(a.g, k, &e0, &e1);
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
-  const int H = a.rs.H, R = a.rs.R;
-  const int64_t RW = R + 4 * H;
+  const int R = a.rs.R;
+  const int64_t RW = a.ldgr, ldr = a.rs.ldr, ldh = a.rs.ldh;
   const int lph = a.rs.lph < 64 ? a.rs.lph : 64;
   const int2* __restrict__ rc = a.g.rc;
   float4 adst[VEC];
@@ -108,9 +110,9 @@ __global__ __launch_bounds__(256) void gat_bwd_col_kernel(ColArgs a) {
         const float* gr = a.GR + (int64_t)p[u].y * RW;           // gathered: one contiguous row
         gv[u][v] = ld4(gr + lc.cofs[v]);
         rt[u][v] = ld4(gr + R + 4 * lc.head[v]);
-        wv[u][v] = ld4(a.Wh + (int64_t)p[u].x * R + lc.cofs[v]);  // row-local (L1 after the first edge)
+        wv[u][v] = ld4(a.Wh + (int64_t)p[u].x * ldr + lc.cofs[v]);  // row-local (L1 after the first edge)
         mk[u][v] = 1.f;
-        if (a.mask) mk[u][v] = a.mask[(int64_t)a.perm[(e + u < e1) ? e + u : e1 - 1] * H + lc.head[v]];
+        if (a.mask) mk[u][v] = a.mask[(int64_t)a.perm[(e + u < e1) ? e + u : e1 - 1] * ldh + lc.head[v]];
       }
     float al[U][VEC], dz[U][VEC];
 #pragma unroll
@@ -337,32 +339,40 @@ extern "C" int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm
   ColArgs a;
   int rc = check_graph(gT, &a.g);
   if (rc) return rc;
-  PYGAT_REQUIRE(make_row_shape(H, Fo, &a.rs), "gat_backward_col: unsupported H=%d F'=%d", H, Fo);
+  const int Fp = padded_width(Fo);
+  PYGAT_REQUIRE(H > 0 && Fp > 0, "gat_backward_col: unsupported H=%d F'=%d", H, Fo);
   PYGAT_REQUIRE(Wh && a_pad && GR && ds && dWh && dt && part, "gat_backward_col: null pointer");
   PYGAT_REQUIRE(!att_mask || perm_t, "gat_backward_col: an attention mask needs perm_t (mask is in forward edge order)");
   PYGAT_REQUIRE(aligned16(Wh) && aligned16(GR) && aligned16(dWh) && aligned16(a_pad) && aligned16(part),
                 "gat_backward_col: row tables must be 16-byte aligned");
-  a.alpha = alpha; a.perm = perm_t; a.mask = att_mask; a.Wh = Wh; a.GR = GR; a.a_pad = a_pad; a.ds = ds;
-  a.dWh = dWh; a.dt = dt; a.part = (float*)part;
-  int lpr, vec;
-  pick_lanes(a.rs, &lpr, &vec);
   hipStream_t st = (hipStream_t)stream;
   const int64_t nslots = num_slots(a.g);
-  const unsigned blocks = (unsigned)cdiv(cdiv(nslots, 64 / lpr), 4);
-  PYGAT_DISPATCH_LANES(lpr, vec,
-                       hipLaunchKernelGGL((gat_bwd_col_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0, st, a));
-  PYGAT_CHECK_LAUNCH("gat_backward_col");
-  const size_t fix_lds = 4 * (size_t)(a.rs.R + 2 * a.rs.H) * sizeof(float);
-  if (a.g.cut) {
-    if (a.g.n_cut > 0) {
-      const unsigned fb = (unsigned)(a.g.n_cut_wide + cdiv(a.g.n_cut - a.g.n_cut_wide, 4));
-      PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_bwd_col_fixup_list_kernel<LPR, VEC>), dim3(fb), dim3(256),
-                                                        fix_lds, st, a));
+  const int hg = head_group_bwd(a.g.n, H, Fp);
+  for (int h0 = 0; h0 < H; h0 += hg) {
+    const int hc = (H - h0 < hg) ? H - h0 : hg;
+    PYGAT_REQUIRE(make_window_shape(H, Fo, hc, &a.rs), "gat_backward_col: unsupported H=%d F'=%d", hc, Fo);
+    a.alpha = alpha; a.perm = perm_t; a.mask = att_mask ? att_mask + h0 : nullptr;
+    a.Wh = Wh + (int64_t)h0 * Fp; a.GR = GR + gr_window_offset(h0, Fp); a.ldgr = (int64_t)H * Fp + 4 * H;
+    a.a_pad = a_pad + (int64_t)h0 * 2 * Fp; a.ds = ds + h0;
+    a.dWh = dWh + (int64_t)h0 * Fp; a.dt = dt + h0; a.part = (float*)part;
+    int lpr, vec;
+    pick_lanes(a.rs, &lpr, &vec);
+    const unsigned blocks = (unsigned)cdiv(cdiv(nslots, 64 / lpr), 4);
+    PYGAT_DISPATCH_LANES(lpr, vec,
+                         hipLaunchKernelGGL((gat_bwd_col_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0, st, a));
+    PYGAT_CHECK_LAUNCH("gat_backward_col");
+    const size_t fix_lds = 4 * (size_t)(a.rs.R + 2 * a.rs.H) * sizeof(float);
+    if (a.g.cut) {
+      if (a.g.n_cut > 0) {
+        const unsigned fb = (unsigned)(a.g.n_cut_wide + cdiv(a.g.n_cut - a.g.n_cut_wide, 4));
+        PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_bwd_col_fixup_list_kernel<LPR, VEC>), dim3(fb), dim3(256),
+                                                          fix_lds, st, a));
+      }
+    } else {
+      PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_bwd_col_fixup_kernel<LPR, VEC>),
+                                                        dim3((unsigned)cdiv(nslots, FIX_SCREEN)), dim3(256), fix_lds, st, a));
     }
-  } else {
-    PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_bwd_col_fixup_kernel<LPR, VEC>),
-                                                      dim3((unsigned)cdiv(nslots, FIX_SCREEN)), dim3(256), fix_lds, st, a));
+    PYGAT_CHECK_LAUNCH("gat_backward_col_fixup");
   }
-  PYGAT_CHECK_LAUNCH("gat_backward_col_fixup");
   return PYGAT_OK;
 }

@@ -34,9 +34,9 @@ __global__ __launch_bounds__(256) void a_grad_partial_kernel(int n, int nblocks,
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int64_t r = i + q * rpb;
-      w[q] = ld4(Wh + r * rs.R + co);
-      a1[q] = ds[r * rs.H + h];
-      a2[q] = dt[r * rs.H + h];
+      w[q] = ld4(Wh + r * rs.ldr + co);
+      a1[q] = ds[r * rs.ldh + h];
+      a2[q] = dt[r * rs.ldh + h];
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -45,8 +45,8 @@ __global__ __launch_bounds__(256) void a_grad_partial_kernel(int n, int nblocks,
     }
   }
   for (; i < r1; i += rpb) {
-    const float4 w = ld4(Wh + i * rs.R + co);
-    const float a1 = ds[i * rs.H + h], a2 = dt[i * rs.H + h];
+    const float4 w = ld4(Wh + i * rs.ldr + co);
+    const float a1 = ds[i * rs.ldh + h], a2 = dt[i * rs.ldh + h];
     as.x = fmaf(a1, w.x, as.x); as.y = fmaf(a1, w.y, as.y); as.z = fmaf(a1, w.z, as.z); as.w = fmaf(a1, w.w, as.w);
     ad.x = fmaf(a2, w.x, ad.x); ad.y = fmaf(a2, w.y, ad.y); ad.z = fmaf(a2, w.z, ad.z); ad.w = fmaf(a2, w.w, ad.w);
   }
@@ -165,16 +165,24 @@ extern "C" size_t pygat_agrad_workspace_bytes(int H, int Fo) {
 extern "C" int pygat_a_grad(int n, int H, int Fo, const float* Wh, const float* ds, const float* dt, float* da,
                             void* ws, void* stream) {
   RowShape rs;
-  PYGAT_REQUIRE(make_row_shape(H, Fo, &rs), "a_grad: unsupported H=%d F'=%d", H, Fo);
+  const int Fp = padded_width(Fo);
+  PYGAT_REQUIRE(H > 0 && Fp > 0 && Fp <= 1024, "a_grad: unsupported H=%d F'=%d", H, Fo);
   PYGAT_REQUIRE(n > 0 && Wh && ds && dt && da && ws && aligned16(Wh) && aligned16(ws), "a_grad: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   // one slab of >= 256 rows per work-group, at most AG_BLOCKS slabs (small graphs: few, short reductions)
   int nblocks = (int)cdiv(n, 256);
   if (nblocks > AG_BLOCKS) nblocks = AG_BLOCKS;
-  hipLaunchKernelGGL(a_grad_partial_kernel, dim3(nblocks), dim3(256), 0, st, n, nblocks, rs, Wh, ds, dt, (float*)ws);
-  hipLaunchKernelGGL(a_grad_final_kernel, dim3((unsigned)cdiv(rs.H * 2 * rs.Fo * 8, 256)), dim3(256), 0, st, rs, nblocks,
-                     (const float*)ws, da);
-  PYGAT_CHECK_LAUNCH("a_grad");
+  // a work-group streams rows of at most 1024 floats (256 threads x 16 B): wider levels go window by window
+  const int hg = (H * Fp <= 1024) ? H : (1024 / Fp);
+  for (int h0 = 0; h0 < H; h0 += hg) {
+    const int hc = (H - h0 < hg) ? H - h0 : hg;
+    PYGAT_REQUIRE(make_window_shape(H, Fo, hc, &rs), "a_grad: unsupported H=%d F'=%d", hc, Fo);
+    hipLaunchKernelGGL(a_grad_partial_kernel, dim3(nblocks), dim3(256), 0, st, n, nblocks, rs, Wh + (int64_t)h0 * Fp,
+                       ds + h0, dt + h0, (float*)ws);
+    hipLaunchKernelGGL(a_grad_final_kernel, dim3((unsigned)cdiv(rs.H * 2 * rs.Fo * 8, 256)), dim3(256), 0, st, rs, nblocks,
+                       (const float*)ws, da + (int64_t)h0 * 2 * Fo);
+    PYGAT_CHECK_LAUNCH("a_grad");
+  }
   return PYGAT_OK;
 }
 

@@ -101,7 +101,6 @@ class GATLevelDropoutFn(torch.autograd.Function):
             st = _stream()
             RW = L.R + 4 * H
             GR = torch.empty(L.N, RW, dtype=f32, device=dev)
-            Gp = GR[:, :L.R]
             ds = torch.empty(L.N, H, dtype=f32, device=dev); dt = torch.empty(L.N, H, dtype=f32, device=dev)
             dWh = torch.empty(L.N, L.R, dtype=f32, device=dev)
             part = torch.empty(lib.pygat_partials_bytes(graph.nnz, L.ts, H, L.Fp) // 4, dtype=f32, device=dev)
@@ -130,12 +129,12 @@ class GATLevelDropoutFn(torch.autograd.Function):
                 c0 = h * L.Fp
                 gemm(True, False, L.Fin, L.Fp, L.N, xh, L.Fin, dWh[:, c0:], L.R, [(L.Fp, dWc[:, c0:], L.R)])
                 if L.skip:
-                    gemm(True, False, L.Fin, L.Fp, L.N, xh, L.Fin, Gp[:, c0:], RW, [(L.Fp, dSc[:, c0:], L.R)])
+                    gemm(True, False, L.Fin, L.Fp, L.N, xh, L.Fin, GR[:, L.gp_col(h):], RW, [(L.Fp, dSc[:, c0:], L.R)])
                 if need_dx:
                     gemm(False, True, L.N, L.Fin, L.Fp, dWh[:, c0:], L.R, Wcat[:, c0:], L.ldw, [(L.Fin, dxh, L.Fin)],
                          split_k=1)
                     if L.skip:
-                        gemm(False, True, L.N, L.Fin, L.Fp, Gp[:, c0:], RW, Wcat[:, L.R + c0:], L.ldw,
+                        gemm(False, True, L.N, L.Fin, L.Fp, GR[:, L.gp_col(h):], RW, Wcat[:, L.R + c0:], L.ldw,
                              [(L.Fin, dxh, L.Fin)], accumulate=True, split_k=1)
                     dx.addcmul_(dxh, mask_x[h])    # back through the per-head input dropout
             dW = torch.empty(H, L.Fin, Fo, dtype=f32, device=dev)

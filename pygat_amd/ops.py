@@ -105,10 +105,20 @@ class _Level:
         self.H, self.Fo, self.skip = H, Fo, skip
         self.Fp = padded_width(Fo)
         self.R = H * self.Fp
-        if self.R > 1024:
-            raise ValueError(f"pygat_amd: H*pad(F') = {self.R} > 1024 per call; shard the heads")
+        self.hg = lib.pygat_head_group(self.N, H, Fo)   # heads per backward pass = layout of a GR row
         self.ldw = -(-(self.R * (2 if skip else 1) + 2 * H) // 4) * 4
         self.ts = 0        # slot length of the nnz-split kernels (rows cut by a slot border cost a partial record)
+
+    def gp_windows(self):
+        """(first column in the R-wide tables, width, first column inside a GR row) of each head window's Gp."""
+        for h0 in range(0, self.H, self.hg):
+            hc = min(self.hg, self.H - h0)
+            yield h0 * self.Fp, hc * self.Fp, h0 * (self.Fp + 4)
+
+    def gp_col(self, h):
+        """Column of head h's Gp slice inside a GR row (include/pygat_amd.h, K3a)."""
+        h0 = (h // self.hg) * self.hg
+        return h0 * (self.Fp + 4) + (h - h0) * self.Fp
 
 
 class GATLevelFn(torch.autograd.Function):
@@ -179,8 +189,7 @@ class GATLevelFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             st = _stream()
             RW = L.R + 4 * H
-            GR = torch.empty(L.N, RW, dtype=f32, device=dev)      # [Gp | (s, m, 1/Z, D) per head]
-            Gp = GR[:, :L.R]                                      # view, row stride RW
+            GR = torch.empty(L.N, RW, dtype=f32, device=dev)      # per head window: [Gp | (s, m, 1/Z, D) per head]
             ds = torch.empty(L.N, H, dtype=f32, device=dev)
             dt = torch.empty(L.N, H, dtype=f32, device=dev)
             dWh = torch.empty(L.N, L.R, dtype=f32, device=dev)
@@ -215,7 +224,8 @@ class GATLevelFn(torch.autograd.Function):
                 check(lib.pygat_unpack_wgrad(H, L.Fin, Fo, dWc.data_ptr(), L.R, 0, dW.data_ptr(), st), "unpack")
             if L.skip and ctx.needs_input_grad[3]:
                 dSc = torch.empty(L.Fin, L.R, dtype=f32, device=dev)
-                gemm(True, False, L.Fin, L.R, L.N, x, L.Fin, Gp, RW, [(L.R, dSc, L.R)])
+                for c0, w, g0 in L.gp_windows():
+                    gemm(True, False, L.Fin, w, L.N, x, L.Fin, GR[:, g0:], RW, [(w, dSc[:, c0:], L.R)])
                 dWs = torch.empty(H, L.Fin, Fo, dtype=f32, device=dev)
                 check(lib.pygat_unpack_wgrad(H, L.Fin, Fo, dSc.data_ptr(), L.R, 0, dWs.data_ptr(), st), "unpack")
             # dx = dWh Wcat[:, :R]^T (+ Gp Wcat[:, R:2R]^T)
@@ -224,8 +234,9 @@ class GATLevelFn(torch.autograd.Function):
                 with _span("k5_xgrad"):
                     gemm(False, True, L.N, L.Fin, L.R, dWh, L.R, Wcat, L.ldw, [(L.Fin, dx, L.Fin)])
                     if L.skip:
-                        gemm(False, True, L.N, L.Fin, L.R, Gp, RW, Wcat[:, L.R:], L.ldw, [(L.Fin, dx, L.Fin)],
-                             accumulate=True, split_k=1)
+                        for c0, w, g0 in L.gp_windows():
+                            gemm(False, True, L.N, L.Fin, w, GR[:, g0:], RW, Wcat[:, L.R + c0:], L.ldw,
+                                 [(L.Fin, dx, L.Fin)], accumulate=True, split_k=1)
         return dx, dW, (da if ctx.needs_input_grad[2] else None), dWs, None, None, None
 
 
@@ -234,15 +245,6 @@ def gat_level(x: torch.Tensor, graph: CSRGraph, Ws: Sequence[torch.Tensor], As: 
     """All heads of one level. Ws: H tensors [Fin,F']; As: H tensors with 2F' elements
     ([2F',1] as in GraphAttentionLayer, layers.py:23, or [1,2F'] as in SpGraphAttentionLayer,
     layers.py:114); Wskips: H tensors [Fin,F'] or None."""
-    H, Fp = len(Ws), padded_width(Ws[0].shape[1])
-    gmax = max(1, 1024 // Fp)          # a kernel call takes rows of at most 1024 floats (H*pad(F'))
-    if H > gmax:                       # more heads than one call holds: head groups, then cat / weighted mean
-        outs = []
-        for s0 in range(0, H, gmax):
-            s1 = min(H, s0 + gmax)
-            o = gat_level(x, graph, Ws[s0:s1], As[s0:s1], None if Wskips is None else Wskips[s0:s1], alpha, concat)
-            outs.append(o if concat else o * ((s1 - s0) / H))
-        return torch.cat(outs, dim=1) if concat else torch.stack(outs, 0).sum(0)
     W = torch.stack(list(Ws), 0)
     a = torch.stack([p.reshape(-1) for p in As], 0)
     Wskip = torch.stack(list(Wskips), 0) if Wskips is not None else None

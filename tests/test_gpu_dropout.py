@@ -13,9 +13,11 @@ from test_gpu_parity import close, params, pg  # noqa: F401
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("H,Fin,Fo,skip,concat", [(3, 10, 8, False, True), (2, 7, 5, True, False), (8, 20, 8, True, True)])
-def test_dropout_explicit_masks(pg, H, Fin, Fo, skip, concat):  # noqa: F811
+@pytest.mark.parametrize("H,Fin,Fo,skip,concat", [(3, 10, 8, False, True), (2, 7, 5, True, False), (8, 20, 8, True, True),
+                                                  (3, 9, 128, True, True), (5, 6, 100, True, False), (6, 5, 128, True, True)])   # last two: head windows
+def test_dropout_explicit_masks(pg, monkeypatch, H, Fin, Fo, skip, concat):  # noqa: F811
     from pygat_amd.dropout import gat_level_dropout
+    monkeypatch.setenv("PYGAT_BWD_WINDOW_BYTES", "0")   # rows > 512 floats: backward in head windows
     N, p = 70, 0.6
     rowptr, col = O.random_symmetric_csr(N, 5, 3, hub=(2, 50))
     E = len(col)

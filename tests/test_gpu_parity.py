@@ -151,12 +151,15 @@ SHAPES = [  # (H, Fin, Fo, skip, concat)
     (1, 64, 7, False, False),    # Cora level 2: 1 head, F'=7 (padded), mean
     (8, 64, 3, False, False),    # Pubmed level 2: 8 heads x 3, mean
     (8, 32, 16, False, True),    # RMAT headline shape (R=128)
-    (4, 50, 256, True, True),    # PPI level 1: skip, R=1024 (VEC=4)
-    (6, 40, 121, True, False),   # PPI level 3: 6 heads x 121, mean, skip (VEC=3)
+    (4, 50, 256, True, True),    # PPI level 1: skip, R=1024 -> 4 head windows of 256 floats
+    (6, 40, 121, True, False),   # PPI level 3: 6 heads x 121, mean, skip -> 3 windows of 2 heads
+    (3, 10, 128, True, True),    # uneven windows: 2 heads + 1 head
+    (5, 12, 100, True, False),   # mean over 5 heads in windows 2 + 2 + 1, padded F'
+    (12, 8, 128, False, True),   # R = 1536: wider than any single pass ever took
     (1, 12, 16, True, True),     # one head of 16 (8-GPU shard of the headline shape)
     (2, 9, 4, False, True),
     (3, 10, 8, True, True),      # NCH = 6: idle lanes in the group
-    (8, 24, 64, False, True),    # R = 512 (VEC=2)
+    (8, 24, 64, False, True),    # R = 512 -> 2 windows of 4 heads
 ]
 
 
@@ -175,6 +178,32 @@ def test_level_fwd_bwd_small(pg, H, Fin, Fo, skip, concat, chunk):
     close(out, ref["out"], "out"); close(dx, ref["dX"], "dX"); close(dW, ref["dW"], "dW"); close(da, ref["da"], "da")
     if skip:
         close(dS, ref["dW_skip"], "dW_skip")
+
+
+WIDE = [s for s in SHAPES if s[0] * max(4, 1 << (s[2] - 1).bit_length()) > 512]
+
+
+@pytest.mark.parametrize("H,Fin,Fo,skip,concat", WIDE)
+def test_level_backward_head_windows(pg, monkeypatch, H, Fin, Fo, skip, concat):
+    """Rows wider than 512 floats on a LARGE graph run the backward in head windows of <= 256 floats (GR laid
+    out window by window).  PYGAT_BWD_WINDOW_BYTES=0 forces that path on a small graph."""
+    monkeypatch.setenv("PYGAT_BWD_WINDOW_BYTES", "0")
+    N = 80
+    hg = pg._lib.lib.pygat_head_group(N, H, Fo)
+    assert 1 <= hg < H and hg * pg.padded_width(Fo) <= 256
+    rowptr, col = O.random_symmetric_csr(N, 6, 21 + H, hub=(5, 60))
+    W, a, Sk = params(H, Fin, Fo, skip, 22 + Fo)
+    gen = torch.Generator().manual_seed(23)
+    x = torch.randn(N, Fin, dtype=torch.float64, generator=gen)
+    G = torch.randn(N, H * Fo if concat else Fo, dtype=torch.float64, generator=gen)
+    ref = O.csr_layer_fwd_bwd(x.numpy(), rowptr, col, W.numpy(), a.numpy(), 0.2, concat, G.numpy(),
+                              None if Sk is None else Sk.numpy())
+    out, dx, dW, da, dS = run_level(pg, x, rowptr, col, W, a, Sk, concat, G, slot=16)
+    close(out, ref["out"], "out"); close(dx, ref["dX"], "dX"); close(dW, ref["dW"], "dW"); close(da, ref["da"], "da")
+    if skip:
+        close(dS, ref["dW_skip"], "dW_skip")
+    monkeypatch.delenv("PYGAT_BWD_WINDOW_BYTES")
+    assert pg._lib.lib.pygat_head_group(N, H, Fo) == min(H, 1024 // pg.padded_width(Fo))
 
 
 def test_eval_matches_both_oracle_formulations(pg):
@@ -296,7 +325,7 @@ def test_single_layer_dropin_matches_oracle_head(pg):
 
 
 def test_more_heads_than_one_call_holds(pg):
-    """8 heads x 256 = 2048 floats per node row: gat_level splits into head groups (cat / weighted mean)."""
+    """8 heads x 256 = 2048 floats per node row: one call, walked as 8 head windows inside the library."""
     N, Fin, Fo, H = 40, 6, 256, 8
     rowptr, col = O.random_symmetric_csr(N, 4, 17)
     W, a, _ = params(H, Fin, Fo, False, 18)
@@ -347,8 +376,6 @@ def test_fuzz_level(pg, seed):
     N = int(rng.integers(1, 400))
     H = int(rng.choice([1, 2, 3, 4, 6, 8]))
     Fo = int(rng.choice([1, 3, 4, 5, 8, 16, 17, 32, 64, 100]))
-    while H * pg.padded_width(Fo) > 1024:
-        H = max(1, H // 2)
     Fin = int(rng.integers(1, 70))
     skip, concat = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
     slot = int(rng.choice([4, 8, 16, 64]))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel-level micro-benchmarks for K2/K3/K4 on the headline workload (development tool).
 
-    python tools/kbench.py [--graph rmat|regular] [--chunk 256] [--iters 20] [--heads 8 --fout 16]
+    python tools/kbench.py [--graph rmat|regular|cora|citeseer|pubmed] [--chunk 256] [--iters 20] [--heads 8 --fout 16]
 
 Times each kernel through the C ABI with HIP events (median of --iters) and prints algorithmic
 GB/s (SURVEY.md 8(d) byte model).  Also usable under `rocprofv3 --pmc ... -- python3 tools/kbench.py`.
@@ -35,6 +35,9 @@ def main():
     H, Fo = args.heads, args.fout
     if args.graph == "rmat":
         rowptr, col = rmat_csr(args.scale, 5_000_000 * (1 << args.scale) // (1 << 20), seed=1, device=dev)
+    elif args.graph in ("cora", "citeseer", "pubmed"):   # real topology (BASELINE.json configs 2-3)
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", f"{args.graph}_csr.npz"))
+        rowptr = torch.from_numpy(z["rowptr"]).to(dev); col = torch.from_numpy(z["col"]).to(dev)
     else:  # every row: self loop + 9 random neighbours (not symmetric; forward-only experiments)
         n = 1 << args.scale
         g = torch.Generator(device=dev).manual_seed(1)

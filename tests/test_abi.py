@@ -34,6 +34,18 @@ def test_every_declared_symbol_is_exported(lib):
     assert sorted(lib.SYMBOLS) == names       # the python binding covers the whole header
 
 
+def test_head_windows_host_logic(lib, monkeypatch):
+    """pygat_head_group is pure host code: one pass unless the graph is large AND rows exceed 512 floats."""
+    hg = lib.lib.pygat_head_group
+    assert hg(1000, 8, 16) == 8 and hg(1 << 20, 8, 16) == 8 and hg(1 << 20, 8, 64) == 8      # R <= 512
+    assert hg(3000, 4, 256) == 4                       # PPI-sized: table 12 MB, launch-bound -> single pass
+    assert hg(1 << 20, 8, 128) == 2 and hg(1 << 20, 4, 256) == 1 and hg(1 << 20, 6, 121) == 2
+    assert hg(1000, 12, 128) == 8                      # R = 1536 > 1024: passes of 1024 floats even when small
+    assert hg(0, 8, 16) == 0 and hg(10, 0, 16) == 0 and hg(10, 8, 300) == 0
+    monkeypatch.setenv("PYGAT_BWD_WINDOW_BYTES", "0")
+    assert hg(10, 6, 121) == 2 and hg(10, 8, 64) == 8
+
+
 def test_abi_version_and_padding(lib):
     assert lib.lib.pygat_abi_version() == lib.ABI_VERSION
     assert [lib.lib.pygat_padded_width(f) for f in (1, 3, 4, 7, 8, 16, 121, 256, 257, 0)] == \

@@ -72,6 +72,34 @@ def test_argument_validation_returns_einval(lib):
     assert lib.lib.pygat_gemm_workspace_bytes(128, 128, 4) == 4 * 128 * 128 * 4
 
 
+QUERIES = {"pygat_abi_version", "pygat_last_error", "pygat_padded_width", "pygat_device_count", "pygat_device_name",
+           "pygat_scan_workspace_bytes", "pygat_gemm_workspace_bytes", "pygat_partials_bytes", "pygat_head_group",
+           "pygat_agrad_workspace_bytes", "pygat_gatv2_workspace_bytes"}
+
+
+def test_every_launcher_rejects_null_arguments(lib):
+    """Each compute entry point, called with null pointers and zero sizes, returns a negative code and
+    leaves a message -- it neither launches nor crashes (the checks run before any HIP call)."""
+    L = lib.lib
+    launchers = [n for n in lib.SYMBOLS if n not in QUERIES]
+    assert len(launchers) >= 18
+    for name in launchers:
+        fn = getattr(L, name)
+        args = []
+        for t in fn.argtypes:
+            if t in (C.c_int, C.c_int64, C.c_size_t):
+                args.append(0)
+            elif t is C.c_float:
+                args.append(0.0)
+            else:                      # void*, pygat_graph*, pygat_out_segments*
+                args.append(None)
+        rc = fn(*args)
+        assert rc < 0, (name, rc)
+        assert len(L.pygat_last_error()) > 0, name
+    # size queries answer 0 for nonsense instead of failing
+    assert L.pygat_partials_bytes(0, 64, 8, 16) == 0 and L.pygat_agrad_workspace_bytes(0, 16) == 0
+
+
 def test_no_cpu_fallback(lib):
     """The product path fails loudly off-GPU instead of silently computing elsewhere."""
     import torch

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PYGAT_ABI_VERSION 4
+#define PYGAT_ABI_VERSION 5
 
 enum {
   PYGAT_OK = 0,
@@ -243,6 +243,32 @@ size_t pygat_gatv2_workspace_bytes(int64_t nnz, int slot_edges, int H, int Fo);
 int pygat_gatv2_backward(const pygat_graph* g, const pygat_graph* gT, const int32_t* perm_t, int H, int Fo,
                          float alpha, const float* WW, const float* a2, const float* GRW,
                          const float* att_mask, float* dwhi_row, float* dWW, float* da, void* ws, void* stream);
+
+/* ------------------------------------------------ K7: train-mode dropout around the projection
+ * The reference drops out inside every head, each head with its own masks (models.py:32,34 call the heads
+ * one after another): the input (layers.py:34,132), Wh (layers.py:37,136), the attention (layers.py:43,153).
+ * Masks are pre-scaled keep masks (0 or 1/(1-p)).  Either the caller passes one explicitly (`mask`,
+ * [H x n x Fin]; tests) or it is drawn in-kernel: Philox-4x32-10, key = *seed (a uint64 in DEVICE memory, so
+ * a captured HIP graph replays with fresh masks when the caller refreshes it), `stream_id` separating the
+ * different masks drawn from one seed.
+ *   pygat_dropout_mask      out[e] = mask, e < count                          (Wh and attention masks)
+ *   pygat_dropout_expand    A'[i, h*Fin + k] = x[i,k] * m_h[i,k]   -> A' [n x H*Fin] (ldo >= H*Fin)
+ *   pygat_pack_blockdiag    B'[h*Fin + k, :] = [ W_h[k,:] in head h's padded columns | same for Wskip ]
+ *                           so that A' B' = [Wh | Sk] for all heads in ONE GEMM (K = H*Fin)
+ *   pygat_unpack_blockdiag  dW[h,k,f] = dB'[h*Fin + k, col_offset + h*Fp + f]  (diagonal blocks of A'^T dWh)
+ *   pygat_dropout_head_sum  dx[i,k] (+)= sum_h m_h[i,k] dxe[i, h*Fin + k]      (dxe = dWh B'^T; same mask/seed/
+ *                           stream_id as the expand call)
+ */
+int pygat_dropout_mask(int64_t count, float p, const void* seed, uint32_t stream_id, float* out, void* stream);
+int pygat_dropout_expand(int n, int Fin, int H, const float* x, int64_t ldx, const float* mask, float p,
+                         const void* seed, uint32_t stream_id, float* out, int64_t ldo, void* stream);
+int pygat_dropout_head_sum(int n, int Fin, int H, const float* dxe, int64_t lde, const float* mask, float p,
+                           const void* seed, uint32_t stream_id, float* dx, int64_t ldx, int accumulate,
+                           void* stream);
+int pygat_pack_blockdiag(int H, int Fin, int Fo, const float* W, const float* w_skip, float* Bp, int64_t ldb,
+                         void* stream);
+int pygat_unpack_blockdiag(int H, int Fin, int Fo, const float* dBp, int64_t ldb, int col_offset, float* dW,
+                           void* stream);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpygat_amd.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 F_ELU = 1
 F_SKIP = 2
 
@@ -27,6 +27,8 @@ SYMBOLS = [
     "pygat_gat_backward_prepare", "pygat_gat_backward_row", "pygat_gat_backward_col",
     "pygat_agrad_workspace_bytes", "pygat_a_grad",
     "pygat_gatv2_forward", "pygat_gatv2_backward_prepare", "pygat_gatv2_workspace_bytes", "pygat_gatv2_backward",
+    "pygat_dropout_mask", "pygat_dropout_expand", "pygat_dropout_head_sum", "pygat_pack_blockdiag",
+    "pygat_unpack_blockdiag",
 ]
 
 
@@ -87,6 +89,12 @@ def _load():
     lib.pygat_gatv2_workspace_bytes.argtypes = [i64, i, i, i]
     lib.pygat_gatv2_workspace_bytes.restype = sz
     lib.pygat_gatv2_backward.argtypes = [C.POINTER(Graph), C.POINTER(Graph), p, i, i, f, p, p, p, p, p, p, p, p, p]
+    u32 = C.c_uint32
+    lib.pygat_dropout_mask.argtypes = [i64, f, p, u32, p, p]
+    lib.pygat_dropout_expand.argtypes = [i, i, i, p, i64, p, f, p, u32, p, i64, p]
+    lib.pygat_dropout_head_sum.argtypes = [i, i, i, p, i64, p, f, p, u32, p, i64, i, p]
+    lib.pygat_pack_blockdiag.argtypes = [i, i, i, p, p, p, i64, p]
+    lib.pygat_unpack_blockdiag.argtypes = [i, i, i, p, i64, i, p, p]
     for s in SYMBOLS:
         fn = getattr(lib, s)
         if fn.restype is C.c_int or s in ("pygat_abi_version", "pygat_padded_width", "pygat_device_count"):

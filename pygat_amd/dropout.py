@@ -9,13 +9,16 @@ heads one after another (models.py:32,34):
     alpha = softmax(...)              -> alpha~ = dropout(alpha) weights the aggregation
                                          (sparse layer: numerators dropped AFTER the row sum)
 
-A per-head input mask means the fused all-heads projection is no longer one GEMM:
-this path runs one MFMA GEMM per head on the masked input (the citation graphs that
-train with dropout are small), re-derives s,t from the dropped Wh (pygat_attn_scores)
-and hands the attention mask to K2/K3b.  Masks are drawn with torch's Philox RNG and
-applied with elementwise multiplies -- the only torch arithmetic in the package; the
-reference's own RNG stream cannot be reproduced bit-for-bit by any other implementation,
-so parity is tested with EXPLICIT masks against the oracle (tests/test_gpu_dropout.py).
+A per-head input mask means the fused all-heads projection is no longer one GEMM on x.
+Here the masked input is written once as one wide operand A' [N, H*Fin] (A'[i, h*Fin+k] =
+x[i,k] m_h[i,k]) and multiplied with the block-diagonal stack of the head weights: ONE MFMA
+GEMM with K = H*Fin for all heads (csrc/k7_dropout.hip; the first version ran one GEMM per
+head and spent a third of a Cora epoch there).  s,t are re-derived from the dropped Wh
+(pygat_attn_scores) and the attention mask goes to K2/K3b/K4.  In training the masks are
+drawn in-kernel (Philox-4x32-10) from one int64 seed taken from torch's generator; the
+reference's own RNG stream cannot be reproduced bit-for-bit by any other implementation, so
+parity is tested with EXPLICIT masks against the oracle (tests/test_gpu_dropout.py), through
+the same kernels.
 """
 from __future__ import annotations
 
@@ -29,8 +32,12 @@ from .graph import CSRGraph, slot_edges_for
 from .ops import _Level, _ptr, _span, _stream, gemm
 
 
+STREAM_X, STREAM_WH, STREAM_ATT = 1, 2, 3     # Philox stream ids of the three masks drawn from one seed
+
+
 def draw_masks(p: float, H: int, N: int, Fin: int, Fo: int, E: int, device, generator=None):
-    """Pre-scaled keep masks (0 or 1/(1-p)): x [H,N,Fin], wh [H,N,Fo], att [E,H]."""
+    """Explicit pre-scaled keep masks (0 or 1/(1-p)) from torch's RNG: x [H,N,Fin], wh [H,N,Fo], att [E,H].
+    Only tests need them materialised; training draws the masks inside the kernels from a seed."""
     keep = 1.0 - p
 
     def mk(*shape):
@@ -39,10 +46,13 @@ def draw_masks(p: float, H: int, N: int, Fin: int, Fo: int, E: int, device, gene
 
 
 class GATLevelDropoutFn(torch.autograd.Function):
-    """forward(x, W[H,Fin,F'], a[H,2F'], Wskip|None, graph, alpha, concat, mask_x, mask_wh, mask_att)."""
+    """forward(x, W[H,Fin,F'], a[H,2F'], Wskip|None, graph, alpha, concat, p, mask_x, mask_wh, mask_att, seed).
+
+    Either the three masks are given (pre-scaled, shapes of `draw_masks`) or `seed` (int64 [1] on the GPU)
+    is, and the masks are drawn in-kernel (csrc/k7_dropout.hip)."""
 
     @staticmethod
-    def forward(ctx, x, W, a, Wskip, graph: CSRGraph, alpha, concat, mask_x, mask_wh, mask_att):
+    def forward(ctx, x, W, a, Wskip, graph: CSRGraph, alpha, concat, p, mask_x, mask_wh, mask_att, seed):
         if not x.is_cuda:
             raise RuntimeError("pygat_amd: inputs must be on the GPU; the hot path has no CPU fallback")
         x = x.contiguous().float(); W = W.contiguous().float(); a = a.contiguous().float()
@@ -50,111 +60,135 @@ class GATLevelDropoutFn(torch.autograd.Function):
         skip = Wskip is not None
         if skip:
             Wskip = Wskip.contiguous().float()
+        explicit = mask_x is not None
+        if explicit == (seed is not None) or (explicit and (mask_wh is None or mask_att is None)):
+            raise ValueError("pygat_amd: pass either the three masks or a seed tensor")
         L = _Level(x, H, Fo, skip)
         L.ts = slot_edges_for(L.R, graph.slot_edges)
         dev, f32 = x.device, torch.float32
-        mask_x = mask_x.to(f32).contiguous(); mask_att = mask_att.to(f32).contiguous()
-        # Wh mask in the padded head-interleaved layout [N, H, Fp]
-        mwh = torch.zeros(L.N, H, L.Fp, dtype=f32, device=dev)
-        mwh[:, :, :Fo] = mask_wh.to(f32).permute(1, 0, 2)
+        HF, R, E = H * Fin, L.R, graph.nnz
+        ncb = R * (2 if skip else 1)
+        p = float(p)
         with torch.cuda.device(dev):
             st = _stream()
-            Wcat = torch.empty(Fin, L.ldw, dtype=f32, device=dev)
+            if explicit:
+                mask_x = mask_x.to(f32).contiguous(); matt = mask_att.to(f32).contiguous()
+                mwh = torch.zeros(L.N, H, L.Fp, dtype=f32, device=dev)      # padded head-interleaved layout
+                mwh[:, :, :Fo] = mask_wh.to(f32).permute(1, 0, 2)
+                mwh = mwh.view(L.N, R)
+            else:
+                seed = seed.contiguous()
+                mwh = torch.empty(L.N, R, dtype=f32, device=dev)
+                matt = torch.empty(E, H, dtype=f32, device=dev)
+                check(lib.pygat_dropout_mask(L.N * R, p, seed.data_ptr(), STREAM_WH, mwh.data_ptr(), st), "dropout_mask")
+                check(lib.pygat_dropout_mask(E * H, p, seed.data_ptr(), STREAM_ATT, matt.data_ptr(), st), "dropout_mask")
+            Wcat = torch.empty(Fin, L.ldw, dtype=f32, device=dev)     # only a_pad is used from this packing
             a_pad = torch.empty(H, 2, L.Fp, dtype=f32, device=dev)
             check(lib.pygat_pack_params(H, Fin, Fo, W.data_ptr(), a.data_ptr(), _ptr(Wskip), Wcat.data_ptr(), L.ldw,
                                         a_pad.data_ptr(), st), "pack_params")
-            Wh = torch.empty(L.N, L.R, dtype=f32, device=dev)
-            Sk = torch.empty(L.N, L.R, dtype=f32, device=dev) if skip else None
-            for h in range(H):                     # per-head masked input (layers.py:34,132)
-                xh = x * mask_x[h]
-                c0 = h * L.Fp
-                gemm(False, False, L.N, L.Fp, Fin, xh, Fin, Wcat[:, c0:], L.ldw, [(L.Fp, Wh[:, c0:], L.R)])
-                if skip:                           # h_prime += mm(h, skip) uses the dropped h (layers.py:48,166)
-                    gemm(False, False, L.N, L.Fp, Fin, xh, Fin, Wcat[:, L.R + c0:], L.ldw, [(L.Fp, Sk[:, c0:], L.R)])
-            Wh.mul_(mwh.view(L.N, L.R))            # layers.py:37,136
+            del Wcat
+            # per-head masked input as ONE operand A' [N, H*Fin] against the block-diagonal weights B' (layers.py:34,132)
+            Bp = torch.empty(HF, ncb, dtype=f32, device=dev)
+            check(lib.pygat_pack_blockdiag(H, Fin, Fo, W.data_ptr(), _ptr(Wskip), Bp.data_ptr(), ncb, st), "pack_blockdiag")
+            Ae = torch.empty(L.N, HF, dtype=f32, device=dev)
+            check(lib.pygat_dropout_expand(L.N, Fin, H, x.data_ptr(), Fin, _ptr(mask_x) if explicit else None, p,
+                                           None if explicit else seed.data_ptr(), STREAM_X, Ae.data_ptr(), HF, st),
+                  "dropout_expand")
+            Wh = torch.empty(L.N, R, dtype=f32, device=dev)
+            Sk = torch.empty(L.N, R, dtype=f32, device=dev) if skip else None   # mm(h, skip) uses the dropped h (layers.py:48,166)
+            with _span("k1_project"):
+                gemm(False, False, L.N, ncb, HF, Ae, HF, Bp, ncb, [(R, Wh, R)] + ([(R, Sk, R)] if skip else []))
+            Wh.mul_(mwh)                           # layers.py:37,136
             s = torch.empty(L.N, H, dtype=f32, device=dev); t = torch.empty(L.N, H, dtype=f32, device=dev)
             check(lib.pygat_attn_scores(L.N, H, Fo, Wh.data_ptr(), a_pad.data_ptr(), s.data_ptr(), t.data_ptr(), st),
                   "attn_scores")
             flags = (_lib.F_ELU if concat else 0) | (_lib.F_SKIP if skip else 0)
-            hattn = torch.empty(L.N, L.R, dtype=f32, device=dev) if not concat else None
+            hattn = torch.empty(L.N, R, dtype=f32, device=dev) if not concat else None
             m = torch.empty(L.N, H, dtype=f32, device=dev); Z = torch.empty(L.N, H, dtype=f32, device=dev)
             out = torch.empty(L.N, H * Fo if concat else Fo, dtype=f32, device=dev)
-            part = torch.empty(lib.pygat_partials_bytes(graph.nnz, L.ts, H, L.Fp) // 4, dtype=f32, device=dev)
+            part = torch.empty(lib.pygat_partials_bytes(E, L.ts, H, L.Fp) // 4, dtype=f32, device=dev)
             with _span("k2_forward"):
                 check(lib.pygat_gat_forward(graph.fwd.ref(L.ts), H, Fo, float(alpha), flags, Wh.data_ptr(), s.data_ptr(),
-                                            a_pad.data_ptr(), _ptr(Sk), mask_att.data_ptr(),
+                                            a_pad.data_ptr(), _ptr(Sk), matt.data_ptr(),
                                             out.data_ptr() if concat else None, _ptr(hattn), m.data_ptr(), Z.data_ptr(),
                                             part.data_ptr(), st), "gat_forward")
             if not concat:
                 check(lib.pygat_head_mean(L.N, H, Fo, hattn.data_ptr(), _ptr(Sk), out.data_ptr(), st), "head_mean")
-        ctx.save_for_backward(x, Wcat, a_pad, Wh, s, t, Sk, out if concat else hattn, m, Z, mask_x, mwh, mask_att)
-        ctx.graph, ctx.L, ctx.alpha, ctx.concat, ctx.flags = graph, L, float(alpha), concat, flags
+        ctx.save_for_backward(Ae, Bp, a_pad, Wh, s, Sk, out if concat else hattn, m, Z, mask_x if explicit else seed,
+                              mwh, matt)
+        ctx.graph, ctx.L, ctx.alpha, ctx.concat, ctx.flags, ctx.p, ctx.explicit = \
+            graph, L, float(alpha), concat, flags, p, explicit
         return out
 
     @staticmethod
     def backward(ctx, G):
-        x, Wcat, a_pad, Wh, s, t, Sk, y, m, Z, mask_x, mwh, mask_att = ctx.saved_tensors
-        graph, L, H, Fo = ctx.graph, ctx.L, ctx.L.H, ctx.L.Fo
-        dev, f32 = x.device, torch.float32
+        Ae, Bp, a_pad, Wh, s, Sk, y, m, Z, mx_or_seed, mwh, matt = ctx.saved_tensors
+        graph, L, H, Fo, p = ctx.graph, ctx.L, ctx.L.H, ctx.L.Fo, ctx.p
+        dev, f32 = Ae.device, torch.float32
         G = G.contiguous().float()
+        HF, R, Fin = H * L.Fin, L.R, L.Fin
+        ncb = Bp.shape[1]
         with torch.cuda.device(dev):
             st = _stream()
-            RW = L.R + 4 * H
+            RW = R + 4 * H
             GR = torch.empty(L.N, RW, dtype=f32, device=dev)
             ds = torch.empty(L.N, H, dtype=f32, device=dev); dt = torch.empty(L.N, H, dtype=f32, device=dev)
-            dWh = torch.empty(L.N, L.R, dtype=f32, device=dev)
+            dWh = torch.empty(L.N, R, dtype=f32, device=dev)
             part = torch.empty(lib.pygat_partials_bytes(graph.nnz, L.ts, H, L.Fp) // 4, dtype=f32, device=dev)
             check(lib.pygat_gat_backward_prepare(L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(), y.data_ptr(),
                                                  _ptr(Sk), s.data_ptr(), m.data_ptr(), Z.data_ptr(), GR.data_ptr(), st),
                   "gat_backward_prepare")
             check(lib.pygat_gat_backward_row(graph.fwd.ref(L.ts), H, Fo, ctx.alpha, Wh.data_ptr(), a_pad.data_ptr(),
-                                             GR.data_ptr(), mask_att.data_ptr(), ds.data_ptr(), part.data_ptr(), st),
+                                             GR.data_ptr(), matt.data_ptr(), ds.data_ptr(), part.data_ptr(), st),
                   "gat_backward_row")
             check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), graph.perm_t.data_ptr(), H, Fo, ctx.alpha,
-                                             Wh.data_ptr(), a_pad.data_ptr(), GR.data_ptr(), mask_att.data_ptr(),
+                                             Wh.data_ptr(), a_pad.data_ptr(), GR.data_ptr(), matt.data_ptr(),
                                              ds.data_ptr(), dWh.data_ptr(), dt.data_ptr(), part.data_ptr(), st),
                   "gat_backward_col")
             da = torch.empty(H, 2 * Fo, dtype=f32, device=dev)
             ws = torch.empty(lib.pygat_agrad_workspace_bytes(H, Fo) // 4, dtype=f32, device=dev)
             check(lib.pygat_a_grad(L.N, H, Fo, Wh.data_ptr(), ds.data_ptr(), dt.data_ptr(), da.data_ptr(), ws.data_ptr(), st),
                   "a_grad")
-            dWh.mul_(mwh.view(L.N, L.R))           # back through the Wh dropout
-            need_dx = ctx.needs_input_grad[0]
-            dWc = torch.zeros(L.Fin, L.R, dtype=f32, device=dev)
-            dSc = torch.zeros(L.Fin, L.R, dtype=f32, device=dev) if L.skip else None
-            dx = torch.zeros(L.N, L.Fin, dtype=f32, device=dev) if need_dx else None
-            dxh = torch.empty(L.N, L.Fin, dtype=f32, device=dev) if need_dx else None
-            for h in range(H):
-                xh = x * mask_x[h]
-                c0 = h * L.Fp
-                gemm(True, False, L.Fin, L.Fp, L.N, xh, L.Fin, dWh[:, c0:], L.R, [(L.Fp, dWc[:, c0:], L.R)])
-                if L.skip:
-                    gemm(True, False, L.Fin, L.Fp, L.N, xh, L.Fin, GR[:, L.gp_col(h):], RW, [(L.Fp, dSc[:, c0:], L.R)])
-                if need_dx:
-                    gemm(False, True, L.N, L.Fin, L.Fp, dWh[:, c0:], L.R, Wcat[:, c0:], L.ldw, [(L.Fin, dxh, L.Fin)],
-                         split_k=1)
-                    if L.skip:
-                        gemm(False, True, L.N, L.Fin, L.Fp, GR[:, L.gp_col(h):], RW, Wcat[:, L.R + c0:], L.ldw,
-                             [(L.Fin, dxh, L.Fin)], accumulate=True, split_k=1)
-                    dx.addcmul_(dxh, mask_x[h])    # back through the per-head input dropout
-            dW = torch.empty(H, L.Fin, Fo, dtype=f32, device=dev)
-            check(lib.pygat_unpack_wgrad(H, L.Fin, Fo, dWc.data_ptr(), L.R, 0, dW.data_ptr(), st), "unpack")
+            dWh.mul_(mwh)                          # back through the Wh dropout
+            # dW_h = (x o m_h)^T dWh_h: the diagonal blocks of A'^T dWh
+            dBp = torch.empty(HF, R, dtype=f32, device=dev)
+            with _span("k5_wgrad"):
+                gemm(True, False, HF, R, L.N, Ae, HF, dWh, R, [(R, dBp, R)])
+            dW = torch.empty(H, Fin, Fo, dtype=f32, device=dev)
+            check(lib.pygat_unpack_blockdiag(H, Fin, Fo, dBp.data_ptr(), R, 0, dW.data_ptr(), st), "unpack_blockdiag")
             dWs = None
             if L.skip:
-                dWs = torch.empty(H, L.Fin, Fo, dtype=f32, device=dev)
-                check(lib.pygat_unpack_wgrad(H, L.Fin, Fo, dSc.data_ptr(), L.R, 0, dWs.data_ptr(), st), "unpack")
-        return dx, dW, da, dWs, None, None, None, None, None, None
+                for c0, w, g0 in L.gp_windows():
+                    gemm(True, False, HF, w, L.N, Ae, HF, GR[:, g0:], RW, [(w, dBp[:, c0:], R)])
+                dWs = torch.empty(H, Fin, Fo, dtype=f32, device=dev)
+                check(lib.pygat_unpack_blockdiag(H, Fin, Fo, dBp.data_ptr(), R, 0, dWs.data_ptr(), st), "unpack_blockdiag")
+            dx = None
+            if ctx.needs_input_grad[0]:
+                # dxe[i, h*Fin + k] = dWh_h[i,:] . W_h[k,:] (+ Gp_h . Wskip_h); folded over the heads under the input masks
+                dxe = torch.empty(L.N, HF, dtype=f32, device=dev)
+                gemm(False, True, L.N, HF, R, dWh, R, Bp, ncb, [(HF, dxe, HF)], split_k=1)
+                if L.skip:
+                    for c0, w, g0 in L.gp_windows():
+                        gemm(False, True, L.N, HF, w, GR[:, g0:], RW, Bp[:, R + c0:], ncb, [(HF, dxe, HF)],
+                             accumulate=True, split_k=1)
+                dx = torch.empty(L.N, Fin, dtype=f32, device=dev)
+                check(lib.pygat_dropout_head_sum(L.N, Fin, H, dxe.data_ptr(), HF,
+                                                 mx_or_seed.data_ptr() if ctx.explicit else None, p,
+                                                 None if ctx.explicit else mx_or_seed.data_ptr(), STREAM_X,
+                                                 dx.data_ptr(), Fin, 0, st), "dropout_head_sum")
+        return dx, dW, da, dWs, None, None, None, None, None, None, None, None
 
 
 def gat_level_dropout(x, graph: CSRGraph, Ws: Sequence[torch.Tensor], As: Sequence[torch.Tensor],
                       Wskips: Optional[Sequence[torch.Tensor]], alpha: float, concat: bool, p: float,
                       head_mean: bool = False, masks: Optional[dict] = None, generator=None) -> torch.Tensor:
-    """One level in training mode with dropout p.  `masks` (tests) = {"x","wh","att"} pre-scaled."""
+    """One level in training mode with dropout p.  `masks` (tests) = {"x","wh","att"} pre-scaled; without them the
+    masks are drawn in-kernel from one int64 seed taken from torch's (graph-safe) generator."""
     del head_mean  # implied by `concat` (models.py:23): concat=False <=> last level <=> head mean
     W = torch.stack(list(Ws), 0)
     a = torch.stack([q.reshape(-1) for q in As], 0)
     Wskip = torch.stack(list(Wskips), 0) if Wskips is not None else None
-    H, Fin, Fo = W.shape
-    if masks is None:
-        masks = draw_masks(p, H, x.shape[0], Fin, Fo, graph.nnz, x.device, generator)
-    return GATLevelDropoutFn.apply(x, W, a, Wskip, graph, alpha, concat, masks["x"], masks["wh"], masks["att"])
+    if masks is not None:
+        return GATLevelDropoutFn.apply(x, W, a, Wskip, graph, alpha, concat, p, masks["x"], masks["wh"], masks["att"], None)
+    seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=x.device, generator=generator)
+    return GATLevelDropoutFn.apply(x, W, a, Wskip, graph, alpha, concat, p, None, None, None, seed)

@@ -87,7 +87,7 @@ def test_every_launcher_rejects_null_arguments(lib):
         fn = getattr(L, name)
         args = []
         for t in fn.argtypes:
-            if t in (C.c_int, C.c_int64, C.c_size_t):
+            if t in (C.c_int, C.c_int64, C.c_size_t, C.c_uint32):
                 args.append(0)
             elif t is C.c_float:
                 args.append(0.0)

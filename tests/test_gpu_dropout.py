@@ -70,3 +70,67 @@ def test_dropout_statistics_and_model_train_mode(pg, topologies):  # noqa: F811
     model0.load_state_dict(model.state_dict())
     model0.train()
     assert torch.allclose(model0(x, g), ye, atol=1e-6)
+
+
+def test_in_kernel_masks_statistics_and_consistency(pg):  # noqa: F811
+    """The Philox masks drawn inside the K7 kernels: keep rate and scale (F.dropout semantics), independence
+    between heads / streams / seeds, determinism for one seed, and the SAME mask in the expand (forward) and
+    head-sum (backward) kernels."""
+    from pygat_amd._lib import lib, check
+    dev = torch.device("cuda", 0)
+    p, keep = 0.6, 0.4
+    seed = torch.tensor([123456789], dtype=torch.int64, device=dev)
+    seed2 = torch.tensor([123456790], dtype=torch.int64, device=dev)
+    n = 1 << 20
+    m1 = torch.empty(n + 3, device=dev); m2 = torch.empty(n + 3, device=dev); m3 = torch.empty(n + 3, device=dev)
+    check(lib.pygat_dropout_mask(n + 3, p, seed.data_ptr(), 2, m1.data_ptr(), None))
+    check(lib.pygat_dropout_mask(n + 3, p, seed.data_ptr(), 3, m2.data_ptr(), None))
+    check(lib.pygat_dropout_mask(n + 3, p, seed2.data_ptr(), 2, m3.data_ptr(), None))
+    m1b = torch.empty_like(m1)
+    check(lib.pygat_dropout_mask(n + 3, p, seed.data_ptr(), 2, m1b.data_ptr(), None))
+    assert torch.equal(m1, m1b)                                              # one seed, one stream -> one mask
+    vals = torch.unique(m1)
+    assert vals.numel() == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1 / keep) < 1e-6
+    sig = (keep * (1 - keep) / n) ** 0.5
+    for m in (m1, m2, m3):
+        assert abs(float((m > 0).float().mean()) - keep) < 5 * sig            # keep rate
+        assert abs(float(m.mean()) - 1.0) < 5 * sig / keep                   # E[mask] = 1
+    for a_, b_ in ((m1, m2), (m1, m3)):                                      # streams / seeds are independent
+        both = float(((a_ > 0) & (b_ > 0)).float().mean())
+        assert abs(both - keep * keep) < 5 * (keep * keep * (1 - keep * keep) / n) ** 0.5
+    # expand: A'[i, h*Fin + k] = x[i,k] * m_h[i,k]; with x = 1 it IS the mask, [N, H, Fin]
+    N, Fin, H = 501, 37, 8          # H*Fin not a multiple of 1024, Fin odd
+    x = torch.ones(N, Fin, device=dev)
+    A = torch.empty(N, H * Fin, device=dev)
+    check(lib.pygat_dropout_expand(N, Fin, H, x.data_ptr(), Fin, None, p, seed.data_ptr(), 1, A.data_ptr(), H * Fin, None))
+    M = A.view(N, H, Fin)
+    assert abs(float((M > 0).float().mean()) - keep) < 5 * (keep * (1 - keep) / M.numel()) ** 0.5
+    agree = float(((M[:, 0] > 0) == (M[:, 1] > 0)).float().mean())            # two heads: independent masks
+    assert abs(agree - (keep * keep + (1 - keep) ** 2)) < 0.02
+    xr = torch.randn(N, Fin, device=dev)
+    A2 = torch.empty_like(A)
+    check(lib.pygat_dropout_expand(N, Fin, H, xr.data_ptr(), Fin, None, p, seed.data_ptr(), 1, A2.data_ptr(), H * Fin, None))
+    assert torch.equal(A2.view(N, H, Fin), xr[:, None, :] * M)
+    # head_sum regenerates the same masks: dx[i,k] = sum_h m_h[i,k] dxe[i,h,k]
+    dxe = torch.randn(N, H * Fin, device=dev)
+    dx = torch.empty(N, Fin, device=dev)
+    check(lib.pygat_dropout_head_sum(N, Fin, H, dxe.data_ptr(), H * Fin, None, p, seed.data_ptr(), 1, dx.data_ptr(), Fin, 0, None))
+    ref = (M.double() * dxe.view(N, H, Fin).double()).sum(1)
+    assert float((dx.double() - ref).abs().max()) < 1e-5
+    # explicit mask [H,N,Fin] through the same kernels
+    mex = (torch.rand(H, N, Fin, device=dev) < keep).float() / keep
+    check(lib.pygat_dropout_expand(N, Fin, H, xr.data_ptr(), Fin, mex.data_ptr(), p, None, 0, A2.data_ptr(), H * Fin, None))
+    assert torch.equal(A2.view(N, H, Fin), xr[:, None, :] * mex.permute(1, 0, 2))
+    # block-diagonal packing round trip
+    Fo = 5
+    W = torch.randn(H, Fin, Fo, device=dev); Wsk = torch.randn(H, Fin, Fo, device=dev)
+    Fp = pg.padded_width(Fo); R = H * Fp
+    Bp = torch.empty(H * Fin, 2 * R, device=dev)
+    check(lib.pygat_pack_blockdiag(H, Fin, Fo, W.data_ptr(), Wsk.data_ptr(), Bp.data_ptr(), 2 * R, None))
+    B4 = Bp.view(H, Fin, 2, H, Fp)
+    for h in range(H):
+        assert torch.equal(B4[h, :, 0, h, :Fo], W[h]) and torch.equal(B4[h, :, 1, h, :Fo], Wsk[h])
+    assert float(Bp.abs().sum()) == pytest.approx(float(W.abs().sum() + Wsk.abs().sum()), rel=1e-5)   # zero elsewhere
+    back = torch.empty(H, Fin, Fo, device=dev)
+    check(lib.pygat_unpack_blockdiag(H, Fin, Fo, Bp.data_ptr(), 2 * R, R, back.data_ptr(), None))
+    assert torch.equal(back, Wsk)

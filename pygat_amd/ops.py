@@ -87,8 +87,12 @@ def gemm(transA: bool, transB: bool, M: int, N: int, K: int, A: torch.Tensor, ld
         nt = -(-N // 32)
         bn = 32 * (nt if nt <= 8 else 4)
         tiles = -(-M // 128) * -(-N // bn)
-        # one work-group per CU: on the weight-gradient shape (huge K) more slabs only add partial-sum traffic
-        split_k = max(1, min(256 // tiles, K // 256)) if tiles < 256 else 1
+        # K slabs: up to ~4 work-groups per CU, slabs of >= 256, at most 256 of them (the weight-gradient
+        # shape: more only adds partial-sum traffic), and the partial sums (written + re-read) below a quarter
+        # of the operand bytes -- the dropout projection [N, H*Fin] x [H*Fin, R] streams a 100+ MB operand
+        # through few output tiles and wants 5-20 slabs, not the 2 that "one work-group per CU" gives
+        by_traffic = int(0.125 * K * (M + N) / (M * N))
+        split_k = max(1, min(256, 1024 // tiles, K // 256, max(by_traffic, 256 // tiles))) if tiles < 1024 else 1
     ws = None
     if split_k > 1:
         ws = torch.empty(lib.pygat_gemm_workspace_bytes(M, N, split_k) // 4, dtype=torch.float32, device=A.device)

@@ -168,13 +168,15 @@ __global__ __launch_bounds__(512) void gemm_smallk_kernel(SmallKArgs g) {
 
 template <bool TB>
 static hipError_t launch_smallk(const SmallKArgs& g, int NT, dim3 grid, size_t lds, hipStream_t st) {
+  int dev = -1;
+  (void)hipGetDevice(&dev);
 #define PYGAT_SMALLK_CASE(n)                                                                              \
   case n: {                                                                                               \
-    static bool attr_set = false;                                                                         \
-    if (!attr_set) {                                                                                      \
+    static bool attr_set[64] = {};   /* per device: the attribute belongs to the device's code object */ \
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {                                                         \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_smallk_kernel<TB, n>),                \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
-      attr_set = true;                                                                                    \
+      if (dev >= 0 && dev < 64) attr_set[dev] = true;                                                     \
     }                                                                                                     \
     hipLaunchKernelGGL((gemm_smallk_kernel<TB, n>), grid, dim3(512), lds, st, g);                         \
   } break;

@@ -80,9 +80,9 @@ class AllGatherColumns(torch.autograd.Function):
         for r in range(world):
             stacked[r, :, :widths[r]] = G[:, offs[r]:offs[r + 1]]
         out = torch.empty(N, wmax, dtype=G.dtype, device=G.device)
-        if G.is_cuda:
+        if dist.get_backend() == "nccl":
             dist.reduce_scatter_tensor(out, stacked.view(world * N, wmax), op=dist.ReduceOp.SUM)
-        else:  # gloo has no reduce_scatter: all-reduce then slice (CPU tests only)
+        else:  # gloo has no reduce_scatter: all-reduce then slice (CPU tests, 1-card rehearsals)
             dist.all_reduce(stacked, op=dist.ReduceOp.SUM)
             out = stacked[rank]
         return out[:, :widths[rank]].contiguous(), None

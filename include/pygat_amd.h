@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PYGAT_ABI_VERSION 5
+#define PYGAT_ABI_VERSION 6
 
 enum {
   PYGAT_OK = 0,
@@ -203,6 +203,8 @@ int pygat_head_mean(int n, int H, int Fo, const float* hattn, const float* sk,
  *        dWh_j = sum_i alpha_ij mask_ij Gp_i + ds_j a_src + dt_j a_dst,  dt_j = sum_i dz_ij
  * Nothing per-edge is stored between the passes.  att_mask [nnz x H] (forward edge order) or NULL;
  * perm_t[k] = forward edge of gT's edge k, needed only to index att_mask (may be NULL without mask).
+ * pygat_gat_backward_col takes EITHER ds (from the row pass; dz_t = NULL) OR dz_t (ds = NULL; see
+ * pygat_gat_backward_rowsum below).
  * part: >= pygat_partials_bytes for both passes.
  */
 int pygat_gat_backward_prepare(int n, int H, int Fo, int flags, int mean_mode,
@@ -215,12 +217,21 @@ int pygat_gat_backward_row(const pygat_graph* g, int H, int Fo, float alpha,
 int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm_t, int H, int Fo, float alpha,
                            const float* Wh, const float* a_pad, const float* GR,
                            const float* att_mask, const float* ds,
-                           float* dWh, float* dt, void* part, void* stream);
+                           float* dWh, float* dt, float* dz_t, void* part, void* stream);
+/* Row sums without the row pass.  The column pass computes every dz_ij anyway (for dt_j): called with ds = NULL
+ * and dz_t [nnz x H] it writes them out per TRANSPOSED edge and leaves the ds_j a_src term out of dWh_j; then
+ *   pygat_gat_backward_rowsum   ds_i = sum over the forward edges k of row i of dz_t[perm_f[k]]
+ * replaces pygat_gat_backward_row: 4H-byte records per edge instead of a gathered Wh row (a quarter less HBM
+ * traffic for the whole backward at 8 heads x 16), fixed summation order, still no atomics; and pygat_a_grad,
+ * which streams Wh, ds, dt anyway, finishes dWh_i += ds_i a_src when given dWh.
+ * g = forward pattern, perm_f[k] = position of forward edge k in gT.  part >= pygat_partials_bytes. */
+int pygat_gat_backward_rowsum(const pygat_graph* g, const int32_t* perm_f, int H, int Fo, const float* dz_t,
+                              float* ds, void* part, void* stream);
 /* da[H x 2F'] : da_src = sum_i ds_i Wh_i, da_dst = sum_j dt_j Wh_j (per head).
- * ws >= pygat_agrad_workspace_bytes(H, Fo). */
+ * ws >= pygat_agrad_workspace_bytes(H, Fo).  dWh (with a_pad) non-NULL: also dWh_i += ds_i a_src, see above. */
 size_t pygat_agrad_workspace_bytes(int H, int Fo);
 int pygat_a_grad(int n, int H, int Fo, const float* Wh, const float* ds, const float* dt,
-                 float* da, void* ws, void* stream);
+                 float* da, void* ws, const float* a_pad, float* dWh, void* stream);
 
 /* ------------------------------------------------ GATv2 (next row of the scope table)
  * The reference's SpGraphAttentionLayerV2 (layers.py:258-313): per head

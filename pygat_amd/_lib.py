@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpygat_amd.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 F_ELU = 1
 F_SKIP = 2
 
@@ -24,7 +24,7 @@ SYMBOLS = [
     "pygat_gemm_workspace_bytes", "pygat_gemm_f32", "pygat_pack_params", "pygat_project", "pygat_attn_scores",
     "pygat_unpack_wgrad",
     "pygat_edge_pairs", "pygat_slot_bounds", "pygat_partials_bytes", "pygat_head_group", "pygat_gat_forward", "pygat_head_mean",
-    "pygat_gat_backward_prepare", "pygat_gat_backward_row", "pygat_gat_backward_col",
+    "pygat_gat_backward_prepare", "pygat_gat_backward_row", "pygat_gat_backward_col", "pygat_gat_backward_rowsum",
     "pygat_agrad_workspace_bytes", "pygat_a_grad",
     "pygat_gatv2_forward", "pygat_gatv2_backward_prepare", "pygat_gatv2_workspace_bytes", "pygat_gatv2_backward",
     "pygat_dropout_mask", "pygat_dropout_expand", "pygat_dropout_head_sum", "pygat_pack_blockdiag",
@@ -80,10 +80,11 @@ def _load():
     lib.pygat_head_mean.argtypes = [i, i, i, p, p, p, p]
     lib.pygat_gat_backward_prepare.argtypes = [i, i, i, i, i, p, p, p, p, p, p, p, p]
     lib.pygat_gat_backward_row.argtypes = [C.POINTER(Graph), i, i, f, p, p, p, p, p, p, p]
-    lib.pygat_gat_backward_col.argtypes = [C.POINTER(Graph), p, i, i, f, p, p, p, p, p, p, p, p, p]
+    lib.pygat_gat_backward_col.argtypes = [C.POINTER(Graph), p, i, i, f, p, p, p, p, p, p, p, p, p, p]
+    lib.pygat_gat_backward_rowsum.argtypes = [C.POINTER(Graph), p, i, i, p, p, p, p]
     lib.pygat_agrad_workspace_bytes.argtypes = [i, i]
     lib.pygat_agrad_workspace_bytes.restype = sz
-    lib.pygat_a_grad.argtypes = [i, i, i, p, p, p, p, p, p]
+    lib.pygat_a_grad.argtypes = [i, i, i, p, p, p, p, p, p, p, p]
     lib.pygat_gatv2_forward.argtypes = [C.POINTER(Graph), i, i, f, i, p, p, p, p, p, p, p, p, p, p]
     lib.pygat_gatv2_backward_prepare.argtypes = [i, i, i, i, i, p, p, p, p, p, p, p, p]
     lib.pygat_gatv2_workspace_bytes.argtypes = [i64, i, i, i]

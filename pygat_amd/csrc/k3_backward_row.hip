@@ -180,6 +180,9 @@ struct RowArgs {
   const float* mask;   // [nnz][Htot] attention dropout mask (forward edge order) or nullptr
   float* ds;           // [n][Htot]
   float* part;         // [2 * nslots][H]
+  // row-sum mode (pygat_gat_backward_rowsum): dz comes from the column pass instead of being recomputed
+  const float* dz_t;   // [nnz][Htot], per TRANSPOSED edge (written by the column pass)
+  const int32_t* perm_f;  // forward edge -> transposed position
 };
 
 template <int VEC>
@@ -273,6 +276,56 @@ __global__ __launch_bounds__(256) void gat_bwd_row_kernel(RowArgs a) {
         if (p[u].x != cur) {
           row_flush<VEC>(a, lc, k, cur, cur == r_first && head_partial, false, acc);
           cur = p[u].x;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += dz[u][v];
+      }
+    }
+  }
+  const bool tail_partial = a.g.rowptr[cur + 1] > e1;
+  row_flush<VEC>(a, lc, k, cur, cur == r_first && head_partial, tail_partial, acc);
+}
+
+// Row-sum pass: ds_i = sum over the forward edges k of row i of dz_t[perm_f[k]] -- the light replacement of the
+// kernel above when the column pass has already written every dz (4H-byte records instead of a gathered Wh row).
+// Same slots, same partial records and fix-up kernels as the row pass.
+template <int LPR, int VEC>
+__global__ __launch_bounds__(256) void gat_bwd_rowsum_kernel(RowArgs a) {
+  constexpr int EPW = 64 / LPR;
+  constexpr int U = 8;
+  const int lane = threadIdx.x & 63;
+  const int64_t k = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * EPW + lane / LPR;
+  if (k >= num_slots(a.g)) return;
+  int64_t e0, e1;
+  slot_range(a.g, k, &e0, &e1);
+  const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
+  const int64_t ldh = a.rs.ldh;
+  const int2* __restrict__ rc = a.g.rc;
+  const int r_first = rc[e0].x;
+  const bool head_partial = a.g.rowptr[r_first] < e0;
+  int cur = r_first;
+  float acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+  for (int64_t e = e0; e < e1; e += U) {
+    int row[U];
+    float dz[U][VEC];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t ee = (e + u < e1) ? e + u : e1 - 1;
+      row[u] = rc[ee].x;
+      const int64_t q = a.perm_f[ee];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) dz[u][v] = a.dz_t[q * ldh + lc.head[v]];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (e + u < e1) {
+        if (row[u] != cur) {
+          row_flush<VEC>(a, lc, k, cur, cur == r_first && head_partial, false, acc);
+          cur = row[u];
 #pragma unroll
           for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
         }
@@ -427,5 +480,36 @@ extern "C" int pygat_gat_backward_row(const pygat_graph* g, int H, int Fo, float
     }
     PYGAT_CHECK_LAUNCH("gat_backward_row_fixup");
   }
+  return PYGAT_OK;
+}
+
+/* ds_i = sum_j dz_ij from the per-edge records of the column pass.  g = forward pattern, perm_f[k] = transposed
+ * position of forward edge k.  (The ds_i a_src term that pass left out of dWh_i is added by pygat_a_grad.) */
+extern "C" int pygat_gat_backward_rowsum(const pygat_graph* g, const int32_t* perm_f, int H, int Fo, const float* dz_t,
+                                         float* ds, void* part, void* stream) {
+  RowArgs a;
+  int rc = check_graph(g, &a.g);
+  if (rc) return rc;
+  const int Fp = padded_width(Fo);
+  PYGAT_REQUIRE(H > 0 && Fp > 0, "gat_backward_rowsum: unsupported H=%d F'=%d", H, Fo);
+  PYGAT_REQUIRE(perm_f && dz_t && ds && part, "gat_backward_rowsum: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nslots = num_slots(a.g);
+  // the records are 4 bytes per head: walk all heads of a row with one lane per head (padded width 4)
+  PYGAT_REQUIRE(make_row_shape(H, 4, &a.rs), "gat_backward_rowsum: too many heads (%d)", H);
+  a.alpha = 0.f; a.Wh = nullptr; a.a_pad = nullptr; a.GR = nullptr; a.ldgr = 0; a.mask = nullptr;
+  a.ds = ds; a.part = (float*)part; a.dz_t = dz_t; a.perm_f = perm_f;
+  int lpr, vec;
+  pick_lanes(a.rs, &lpr, &vec);
+  const unsigned blocks = (unsigned)cdiv(cdiv(nslots, 64 / lpr), 4);
+  PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_bwd_rowsum_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0, st, a));
+  PYGAT_CHECK_LAUNCH("gat_backward_rowsum");
+  if (a.g.cut) {
+    if (a.g.n_cut > 0)
+      hipLaunchKernelGGL(gat_bwd_row_fixup_list_kernel, dim3((unsigned)cdiv(a.g.n_cut, 4)), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(gat_bwd_row_fixup_kernel, dim3((unsigned)cdiv(nslots * H, 256)), dim3(256), 0, st, a);
+  }
+  PYGAT_CHECK_LAUNCH("gat_backward_rowsum_fixup");
   return PYGAT_OK;
 }

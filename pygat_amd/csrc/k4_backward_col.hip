@@ -24,7 +24,8 @@ struct ColArgs {
   const float* GR;
   int64_t ldgr;         // row stride of GR
   const float* a_pad;
-  const float* ds;
+  const float* ds;      // row sums from the row pass K3b, or nullptr: then the ds_j a_src term is left out here
+  float* dz_t;          // [nnz][Htot] or nullptr: dz of every TRANSPOSED edge, for the row-sum pass that follows
   float* dWh;
   float* dt;
   float* part;  // [2 * nslots][R + 2H]: acc[R], dt[H]
@@ -39,7 +40,7 @@ __device__ __forceinline__ void col_finish(const ColArgs& a, const LaneCols<VEC>
   for (int v = 0; v < VEC; ++v) {
     if (!lc.valid[v]) continue;
     const int co = lc.cofs[v], h = lc.head[v], f0 = co & (Fp - 1);
-    const float dsj = a.ds[(int64_t)j * ldh + h];
+    const float dsj = a.ds ? a.ds[(int64_t)j * ldh + h] : 0.f;
     const float4 as = ld4(a.a_pad + (int64_t)h * 2 * Fp + f0);
     const float4 ad = ld4(a.a_pad + (int64_t)h * 2 * Fp + Fp + f0);
     float4 o;
@@ -69,7 +70,23 @@ __device__ __forceinline__ void col_flush(const ColArgs& a, const LaneCols<VEC>&
   }
 }
 
-template <int LPR, int VEC>
+// one of U registers by a runtime index (U = 2 or 4)
+template <int U, typename T>
+__device__ __forceinline__ T pick(const T (&x)[U], int u) {
+  T r = x[0];
+#pragma unroll
+  for (int q = 1; q < U; ++q) r = (u == q) ? x[q] : r;
+  return r;
+}
+
+// WRITE_DZ: this pass computes every dz_ij anyway (for dt_j); written out per transposed edge (sequential
+// 4H-byte records) they let the row sums ds_i = sum_j dz_ij be taken by a light pass that fetches the
+// records through perm_f (pygat_gat_backward_rowsum) instead of the row pass K3b, which gathers a whole
+// Wh_j row per forward edge just to recompute them.  (Scattering the records to their forward positions
+// here, so that the row sums become a pure stream, was measured too: the random 32-byte stores cost K4
+// 0.48 ms and saved 0.10 ms there.)
+// The lanes of a head all hold dz for the U edges of a round: lane (u mod S) of the head stores edge u.
+template <int LPR, int VEC, bool WRITE_DZ>
 __global__ __launch_bounds__(256) void gat_bwd_col_kernel(ColArgs a) {
   constexpr int EPW = 64 / LPR;
   constexpr int U = (VEC == 1) ? 4 : 2;
@@ -127,6 +144,16 @@ __global__ __launch_bounds__(256) void gat_bwd_col_kernel(ColArgs a) {
         dz[u][v] = a0 * (mk[u][v] * dp - rt[u][v].w) * (zz > 0.f ? 1.f : a.alpha);
         al[u][v] = a0 * mk[u][v];
       }
+    if constexpr (WRITE_DZ) {
+      const int S = lph < U ? lph : U;                  // lanes of a head that store (1, 2 or 4)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const int lih = (lc.cofs[v] >> 2) & (lph - 1);  // lane inside its head
+#pragma unroll
+        for (int u = 0; u < U; ++u)                      // lane (u mod S) of the head stores edge u
+          if (lih == (u & (S - 1)) && lc.valid[v] && e + u < e1) a.dz_t[(e + u) * ldh + lc.head[v]] = dz[u][v];
+      }
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (e + u < e1) {
@@ -334,14 +361,17 @@ using namespace pygat;
 
 extern "C" int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm_t, int H, int Fo, float alpha,
                                       const float* Wh, const float* a_pad, const float* GR,
-                                      const float* att_mask, const float* ds, float* dWh, float* dt, void* part,
-                                      void* stream) {
+                                      const float* att_mask, const float* ds, float* dWh, float* dt, float* dz_t,
+                                      void* part, void* stream) {
+
   ColArgs a;
   int rc = check_graph(gT, &a.g);
   if (rc) return rc;
   const int Fp = padded_width(Fo);
   PYGAT_REQUIRE(H > 0 && Fp > 0, "gat_backward_col: unsupported H=%d F'=%d", H, Fo);
-  PYGAT_REQUIRE(Wh && a_pad && GR && ds && dWh && dt && part, "gat_backward_col: null pointer");
+  PYGAT_REQUIRE(Wh && a_pad && GR && dWh && dt && part, "gat_backward_col: null pointer");
+  PYGAT_REQUIRE((ds != nullptr) != (dz_t != nullptr),
+                "gat_backward_col: pass either ds (row sums known) or dz_t (row sums taken afterwards), not both");
   PYGAT_REQUIRE(!att_mask || perm_t, "gat_backward_col: an attention mask needs perm_t (mask is in forward edge order)");
   PYGAT_REQUIRE(aligned16(Wh) && aligned16(GR) && aligned16(dWh) && aligned16(a_pad) && aligned16(part),
                 "gat_backward_col: row tables must be 16-byte aligned");
@@ -353,13 +383,18 @@ extern "C" int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm
     PYGAT_REQUIRE(make_window_shape(H, Fo, hc, &a.rs), "gat_backward_col: unsupported H=%d F'=%d", hc, Fo);
     a.alpha = alpha; a.perm = perm_t; a.mask = att_mask ? att_mask + h0 : nullptr;
     a.Wh = Wh + (int64_t)h0 * Fp; a.GR = GR + gr_window_offset(h0, Fp); a.ldgr = (int64_t)H * Fp + 4 * H;
-    a.a_pad = a_pad + (int64_t)h0 * 2 * Fp; a.ds = ds + h0;
+    a.a_pad = a_pad + (int64_t)h0 * 2 * Fp; a.ds = ds ? ds + h0 : nullptr; a.dz_t = dz_t ? dz_t + h0 : nullptr;
     a.dWh = dWh + (int64_t)h0 * Fp; a.dt = dt + h0; a.part = (float*)part;
     int lpr, vec;
     pick_lanes(a.rs, &lpr, &vec);
     const unsigned blocks = (unsigned)cdiv(cdiv(nslots, 64 / lpr), 4);
-    PYGAT_DISPATCH_LANES(lpr, vec,
-                         hipLaunchKernelGGL((gat_bwd_col_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0, st, a));
+    if (dz_t) {
+      PYGAT_DISPATCH_LANES(lpr, vec,
+                           hipLaunchKernelGGL((gat_bwd_col_kernel<LPR, VEC, true>), dim3(blocks), dim3(256), 0, st, a));
+    } else {
+      PYGAT_DISPATCH_LANES(lpr, vec,
+                           hipLaunchKernelGGL((gat_bwd_col_kernel<LPR, VEC, false>), dim3(blocks), dim3(256), 0, st, a));
+    }
     PYGAT_CHECK_LAUNCH("gat_backward_col");
     const size_t fix_lds = 4 * (size_t)(a.rs.R + 2 * a.rs.H) * sizeof(float);
     if (a.g.cut) {

@@ -12,10 +12,13 @@ namespace pygat {
 // da_src[h][f] = sum_i ds[i][h] Wh[i][h*Fp+f], da_dst likewise with dt (layers.py:60-61 autograd).
 constexpr int AG_BLOCKS = 1024;
 
+// With dWh != nullptr the same stream also finishes dWh_i += ds_i a_src -- the term a column pass that ran
+// before the row sums were known (pygat_gat_backward_col with dz_t) had to leave out.
 __global__ __launch_bounds__(256) void a_grad_partial_kernel(int n, int nblocks, RowShape rs, const float* __restrict__ Wh,
                                                              const float* __restrict__ ds,
                                                              const float* __restrict__ dt,
-                                                             float* __restrict__ ws) {
+                                                             float* __restrict__ ws, const float* __restrict__ a_pad,
+                                                             float* __restrict__ dWh) {
   // TPR threads per row (power of two >= NCH, <= 256), 256/TPR rows in flight per block
   int tpr = 1;
   while (tpr < rs.NCH) tpr <<= 1;
@@ -27,9 +30,11 @@ __global__ __launch_bounds__(256) void a_grad_partial_kernel(int n, int nblocks,
   const int64_t r0 = blockIdx.x * rows_per_block;
   const int64_t r1 = (r0 + rows_per_block < n) ? r0 + rows_per_block : n;
   float4 as = make_float4(0.f, 0.f, 0.f, 0.f), ad = as;
+  float4 asrc = as;
+  if (dWh) asrc = ld4(a_pad + (int64_t)h * 2 * rs.Fp + (co & (rs.Fp - 1)));
   int64_t i = r0 + rg;
   for (; i + 3 * rpb < r1; i += 4 * rpb) {  // 4 rows in flight per thread: the kernel is a pure stream
-    float4 w[4];
+    float4 w[4], d[4];
     float a1[4], a2[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -37,6 +42,15 @@ __global__ __launch_bounds__(256) void a_grad_partial_kernel(int n, int nblocks,
       w[q] = ld4(Wh + r * rs.ldr + co);
       a1[q] = ds[r * rs.ldh + h];
       a2[q] = dt[r * rs.ldh + h];
+      if (dWh) d[q] = ld4(dWh + r * rs.ldr + co);
+    }
+    if (dWh && valid) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        d[q].x = fmaf(a1[q], asrc.x, d[q].x); d[q].y = fmaf(a1[q], asrc.y, d[q].y);
+        d[q].z = fmaf(a1[q], asrc.z, d[q].z); d[q].w = fmaf(a1[q], asrc.w, d[q].w);
+        st4(dWh + (i + q * rpb) * rs.ldr + co, d[q]);
+      }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -47,6 +61,11 @@ __global__ __launch_bounds__(256) void a_grad_partial_kernel(int n, int nblocks,
   for (; i < r1; i += rpb) {
     const float4 w = ld4(Wh + i * rs.ldr + co);
     const float a1 = ds[i * rs.ldh + h], a2 = dt[i * rs.ldh + h];
+    if (dWh && valid) {
+      float4 d = ld4(dWh + i * rs.ldr + co);
+      d.x = fmaf(a1, asrc.x, d.x); d.y = fmaf(a1, asrc.y, d.y); d.z = fmaf(a1, asrc.z, d.z); d.w = fmaf(a1, asrc.w, d.w);
+      st4(dWh + i * rs.ldr + co, d);
+    }
     as.x = fmaf(a1, w.x, as.x); as.y = fmaf(a1, w.y, as.y); as.z = fmaf(a1, w.z, as.z); as.w = fmaf(a1, w.w, as.w);
     ad.x = fmaf(a2, w.x, ad.x); ad.y = fmaf(a2, w.y, ad.y); ad.z = fmaf(a2, w.z, ad.z); ad.w = fmaf(a2, w.w, ad.w);
   }
@@ -163,11 +182,12 @@ extern "C" size_t pygat_agrad_workspace_bytes(int H, int Fo) {
 }
 
 extern "C" int pygat_a_grad(int n, int H, int Fo, const float* Wh, const float* ds, const float* dt, float* da,
-                            void* ws, void* stream) {
+                            void* ws, const float* a_pad, float* dWh, void* stream) {
   RowShape rs;
   const int Fp = padded_width(Fo);
   PYGAT_REQUIRE(H > 0 && Fp > 0 && Fp <= 1024, "a_grad: unsupported H=%d F'=%d", H, Fo);
   PYGAT_REQUIRE(n > 0 && Wh && ds && dt && da && ws && aligned16(Wh) && aligned16(ws), "a_grad: bad arguments");
+  PYGAT_REQUIRE(!dWh || (a_pad && aligned16(dWh) && aligned16(a_pad)), "a_grad: dWh needs a_pad, both 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   // one slab of >= 256 rows per work-group, at most AG_BLOCKS slabs (small graphs: few, short reductions)
   int nblocks = (int)cdiv(n, 256);
@@ -178,7 +198,8 @@ extern "C" int pygat_a_grad(int n, int H, int Fo, const float* Wh, const float* 
     const int hc = (H - h0 < hg) ? H - h0 : hg;
     PYGAT_REQUIRE(make_window_shape(H, Fo, hc, &rs), "a_grad: unsupported H=%d F'=%d", hc, Fo);
     hipLaunchKernelGGL(a_grad_partial_kernel, dim3(nblocks), dim3(256), 0, st, n, nblocks, rs, Wh + (int64_t)h0 * Fp,
-                       ds + h0, dt + h0, (float*)ws);
+                       ds + h0, dt + h0, (float*)ws, a_pad ? a_pad + (int64_t)h0 * 2 * Fp : nullptr,
+                       dWh ? dWh + (int64_t)h0 * Fp : nullptr);
     hipLaunchKernelGGL(a_grad_final_kernel, dim3((unsigned)cdiv(rs.H * 2 * rs.Fo * 8, 256)), dim3(256), 0, st, rs, nblocks,
                        (const float*)ws, da + (int64_t)h0 * 2 * Fo);
     PYGAT_CHECK_LAUNCH("a_grad");

@@ -16,6 +16,7 @@ library.  There is no CPU or eager fallback.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -44,6 +45,12 @@ class KernelTimer:
 
 
 TIMER: Optional[KernelTimer] = None
+
+# Backward flavour.  False (default): the column pass K4 writes dz per transposed edge and a light row-sum pass
+# (4H-byte records fetched through perm_f) takes ds_i = sum_j dz_ij -- no second gather of a Wh row per edge.
+# True (or PYGAT_TWO_GATHER_BACKWARD=1): the row pass K3b recomputes dz from a gathered Wh_j first, then K4.
+# Both are free of atomics and bitwise reproducible; they differ only in the summation order of ds.
+TWO_GATHER_BACKWARD: bool = os.environ.get("PYGAT_TWO_GATHER_BACKWARD", "0") == "1"
 
 
 class _span:
@@ -203,21 +210,35 @@ class GATLevelFn(torch.autograd.Function):
                 check(lib.pygat_gat_backward_prepare(L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(),
                                                      y.data_ptr(), _ptr(Sk), s.data_ptr(), m.data_ptr(), Z.data_ptr(),
                                                      GR.data_ptr(), st), "gat_backward_prepare")
-            with _span("k3b_row"):
-                check(lib.pygat_gat_backward_row(graph.fwd.ref(L.ts), H, Fo, ctx.alpha, Wh.data_ptr(),
-                                                 a_pad.data_ptr(), GR.data_ptr(), None, ds.data_ptr(),
-                                                 part.data_ptr(), st), "gat_backward_row")
-            with _span("k4_backward_col"):
-                check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), None, H, Fo, ctx.alpha, Wh.data_ptr(),
-                                                 a_pad.data_ptr(), GR.data_ptr(), None, ds.data_ptr(),
-                                                 dWh.data_ptr(), dt.data_ptr(), part.data_ptr(), st),
-                      "gat_backward_col")
-            # da
+            if TWO_GATHER_BACKWARD:
+                with _span("k3b_row"):
+                    check(lib.pygat_gat_backward_row(graph.fwd.ref(L.ts), H, Fo, ctx.alpha, Wh.data_ptr(),
+                                                     a_pad.data_ptr(), GR.data_ptr(), None, ds.data_ptr(),
+                                                     part.data_ptr(), st), "gat_backward_row")
+                with _span("k4_backward_col"):
+                    check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), None, H, Fo, ctx.alpha, Wh.data_ptr(),
+                                                     a_pad.data_ptr(), GR.data_ptr(), None, ds.data_ptr(),
+                                                     dWh.data_ptr(), dt.data_ptr(), None, part.data_ptr(), st),
+                          "gat_backward_col")
+            else:
+                dz_t = torch.empty(graph.nnz, H, dtype=f32, device=dev)
+                with _span("k4_backward_col"):
+                    check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), None, H, Fo, ctx.alpha, Wh.data_ptr(),
+                                                     a_pad.data_ptr(), GR.data_ptr(), None, None,
+                                                     dWh.data_ptr(), dt.data_ptr(), dz_t.data_ptr(), part.data_ptr(), st),
+                          "gat_backward_col")
+                with _span("k3c_rowsum"):
+                    check(lib.pygat_gat_backward_rowsum(graph.fwd.ref(L.ts), graph.perm_f.data_ptr(), H, Fo,
+                                                        dz_t.data_ptr(), ds.data_ptr(), part.data_ptr(), st),
+                          "gat_backward_rowsum")
+            # da; after the row-sum flavour the same stream also finishes dWh_i += ds_i a_src
             da = torch.empty(H, 2 * Fo, dtype=f32, device=dev)
             ws = torch.empty(lib.pygat_agrad_workspace_bytes(H, Fo) // 4, dtype=f32, device=dev)
+            finish = not TWO_GATHER_BACKWARD
             with _span("k5_agrad"):
                 check(lib.pygat_a_grad(L.N, H, Fo, Wh.data_ptr(), ds.data_ptr(), dt.data_ptr(), da.data_ptr(),
-                                       ws.data_ptr(), st), "a_grad")
+                                       ws.data_ptr(), a_pad.data_ptr() if finish else None,
+                                       dWh.data_ptr() if finish else None, st), "a_grad")
             # dW = x^T dWh (split-K over the nodes), dWskip = x^T Gp
             dW = dWs = dx = None
             if ctx.needs_input_grad[1]:

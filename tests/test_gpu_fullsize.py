@@ -57,12 +57,22 @@ def test_fullsize_against_c_oracle(world):
         assert np.abs(got - want).max() <= 2e-4 * np.abs(want).max(), name
 
 
-def test_fullsize_properties(world):
+def test_fullsize_properties(world, monkeypatch):
     w = world
     pg, graph, H, Fo = w["pg"], w["graph"], w["H"], w["Fo"]
+    monkeypatch.setattr(pg.ops, "TWO_GATHER_BACKWARD", True)
     out1, dW1, da1 = run(w, w["X"], w["W"], w["a"], w["G"])
     out2, dW2, da2 = run(w, w["X"], w["W"], w["a"], w["G"])
     assert torch.equal(out1, out2) and torch.equal(dW1, dW2) and torch.equal(da1, da2)   # no atomics: bitwise
+    # the default backward (row sums of K4's per-edge dz) is bitwise reproducible too and agrees with the
+    # two-gather one up to the summation order of ds
+    monkeypatch.setattr(pg.ops, "TWO_GATHER_BACKWARD", False)
+    out3, dW3f, da3f = run(w, w["X"], w["W"], w["a"], w["G"])
+    out4, dW4f, da4f = run(w, w["X"], w["W"], w["a"], w["G"])
+    assert torch.equal(out3, out1) and torch.equal(dW3f, dW4f) and torch.equal(da3f, da4f)
+    assert float((dW3f - dW1).abs().max()) <= 1e-5 * float(dW1.abs().max())
+    assert float((da3f - da1).abs().max()) <= 1e-5 * float(da1.abs().max())
+    dW1, da1 = dW3f, da3f
     _, dW3, da3 = run(w, w["X"], w["W"], w["a"], 2.0 * w["G"])
     assert torch.allclose(dW3, 2 * dW1, rtol=1e-5, atol=1e-6 * float(dW1.abs().max()))   # backward linear in G
     assert torch.allclose(da3, 2 * da1, rtol=1e-5, atol=1e-6 * float(da1.abs().max()))

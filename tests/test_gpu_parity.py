@@ -163,9 +163,16 @@ SHAPES = [  # (H, Fin, Fo, skip, concat)
 ]
 
 
+@pytest.fixture(params=["rowsum", "two-gather"])
+def backward_mode(request, pg, monkeypatch):
+    """Both backward flavours of pygat_amd.ops: K4 + row sums of its per-edge dz / K3b (second gather) + K4."""
+    monkeypatch.setattr(pg.ops, "TWO_GATHER_BACKWARD", request.param == "two-gather")
+    return request.param
+
+
 @pytest.mark.parametrize("H,Fin,Fo,skip,concat", SHAPES)
 @pytest.mark.parametrize("chunk", [64, 8])
-def test_level_fwd_bwd_small(pg, H, Fin, Fo, skip, concat, chunk):
+def test_level_fwd_bwd_small(pg, backward_mode, H, Fin, Fo, skip, concat, chunk):
     N = 96
     rowptr, col = O.random_symmetric_csr(N, 5, 11 + H, hub=(3, 70))
     W, a, Sk = params(H, Fin, Fo, skip, 12 + Fo)
@@ -184,7 +191,7 @@ WIDE = [s for s in SHAPES if s[0] * max(4, 1 << (s[2] - 1).bit_length()) > 512]
 
 
 @pytest.mark.parametrize("H,Fin,Fo,skip,concat", WIDE)
-def test_level_backward_head_windows(pg, monkeypatch, H, Fin, Fo, skip, concat):
+def test_level_backward_head_windows(pg, monkeypatch, backward_mode, H, Fin, Fo, skip, concat):
     """Rows wider than 512 floats on a LARGE graph run the backward in head windows of <= 256 floats (GR laid
     out window by window).  PYGAT_BWD_WINDOW_BYTES=0 forces that path on a small graph."""
     monkeypatch.setenv("PYGAT_BWD_WINDOW_BYTES", "0")
@@ -370,8 +377,9 @@ def test_project(pg, H, Fo, skip):
 
 
 @pytest.mark.parametrize("seed", range(24))
-def test_fuzz_level(pg, seed):
+def test_fuzz_level(pg, monkeypatch, seed):
     """Random shapes / patterns / slot lengths (fixed seeds): forward + all gradients vs the fp64 oracle."""
+    monkeypatch.setattr(pg.ops, "TWO_GATHER_BACKWARD", seed % 3 == 0)      # a third of the cases on the two-gather backward
     rng = np.random.default_rng(1000 + seed)
     N = int(rng.integers(1, 400))
     H = int(rng.choice([1, 2, 3, 4, 6, 8]))

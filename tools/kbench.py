@@ -73,7 +73,7 @@ def main():
 
     def k4():
         check(lib.pygat_gat_backward_col(graph.bwd.ref(), None, H, Fo, 0.2, P(Wh), P(a_pad), P(GR), None, P(ds),
-                                         P(dWh), P(dt), P(part), None))
+                                         P(dWh), P(dt), None, P(part), None))
 
     b_fwd = E * (4 + 4 * H + 4 * R) + N * (4 + 4 * H + 4 * R + 8 * H)
     b_k3a = N * (12 * R + 12 * H + 16 * H)

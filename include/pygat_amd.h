@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PYGAT_ABI_VERSION 6
+#define PYGAT_ABI_VERSION 7
 
 enum {
   PYGAT_OK = 0,
@@ -232,6 +232,17 @@ int pygat_gat_backward_rowsum(const pygat_graph* g, const int32_t* perm_f, int H
 size_t pygat_agrad_workspace_bytes(int H, int Fo);
 int pygat_a_grad(int n, int H, int Fo, const float* Wh, const float* ds, const float* dt,
                  float* da, void* ws, const float* a_pad, float* dWh, void* stream);
+
+/* Weight gradient of one level, the backward counterpart of pygat_project (autograd of layers.py:35,134):
+ *   dW[h] = X^T dWh[:, head h]                       dW [H x Fin x F'], X [n x Fin], dWh [n x R]
+ * With ds [n x H] (and a_pad) the dWh passed in still lacks its ds_i a_src term (pygat_gat_backward_col with
+ * dz_t): X^T(dWh' + ds (x) a_src) = X^T dWh' + (X^T ds) (x) a_src, so ds rides along as H extra columns of the
+ * same GEMM and the rank-1 terms are added while unpacking -- dWh is not read-modified-written for it (then
+ * pygat_a_grad is called WITHOUT dWh).  ds = NULL: plain X^T dWh.
+ * ws >= pygat_wgrad_workspace_bytes(Fin, H, F', split_k); split_k as in pygat_gemm_f32. */
+size_t pygat_wgrad_workspace_bytes(int Fin, int H, int Fo, int split_k);
+int pygat_wgrad(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const float* dWh, const float* ds,
+                const float* a_pad, float* dW, int split_k, void* ws, void* stream);
 
 /* ------------------------------------------------ GATv2 (next row of the scope table)
  * The reference's SpGraphAttentionLayerV2 (layers.py:258-313): per head

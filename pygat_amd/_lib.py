@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpygat_amd.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 F_ELU = 1
 F_SKIP = 2
 
@@ -25,7 +25,7 @@ SYMBOLS = [
     "pygat_unpack_wgrad",
     "pygat_edge_pairs", "pygat_slot_bounds", "pygat_partials_bytes", "pygat_head_group", "pygat_gat_forward", "pygat_head_mean",
     "pygat_gat_backward_prepare", "pygat_gat_backward_row", "pygat_gat_backward_col", "pygat_gat_backward_rowsum",
-    "pygat_agrad_workspace_bytes", "pygat_a_grad",
+    "pygat_agrad_workspace_bytes", "pygat_a_grad", "pygat_wgrad_workspace_bytes", "pygat_wgrad",
     "pygat_gatv2_forward", "pygat_gatv2_backward_prepare", "pygat_gatv2_workspace_bytes", "pygat_gatv2_backward",
     "pygat_dropout_mask", "pygat_dropout_expand", "pygat_dropout_head_sum", "pygat_pack_blockdiag",
     "pygat_unpack_blockdiag",
@@ -91,6 +91,9 @@ def _load():
     lib.pygat_gatv2_workspace_bytes.restype = sz
     lib.pygat_gatv2_backward.argtypes = [C.POINTER(Graph), C.POINTER(Graph), p, i, i, f, p, p, p, p, p, p, p, p, p]
     u32 = C.c_uint32
+    lib.pygat_wgrad_workspace_bytes.argtypes = [i, i, i, i]
+    lib.pygat_wgrad_workspace_bytes.restype = sz
+    lib.pygat_wgrad.argtypes = [i, i, i, i, p, i64, p, p, p, p, i, p, p]
     lib.pygat_dropout_mask.argtypes = [i64, f, p, u32, p, p]
     lib.pygat_dropout_expand.argtypes = [i, i, i, p, i64, p, f, p, u32, p, i64, p]
     lib.pygat_dropout_head_sum.argtypes = [i, i, i, p, i64, p, f, p, u32, p, i64, i, p]

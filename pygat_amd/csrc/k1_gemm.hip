@@ -259,7 +259,7 @@ static int launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
 int try_gemm_smallk(int transB, int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                     const pygat_out_segments* out, int accumulate, hipStream_t st);
 int try_gemm_tn_stream(int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
-                       int max_splits, float* ws, hipStream_t st);
+                       int max_splits, float* ws, hipStream_t st, int N1, const float* B2, int64_t ldb2);
 
 }  // namespace pygat
 
@@ -291,7 +291,7 @@ extern "C" int pygat_gemm_f32(int transA, int transB, int M, int N, int64_t K, c
     if (r == 1) return PYGAT_OK;
   }
   if (transA && !transB && split_k > 1) {  // weight gradient: huge K, small M x N, no LDS
-    int r = try_gemm_tn_stream(M, N, K, A, lda, B, ldb, split_k, (float*)ws, st);
+    int r = try_gemm_tn_stream(M, N, K, A, lda, B, ldb, split_k, (float*)ws, st, N, nullptr, 0);
     if (r < 0) return r;
     if (r >= 1) {
       int64_t tot = (int64_t)M * N;
@@ -342,4 +342,74 @@ extern "C" int pygat_project(int n, int Fin, int H, int Fo, const float* X, int6
   seg.col_start[k] = ncols;
   seg.nseg = k;
   return pygat_gemm_f32(0, 0, n, ncols, Fin, X, ldx, Wcat, ldw, &seg, 0, split_k, ws, stream);
+}
+
+// Weight gradient of one level (autograd of layers.py:35,134):  dW_h = X^T dWh_h, all heads in one GEMM.
+// With ds != NULL the dWh passed in lacks its ds_i a_src term (pygat_gat_backward_col called with dz_t):
+//   X^T (dWh' + ds (x) a_src) = X^T dWh' + (X^T ds) (x) a_src,
+// so ds rides along as H extra B columns of the same GEMM (a fifth 32-column MFMA tile on the streamed-K
+// path) and the rank-1 terms are added while unpacking -- dWh is never read-modified-written for it.
+namespace pygat {
+__global__ __launch_bounds__(256) void unpack_wgrad_rank1_kernel(int H, int Fin, int Fo, int Fp, const float* __restrict__ dWc,
+                                                                 int64_t ld, int with_ds, const float* __restrict__ a_pad,
+                                                                 float* __restrict__ dW) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)H * Fin * Fo) return;
+  const int f = (int)(idx % Fo);
+  const int k = (int)((idx / Fo) % Fin);
+  const int h = (int)(idx / ((int64_t)Fo * Fin));
+  float v = dWc[(int64_t)k * ld + h * Fp + f];
+  if (with_ds) v = fmaf(dWc[(int64_t)k * ld + H * Fp + h], a_pad[(int64_t)h * 2 * Fp + f], v);
+  dW[idx] = v;
+}
+}  // namespace pygat
+
+extern "C" size_t pygat_wgrad_workspace_bytes(int Fin, int H, int Fo, int split_k) {
+  const int Fp = padded_width(Fo);
+  if (Fin <= 0 || H <= 0 || Fp <= 0) return 0;
+  if (split_k < 1) split_k = 1;
+  const size_t ncols = (size_t)H * Fp + (size_t)((H + 3) / 4) * 4;
+  return (size_t)(split_k + 1) * (size_t)Fin * ncols * sizeof(float);
+}
+
+extern "C" int pygat_wgrad(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const float* dWh, const float* ds,
+                           const float* a_pad, float* dW, int split_k, void* ws, void* stream) {
+  const int Fp = padded_width(Fo);
+  PYGAT_REQUIRE(n > 0 && Fin > 0 && H > 0 && Fp > 0 && X && dWh && dW && ws && ldx >= Fin, "wgrad: bad arguments");
+  PYGAT_REQUIRE(!ds || a_pad, "wgrad: ds needs a_pad");
+  if (split_k < 1) split_k = 1;
+  hipStream_t st = (hipStream_t)stream;
+  const int R = H * Fp;
+  const int ldc = R + ((H + 3) / 4) * 4;            // [dWc (R) | X^T ds (H, padded)]
+  float* dWc = (float*)ws;
+  float* slabs = dWc + (size_t)Fin * ldc;
+  pygat_out_segments seg;
+  seg.nseg = 1; seg.col_start[0] = 0; seg.ptr[0] = dWc; seg.ld[0] = ldc;
+  bool done = false;
+  if (ds && split_k > 1) {                          // one streamed-K GEMM over [dWh | ds]
+    seg.col_start[1] = R + H;
+    int r = try_gemm_tn_stream(Fin, R + H, n, X, ldx, dWh, R, split_k, slabs, st, R, ds, H);
+    if (r < 0) return r;
+    if (r >= 1) {
+      const int64_t tot = (int64_t)Fin * (R + H);
+      hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)cdiv(tot, 64)), dim3(512), 0, st, Fin, R + H, r,
+                         (const float*)slabs, seg, 0);
+      PYGAT_CHECK_LAUNCH("wgrad(reduce)");
+      done = true;
+    }
+  }
+  if (!done) {                                      // any shape: the general path, once per operand
+    seg.col_start[1] = R;
+    int rc = pygat_gemm_f32(1, 0, Fin, R, n, X, ldx, dWh, R, &seg, 0, split_k, slabs, stream);
+    if (rc) return rc;
+    if (ds) {
+      seg.col_start[1] = H; seg.ptr[0] = dWc + R;
+      rc = pygat_gemm_f32(1, 0, Fin, H, n, X, ldx, ds, H, &seg, 0, split_k, slabs, stream);
+      if (rc) return rc;
+    }
+  }
+  hipLaunchKernelGGL(unpack_wgrad_rank1_kernel, dim3((unsigned)cdiv((int64_t)H * Fin * Fo, 256)), dim3(256), 0, st, H, Fin,
+                     Fo, Fp, (const float*)dWc, (int64_t)ldc, ds ? 1 : 0, a_pad, dW);
+  PYGAT_CHECK_LAUNCH("wgrad(unpack)");
+  return PYGAT_OK;
 }

@@ -234,6 +234,11 @@ struct TnArgs {
   int64_t ldb;
   int64_t k_per_split;
   float* ws;  // [splits][M][N]
+  // optional second B operand: columns [N1, N) come from B2 (its own leading dimension); N1 % 32 == 0 so a
+  // 32-column tile never straddles the two.  N1 == N: none.  (dW = X^T [dWh | ds], pygat_wgrad)
+  int N1;
+  const float* B2;
+  int64_t ldb2;
 };
 
 template <int NT, int UK>
@@ -246,10 +251,14 @@ __global__ __launch_bounds__(256) void gemm_tn_stream_kernel(TnArgs g) {
   const int64_t kend = (kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K;
   const float* ap = g.A + (m < g.M ? m : 0);
   const float* bp[NT];
+  int64_t ldt[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = n0 + 32 * nt + fr;
-    bp[nt] = g.B + (n < g.N ? n : 0);
+    const bool second = g.B2 != nullptr && n0 + 32 * nt >= g.N1;   // wave-uniform; tiles past N read a clamped column
+    const int nn = second ? n - g.N1 : n, lim = second ? g.N - g.N1 : (g.B2 ? g.N1 : g.N);
+    bp[nt] = (second ? g.B2 : g.B) + (nn < lim ? nn : 0);
+    ldt[nt] = second ? g.ldb2 : g.ldb;
   }
   f32x16 acc[NT];
 #pragma unroll
@@ -264,7 +273,7 @@ __global__ __launch_bounds__(256) void gemm_tn_stream_kernel(TnArgs g) {
   _Pragma("unroll") for (int u = 0; u < UK; ++u) {                                            \
     const int64_t k = (KBASE) + 2 * u + fh;                                                   \
     AX[u] = ap[k * g.lda];                                                                    \
-    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) BX[u][nt] = bp[nt][k * g.ldb];          \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) BX[u][nt] = bp[nt][k * ldt[nt]];       \
   }
 #define PYGAT_TN_MMA(AX, BX)                                                                  \
   _Pragma("unroll") for (int u = 0; u < UK; ++u)                                              \
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(256) void gemm_tn_stream_kernel(TnArgs g) {
     const float av = ap[kk * g.lda] * keep;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
-      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[nt][kk * g.ldb], acc[nt], 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[nt][kk * ldt[nt]], acc[nt], 0, 0, 0);
   }
   float* base = g.ws + (int64_t)blockIdx.x * g.M * g.N;
 #pragma unroll
@@ -399,19 +408,23 @@ __global__ __launch_bounds__(256) void gemm_tn_wide_kernel(TnArgs g) {
 // picks the slab count, launches; returns the number of slabs written to ws (>= 1), 0 if the shape
 // does not qualify, < 0 on error.  ws must hold max_splits * M * N floats.
 int try_gemm_tn_stream(int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
-                       int max_splits, float* ws, hipStream_t st) {
+                       int max_splits, float* ws, hipStream_t st, int N1, const float* B2, int64_t ldb2) {
   if (K < 4096 || (int64_t)M * N > 512 * 512 || max_splits < 1 || !ws) return 0;
+  if (!B2) N1 = N;
+  if (B2 && (N1 <= 0 || N1 >= N || (N1 % 32) != 0)) return 0;
   const int nt_needed = (int)cdiv(N, 32);
-  const int NT = nt_needed < 4 ? nt_needed : 4;
+  // a fifth tile for the few extra columns of a second operand: one pass over A instead of two column tiles
+  const int NT = nt_needed < 4 ? nt_needed : ((B2 && nt_needed == 5) ? 5 : 4);
   const int tiles_m = (int)cdiv(M, 128), tiles_n = (int)cdiv(N, 32 * NT);
   int splits = max_splits;
   int64_t kps = cdiv(cdiv(K, splits), 16) * 16;
   splits = (int)cdiv(K, kps);
   TnArgs g;
   g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.k_per_split = kps; g.ws = ws;
+  g.N1 = N1; g.B2 = B2; g.ldb2 = ldb2;
   // the wide-load variant re-fetches A four times (once per wave) and measured slower (3.5 GB of HBM
   // reads for a 1 GB problem); it stays selectable for experiments
-  const bool wide = getenv("PYGAT_TN_WIDE") && aligned16(A) && aligned16(B) && (lda % 4) == 0 && (ldb % 4) == 0 && (M % 4) == 0 && (N % 4) == 0 &&
+  const bool wide = !B2 && getenv("PYGAT_TN_WIDE") && aligned16(A) && aligned16(B) && (lda % 4) == 0 && (ldb % 4) == 0 && (M % 4) == 0 && (N % 4) == 0 &&
                     M >= 4 && N >= 4;
   if (wide) {
     dim3 gridw((unsigned)splits, (unsigned)tiles_m, (unsigned)cdiv(N, 128));
@@ -425,11 +438,15 @@ int try_gemm_tn_stream(int M, int N, int64_t K, const float* A, int64_t lda, con
   }
   dim3 grid((unsigned)splits, (unsigned)tiles_m, (unsigned)tiles_n);
   const char* uke = getenv("PYGAT_TN_UK");
-  const int uk = uke ? atoi(uke) : 8;
+  const int uk = uke ? atoi(uke) : (NT == 5 ? 4 : 8);
   switch (NT) {
     case 1: hipLaunchKernelGGL((gemm_tn_stream_kernel<1, 8>), grid, dim3(256), 0, st, g); break;
     case 2: hipLaunchKernelGGL((gemm_tn_stream_kernel<2, 8>), grid, dim3(256), 0, st, g); break;
     case 3: hipLaunchKernelGGL((gemm_tn_stream_kernel<3, 8>), grid, dim3(256), 0, st, g); break;
+    case 5:
+      if (uk == 8) hipLaunchKernelGGL((gemm_tn_stream_kernel<5, 8>), grid, dim3(256), 0, st, g);
+      else hipLaunchKernelGGL((gemm_tn_stream_kernel<5, 4>), grid, dim3(256), 0, st, g);
+      break;
     default:
       if (uk == 4) hipLaunchKernelGGL((gemm_tn_stream_kernel<4, 4>), grid, dim3(256), 0, st, g);
       else if (uk == 2) hipLaunchKernelGGL((gemm_tn_stream_kernel<4, 2>), grid, dim3(256), 0, st, g);

@@ -87,19 +87,23 @@ def _segments(cols_ptr_ld) -> _lib.OutSegments:
     return seg
 
 
+def _split_k(M: int, N: int, K: int) -> int:
+    """K slabs of a GEMM: up to ~4 work-groups per CU, slabs of >= 256, at most 256 of them (the weight-gradient
+    shape: more only adds partial-sum traffic), and the partial sums (written + re-read) below a quarter of the
+    operand bytes -- the dropout projection [N, H*Fin] x [H*Fin, R] streams a 100+ MB operand through few output
+    tiles and wants 5-20 slabs, not the 2 that "one work-group per CU" gives."""
+    nt = -(-N // 32)
+    bn = 32 * (nt if nt <= 8 else 4)
+    tiles = -(-M // 128) * -(-N // bn)
+    by_traffic = int(0.125 * K * (M + N) / (M * N))
+    return max(1, min(256, 1024 // tiles, K // 256, max(by_traffic, 256 // tiles))) if tiles < 1024 else 1
+
+
 def gemm(transA: bool, transB: bool, M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor,
          ldb: int, segments, accumulate: bool = False, split_k: Optional[int] = None) -> None:
     """C = op(A) op(B) on the fp32 MFMA kernel; `segments` = [(ncols, tensor, ld), ...]."""
     if split_k is None:
-        nt = -(-N // 32)
-        bn = 32 * (nt if nt <= 8 else 4)
-        tiles = -(-M // 128) * -(-N // bn)
-        # K slabs: up to ~4 work-groups per CU, slabs of >= 256, at most 256 of them (the weight-gradient
-        # shape: more only adds partial-sum traffic), and the partial sums (written + re-read) below a quarter
-        # of the operand bytes -- the dropout projection [N, H*Fin] x [H*Fin, R] streams a 100+ MB operand
-        # through few output tiles and wants 5-20 slabs, not the 2 that "one work-group per CU" gives
-        by_traffic = int(0.125 * K * (M + N) / (M * N))
-        split_k = max(1, min(256, 1024 // tiles, K // 256, max(by_traffic, 256 // tiles))) if tiles < 1024 else 1
+        split_k = _split_k(M, N, K)
     ws = None
     if split_k > 1:
         ws = torch.empty(lib.pygat_gemm_workspace_bytes(M, N, split_k) // 4, dtype=torch.float32, device=A.device)
@@ -234,7 +238,10 @@ class GATLevelFn(torch.autograd.Function):
             # da; after the row-sum flavour the same stream also finishes dWh_i += ds_i a_src
             da = torch.empty(H, 2 * Fo, dtype=f32, device=dev)
             ws = torch.empty(lib.pygat_agrad_workspace_bytes(H, Fo) // 4, dtype=f32, device=dev)
-            finish = not TWO_GATHER_BACKWARD
+            # ... unless nothing but the weight-gradient GEMM consumes dWh: there ds rides along as extra columns
+            # (pygat_wgrad) and dWh is never rewritten
+            fold_ds = (not TWO_GATHER_BACKWARD) and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]
+            finish = (not TWO_GATHER_BACKWARD) and not fold_ds
             with _span("k5_agrad"):
                 check(lib.pygat_a_grad(L.N, H, Fo, Wh.data_ptr(), ds.data_ptr(), dt.data_ptr(), da.data_ptr(),
                                        ws.data_ptr(), a_pad.data_ptr() if finish else None,
@@ -242,11 +249,13 @@ class GATLevelFn(torch.autograd.Function):
             # dW = x^T dWh (split-K over the nodes), dWskip = x^T Gp
             dW = dWs = dx = None
             if ctx.needs_input_grad[1]:
-                dWc = torch.empty(L.Fin, L.R, dtype=f32, device=dev)
-                with _span("k5_wgrad"):
-                    gemm(True, False, L.Fin, L.R, L.N, x, L.Fin, dWh, L.R, [(L.R, dWc, L.R)])
+                split_k = _split_k(L.Fin, L.R + (H if fold_ds else 0), L.N)
+                wsw = torch.empty(lib.pygat_wgrad_workspace_bytes(L.Fin, H, Fo, split_k) // 4, dtype=f32, device=dev)
                 dW = torch.empty(H, L.Fin, Fo, dtype=f32, device=dev)
-                check(lib.pygat_unpack_wgrad(H, L.Fin, Fo, dWc.data_ptr(), L.R, 0, dW.data_ptr(), st), "unpack")
+                with _span("k5_wgrad"):
+                    check(lib.pygat_wgrad(L.N, L.Fin, H, Fo, x.data_ptr(), L.Fin, dWh.data_ptr(),
+                                          ds.data_ptr() if fold_ds else None, a_pad.data_ptr(), dW.data_ptr(), split_k,
+                                          wsw.data_ptr(), st), "wgrad")
             if L.skip and ctx.needs_input_grad[3]:
                 dSc = torch.empty(L.Fin, L.R, dtype=f32, device=dev)
                 for c0, w, g0 in L.gp_windows():

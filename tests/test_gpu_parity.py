@@ -405,3 +405,34 @@ def test_fuzz_level(pg, monkeypatch, seed):
     close(dW, ref["dW"], "dW " + tag); close(da, ref["da"], "da " + tag)
     if skip:
         close(dS, ref["dW_skip"], "dW_skip " + tag)
+
+
+@pytest.mark.parametrize("n,Fin,H,Fo,with_ds", [
+    (5000, 50, 8, 16, True),     # streamed-K path, [dWh | ds] as one 5-tile GEMM (the headline shape)
+    (5000, 50, 8, 16, False),
+    (9000, 20, 8, 32, True),     # R = 256: three column tiles, the ds columns in the last one
+    (5000, 33, 3, 5, True),      # R = 24 is not a multiple of 32: general path, one GEMM per operand
+    (300, 7, 2, 4, True),        # small K: general path
+    (4500, 129, 4, 100, True),   # padded heads (Fp 128), M not a multiple of 128
+])
+def test_wgrad_with_ds_columns(pg, n, Fin, H, Fo, with_ds):
+    """pygat_wgrad: dW_h = X^T (dWh'_h + ds_h (x) a_src_h), the ds term riding along as extra GEMM columns."""
+    from pygat_amd._lib import lib, check
+    from pygat_amd.ops import _split_k
+    dev = torch.device("cuda", 0)
+    Fp = pg.padded_width(Fo); R = H * Fp
+    gen = torch.Generator().manual_seed(n + Fo)
+    X = torch.randn(n, Fin, generator=gen, dtype=torch.float64)
+    dWh = torch.zeros(n, H, Fp, dtype=torch.float64); dWh[:, :, :Fo] = torch.randn(n, H, Fo, generator=gen, dtype=torch.float64)
+    ds = torch.randn(n, H, generator=gen, dtype=torch.float64)
+    a_pad = torch.zeros(H, 2, Fp, dtype=torch.float64); a_pad[:, :, :Fo] = torch.randn(H, 2, Fo, generator=gen, dtype=torch.float64)
+    full = dWh + (ds[:, :, None] * a_pad[None, :, 0, :] if with_ds else 0.0)
+    ref = torch.einsum("nk,nhf->hkf", X, full[:, :, :Fo])
+    split_k = _split_k(Fin, R + (H if with_ds else 0), n)
+    ws = torch.empty(lib.pygat_wgrad_workspace_bytes(Fin, H, Fo, split_k) // 4, device=dev)
+    dW = torch.empty(H, Fin, Fo, device=dev)
+    Xd, dd, sd, ad = (t.float().to(dev).contiguous() for t in (X, dWh.view(n, R), ds, a_pad))
+    check(lib.pygat_wgrad(n, Fin, H, Fo, Xd.data_ptr(), Fin, dd.data_ptr(), sd.data_ptr() if with_ds else None,
+                          ad.data_ptr(), dW.data_ptr(), split_k, ws.data_ptr(), None))
+    torch.cuda.synchronize()
+    close(dW, ref.numpy(), "dW", tol=3e-6 * n ** 0.5)

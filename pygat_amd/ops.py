@@ -87,12 +87,17 @@ def _segments(cols_ptr_ld) -> _lib.OutSegments:
     return seg
 
 
-def _split_k(M: int, N: int, K: int) -> int:
-    """K slabs of a GEMM: up to ~4 work-groups per CU, slabs of >= 256, at most 256 of them (the weight-gradient
-    shape: more only adds partial-sum traffic), and the partial sums (written + re-read) below a quarter of the
-    operand bytes -- the dropout projection [N, H*Fin] x [H*Fin, R] streams a 100+ MB operand through few output
-    tiles and wants 5-20 slabs, not the 2 that "one work-group per CU" gives."""
+def _split_k(M: int, N: int, K: int, streamed_k: bool = False) -> int:
+    """K slabs of a GEMM.  General kernel: up to ~4 work-groups per CU, slabs of >= 256, at most 256 of them,
+    and the partial sums (written + re-read) below a quarter of the operand bytes -- the dropout projection
+    [N, H*Fin] x [H*Fin, R] streams a 100+ MB operand through few output tiles and wants 5-20 slabs, not the 2
+    that "one work-group per CU" gives.  Streamed-K weight gradient (transA, K >= 4096, tools/gemm_tn_sweep.py):
+    exactly one work-group per CU is the optimum at every width -- slabs x column tiles = 256 (128 columns:
+    256 slabs 0.37 ms; 512 columns: 64 slabs 1.41 ms against 2.68 ms with 256; 1024 columns: 32 slabs)."""
     nt = -(-N // 32)
+    if streamed_k and K >= 4096 and M * N <= 512 * 512:
+        tiles = -(-M // 128) * -(-N // (32 * min(nt, 5 if nt == 5 else 4)))
+        return max(1, min(256 // tiles, K // 256)) if tiles < 256 else 1
     bn = 32 * (nt if nt <= 8 else 4)
     tiles = -(-M // 128) * -(-N // bn)
     by_traffic = int(0.125 * K * (M + N) / (M * N))
@@ -103,7 +108,7 @@ def gemm(transA: bool, transB: bool, M: int, N: int, K: int, A: torch.Tensor, ld
          ldb: int, segments, accumulate: bool = False, split_k: Optional[int] = None) -> None:
     """C = op(A) op(B) on the fp32 MFMA kernel; `segments` = [(ncols, tensor, ld), ...]."""
     if split_k is None:
-        split_k = _split_k(M, N, K)
+        split_k = _split_k(M, N, K, streamed_k=transA and not transB)
     ws = None
     if split_k > 1:
         ws = torch.empty(lib.pygat_gemm_workspace_bytes(M, N, split_k) // 4, dtype=torch.float32, device=A.device)
@@ -249,7 +254,7 @@ class GATLevelFn(torch.autograd.Function):
             # dW = x^T dWh (split-K over the nodes), dWskip = x^T Gp
             dW = dWs = dx = None
             if ctx.needs_input_grad[1]:
-                split_k = _split_k(L.Fin, L.R + (H if fold_ds else 0), L.N)
+                split_k = _split_k(L.Fin, L.R + (H if fold_ds else 0), L.N, streamed_k=True)
                 wsw = torch.empty(lib.pygat_wgrad_workspace_bytes(L.Fin, H, Fo, split_k) // 4, dtype=f32, device=dev)
                 dW = torch.empty(H, L.Fin, Fo, dtype=f32, device=dev)
                 with _span("k5_wgrad"):

@@ -428,7 +428,7 @@ def test_wgrad_with_ds_columns(pg, n, Fin, H, Fo, with_ds):
     a_pad = torch.zeros(H, 2, Fp, dtype=torch.float64); a_pad[:, :, :Fo] = torch.randn(H, 2, Fo, generator=gen, dtype=torch.float64)
     full = dWh + (ds[:, :, None] * a_pad[None, :, 0, :] if with_ds else 0.0)
     ref = torch.einsum("nk,nhf->hkf", X, full[:, :, :Fo])
-    split_k = _split_k(Fin, R + (H if with_ds else 0), n)
+    split_k = _split_k(Fin, R + (H if with_ds else 0), n, streamed_k=True)
     ws = torch.empty(lib.pygat_wgrad_workspace_bytes(Fin, H, Fo, split_k) // 4, device=dev)
     dW = torch.empty(H, Fin, Fo, device=dev)
     Xd, dd, sd, ad = (t.float().to(dev).contiguous() for t in (X, dWh.view(n, R), ds, a_pad))

@@ -85,3 +85,34 @@ def test_fullsize_properties(world, monkeypatch):
     # rows sum to one: with Wh = all-ones the aggregation returns exactly the normaliser ratio 1
     deg = (w["rowptr"][1:] - w["rowptr"][:-1])
     assert int(deg.min()) >= 1 and int(deg.max()) > 20000
+
+
+def test_wide_rows_at_scale_against_c_oracle():
+    """8 heads x 128 on an R-MAT graph of 2^18 nodes: rows of 1024 floats, a 1 GB gathered table -- the size at
+    which the backward switches to head windows of 256 floats (pygat_head_group < H) without any test override.
+    Forward, dW and da against the C oracle."""
+    import pygat_amd as pg
+    from pygat_amd.rmat import rmat_csr
+    from oracle import c_oracle
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
+    dev = torch.device("cuda", 0)
+    rowptr, col = rmat_csr(18, 1_250_000, seed=3, device=dev)
+    graph = pg.CSRGraph(rowptr, col)
+    H, Fo, Fin = 8, 128, 32
+    assert pg._lib.lib.pygat_head_group(graph.n, H, Fo) == 2          # windows of 2 heads x 128 floats
+    g = torch.Generator(device=dev).manual_seed(5)
+    X = torch.randn(graph.n, Fin, generator=g, device=dev)
+    W = (torch.randn(H, Fin, Fo, generator=g, device=dev) * (1.414 * (2.0 / (Fin + Fo)) ** 0.5)).requires_grad_(True)
+    a = (torch.randn(H, 2 * Fo, generator=g, device=dev) * (1.414 * (2.0 / (1 + 2 * Fo)) ** 0.5)).requires_grad_(True)
+    G = torch.randn(graph.n, H * Fo, generator=g, device=dev)
+    out = pg.GATLevelFn.apply(X, W, a, None, graph, 0.2, True)
+    out.backward(G)
+    torch.cuda.synchronize()
+    ref = c_oracle.level(X.cpu().numpy(), rowptr.cpu().numpy(), col.cpu().numpy(), W.detach().cpu().numpy(),
+                         a.detach().cpu().numpy(), 0.2, True, G.cpu().numpy(), want_dx=False)
+    o = out.detach().cpu().numpy()
+    assert np.isfinite(o).all()
+    assert np.abs(o - ref["out"]).max() <= 1e-5 * max(1.0, np.abs(ref["out"]).max())
+    for got, want, name in ((W.grad, ref["dW"], "dW"), (a.grad, ref["da"], "da")):
+        got = got.cpu().numpy()
+        assert np.abs(got - want).max() <= 2e-4 * np.abs(want).max(), name

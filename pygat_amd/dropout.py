@@ -138,7 +138,7 @@ class GATLevelDropoutFn(torch.autograd.Function):
             check(lib.pygat_gat_backward_prepare(L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(), y.data_ptr(),
                                                  _ptr(Sk), s.data_ptr(), m.data_ptr(), Z.data_ptr(), GR.data_ptr(), st),
                   "gat_backward_prepare")
-            two_gather = ops.TWO_GATHER_BACKWARD
+            two_gather = ops.two_gather_backward(L.R)
             if two_gather:
                 check(lib.pygat_gat_backward_row(graph.fwd.ref(L.ts), H, Fo, ctx.alpha, Wh.data_ptr(), a_pad.data_ptr(),
                                                  GR.data_ptr(), matt.data_ptr(), ds.data_ptr(), part.data_ptr(), st),

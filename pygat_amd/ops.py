@@ -46,11 +46,20 @@ class KernelTimer:
 
 TIMER: Optional[KernelTimer] = None
 
-# Backward flavour.  False (default): the column pass K4 writes dz per transposed edge and a light row-sum pass
-# (4H-byte records fetched through perm_f) takes ds_i = sum_j dz_ij -- no second gather of a Wh row per edge.
-# True (or PYGAT_TWO_GATHER_BACKWARD=1): the row pass K3b recomputes dz from a gathered Wh_j first, then K4.
-# Both are free of atomics and bitwise reproducible; they differ only in the summation order of ds.
-TWO_GATHER_BACKWARD: bool = os.environ.get("PYGAT_TWO_GATHER_BACKWARD", "0") == "1"
+# Backward flavour.  False: the column pass K4 writes dz per transposed edge and a light row-sum pass (4H-byte
+# records fetched through perm_f) takes ds_i = sum_j dz_ij -- no second gather of a Wh row per edge.
+# True: the row pass K3b recomputes dz from a gathered Wh_j first, then K4.  None (default) = by row width:
+# a record fetch costs one 64-byte sector whatever H is, so below 64 floats per row (1-2 heads of 16: the
+# shard of an 8- or 4-GPU head-parallel run) the second gather is the cheaper one (config-5 graph, one
+# head: 1.15 ms against 1.46 ms per step; four heads: 2.45 against 2.34; eight: 4.30 against 3.84).
+# PYGAT_TWO_GATHER_BACKWARD=1/0 forces either.  Both are free of atomics and bitwise reproducible; they
+# differ only in the summation order of ds.
+_env = os.environ.get("PYGAT_TWO_GATHER_BACKWARD")
+TWO_GATHER_BACKWARD: Optional[bool] = None if _env is None else (_env == "1")
+
+
+def two_gather_backward(row_floats: int) -> bool:
+    return TWO_GATHER_BACKWARD if TWO_GATHER_BACKWARD is not None else row_floats < 64
 
 
 class _span:
@@ -219,7 +228,8 @@ class GATLevelFn(torch.autograd.Function):
                 check(lib.pygat_gat_backward_prepare(L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(),
                                                      y.data_ptr(), _ptr(Sk), s.data_ptr(), m.data_ptr(), Z.data_ptr(),
                                                      GR.data_ptr(), st), "gat_backward_prepare")
-            if TWO_GATHER_BACKWARD:
+            two_gather = two_gather_backward(L.R)
+            if two_gather:
                 with _span("k3b_row"):
                     check(lib.pygat_gat_backward_row(graph.fwd.ref(L.ts), H, Fo, ctx.alpha, Wh.data_ptr(),
                                                      a_pad.data_ptr(), GR.data_ptr(), None, ds.data_ptr(),
@@ -245,8 +255,9 @@ class GATLevelFn(torch.autograd.Function):
             ws = torch.empty(lib.pygat_agrad_workspace_bytes(H, Fo) // 4, dtype=f32, device=dev)
             # ... unless nothing but the weight-gradient GEMM consumes dWh: there ds rides along as extra columns
             # (pygat_wgrad) and dWh is never rewritten
-            fold_ds = (not TWO_GATHER_BACKWARD) and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]
-            finish = (not TWO_GATHER_BACKWARD) and not fold_ds
+            fold_ds = ((not two_gather) and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]
+                       and L.R % 32 == 0 and L.N >= 4096)      # the streamed-K GEMM takes [dWh | ds] in one pass
+            finish = (not two_gather) and not fold_ds
             with _span("k5_agrad"):
                 check(lib.pygat_a_grad(L.N, H, Fo, Wh.data_ptr(), ds.data_ptr(), dt.data_ptr(), da.data_ptr(),
                                        ws.data_ptr(), a_pad.data_ptr() if finish else None,

@@ -438,7 +438,7 @@ int try_gemm_tn_stream(int M, int N, int64_t K, const float* A, int64_t lda, con
   }
   dim3 grid((unsigned)splits, (unsigned)tiles_m, (unsigned)tiles_n);
   const char* uke = getenv("PYGAT_TN_UK");
-  const int uk = uke ? atoi(uke) : (NT == 5 ? 4 : 8);
+  const int uk = uke ? atoi(uke) : 8;
   switch (NT) {
     case 1: hipLaunchKernelGGL((gemm_tn_stream_kernel<1, 8>), grid, dim3(256), 0, st, g); break;
     case 2: hipLaunchKernelGGL((gemm_tn_stream_kernel<2, 8>), grid, dim3(256), 0, st, g); break;

@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void gat_bwd_row_kernel(RowArgs a) {
 template <int LPR, int VEC>
 __global__ __launch_bounds__(256) void gat_bwd_rowsum_kernel(RowArgs a) {
   constexpr int EPW = 64 / LPR;
-  constexpr int U = 8;
+  constexpr int U = 16;
   const int lane = threadIdx.x & 63;
   const int64_t k = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * EPW + lane / LPR;
   if (k >= num_slots(a.g)) return;

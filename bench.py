@@ -47,6 +47,13 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--verify", action="store_true", help="check the gathered sharded output against the unsharded level")
+    ap.add_argument("--forward-exchange", choices=["auto", "allgather", "replicate"], default="auto",
+                    help="N>1, how every rank gets the other ranks' head outputs: RCCL all-gather over xGMI, or no "
+                         "collective at all -- recompute their heads forward-only (K1+K2) and back-propagate only the own "
+                         "ones.  auto = replicate at 2 GPUs (256 MB over ONE xGMI link takes longer than the whole "
+                         "single-GPU step), all-gather from 4 GPUs on (3-7 links in parallel)")
+    ap.add_argument("--as-rank-of", type=int, default=0,
+                    help="single process: run the work of rank 0 of a world of this size (per-rank time model, no collectives)")
     return ap.parse_args()
 
 
@@ -109,7 +116,8 @@ def main():
     g4 = torch.Generator(device=dev).manual_seed(4)
     G = torch.randn(N, H * Fo, generator=g4, device=dev)
 
-    parts = partition_heads(H, world)
+    model_world = args.as_rank_of if (world == 1 and args.as_rank_of > 1) else world
+    parts = partition_heads(H, model_world)
     hs, he = parts[rank]
     h_loc = he - hs
     widths = [(e - s) * Fo for s, e in parts]
@@ -118,14 +126,28 @@ def main():
     G_loc = G[:, hs * Fo:he * Fo].contiguous()
     Xb = X.requires_grad_(True) if args.dx else X
 
-    use_pg = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    replicate = model_world > 1 and (args.forward_exchange == "replicate" or
+                                     (args.forward_exchange == "auto" and model_world == 2))
+    use_pg = (world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1") and not replicate
     gbuf = torch.empty(world * N, h_loc * Fo, device=dev) if use_pg else None
+    if replicate:     # the other ranks' heads, forward only
+        others = [h for h in range(H) if not (hs <= h < he)]
+        W_oth, a_oth = W[others].contiguous(), a[others].contiguous()
+        full_buf = torch.empty(N, H * Fo, device=dev)
 
     def step():
         W_loc.grad = a_loc.grad = None
         if args.dx:
             Xb.grad = None
         out = pg.GATLevelFn.apply(Xb, W_loc, a_loc, None, graph, 0.2, True)
+        if replicate:
+            with torch.no_grad():
+                oth = pg.GATLevelFn.apply(X.detach(), W_oth, a_oth, None, graph, 0.2, True)
+            out.backward(G_loc)
+            fb = full_buf.view(N, H, Fo)                  # concatenation in head order (models.py:32)
+            fb[:, hs:he] = out.detach().view(N, h_loc, Fo)
+            fb[:, others] = oth.view(N, len(others), Fo)
+            return full_buf
         if use_pg:
             # RCCL all-gather of the head outputs (models.py:32 torch.cat) on RCCL's own stream; this
             # level's backward does not depend on it, so it overlaps K3/K4/K5 and is joined at the end.
@@ -195,7 +217,9 @@ def main():
                                    f"{int((rowptr[1:] - rowptr[:-1]).max())}), Fin {Fin}, {H} heads x {Fo}, concat+ELU, "
                                    f"dropout 0, fwd+bwd (dW, da{', dX' if args.dx else ''})",
                        "nodes": N, "edges": E, "fin": Fin, "heads": H, "f_out": Fo,
-                       "parallelism": f"head-parallel x{world}" if world > 1 else "single GPU",
+                       "parallelism": (f"head-parallel x{model_world}" + (", forward replicated" if replicate else "")
+                                       + (" (rank-0 work only, modelled)" if model_world != world else ""))
+                       if model_world > 1 else "single GPU",
                        "heads_per_gpu": h_loc},
             "roofline": {"kernel": "k2_forward (gat_fwd_kernel + gat_fwd_fixup_kernel)", "bound": "hbm", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,

@@ -76,6 +76,11 @@ def cpu_baseline(args, rowptr, col, X, W, a, G):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON record: native libraries (RCCL prints a version banner on its
+    # first collective) get stderr instead
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -233,7 +238,7 @@ def main():
             except Exception as ex:  # the GPU number stays valid without the CPU leg
                 line["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": os.cpu_count(), "kind": "port",
                                         "sample": f"failed: {ex!r}"}
-        print(json.dumps(line))
+        print(json.dumps(line), file=real_stdout, flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

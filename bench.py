@@ -49,9 +49,9 @@ def parse():
     ap.add_argument("--verify", action="store_true", help="check the gathered sharded output against the unsharded level")
     ap.add_argument("--forward-exchange", choices=["auto", "allgather", "replicate"], default="auto",
                     help="N>1, how every rank gets the other ranks' head outputs: RCCL all-gather over xGMI, or no "
-                         "collective at all -- recompute their heads forward-only (K1+K2) and back-propagate only the own "
-                         "ones.  auto = replicate at 2 GPUs (256 MB over ONE xGMI link takes longer than the whole "
-                         "single-GPU step), all-gather from 4 GPUs on (3-7 links in parallel)")
+                         "collective at all -- run the forward of ALL heads (K1+K2) and back-propagate only the own ones "
+                         "(GATLevelFn bwd_heads).  auto = replicate at 2 and 4 GPUs (receiving 256 / 3x128 MB over 1 / 3 "
+                         "xGMI links takes longer than 0.4-0.9 ms of extra forward), all-gather at 8 (7 links in parallel)")
     ap.add_argument("--as-rank-of", type=int, default=0,
                     help="single process: run the work of rank 0 of a world of this size (per-rank time model, no collectives)")
     return ap.parse_args()
@@ -132,27 +132,23 @@ def main():
     Xb = X.requires_grad_(True) if args.dx else X
 
     replicate = model_world > 1 and (args.forward_exchange == "replicate" or
-                                     (args.forward_exchange == "auto" and model_world == 2))
+                                     (args.forward_exchange == "auto" and model_world <= 4))
     use_pg = (world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1") and not replicate
     gbuf = torch.empty(world * N, h_loc * Fo, device=dev) if use_pg else None
-    if replicate:     # the other ranks' heads, forward only
-        others = [h for h in range(H) if not (hs <= h < he)]
-        W_oth, a_oth = W[others].contiguous(), a[others].contiguous()
-        full_buf = torch.empty(N, H * Fo, device=dev)
+    if replicate:     # forward of ALL heads in one call, backward of the own ones (GATLevelFn bwd_heads)
+        W_all = W.clone().requires_grad_(True)
+        a_all = a.clone().requires_grad_(True)
 
     def step():
         W_loc.grad = a_loc.grad = None
         if args.dx:
             Xb.grad = None
-        out = pg.GATLevelFn.apply(Xb, W_loc, a_loc, None, graph, 0.2, True)
         if replicate:
-            with torch.no_grad():
-                oth = pg.GATLevelFn.apply(X.detach(), W_oth, a_oth, None, graph, 0.2, True)
-            out.backward(G_loc)
-            fb = full_buf.view(N, H, Fo)                  # concatenation in head order (models.py:32)
-            fb[:, hs:he] = out.detach().view(N, h_loc, Fo)
-            fb[:, others] = oth.view(N, len(others), Fo)
-            return full_buf
+            W_all.grad = a_all.grad = None
+            full = pg.GATLevelFn.apply(X.detach(), W_all, a_all, None, graph, 0.2, True, (hs, h_loc))
+            full.backward(G)                              # only the columns of the own heads are read
+            return full
+        out = pg.GATLevelFn.apply(Xb, W_loc, a_loc, None, graph, 0.2, True)
         if use_pg:
             # RCCL all-gather of the head outputs (models.py:32 torch.cat) on RCCL's own stream; this
             # level's backward does not depend on it, so it overlaps K3/K4/K5 and is joined at the end.

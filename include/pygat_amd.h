@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PYGAT_ABI_VERSION 7
+#define PYGAT_ABI_VERSION 8
 
 enum {
   PYGAT_OK = 0,
@@ -206,18 +206,25 @@ int pygat_head_mean(int n, int H, int Fo, const float* hattn, const float* sk,
  * pygat_gat_backward_col takes EITHER ds (from the row pass; dz_t = NULL) OR dz_t (ds = NULL; see
  * pygat_gat_backward_rowsum below).
  * part: >= pygat_partials_bytes for both passes.
+ *
+ * Head range.  The backward entry points (prepare, row, col, rowsum, a_grad, wgrad) end in (h_first, h_count):
+ * gradients are produced for the heads [h_first, h_first + h_count) of the level only; 0, 0 = all heads.  The
+ * level's tables keep their full width (H heads) and are addressed with the level's strides; only GR, which
+ * nothing but the backward touches, is then COMPACT for the range ([n x h_count*(Fp+4)], same layout rules with
+ * h_count in place of H), and dW / da rows outside the range are left untouched.  Use: a rank of a head-parallel
+ * run that ran the forward for all heads (cheaper than receiving them over one xGMI link) back-propagates its own.
  */
 int pygat_gat_backward_prepare(int n, int H, int Fo, int flags, int mean_mode,
                                const float* G, const float* y, const float* sk,
                                const float* s, const float* m, const float* Z,
-                               float* GR, void* stream);
+                               float* GR, int h_first, int h_count, void* stream);
 int pygat_gat_backward_row(const pygat_graph* g, int H, int Fo, float alpha,
                            const float* Wh, const float* a_pad, const float* GR,
-                           const float* att_mask, float* ds, void* part, void* stream);
+                           const float* att_mask, float* ds, void* part, int h_first, int h_count, void* stream);
 int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm_t, int H, int Fo, float alpha,
                            const float* Wh, const float* a_pad, const float* GR,
                            const float* att_mask, const float* ds,
-                           float* dWh, float* dt, float* dz_t, void* part, void* stream);
+                           float* dWh, float* dt, float* dz_t, void* part, int h_first, int h_count, void* stream);
 /* Row sums without the row pass.  The column pass computes every dz_ij anyway (for dt_j): called with ds = NULL
  * and dz_t [nnz x H] it writes them out per TRANSPOSED edge and leaves the ds_j a_src term out of dWh_j; then
  *   pygat_gat_backward_rowsum   ds_i = sum over the forward edges k of row i of dz_t[perm_f[k]]
@@ -226,12 +233,12 @@ int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm_t, int H, 
  * which streams Wh, ds, dt anyway, finishes dWh_i += ds_i a_src when given dWh.
  * g = forward pattern, perm_f[k] = position of forward edge k in gT.  part >= pygat_partials_bytes. */
 int pygat_gat_backward_rowsum(const pygat_graph* g, const int32_t* perm_f, int H, int Fo, const float* dz_t,
-                              float* ds, void* part, void* stream);
+                              float* ds, void* part, int h_first, int h_count, void* stream);
 /* da[H x 2F'] : da_src = sum_i ds_i Wh_i, da_dst = sum_j dt_j Wh_j (per head).
  * ws >= pygat_agrad_workspace_bytes(H, Fo).  dWh (with a_pad) non-NULL: also dWh_i += ds_i a_src, see above. */
 size_t pygat_agrad_workspace_bytes(int H, int Fo);
 int pygat_a_grad(int n, int H, int Fo, const float* Wh, const float* ds, const float* dt,
-                 float* da, void* ws, const float* a_pad, float* dWh, void* stream);
+                 float* da, void* ws, const float* a_pad, float* dWh, int h_first, int h_count, void* stream);
 
 /* Weight gradient of one level, the backward counterpart of pygat_project (autograd of layers.py:35,134):
  *   dW[h] = X^T dWh[:, head h]                       dW [H x Fin x F'], X [n x Fin], dWh [n x R]
@@ -242,7 +249,7 @@ int pygat_a_grad(int n, int H, int Fo, const float* Wh, const float* ds, const f
  * ws >= pygat_wgrad_workspace_bytes(Fin, H, F', split_k); split_k as in pygat_gemm_f32. */
 size_t pygat_wgrad_workspace_bytes(int Fin, int H, int Fo, int split_k);
 int pygat_wgrad(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const float* dWh, const float* ds,
-                const float* a_pad, float* dW, int split_k, void* ws, void* stream);
+                const float* a_pad, float* dW, int split_k, void* ws, int h_first, int h_count, void* stream);
 
 /* ------------------------------------------------ GATv2 (next row of the scope table)
  * The reference's SpGraphAttentionLayerV2 (layers.py:258-313): per head

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpygat_amd.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 F_ELU = 1
 F_SKIP = 2
 
@@ -78,13 +78,13 @@ def _load():
     lib.pygat_head_group.restype = i
     lib.pygat_gat_forward.argtypes = [C.POINTER(Graph), i, i, f, i, p, p, p, p, p, p, p, p, p, p, p]
     lib.pygat_head_mean.argtypes = [i, i, i, p, p, p, p]
-    lib.pygat_gat_backward_prepare.argtypes = [i, i, i, i, i, p, p, p, p, p, p, p, p]
-    lib.pygat_gat_backward_row.argtypes = [C.POINTER(Graph), i, i, f, p, p, p, p, p, p, p]
-    lib.pygat_gat_backward_col.argtypes = [C.POINTER(Graph), p, i, i, f, p, p, p, p, p, p, p, p, p, p]
-    lib.pygat_gat_backward_rowsum.argtypes = [C.POINTER(Graph), p, i, i, p, p, p, p]
+    lib.pygat_gat_backward_prepare.argtypes = [i, i, i, i, i, p, p, p, p, p, p, p, i, i, p]
+    lib.pygat_gat_backward_row.argtypes = [C.POINTER(Graph), i, i, f, p, p, p, p, p, p, i, i, p]
+    lib.pygat_gat_backward_col.argtypes = [C.POINTER(Graph), p, i, i, f, p, p, p, p, p, p, p, p, p, i, i, p]
+    lib.pygat_gat_backward_rowsum.argtypes = [C.POINTER(Graph), p, i, i, p, p, p, i, i, p]
     lib.pygat_agrad_workspace_bytes.argtypes = [i, i]
     lib.pygat_agrad_workspace_bytes.restype = sz
-    lib.pygat_a_grad.argtypes = [i, i, i, p, p, p, p, p, p, p, p]
+    lib.pygat_a_grad.argtypes = [i, i, i, p, p, p, p, p, p, p, i, i, p]
     lib.pygat_gatv2_forward.argtypes = [C.POINTER(Graph), i, i, f, i, p, p, p, p, p, p, p, p, p, p]
     lib.pygat_gatv2_backward_prepare.argtypes = [i, i, i, i, i, p, p, p, p, p, p, p, p]
     lib.pygat_gatv2_workspace_bytes.argtypes = [i64, i, i, i]
@@ -93,7 +93,7 @@ def _load():
     u32 = C.c_uint32
     lib.pygat_wgrad_workspace_bytes.argtypes = [i, i, i, i]
     lib.pygat_wgrad_workspace_bytes.restype = sz
-    lib.pygat_wgrad.argtypes = [i, i, i, i, p, i64, p, p, p, p, i, p, p]
+    lib.pygat_wgrad.argtypes = [i, i, i, i, p, i64, p, p, p, p, i, p, i, i, p]
     lib.pygat_dropout_mask.argtypes = [i64, f, p, u32, p, p]
     lib.pygat_dropout_expand.argtypes = [i, i, i, p, i64, p, f, p, u32, p, i64, p]
     lib.pygat_dropout_head_sum.argtypes = [i, i, i, p, i64, p, f, p, u32, p, i64, i, p]

@@ -72,6 +72,16 @@ static inline bool make_window_shape(int Htot, int Fo, int hc, RowShape* rs) {
   rs->Htot = Htot; rs->ldr = (int64_t)Htot * rs->Fp; rs->ldh = Htot; rs->ldo = (int64_t)Htot * Fo;
   return true;
 }
+// A backward call may cover only the heads [hb, hb+hr) of a level with H heads (h_count == 0: all of them):
+// the level's tables (Wh, G, out, s, m, Z, ds, dt, dWh, dz_t, masks) keep their full width and are addressed with
+// the level's strides, while GR -- written and read only by the backward -- is compact for the range.
+struct HeadRange { int hb, hr; };
+static inline bool make_head_range(int H, int h_first, int h_count, HeadRange* r) {
+  if (h_count == 0 && h_first == 0) { r->hb = 0; r->hr = H; return H > 0; }
+  if (h_first < 0 || h_count <= 0 || h_first + h_count > H) return false;
+  r->hb = h_first; r->hr = h_count;
+  return true;
+}
 // column offset of a window inside a GR row [Gp(window) | rowtab(window)] ... : h0 * (Fp + 4)
 static inline int64_t gr_window_offset(int h0, int Fp) { return (int64_t)h0 * (Fp + 4); }
 

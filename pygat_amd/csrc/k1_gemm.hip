@@ -373,10 +373,19 @@ extern "C" size_t pygat_wgrad_workspace_bytes(int Fin, int H, int Fo, int split_
 }
 
 extern "C" int pygat_wgrad(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const float* dWh, const float* ds,
-                           const float* a_pad, float* dW, int split_k, void* ws, void* stream) {
+                           const float* a_pad, float* dW, int split_k, void* ws, int h_first, int h_count, void* stream) {
   const int Fp = padded_width(Fo);
   PYGAT_REQUIRE(n > 0 && Fin > 0 && H > 0 && Fp > 0 && X && dWh && dW && ws && ldx >= Fin, "wgrad: bad arguments");
   PYGAT_REQUIRE(!ds || a_pad, "wgrad: ds needs a_pad");
+  if (h_count == 0 && h_first == 0) h_count = H;
+  PYGAT_REQUIRE(h_first >= 0 && h_count > 0 && h_first + h_count <= H, "wgrad: bad head range [%d, +%d) of %d", h_first, h_count, H);
+  // a head range: the operands keep the level's width (strides), the GEMM covers the range's columns only
+  const int64_t ldd = (int64_t)H * Fp, lds = H;
+  dWh += (int64_t)h_first * Fp;
+  if (ds) ds += h_first;
+  if (a_pad) a_pad += (int64_t)h_first * 2 * Fp;
+  dW += (int64_t)h_first * Fin * Fo;
+  H = h_count;
   if (split_k < 1) split_k = 1;
   hipStream_t st = (hipStream_t)stream;
   const int R = H * Fp;
@@ -388,7 +397,7 @@ extern "C" int pygat_wgrad(int n, int Fin, int H, int Fo, const float* X, int64_
   bool done = false;
   if (ds && split_k > 1) {                          // one streamed-K GEMM over [dWh | ds]
     seg.col_start[1] = R + H;
-    int r = try_gemm_tn_stream(Fin, R + H, n, X, ldx, dWh, R, split_k, slabs, st, R, ds, H);
+    int r = try_gemm_tn_stream(Fin, R + H, n, X, ldx, dWh, ldd, split_k, slabs, st, R, ds, lds);
     if (r < 0) return r;
     if (r >= 1) {
       const int64_t tot = (int64_t)Fin * (R + H);
@@ -400,11 +409,11 @@ extern "C" int pygat_wgrad(int n, int Fin, int H, int Fo, const float* X, int64_
   }
   if (!done) {                                      // any shape: the general path, once per operand
     seg.col_start[1] = R;
-    int rc = pygat_gemm_f32(1, 0, Fin, R, n, X, ldx, dWh, R, &seg, 0, split_k, slabs, stream);
+    int rc = pygat_gemm_f32(1, 0, Fin, R, n, X, ldx, dWh, ldd, &seg, 0, split_k, slabs, stream);
     if (rc) return rc;
     if (ds) {
       seg.col_start[1] = H; seg.ptr[0] = dWc + R;
-      rc = pygat_gemm_f32(1, 0, Fin, H, n, X, ldx, ds, H, &seg, 0, split_k, slabs, stream);
+      rc = pygat_gemm_f32(1, 0, Fin, H, n, X, ldx, ds, lds, &seg, 0, split_k, slabs, stream);
       if (rc) return rc;
     }
   }

@@ -31,8 +31,9 @@ struct PrepArgs {
   const float* Z;
   float* GR;        // [n][ldgr]: per backward head window [Gp | 4-float records]  [| copy of Whi (R), GATv2]
   int64_t ldgr;
-  int h0p;          // first head (of the level) covered by this pass
+  int h0p;          // first head covered by this pass, counted inside the head range of the call
   int gr_hg;        // heads per backward window: fixes where a head's Gp and record live inside a GR row
+  int gr_heads;     // heads of the range (GR is laid out for them alone)
   const float* whi; // GATv2: table whose first R floats per row are copied behind the rowtab, else nullptr
   int64_t ld_whi;
 };
@@ -44,7 +45,7 @@ __device__ __forceinline__ int64_t gr_gp_off(const PrepArgs& a, int co, int h) {
 }
 __device__ __forceinline__ int64_t gr_rt_off(const PrepArgs& a, int h) {
   const int gh = a.h0p + h, w0 = (gh / a.gr_hg) * a.gr_hg;
-  const int hcw = (a.rs.Htot - w0 < a.gr_hg) ? a.rs.Htot - w0 : a.gr_hg;
+  const int hcw = (a.gr_heads - w0 < a.gr_hg) ? a.gr_heads - w0 : a.gr_hg;
   return (int64_t)w0 * (a.rs.Fp + 4) + (int64_t)hcw * a.rs.Fp + 4 * (gh - w0);
 }
 
@@ -381,12 +382,12 @@ using namespace pygat;
 
 static int launch_prepare(int n, int H, int Fo, int flags, int mean_mode, const float* G, const float* y,
                           const float* sk, const float* s, const float* m, const float* Z, float* GR,
-                          const float* whi, int64_t ld_whi, void* stream);
+                          const float* whi, int64_t ld_whi, int h_first, int h_count, void* stream);
 
 extern "C" int pygat_gat_backward_prepare(int n, int H, int Fo, int flags, int mean_mode, const float* G,
                                           const float* y, const float* sk, const float* s, const float* m,
-                                          const float* Z, float* GR, void* stream) {
-  return launch_prepare(n, H, Fo, flags, mean_mode, G, y, sk, s, m, Z, GR, nullptr, 0, stream);
+                                          const float* Z, float* GR, int h_first, int h_count, void* stream) {
+  return launch_prepare(n, H, Fo, flags, mean_mode, G, y, sk, s, m, Z, GR, nullptr, 0, h_first, h_count, stream);
 }
 
 /* GATv2: GRW [n x (2R + 4H)] = [Gp | (., m, 1/Z, D) | Whi], Whi copied from WW [n x 2R] */
@@ -396,15 +397,18 @@ extern "C" int pygat_gatv2_backward_prepare(int n, int H, int Fo, int flags, int
   if (!WW) { pygat::set_error("gatv2_backward_prepare: null WW"); return PYGAT_EINVAL; }
   int Fp = pygat::padded_width(Fo);
   return launch_prepare(n, H, Fo, flags, mean_mode, G, y, sk, m /* s slot unused in V2 */, m, Z, GRW, WW,
-                        2 * (int64_t)H * Fp, stream);
+                        2 * (int64_t)H * Fp, 0, 0, stream);
 }
 
 static int launch_prepare(int n, int H, int Fo, int flags, int mean_mode, const float* G, const float* y,
                           const float* sk, const float* s, const float* m, const float* Z, float* GR,
-                          const float* whi, int64_t ld_whi, void* stream) {
+                          const float* whi, int64_t ld_whi, int h_first, int h_count, void* stream) {
   PrepArgs a;
   const int Fp = padded_width(Fo);
+  HeadRange rg;
   PYGAT_REQUIRE(H > 0 && Fp > 0, "gat_backward_prepare: unsupported H=%d F'=%d", H, Fo);
+  PYGAT_REQUIRE(make_head_range(H, h_first, h_count, &rg) && (!whi || rg.hr == H),
+                "gat_backward_prepare: bad head range [%d, +%d) of %d", h_first, h_count, H);
   PYGAT_REQUIRE(n > 0 && G && y && s && m && Z && GR, "gat_backward_prepare: null pointer");
   PYGAT_REQUIRE(!(flags & PYGAT_F_SKIP) || sk, "gat_backward_prepare: PYGAT_F_SKIP without sk");
   PYGAT_REQUIRE(!(mean_mode && (flags & PYGAT_F_ELU)), "gat_backward_prepare: the head mean never carries an ELU (models.py:23)");
@@ -412,18 +416,19 @@ static int launch_prepare(int n, int H, int Fo, int flags, int mean_mode, const 
                     (mean_mode ? aligned16(y) : (Fo != Fp || (aligned16(G) && aligned16(y)))),
                 "gat_backward_prepare: row tables must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  const int hg = whi ? H : head_group_fwd(H, Fp);   // kernel passes (GATv2 is not windowed)
-  for (int h0 = 0; h0 < H; h0 += hg) {
-    const int hc = (H - h0 < hg) ? H - h0 : hg;
+  const int hg = whi ? H : head_group_fwd(rg.hr, Fp);   // kernel passes (GATv2 is not windowed)
+  for (int h0 = 0; h0 < rg.hr; h0 += hg) {
+    const int hc = (rg.hr - h0 < hg) ? rg.hr - h0 : hg;
+    const int gh = rg.hb + h0;                             // first head of the pass inside the level
     PYGAT_REQUIRE(make_window_shape(H, Fo, hc, &a.rs), "gat_backward_prepare: unsupported H=%d F'=%d", hc, Fo);
     a.n = n; a.flags = flags; a.mean_mode = mean_mode;
     // mean mode: G is [n, F'] (shared by the heads), y = hattn [n, R]; concat: G and y = out are [n, H*F']
-    a.G = mean_mode ? G : G + (int64_t)h0 * Fo;
-    a.y = mean_mode ? y + (int64_t)h0 * Fp : y + (int64_t)h0 * Fo;
-    a.sk = sk ? sk + (int64_t)h0 * Fp : nullptr;
-    a.s = s + h0; a.m = m + h0; a.Z = Z + h0;
-    a.ldgr = (int64_t)H * Fp * (whi ? 2 : 1) + 4 * H;
-    a.GR = GR; a.h0p = h0; a.gr_hg = whi ? H : head_group_bwd(n, H, Fp);
+    a.G = mean_mode ? G : G + (int64_t)gh * Fo;
+    a.y = mean_mode ? y + (int64_t)gh * Fp : y + (int64_t)gh * Fo;
+    a.sk = sk ? sk + (int64_t)gh * Fp : nullptr;
+    a.s = s + gh; a.m = m + gh; a.Z = Z + gh;
+    a.ldgr = (int64_t)rg.hr * Fp * (whi ? 2 : 1) + 4 * rg.hr;
+    a.GR = GR; a.h0p = h0; a.gr_hg = whi ? H : head_group_bwd(n, rg.hr, Fp); a.gr_heads = rg.hr;
     a.whi = whi; a.ld_whi = ld_whi;
     int lpr, vec;
     pick_lanes(a.rs, &lpr, &vec);
@@ -450,23 +455,26 @@ static int launch_prepare(int n, int H, int Fo, int flags, int mean_mode, const 
 
 extern "C" int pygat_gat_backward_row(const pygat_graph* g, int H, int Fo, float alpha, const float* Wh,
                                       const float* a_pad, const float* GR, const float* att_mask, float* ds,
-                                      void* part, void* stream) {
+                                      void* part, int h_first, int h_count, void* stream) {
   RowArgs a;
   int rc = check_graph(g, &a.g);
   if (rc) return rc;
   const int Fp = padded_width(Fo);
+  HeadRange rg;
   PYGAT_REQUIRE(H > 0 && Fp > 0, "gat_backward_row: unsupported H=%d F'=%d", H, Fo);
+  PYGAT_REQUIRE(make_head_range(H, h_first, h_count, &rg), "gat_backward_row: bad head range [%d, +%d) of %d", h_first, h_count, H);
   PYGAT_REQUIRE(Wh && a_pad && GR && ds && part, "gat_backward_row: null pointer");
   PYGAT_REQUIRE(aligned16(Wh) && aligned16(GR) && aligned16(a_pad), "gat_backward_row: row tables must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int64_t nslots = num_slots(a.g);
-  const int hg = head_group_bwd(a.g.n, H, Fp);
-  for (int h0 = 0; h0 < H; h0 += hg) {
-    const int hc = (H - h0 < hg) ? H - h0 : hg;
+  const int hg = head_group_bwd(a.g.n, rg.hr, Fp);
+  for (int h0 = 0; h0 < rg.hr; h0 += hg) {
+    const int hc = (rg.hr - h0 < hg) ? rg.hr - h0 : hg;
+    const int gh = rg.hb + h0;
     PYGAT_REQUIRE(make_window_shape(H, Fo, hc, &a.rs), "gat_backward_row: unsupported H=%d F'=%d", hc, Fo);
-    a.alpha = alpha; a.Wh = Wh + (int64_t)h0 * Fp; a.a_pad = a_pad + (int64_t)h0 * 2 * Fp;
-    a.GR = GR + gr_window_offset(h0, Fp); a.ldgr = (int64_t)H * Fp + 4 * H;
-    a.mask = att_mask ? att_mask + h0 : nullptr; a.ds = ds + h0; a.part = (float*)part;
+    a.alpha = alpha; a.Wh = Wh + (int64_t)gh * Fp; a.a_pad = a_pad + (int64_t)gh * 2 * Fp;
+    a.GR = GR + gr_window_offset(h0, Fp); a.ldgr = (int64_t)rg.hr * Fp + 4 * rg.hr;
+    a.mask = att_mask ? att_mask + gh : nullptr; a.ds = ds + gh; a.part = (float*)part;
     int lpr, vec;
     pick_lanes(a.rs, &lpr, &vec);
     const unsigned blocks = (unsigned)cdiv(cdiv(nslots, 64 / lpr), 4);
@@ -486,19 +494,22 @@ extern "C" int pygat_gat_backward_row(const pygat_graph* g, int H, int Fo, float
 /* ds_i = sum_j dz_ij from the per-edge records of the column pass.  g = forward pattern, perm_f[k] = transposed
  * position of forward edge k.  (The ds_i a_src term that pass left out of dWh_i is added by pygat_a_grad.) */
 extern "C" int pygat_gat_backward_rowsum(const pygat_graph* g, const int32_t* perm_f, int H, int Fo, const float* dz_t,
-                                         float* ds, void* part, void* stream) {
+                                         float* ds, void* part, int h_first, int h_count, void* stream) {
   RowArgs a;
   int rc = check_graph(g, &a.g);
   if (rc) return rc;
   const int Fp = padded_width(Fo);
+  HeadRange rg;
   PYGAT_REQUIRE(H > 0 && Fp > 0, "gat_backward_rowsum: unsupported H=%d F'=%d", H, Fo);
+  PYGAT_REQUIRE(make_head_range(H, h_first, h_count, &rg), "gat_backward_rowsum: bad head range [%d, +%d) of %d", h_first, h_count, H);
   PYGAT_REQUIRE(perm_f && dz_t && ds && part, "gat_backward_rowsum: null pointer");
   hipStream_t st = (hipStream_t)stream;
   const int64_t nslots = num_slots(a.g);
   // the records are 4 bytes per head: walk all heads of a row with one lane per head (padded width 4)
-  PYGAT_REQUIRE(make_row_shape(H, 4, &a.rs), "gat_backward_rowsum: too many heads (%d)", H);
+  PYGAT_REQUIRE(make_row_shape(rg.hr, 4, &a.rs), "gat_backward_rowsum: too many heads (%d)", rg.hr);
+  a.rs.Htot = H; a.rs.ldh = H;          // ds and the records keep the level's width
   a.alpha = 0.f; a.Wh = nullptr; a.a_pad = nullptr; a.GR = nullptr; a.ldgr = 0; a.mask = nullptr;
-  a.ds = ds; a.part = (float*)part; a.dz_t = dz_t; a.perm_f = perm_f;
+  a.ds = ds + rg.hb; a.part = (float*)part; a.dz_t = dz_t + rg.hb; a.perm_f = perm_f;
   int lpr, vec;
   pick_lanes(a.rs, &lpr, &vec);
   const unsigned blocks = (unsigned)cdiv(cdiv(nslots, 64 / lpr), 4);
@@ -508,7 +519,7 @@ extern "C" int pygat_gat_backward_rowsum(const pygat_graph* g, const int32_t* pe
     if (a.g.n_cut > 0)
       hipLaunchKernelGGL(gat_bwd_row_fixup_list_kernel, dim3((unsigned)cdiv(a.g.n_cut, 4)), dim3(256), 0, st, a);
   } else {
-    hipLaunchKernelGGL(gat_bwd_row_fixup_kernel, dim3((unsigned)cdiv(nslots * H, 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(gat_bwd_row_fixup_kernel, dim3((unsigned)cdiv(nslots * rg.hr, 256)), dim3(256), 0, st, a);
   }
   PYGAT_CHECK_LAUNCH("gat_backward_rowsum_fixup");
   return PYGAT_OK;

@@ -362,13 +362,15 @@ using namespace pygat;
 extern "C" int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm_t, int H, int Fo, float alpha,
                                       const float* Wh, const float* a_pad, const float* GR,
                                       const float* att_mask, const float* ds, float* dWh, float* dt, float* dz_t,
-                                      void* part, void* stream) {
+                                      void* part, int h_first, int h_count, void* stream) {
 
   ColArgs a;
   int rc = check_graph(gT, &a.g);
   if (rc) return rc;
   const int Fp = padded_width(Fo);
+  HeadRange rg;
   PYGAT_REQUIRE(H > 0 && Fp > 0, "gat_backward_col: unsupported H=%d F'=%d", H, Fo);
+  PYGAT_REQUIRE(make_head_range(H, h_first, h_count, &rg), "gat_backward_col: bad head range [%d, +%d) of %d", h_first, h_count, H);
   PYGAT_REQUIRE(Wh && a_pad && GR && dWh && dt && part, "gat_backward_col: null pointer");
   PYGAT_REQUIRE((ds != nullptr) != (dz_t != nullptr),
                 "gat_backward_col: pass either ds (row sums known) or dz_t (row sums taken afterwards), not both");
@@ -377,14 +379,15 @@ extern "C" int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm
                 "gat_backward_col: row tables must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int64_t nslots = num_slots(a.g);
-  const int hg = head_group_bwd(a.g.n, H, Fp);
-  for (int h0 = 0; h0 < H; h0 += hg) {
-    const int hc = (H - h0 < hg) ? H - h0 : hg;
+  const int hg = head_group_bwd(a.g.n, rg.hr, Fp);
+  for (int h0 = 0; h0 < rg.hr; h0 += hg) {
+    const int hc = (rg.hr - h0 < hg) ? rg.hr - h0 : hg;
+    const int gh = rg.hb + h0;
     PYGAT_REQUIRE(make_window_shape(H, Fo, hc, &a.rs), "gat_backward_col: unsupported H=%d F'=%d", hc, Fo);
-    a.alpha = alpha; a.perm = perm_t; a.mask = att_mask ? att_mask + h0 : nullptr;
-    a.Wh = Wh + (int64_t)h0 * Fp; a.GR = GR + gr_window_offset(h0, Fp); a.ldgr = (int64_t)H * Fp + 4 * H;
-    a.a_pad = a_pad + (int64_t)h0 * 2 * Fp; a.ds = ds ? ds + h0 : nullptr; a.dz_t = dz_t ? dz_t + h0 : nullptr;
-    a.dWh = dWh + (int64_t)h0 * Fp; a.dt = dt + h0; a.part = (float*)part;
+    a.alpha = alpha; a.perm = perm_t; a.mask = att_mask ? att_mask + gh : nullptr;
+    a.Wh = Wh + (int64_t)gh * Fp; a.GR = GR + gr_window_offset(h0, Fp); a.ldgr = (int64_t)rg.hr * Fp + 4 * rg.hr;
+    a.a_pad = a_pad + (int64_t)gh * 2 * Fp; a.ds = ds ? ds + gh : nullptr; a.dz_t = dz_t ? dz_t + gh : nullptr;
+    a.dWh = dWh + (int64_t)gh * Fp; a.dt = dt + gh; a.part = (float*)part;
     int lpr, vec;
     pick_lanes(a.rs, &lpr, &vec);
     const unsigned blocks = (unsigned)cdiv(cdiv(nslots, 64 / lpr), 4);

@@ -182,10 +182,12 @@ extern "C" size_t pygat_agrad_workspace_bytes(int H, int Fo) {
 }
 
 extern "C" int pygat_a_grad(int n, int H, int Fo, const float* Wh, const float* ds, const float* dt, float* da,
-                            void* ws, const float* a_pad, float* dWh, void* stream) {
+                            void* ws, const float* a_pad, float* dWh, int h_first, int h_count, void* stream) {
   RowShape rs;
   const int Fp = padded_width(Fo);
+  HeadRange rg;
   PYGAT_REQUIRE(H > 0 && Fp > 0 && Fp <= 1024, "a_grad: unsupported H=%d F'=%d", H, Fo);
+  PYGAT_REQUIRE(make_head_range(H, h_first, h_count, &rg), "a_grad: bad head range [%d, +%d) of %d", h_first, h_count, H);
   PYGAT_REQUIRE(n > 0 && Wh && ds && dt && da && ws && aligned16(Wh) && aligned16(ws), "a_grad: bad arguments");
   PYGAT_REQUIRE(!dWh || (a_pad && aligned16(dWh) && aligned16(a_pad)), "a_grad: dWh needs a_pad, both 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
@@ -193,15 +195,16 @@ extern "C" int pygat_a_grad(int n, int H, int Fo, const float* Wh, const float* 
   int nblocks = (int)cdiv(n, 256);
   if (nblocks > AG_BLOCKS) nblocks = AG_BLOCKS;
   // a work-group streams rows of at most 1024 floats (256 threads x 16 B): wider levels go window by window
-  const int hg = (H * Fp <= 1024) ? H : (1024 / Fp);
-  for (int h0 = 0; h0 < H; h0 += hg) {
-    const int hc = (H - h0 < hg) ? H - h0 : hg;
+  const int hg = (rg.hr * Fp <= 1024) ? rg.hr : (1024 / Fp);
+  for (int h0 = 0; h0 < rg.hr; h0 += hg) {
+    const int hc = (rg.hr - h0 < hg) ? rg.hr - h0 : hg;
+    const int gh = rg.hb + h0;
     PYGAT_REQUIRE(make_window_shape(H, Fo, hc, &rs), "a_grad: unsupported H=%d F'=%d", hc, Fo);
-    hipLaunchKernelGGL(a_grad_partial_kernel, dim3(nblocks), dim3(256), 0, st, n, nblocks, rs, Wh + (int64_t)h0 * Fp,
-                       ds + h0, dt + h0, (float*)ws, a_pad ? a_pad + (int64_t)h0 * 2 * Fp : nullptr,
-                       dWh ? dWh + (int64_t)h0 * Fp : nullptr);
+    hipLaunchKernelGGL(a_grad_partial_kernel, dim3(nblocks), dim3(256), 0, st, n, nblocks, rs, Wh + (int64_t)gh * Fp,
+                       ds + gh, dt + gh, (float*)ws, a_pad ? a_pad + (int64_t)gh * 2 * Fp : nullptr,
+                       dWh ? dWh + (int64_t)gh * Fp : nullptr);
     hipLaunchKernelGGL(a_grad_final_kernel, dim3((unsigned)cdiv(rs.H * 2 * rs.Fo * 8, 256)), dim3(256), 0, st, rs, nblocks,
-                       (const float*)ws, da + (int64_t)h0 * 2 * Fo);
+                       (const float*)ws, da + (int64_t)gh * 2 * Fo);
     PYGAT_CHECK_LAUNCH("a_grad");
   }
   return PYGAT_OK;

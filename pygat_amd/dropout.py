@@ -136,29 +136,29 @@ class GATLevelDropoutFn(torch.autograd.Function):
             dWh = torch.empty(L.N, R, dtype=f32, device=dev)
             part = torch.empty(lib.pygat_partials_bytes(graph.nnz, L.ts, H, L.Fp) // 4, dtype=f32, device=dev)
             check(lib.pygat_gat_backward_prepare(L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(), y.data_ptr(),
-                                                 _ptr(Sk), s.data_ptr(), m.data_ptr(), Z.data_ptr(), GR.data_ptr(), st),
+                                                 _ptr(Sk), s.data_ptr(), m.data_ptr(), Z.data_ptr(), GR.data_ptr(), 0, 0, st),
                   "gat_backward_prepare")
             two_gather = ops.two_gather_backward(L.R)
             if two_gather:
                 check(lib.pygat_gat_backward_row(graph.fwd.ref(L.ts), H, Fo, ctx.alpha, Wh.data_ptr(), a_pad.data_ptr(),
-                                                 GR.data_ptr(), matt.data_ptr(), ds.data_ptr(), part.data_ptr(), st),
+                                                 GR.data_ptr(), matt.data_ptr(), ds.data_ptr(), part.data_ptr(), 0, 0, st),
                       "gat_backward_row")
                 check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), graph.perm_t.data_ptr(), H, Fo, ctx.alpha,
                                                  Wh.data_ptr(), a_pad.data_ptr(), GR.data_ptr(), matt.data_ptr(),
-                                                 ds.data_ptr(), dWh.data_ptr(), dt.data_ptr(), None, part.data_ptr(), st),
+                                                 ds.data_ptr(), dWh.data_ptr(), dt.data_ptr(), None, part.data_ptr(), 0, 0, st),
                       "gat_backward_col")
             else:      # K4 writes dz per transposed edge, the row sums come from those records (ops.GATLevelFn)
                 dz_t = torch.empty(graph.nnz, H, dtype=f32, device=dev)
                 check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), graph.perm_t.data_ptr(), H, Fo, ctx.alpha,
                                                  Wh.data_ptr(), a_pad.data_ptr(), GR.data_ptr(), matt.data_ptr(),
-                                                 None, dWh.data_ptr(), dt.data_ptr(), dz_t.data_ptr(), part.data_ptr(), st),
+                                                 None, dWh.data_ptr(), dt.data_ptr(), dz_t.data_ptr(), part.data_ptr(), 0, 0, st),
                       "gat_backward_col")
                 check(lib.pygat_gat_backward_rowsum(graph.fwd.ref(L.ts), graph.perm_f.data_ptr(), H, Fo, dz_t.data_ptr(),
-                                                    ds.data_ptr(), part.data_ptr(), st), "gat_backward_rowsum")
+                                                    ds.data_ptr(), part.data_ptr(), 0, 0, st), "gat_backward_rowsum")
             da = torch.empty(H, 2 * Fo, dtype=f32, device=dev)
             ws = torch.empty(lib.pygat_agrad_workspace_bytes(H, Fo) // 4, dtype=f32, device=dev)
             check(lib.pygat_a_grad(L.N, H, Fo, Wh.data_ptr(), ds.data_ptr(), dt.data_ptr(), da.data_ptr(), ws.data_ptr(),
-                                   None if two_gather else a_pad.data_ptr(), None if two_gather else dWh.data_ptr(), st),
+                                   None if two_gather else a_pad.data_ptr(), None if two_gather else dWh.data_ptr(), 0, 0, st),
                   "a_grad")
             dWh.mul_(mwh)                          # back through the Wh dropout
             # dW_h = (x o m_h)^T dWh_h: the diagonal blocks of A'^T dWh

@@ -151,10 +151,15 @@ class _Level:
 
 
 class GATLevelFn(torch.autograd.Function):
-    """forward(x, W[H,Fin,F'], a[H,2F'], Wskip[H,Fin,F']|None, graph, alpha, concat) -> out."""
+    """forward(x, W[H,Fin,F'], a[H,2F'], Wskip[H,Fin,F']|None, graph, alpha, concat[, bwd_heads]) -> out.
+
+    bwd_heads = (first, count): the forward covers all H heads, the backward only that range -- dW / da of the
+    other heads come back as zeros.  For a rank of a head-parallel run that computes every head's forward
+    itself (cheaper than receiving the outputs over xGMI) and owns the gradients of its own heads only.
+    Needs Wskip = None and no gradient into x."""
 
     @staticmethod
-    def forward(ctx, x, W, a, Wskip, graph: CSRGraph, alpha: float, concat: bool):
+    def forward(ctx, x, W, a, Wskip, graph: CSRGraph, alpha: float, concat: bool, bwd_heads=None):
         if not x.is_cuda:
             raise RuntimeError("pygat_amd: inputs must be on the GPU; the hot path has no CPU fallback")
         x = x.contiguous().float()
@@ -207,6 +212,14 @@ class GATLevelFn(torch.autograd.Function):
             # concat: the backward recovers hattn from `out` (no second [N,R] table is written)
             ctx.save_for_backward(x, Wcat, a_pad, Wh, s, Sk, out if concat else hattn, m, Z)
             ctx.graph, ctx.L, ctx.alpha, ctx.concat, ctx.flags = graph, L, float(alpha), concat, flags
+            ctx.bwd_heads = None
+            if bwd_heads is not None:
+                hb, hr = int(bwd_heads[0]), int(bwd_heads[1])
+                if not (0 <= hb and 0 < hr and hb + hr <= H):
+                    raise ValueError(f"bwd_heads {bwd_heads} outside the {H} heads of the level")
+                if skip or ctx.needs_input_grad[0]:
+                    raise ValueError("pygat_amd: bwd_heads supports neither a skip projection nor a gradient into x")
+                ctx.bwd_heads = (hb, hr)
         return out
 
     @staticmethod
@@ -215,9 +228,12 @@ class GATLevelFn(torch.autograd.Function):
         graph, L, H, Fo = ctx.graph, ctx.L, ctx.L.H, ctx.L.Fo
         dev, f32 = x.device, torch.float32
         G = G.contiguous().float()
+        ranged = ctx.bwd_heads is not None
+        hb, hr = ctx.bwd_heads if ranged else (0, 0)       # (0, 0) = all heads in the C ABI
+        Hb = hr if ranged else H                            # heads this backward covers
         with torch.cuda.device(dev):
             st = _stream()
-            RW = L.R + 4 * H
+            RW = Hb * (L.Fp + 4)                            # GR is compact for the covered heads
             GR = torch.empty(L.N, RW, dtype=f32, device=dev)      # per head window: [Gp | (s, m, 1/Z, D) per head]
             ds = torch.empty(L.N, H, dtype=f32, device=dev)
             dt = torch.empty(L.N, H, dtype=f32, device=dev)
@@ -227,51 +243,51 @@ class GATLevelFn(torch.autograd.Function):
             with _span("k3a_prepare"):
                 check(lib.pygat_gat_backward_prepare(L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(),
                                                      y.data_ptr(), _ptr(Sk), s.data_ptr(), m.data_ptr(), Z.data_ptr(),
-                                                     GR.data_ptr(), st), "gat_backward_prepare")
-            two_gather = two_gather_backward(L.R)
+                                                     GR.data_ptr(), hb, hr, st), "gat_backward_prepare")
+            two_gather = two_gather_backward(Hb * L.Fp)
             if two_gather:
                 with _span("k3b_row"):
                     check(lib.pygat_gat_backward_row(graph.fwd.ref(L.ts), H, Fo, ctx.alpha, Wh.data_ptr(),
                                                      a_pad.data_ptr(), GR.data_ptr(), None, ds.data_ptr(),
-                                                     part.data_ptr(), st), "gat_backward_row")
+                                                     part.data_ptr(), hb, hr, st), "gat_backward_row")
                 with _span("k4_backward_col"):
                     check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), None, H, Fo, ctx.alpha, Wh.data_ptr(),
                                                      a_pad.data_ptr(), GR.data_ptr(), None, ds.data_ptr(),
-                                                     dWh.data_ptr(), dt.data_ptr(), None, part.data_ptr(), st),
+                                                     dWh.data_ptr(), dt.data_ptr(), None, part.data_ptr(), hb, hr, st),
                           "gat_backward_col")
             else:
                 dz_t = torch.empty(graph.nnz, H, dtype=f32, device=dev)
                 with _span("k4_backward_col"):
                     check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), None, H, Fo, ctx.alpha, Wh.data_ptr(),
                                                      a_pad.data_ptr(), GR.data_ptr(), None, None,
-                                                     dWh.data_ptr(), dt.data_ptr(), dz_t.data_ptr(), part.data_ptr(), st),
+                                                     dWh.data_ptr(), dt.data_ptr(), dz_t.data_ptr(), part.data_ptr(), hb, hr, st),
                           "gat_backward_col")
                 with _span("k3c_rowsum"):
                     check(lib.pygat_gat_backward_rowsum(graph.fwd.ref(L.ts), graph.perm_f.data_ptr(), H, Fo,
-                                                        dz_t.data_ptr(), ds.data_ptr(), part.data_ptr(), st),
+                                                        dz_t.data_ptr(), ds.data_ptr(), part.data_ptr(), hb, hr, st),
                           "gat_backward_rowsum")
             # da; after the row-sum flavour the same stream also finishes dWh_i += ds_i a_src
-            da = torch.empty(H, 2 * Fo, dtype=f32, device=dev)
+            da = (torch.zeros if ranged else torch.empty)(H, 2 * Fo, dtype=f32, device=dev)
             ws = torch.empty(lib.pygat_agrad_workspace_bytes(H, Fo) // 4, dtype=f32, device=dev)
             # ... unless nothing but the weight-gradient GEMM consumes dWh: there ds rides along as extra columns
             # (pygat_wgrad) and dWh is never rewritten
             fold_ds = ((not two_gather) and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]
-                       and L.R % 32 == 0 and L.N >= 4096)      # the streamed-K GEMM takes [dWh | ds] in one pass
+                       and (Hb * L.Fp) % 32 == 0 and L.N >= 4096)   # the streamed-K GEMM takes [dWh | ds] in one pass
             finish = (not two_gather) and not fold_ds
             with _span("k5_agrad"):
                 check(lib.pygat_a_grad(L.N, H, Fo, Wh.data_ptr(), ds.data_ptr(), dt.data_ptr(), da.data_ptr(),
                                        ws.data_ptr(), a_pad.data_ptr() if finish else None,
-                                       dWh.data_ptr() if finish else None, st), "a_grad")
+                                       dWh.data_ptr() if finish else None, hb, hr, st), "a_grad")
             # dW = x^T dWh (split-K over the nodes), dWskip = x^T Gp
             dW = dWs = dx = None
             if ctx.needs_input_grad[1]:
-                split_k = _split_k(L.Fin, L.R + (H if fold_ds else 0), L.N, streamed_k=True)
+                split_k = _split_k(L.Fin, Hb * L.Fp + (Hb if fold_ds else 0), L.N, streamed_k=True)
                 wsw = torch.empty(lib.pygat_wgrad_workspace_bytes(L.Fin, H, Fo, split_k) // 4, dtype=f32, device=dev)
-                dW = torch.empty(H, L.Fin, Fo, dtype=f32, device=dev)
+                dW = (torch.zeros if ranged else torch.empty)(H, L.Fin, Fo, dtype=f32, device=dev)
                 with _span("k5_wgrad"):
                     check(lib.pygat_wgrad(L.N, L.Fin, H, Fo, x.data_ptr(), L.Fin, dWh.data_ptr(),
                                           ds.data_ptr() if fold_ds else None, a_pad.data_ptr(), dW.data_ptr(), split_k,
-                                          wsw.data_ptr(), st), "wgrad")
+                                          wsw.data_ptr(), hb, hr, st), "wgrad")
             if L.skip and ctx.needs_input_grad[3]:
                 dSc = torch.empty(L.Fin, L.R, dtype=f32, device=dev)
                 for c0, w, g0 in L.gp_windows():
@@ -287,7 +303,7 @@ class GATLevelFn(torch.autograd.Function):
                         for c0, w, g0 in L.gp_windows():
                             gemm(False, True, L.N, L.Fin, w, GR[:, g0:], RW, Wcat[:, L.R + c0:], L.ldw,
                                  [(L.Fin, dx, L.Fin)], accumulate=True, split_k=1)
-        return dx, dW, (da if ctx.needs_input_grad[2] else None), dWs, None, None, None
+        return dx, dW, (da if ctx.needs_input_grad[2] else None), dWs, None, None, None, None
 
 
 def gat_level(x: torch.Tensor, graph: CSRGraph, Ws: Sequence[torch.Tensor], As: Sequence[torch.Tensor],

@@ -433,6 +433,39 @@ def test_wgrad_with_ds_columns(pg, n, Fin, H, Fo, with_ds):
     dW = torch.empty(H, Fin, Fo, device=dev)
     Xd, dd, sd, ad = (t.float().to(dev).contiguous() for t in (X, dWh.view(n, R), ds, a_pad))
     check(lib.pygat_wgrad(n, Fin, H, Fo, Xd.data_ptr(), Fin, dd.data_ptr(), sd.data_ptr() if with_ds else None,
-                          ad.data_ptr(), dW.data_ptr(), split_k, ws.data_ptr(), None))
+                          ad.data_ptr(), dW.data_ptr(), split_k, ws.data_ptr(), 0, 0, None))
     torch.cuda.synchronize()
     close(dW, ref.numpy(), "dW", tol=3e-6 * n ** 0.5)
+
+
+@pytest.mark.parametrize("H,Fo,rng", [(8, 16, (2, 4)), (8, 16, (7, 1)), (5, 7, (0, 2)), (6, 64, (3, 3))])
+def test_backward_head_range(pg, backward_mode, H, Fo, rng):
+    """GATLevelFn(..., bwd_heads): forward for all heads, gradients only for a head range -- equal to the same
+    rows of the full backward, zeros elsewhere (the rank of a head-parallel run that recomputes the others'
+    forward instead of receiving it)."""
+    N, Fin = 150, 12
+    rowptr, col = O.random_symmetric_csr(N, 6, 31 + H, hub=(4, 100))
+    W, a, _ = params(H, Fin, Fo, False, 32 + Fo)
+    gen = torch.Generator().manual_seed(33)
+    x = torch.randn(N, Fin, generator=gen)
+    G = torch.randn(N, H * Fo, generator=gen)
+    dev = "cuda:0"
+    g = pg.CSRGraph(torch.as_tensor(rowptr, device=dev), torch.as_tensor(col, device=dev), slot_edges=16)
+
+    def run(bh):
+        Wd = W.float().to(dev).requires_grad_(True); ad = a.float().to(dev).requires_grad_(True)
+        out = pg.GATLevelFn.apply(x.to(dev), Wd, ad, None, g, 0.2, True, bh)
+        out.backward(G.to(dev))
+        torch.cuda.synchronize()
+        return out.detach(), Wd.grad, ad.grad
+    out_f, dW_f, da_f = run(None)
+    out_r, dW_r, da_r = run(rng)
+    hb, hr = rng
+    assert torch.equal(out_f, out_r)
+    sel = torch.zeros(H, dtype=torch.bool); sel[hb:hb + hr] = True
+    scale = lambda t: max(1.0, float(t.abs().max()))  # noqa: E731
+    assert float((dW_r[sel] - dW_f[sel]).abs().max()) <= 2e-6 * scale(dW_f)     # summation order may differ
+    assert float((da_r[sel] - da_f[sel]).abs().max()) <= 2e-6 * scale(da_f)
+    assert float(dW_r[~sel].abs().max()) == 0.0 and float(da_r[~sel].abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        pg.GATLevelFn.apply(x.to(dev), W.float().to(dev).requires_grad_(True), a.float().to(dev), None, g, 0.2, True, (H - 1, 2))

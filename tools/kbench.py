@@ -66,14 +66,14 @@ def main():
     GR = torch.empty(N, R + 4 * H, device=dev)
 
     def k3a():
-        check(lib.pygat_gat_backward_prepare(N, H, Fo, _lib.F_ELU, 0, P(G), P(out), None, P(s), P(m), P(Z), P(GR), None))
+        check(lib.pygat_gat_backward_prepare(N, H, Fo, _lib.F_ELU, 0, P(G), P(out), None, P(s), P(m), P(Z), P(GR), 0, 0, None))
 
     def k3b():
-        check(lib.pygat_gat_backward_row(graph.fwd.ref(), H, Fo, 0.2, P(Wh), P(a_pad), P(GR), None, P(ds), P(part), None))
+        check(lib.pygat_gat_backward_row(graph.fwd.ref(), H, Fo, 0.2, P(Wh), P(a_pad), P(GR), None, P(ds), P(part), 0, 0, None))
 
     def k4():
         check(lib.pygat_gat_backward_col(graph.bwd.ref(), None, H, Fo, 0.2, P(Wh), P(a_pad), P(GR), None, P(ds),
-                                         P(dWh), P(dt), None, P(part), None))
+                                         P(dWh), P(dt), None, P(part), 0, 0, None))
 
     b_fwd = E * (4 + 4 * H + 4 * R) + N * (4 + 4 * H + 4 * R + 8 * H)
     b_k3a = N * (12 * R + 12 * H + 16 * H)

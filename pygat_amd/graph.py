@@ -200,10 +200,19 @@ class CSRGraph:
         return CSRGraph(torch.cat(rps).to(torch.int32), torch.cat(cols).to(torch.int32))
 
     @staticmethod
-    def from_edge_index(row: torch.Tensor, col: torch.Tensor, n: int,
-                        slot_edges: Optional[int] = None) -> "CSRGraph":
-        """COO (row=i, col=j), duplicates removed, rows sorted."""
-        key = torch.unique(row.long() * n + col.long())
+    def from_edge_index(row: torch.Tensor, col: torch.Tensor, n: int, slot_edges: Optional[int] = None,
+                        symmetrize: bool = False, self_loops: bool = False) -> "CSRGraph":
+        """COO (row=i, col=j), duplicates removed, rows sorted.  symmetrize + self_loops build the pattern of
+        A + A^T + I straight from a citation edge list, i.e. what the reference's loader produces through
+        `adj + adj.T.multiply(adj.T > adj) - ...` and `normalize_adj(adj + sp.eye(n))` before densifying
+        (utils.py:49-55); the values of that normalisation are never used by any layer (layers.py:41,129)."""
+        row, col = row.long(), col.long()
+        if symmetrize:
+            row, col = torch.cat([row, col]), torch.cat([col, row])
+        if self_loops:
+            d = torch.arange(n, device=row.device)
+            row, col = torch.cat([row, d]), torch.cat([col, d])
+        key = torch.unique(row * n + col)
         r, c = key // n, key % n
         rowptr = torch.zeros(n + 1, dtype=torch.int64, device=row.device)
         rowptr[1:] = torch.cumsum(torch.bincount(r, minlength=n), 0)

@@ -469,3 +469,20 @@ def test_backward_head_range(pg, backward_mode, H, Fo, rng):
     assert float(dW_r[~sel].abs().max()) == 0.0 and float(da_r[~sel].abs().max()) == 0.0
     with pytest.raises(ValueError):
         pg.GATLevelFn.apply(x.to(dev), W.float().to(dev).requires_grad_(True), a.float().to(dev), None, g, 0.2, True, (H - 1, 2))
+
+
+def test_edge_list_intake_symmetrize_self_loops(pg, topologies):
+    """CSRGraph.from_edge_index(symmetrize, self_loops) rebuilds the A + A^T + I pattern of utils.py:49-52 from a
+    one-directional edge list: the Cora fixture (built that way on the CPU from data/cora/cora.cites) comes back
+    bit for bit from its strict upper triangle."""
+    rowptr, col = topologies["cora"]
+    N = len(rowptr) - 1
+    rows = np.repeat(np.arange(N), np.diff(rowptr))
+    keep = rows < col                                  # one direction, no diagonal
+    dev = "cuda:0"
+    r = torch.as_tensor(rows[keep], device=dev); c = torch.as_tensor(col[keep].astype(np.int64), device=dev)
+    r = torch.cat([r, r[:7]]); c = torch.cat([c, c[:7]])   # duplicates are dropped
+    g = pg.CSRGraph.from_edge_index(r, c, N, symmetrize=True, self_loops=True)
+    assert np.array_equal(g.fwd.rowptr.cpu().numpy(), rowptr) and np.array_equal(g.fwd.col.cpu().numpy(), col)
+    plain = pg.CSRGraph.from_edge_index(torch.as_tensor(rows, device=dev), torch.as_tensor(col.astype(np.int64), device=dev), N)
+    assert np.array_equal(plain.fwd.col.cpu().numpy(), col)

@@ -131,3 +131,25 @@ def test_dropin_constructor_and_state_dict_cpu(lib):
     assert "attention_layer_3_head_6.skip_projection" in keys and len(keys) == (4 + 4 + 6) * 3
     assert tuple(m.state_dict()["attention_layer_2_head_1.W"].shape) == (1024, 256)
     assert tuple(m.state_dict()["attention_layer_3_head_1.W"].shape) == (1024, 121)
+
+
+def test_host_policies(lib, monkeypatch):
+    """Pure host decisions of the python layer (no kernel involved): slot length by graph size, backward flavour by
+    row width, K slabs of the GEMM wrapper."""
+    from pygat_amd import ops
+    from pygat_amd.graph import auto_slot_edges, slot_edges_for
+    assert auto_slot_edges(13_264) == 4 and auto_slot_edges(108_365) == 8 and auto_slot_edges(10_758_702) == 64
+    assert slot_edges_for(16, 64) == 32 and slot_edges_for(128, 64) == 64 and slot_edges_for(16, 8) == 8
+    monkeypatch.setattr(ops, "TWO_GATHER_BACKWARD", None)
+    assert ops.two_gather_backward(16) and ops.two_gather_backward(32) and not ops.two_gather_backward(64)
+    monkeypatch.setattr(ops, "TWO_GATHER_BACKWARD", True)
+    assert ops.two_gather_backward(1024)
+    monkeypatch.setattr(ops, "TWO_GATHER_BACKWARD", False)
+    assert not ops.two_gather_backward(16)
+    # streamed-K weight gradient: slabs x column tiles = 256 (one work-group per CU)
+    assert ops._split_k(128, 128, 1 << 20, streamed_k=True) == 256
+    assert ops._split_k(128, 136, 1 << 20, streamed_k=True) == 256      # [dWh | ds]: still one 5-tile column block
+    assert ops._split_k(128, 520, 1 << 20, streamed_k=True) == 51
+    # general kernel: the dropout projection shapes get more than "one work-group per CU"
+    assert ops._split_k(2708, 64, 11464) == 22 and ops._split_k(11464, 64, 2708, streamed_k=True) == 5
+    assert ops._split_k(1 << 20, 128, 128) == 1

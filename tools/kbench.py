@@ -75,12 +75,22 @@ def main():
         check(lib.pygat_gat_backward_col(graph.bwd.ref(), None, H, Fo, 0.2, P(Wh), P(a_pad), P(GR), None, P(ds),
                                          P(dWh), P(dt), None, P(part), 0, 0, None))
 
+    dz_t = torch.empty(E, H, device=dev)
+
+    def k4dz():   # default backward: K4 writes its dz per transposed edge ...
+        check(lib.pygat_gat_backward_col(graph.bwd.ref(), None, H, Fo, 0.2, P(Wh), P(a_pad), P(GR), None, None,
+                                         P(dWh), P(dt), P(dz_t), P(part), 0, 0, None))
+
+    def k3c():    # ... and the row sums are taken from those records
+        check(lib.pygat_gat_backward_rowsum(graph.fwd.ref(), graph.perm_f.data_ptr(), H, Fo, P(dz_t), P(ds), P(part), 0, 0, None))
+
     b_fwd = E * (4 + 4 * H + 4 * R) + N * (4 + 4 * H + 4 * R + 8 * H)
     b_k3a = N * (12 * R + 12 * H + 16 * H)
     b_k3 = E * (4 + 4 * R + 8 * H) + N * (4 + 8 * R + 16 * H)
     b_k4 = E * (8 + 4 * R + 8 * H) + N * (4 + 8 * R + 8 * H)
     runs = [("k2_train", lambda: k2(True), b_fwd), ("k2_eval", lambda: k2(False), b_fwd - N * 8 * H),
-            ("k3a_prep", k3a, b_k3a), ("k3b_row", k3b, b_k3 - b_k3a), ("k4_col", k4, b_k4)]
+            ("k3a_prep", k3a, b_k3a), ("k3b_row", k3b, b_k3 - b_k3a), ("k4_col", k4, b_k4),
+            ("k4_col_dz", k4dz, b_k4 + E * 4 * H), ("k3c_rowsum", k3c, E * (12 + 4 * H) + N * 4 * H)]
     if args.only:
         runs = [r for r in runs if r[0] in args.only.split(",")]
     deg = (rowptr[1:] - rowptr[:-1])

@@ -14,6 +14,9 @@ def load():
     lib.gat_oracle_level.argtypes = [C.c_int64, C.c_int64, p, p, p, p, p, C.c_int, C.c_int, C.c_int, C.c_float,
                                      C.c_int, p, p, p, p, p, p, p, p]
     lib.gat_oracle_level.restype = C.c_int
+    lib.gat_oracle_level_f64.argtypes = [C.c_int64, C.c_int64, p, p, p, p, p, C.c_int, C.c_int, C.c_int, C.c_double,
+                                         C.c_int, p, p, p, p, p, p, p, p]
+    lib.gat_oracle_level_f64.restype = C.c_int
     lib.gat_oracle_threads.restype = C.c_int
     return lib
 
@@ -28,17 +31,20 @@ def transpose_pattern(rowptr, col):
     return rp_t.astype(np.int32), src[order].astype(np.int32), order.astype(np.int32)
 
 
-def level(X, rowptr, col, W, a, alpha, concat, G, want_dx=True, lib=None, tp=None):
+def level(X, rowptr, col, W, a, alpha, concat, G, want_dx=True, lib=None, tp=None, dtype=np.float32):
+    """dtype=np.float32: the fp32 port (gat_oracle_level); np.float64: the same source built with REAL = double
+    (gat_oracle_level_f64) -- ground truth for the full-size tests."""
     lib = lib or load()
-    X = np.ascontiguousarray(X, dtype=np.float32); W = np.ascontiguousarray(W, dtype=np.float32)
-    a = np.ascontiguousarray(a, dtype=np.float32); G = np.ascontiguousarray(G, dtype=np.float32)
+    X = np.ascontiguousarray(X, dtype=dtype); W = np.ascontiguousarray(W, dtype=dtype)
+    a = np.ascontiguousarray(a, dtype=dtype); G = np.ascontiguousarray(G, dtype=dtype)
     rowptr = np.ascontiguousarray(rowptr, dtype=np.int32); col = np.ascontiguousarray(col, dtype=np.int32)
     rp_t, col_t, perm_t = tp if tp is not None else transpose_pattern(rowptr, col)
     N, Fin = X.shape; H, _, F = W.shape
     out = np.empty_like(G); dW = np.empty_like(W); da = np.empty_like(a)
     dX = np.empty_like(X) if want_dx else None
     ptr = lambda v: None if v is None else v.ctypes.data
-    rc = lib.gat_oracle_level(N, len(col), ptr(rowptr), ptr(col), ptr(rp_t), ptr(col_t), ptr(perm_t), Fin, H, F,
+    fn = lib.gat_oracle_level_f64 if np.dtype(dtype) == np.float64 else lib.gat_oracle_level
+    rc = fn(N, len(col), ptr(rowptr), ptr(col), ptr(rp_t), ptr(col_t), ptr(perm_t), Fin, H, F,
                               alpha, int(concat), ptr(X), ptr(W), ptr(a), ptr(G), ptr(out), ptr(dW), ptr(da), ptr(dX))
     if rc != 0:
         raise MemoryError("gat_oracle_level: allocation failed")

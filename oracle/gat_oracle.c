@@ -21,8 +21,24 @@
  *   out  = ELU(hp) if concat else hp               layers.py:168-173; heads concatenated
  *          (models.py:32) or averaged (models.py:34)
  *   backward = chain rule through the above, per edge (no N x N as in layers.py:85).
+ *
+ * Built twice from this one source (oracle/Makefile): REAL = float -> gat_oracle_level (fp32 like the
+ * reference; long sums already run in double), and -DORACLE_F64 -> gat_oracle_level_f64, the fp64 ground
+ * truth the full-size GPU tests price BOTH fp32 implementations against (forward atol 1e-5,
+ * gradients <= max(1e-5, 4 x the fp32 oracle's own error against fp64)).
  */
 #include <math.h>
+#ifdef ORACLE_F64
+typedef double REAL;
+#define FN(name) name##_f64
+#define EXPR(x) exp(x)
+#define EXPM1R(x) expm1(x)
+#else
+typedef float REAL;
+#define FN(name) name
+#define EXPR(x) expf(x)
+#define EXPM1R(x) expm1f(x)
+#endif
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -30,7 +46,7 @@
 #include <omp.h>
 #endif
 
-int gat_oracle_threads(void) {
+int FN(gat_oracle_threads)(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();
 #else
@@ -39,22 +55,22 @@ int gat_oracle_threads(void) {
 }
 
 /* C[M x N] = A[M x K] * B[K x N] (row-major), or with A transposed: C[M x N] = A[K x M]^T B[K x N] */
-static void gemm_nn(int64_t M, int N, int K, const float* A, const float* B, float* C) {
+static void gemm_nn(int64_t M, int N, int K, const REAL* A, const REAL* B, REAL* C) {
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < M; ++i) {
-    float* c = C + i * N;
-    for (int n = 0; n < N; ++n) c[n] = 0.f;
+    REAL* c = C + i * N;
+    for (int n = 0; n < N; ++n) c[n] = (REAL)0;
     for (int k = 0; k < K; ++k) {
-      const float a = A[i * K + k];
-      const float* b = B + (int64_t)k * N;
+      const REAL a = A[i * K + k];
+      const REAL* b = B + (int64_t)k * N;
       for (int n = 0; n < N; ++n) c[n] += a * b[n];
     }
   }
 }
 
 /* dW[K x N] = X[M x K]^T dWh[M x N]: per-thread private accumulators, reduced in thread order */
-static void gemm_tn(int64_t M, int N, int K, const float* X, const float* D, float* out) {
-  int nt = gat_oracle_threads();
+static void gemm_tn(int64_t M, int N, int K, const REAL* X, const REAL* D, REAL* out) {
+  int nt = FN(gat_oracle_threads)();
   double* acc = (double*)calloc((size_t)nt * K * N, sizeof(double));
 #pragma omp parallel
   {
@@ -69,7 +85,7 @@ static void gemm_tn(int64_t M, int N, int K, const float* X, const float* D, flo
       for (int k = 0; k < K; ++k) {
         const double x = X[i * K + k];
         if (x == 0.0) continue;
-        const float* d = D + i * N;
+        const REAL* d = D + i * N;
         double* r = a + (size_t)k * N;
         for (int n = 0; n < N; ++n) r[n] += x * d[n];
       }
@@ -77,7 +93,7 @@ static void gemm_tn(int64_t M, int N, int K, const float* X, const float* D, flo
   for (int64_t q = 0; q < (int64_t)K * N; ++q) {
     double s = 0;
     for (int t = 0; t < nt; ++t) s += acc[(size_t)t * K * N + q];
-    out[q] = (float)s;
+    out[q] = (REAL)s;
   }
   free(acc);
 }
@@ -90,34 +106,34 @@ static void gemm_tn(int64_t M, int N, int K, const float* X, const float* D, flo
  * outputs: out (same shape as G), dW [H x Fin x F], da [H x 2F], dX [N x Fin] (may be NULL).
  * returns 0, or -1 on allocation failure.
  */
-int gat_oracle_level(int64_t N, int64_t E, const int32_t* rowptr, const int32_t* col,
+int FN(gat_oracle_level)(int64_t N, int64_t E, const int32_t* rowptr, const int32_t* col,
                      const int32_t* rowptr_t, const int32_t* col_t, const int32_t* perm_t,
-                     int Fin, int H, int F, float alpha, int concat,
-                     const float* X, const float* W, const float* a, const float* G,
-                     float* out, float* dW, float* da, float* dX) {
-  float* Wh = (float*)malloc((size_t)N * F * sizeof(float));
-  float* s = (float*)malloc((size_t)N * sizeof(float));
-  float* t = (float*)malloc((size_t)N * sizeof(float));
-  float* hp = (float*)malloc((size_t)N * F * sizeof(float));
-  float* Gp = (float*)malloc((size_t)N * F * sizeof(float));
-  float* al = (float*)malloc((size_t)E * sizeof(float));
-  float* dz = (float*)malloc((size_t)E * sizeof(float));
-  float* ds = (float*)malloc((size_t)N * sizeof(float));
-  float* dt = (float*)malloc((size_t)N * sizeof(float));
-  float* dWh = (float*)malloc((size_t)N * F * sizeof(float));
+                     int Fin, int H, int F, REAL alpha, int concat,
+                     const REAL* X, const REAL* W, const REAL* a, const REAL* G,
+                     REAL* out, REAL* dW, REAL* da, REAL* dX) {
+  REAL* Wh = (REAL*)malloc((size_t)N * F * sizeof(REAL));
+  REAL* s = (REAL*)malloc((size_t)N * sizeof(REAL));
+  REAL* t = (REAL*)malloc((size_t)N * sizeof(REAL));
+  REAL* hp = (REAL*)malloc((size_t)N * F * sizeof(REAL));
+  REAL* Gp = (REAL*)malloc((size_t)N * F * sizeof(REAL));
+  REAL* al = (REAL*)malloc((size_t)E * sizeof(REAL));
+  REAL* dz = (REAL*)malloc((size_t)E * sizeof(REAL));
+  REAL* ds = (REAL*)malloc((size_t)N * sizeof(REAL));
+  REAL* dt = (REAL*)malloc((size_t)N * sizeof(REAL));
+  REAL* dWh = (REAL*)malloc((size_t)N * F * sizeof(REAL));
   if (!Wh || !s || !t || !hp || !Gp || !al || !dz || !ds || !dt || !dWh) return -1;
   const int OC = concat ? H * F : F;
-  if (!concat) memset(out, 0, (size_t)N * F * sizeof(float));
-  if (dX) memset(dX, 0, (size_t)N * Fin * sizeof(float));
+  if (!concat) memset(out, 0, (size_t)N * F * sizeof(REAL));
+  if (dX) memset(dX, 0, (size_t)N * Fin * sizeof(REAL));
 
   for (int h = 0; h < H; ++h) {
-    const float* Wm = W + (size_t)h * Fin * F;
-    const float* as = a + (size_t)h * 2 * F;
-    const float* ad = as + F;
+    const REAL* Wm = W + (size_t)h * Fin * F;
+    const REAL* as = a + (size_t)h * 2 * F;
+    const REAL* ad = as + F;
     gemm_nn(N, F, Fin, X, Wm, Wh);
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < N; ++i) {
-      float x = 0.f, y = 0.f;
+      REAL x = (REAL)0, y = (REAL)0;
       for (int f = 0; f < F; ++f) { x += Wh[i * F + f] * as[f]; y += Wh[i * F + f] * ad[f]; }
       s[i] = x; t[i] = y;
     }
@@ -125,63 +141,63 @@ int gat_oracle_level(int64_t N, int64_t E, const int32_t* rowptr, const int32_t*
 #pragma omp parallel for schedule(dynamic, 256)
     for (int64_t i = 0; i < N; ++i) {
       const int b = rowptr[i], e = rowptr[i + 1];
-      float m = -INFINITY;
+      REAL m = -INFINITY;
       for (int k = b; k < e; ++k) {
-        float z = s[i] + t[col[k]];
-        float ev = z > 0.f ? z : alpha * z;
+        REAL z = s[i] + t[col[k]];
+        REAL ev = z > (REAL)0 ? z : alpha * z;
         al[k] = ev;
         if (ev > m) m = ev;
       }
       /* row sums in double: a hub row has 10^4+ terms and fp32 running sums would make the ORACLE the
          less accurate side of the comparison */
       double Zd = 0.0;
-      for (int k = b; k < e; ++k) { al[k] = expf(al[k] - m); Zd += al[k]; }
-      const float Z = (float)Zd;
-      float* hr = hp + i * F;
+      for (int k = b; k < e; ++k) { al[k] = EXPR(al[k] - m); Zd += al[k]; }
+      const REAL Z = (REAL)Zd;
+      REAL* hr = hp + i * F;
       for (int f = 0; f < F; ++f) {
         double acc = 0.0;
         for (int k = b; k < e; ++k) acc += (double)al[k] * Wh[(int64_t)col[k] * F + f];
-        hr[f] = (float)acc;
+        hr[f] = (REAL)acc;
       }
       double D = 0.0;
       for (int f = 0; f < F; ++f) {
         hr[f] /= Z;
-        float g, o;
+        REAL g, o;
         if (concat) {
-          o = hr[f] > 0.f ? hr[f] : expm1f(hr[f]);
+          o = hr[f] > (REAL)0 ? hr[f] : EXPM1R(hr[f]);
           out[i * OC + h * F + f] = o;
-          g = G[i * OC + h * F + f] * (hr[f] > 0.f ? 1.f : expf(hr[f]));
+          g = G[i * OC + h * F + f] * (hr[f] > (REAL)0 ? (REAL)1 : EXPR(hr[f]));
         } else {
-          out[i * OC + f] += hr[f] / (float)H;
-          g = G[i * OC + f] / (float)H;
+          out[i * OC + f] += hr[f] / (REAL)H;
+          g = G[i * OC + f] / (REAL)H;
         }
         Gp[i * F + f] = g;
         D += (double)g * hr[f];
       }
       double dsi = 0.0;
       for (int k = b; k < e; ++k) {
-        const float* wj = Wh + (int64_t)col[k] * F;
-        float dp = 0.f;
+        const REAL* wj = Wh + (int64_t)col[k] * F;
+        REAL dp = (REAL)0;
         for (int f = 0; f < F; ++f) dp += Gp[i * F + f] * wj[f];
         al[k] /= Z;
-        float z = s[i] + t[col[k]];
-        dz[k] = al[k] * (dp - (float)D) * (z > 0.f ? 1.f : alpha);
+        REAL z = s[i] + t[col[k]];
+        dz[k] = al[k] * (dp - (REAL)D) * (z > (REAL)0 ? (REAL)1 : alpha);
         dsi += dz[k];
       }
-      ds[i] = (float)dsi;
+      ds[i] = (REAL)dsi;
     }
     /* column pass over the transposed pattern */
 #pragma omp parallel for schedule(dynamic, 256)
     for (int64_t j = 0; j < N; ++j) {
-      float* dr = dWh + j * F;
+      REAL* dr = dWh + j * F;
       double dtd = 0.0;
       for (int k = rowptr_t[j]; k < rowptr_t[j + 1]; ++k) dtd += dz[perm_t[k]];
-      const float dtj = (float)dtd;
+      const REAL dtj = (REAL)dtd;
       dt[j] = dtj;
       for (int f = 0; f < F; ++f) {
         double acc = 0.0;
         for (int k = rowptr_t[j]; k < rowptr_t[j + 1]; ++k) acc += (double)al[perm_t[k]] * Gp[(int64_t)col_t[k] * F + f];
-        dr[f] = (float)acc + ds[j] * as[f] + dtj * ad[f];
+        dr[f] = (REAL)acc + ds[j] * as[f] + dtj * ad[f];
       }
     }
     /* da */
@@ -189,15 +205,15 @@ int gat_oracle_level(int64_t N, int64_t E, const int32_t* rowptr, const int32_t*
       double x = 0, y = 0;
 #pragma omp parallel for reduction(+ : x, y) schedule(static)
       for (int64_t i = 0; i < N; ++i) { x += (double)ds[i] * Wh[i * F + f]; y += (double)dt[i] * Wh[i * F + f]; }
-      da[(size_t)h * 2 * F + f] = (float)x;
-      da[(size_t)h * 2 * F + F + f] = (float)y;
+      da[(size_t)h * 2 * F + f] = (REAL)x;
+      da[(size_t)h * 2 * F + F + f] = (REAL)y;
     }
     gemm_tn(N, F, Fin, X, dWh, dW + (size_t)h * Fin * F);
     if (dX) {
 #pragma omp parallel for schedule(static)
       for (int64_t i = 0; i < N; ++i)
         for (int k = 0; k < Fin; ++k) {
-          float acc = 0.f;
+          REAL acc = (REAL)0;
           for (int f = 0; f < F; ++f) acc += dWh[i * F + f] * Wm[(size_t)k * F + f];
           dX[i * Fin + k] += acc;
         }

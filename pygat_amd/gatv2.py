@@ -195,11 +195,6 @@ class _V2Base(nn.Module):
         self.dropout, self.in_features, self.out_features = dropout, in_features, out_features
         self.alpha, self.concat, self.skip_connection = alpha, concat, skip_connection
 
-    def _check_dropout(self):
-        if self.training and self.dropout > 0.0:
-            raise NotImplementedError("pygat_amd: train-mode dropout is not implemented for GraphAttentionLayerV2 "
-                                      "(the dense V2 layer); use SpGraphAttentionLayerV2, dropout=0 or eval()")
-
     def __repr__(self):  # layers.py:231-232,315-316
         return self.__class__.__name__ + ' (' + str(self.in_features) + ' -> ' + str(self.out_features) + ')'
 
@@ -218,9 +213,6 @@ class SpGraphAttentionLayerV2(_V2Base):
             self.skip_projection = nn.Parameter(torch.empty(size=(in_features, out_features)))
             nn.init.xavier_uniform_(self.skip_projection.data, gain=1.414)
 
-    def _check_dropout(self):   # the sparse V2 layer supports train-mode dropout
-        return None
-
     def forward(self, input, adj):
         return gatv2_level(input, as_graph(adj, self.pattern_mode), [self.W], [self.a],
                            [self.skip_projection] if self.skip_connection else None, self.alpha, self.concat,
@@ -229,7 +221,7 @@ class SpGraphAttentionLayerV2(_V2Base):
 
 class GraphAttentionLayerV2(_V2Base):
     """Same constructor / parameters / initialisers as reference layers.py:183-202; same function as
-    the reference computes (neighbour mean of h W[Fin:], see module docstring)."""
+    the reference computes (neighbour mean of h W[Fin:], see module docstring), train-mode dropout included."""
     pattern_mode = "positive"
 
     def __init__(self, in_features, out_features, dropout, alpha, concat=True, skip_connection=False):
@@ -242,11 +234,21 @@ class GraphAttentionLayerV2(_V2Base):
             self.skip_projection = nn.Parameter(torch.empty(size=(in_features, out_features)))
             nn.init.xavier_uniform_(self.skip_projection.data, gain=1.414)
 
-    def forward(self, h, adj):
-        self._check_dropout()
+    def forward(self, h, adj, masks=None):
+        """`masks` (tests only): explicit pre-scaled keep masks {"x" [1,N,Fin], "wh" [1,N,F'] (the Wh2 mask,
+        layers.py:212), "att" [E,1]} instead of in-kernel draws."""
         Fo = self.out_features
         zero_a = torch.zeros(2 * Fo, 1, dtype=self.W.dtype, device=self.W.device)   # uniform attention
-        out = gat_level(h, as_graph(adj, self.pattern_mode), [self.W[self.in_features:]], [zero_a],
-                        [self.skip_projection] if self.skip_connection else None, self.alpha, self.concat)
+        graph = as_graph(adj, self.pattern_mode)
+        skips = [self.skip_projection] if self.skip_connection else None
+        if self.training and self.dropout > 0.0:
+            # layers.py:206-221: dropout on h, on Wh1 and Wh2, on the attention; the skip term uses the dropped h
+            # (layers.py:225).  Wh1 only feeds the logits, which are constant along a row, so its mask never
+            # reaches the output: the layer is gat_level_dropout on W[Fin:] with a = 0.
+            from .dropout import gat_level_dropout
+            out = gat_level_dropout(h, graph, [self.W[self.in_features:]], [zero_a], skips, self.alpha, self.concat,
+                                    self.dropout, masks=masks)
+        else:
+            out = gat_level(h, graph, [self.W[self.in_features:]], [zero_a], skips, self.alpha, self.concat)
         # the reference's autograd gives a and W[:Fin] exactly-zero gradients (not None): keep them in the graph
         return out + 0.0 * (self.a.sum() + self.W[:self.in_features].sum())

@@ -119,6 +119,8 @@ class CSRGraph:
         self.nnz = col.numel()
         if self.nnz == 0:
             raise ValueError("CSRGraph: empty pattern")
+        if validate:
+            self._validate(rowptr, col)
         if slot_edges is None:
             slot_edges = auto_slot_edges(int(col.numel()))
         if slot_edges < 4 or slot_edges % 4:
@@ -142,6 +144,28 @@ class CSRGraph:
             self.bwd, self.perm_t, self.perm_f = self.fwd, perm, perm
         else:
             self._build_transpose()
+
+    @staticmethod
+    def _validate(rowptr: torch.Tensor, col: torch.Tensor):
+        """The kernels index Wh[col[k]] and rowptr[col[k]] unchecked: a malformed pattern would be an out-of-bounds
+        device access.  One pass of device-side checks at graph build (outside any timed region)."""
+        n, nnz = rowptr.numel() - 1, col.numel()
+        rp = rowptr.long()
+        deg = rp[1:] - rp[:-1]
+        bad_rp = (rp[0] != 0) | (rp[-1] != nnz) | (deg < 0).any()
+        bad_col = (col < 0).any() | (col >= n).any()
+        if bool(bad_rp | bad_col):
+            raise ValueError("CSRGraph: malformed CSR (need rowptr[0] == 0, rowptr[-1] == nnz, rowptr non-decreasing, "
+                             "0 <= col < n)")
+        if nnz > 1:
+            # columns strictly increasing inside every row (sorted, no duplicates): the mirror permutation of a
+            # symmetric pattern is found by binary search and must be a bijection
+            first = torch.zeros(nnz, dtype=torch.bool, device=col.device)
+            starts = rp[:-1][deg > 0]
+            first[starts] = True
+            if bool(((col[1:] <= col[:-1]) & ~first[1:]).any()):
+                raise ValueError("CSRGraph: columns must be strictly increasing within each row (sort and "
+                                 "de-duplicate the edge list; from_edge_index does)")
 
     def _build_transpose(self):
         rowptr, col = self.fwd.rowptr.long(), self.fwd.col.long()

@@ -9,7 +9,10 @@ list comprehension, models.py:32,34):
     last level   : mean(stack(heads, 1), 1)     -> head-mean kernel
 
 With `torch.distributed` initialised and `head_parallel=True` the heads of each level are sharded over
-the ranks (pygat_amd.dist).
+the ranks (pygat_amd.dist).  Every rank keeps ALL parameters (the module is a full replica, so `state_dict`
+has the reference's keys everywhere), but only the heads a rank owns receive gradients and are stepped by its
+optimiser: call `sync_head_parameters()` before `state_dict()` / checkpointing (train.py:201,233) or before
+switching `head_parallel` off.
 """
 from __future__ import annotations
 
@@ -23,10 +26,12 @@ from .ops import gat_level
 
 class GAT(nn.Module):
     def __init__(self, nfeat, nheads, nlayers, dropout, alpha, layer_type=GraphAttentionLayer,
-                 skip_connection=False, head_parallel=False):
+                 skip_connection=False, head_parallel=False, level_fn=None):
         super().__init__()
         self.dropout, self.alpha = dropout, alpha
         self.skip_connection, self.head_parallel = skip_connection, head_parallel
+        # test hook (CPU gloo tests of the sharding algebra swap the HIP level for the oracle); None = HIP path
+        self.level_fn = level_fn
         widths = [1] + list(nheads)          # heads feeding level i (the input counts as one head)
         self.gat_layers = []                 # plain lists like the reference: registration is by name below
         for lvl in range(nlayers):
@@ -43,7 +48,7 @@ class GAT(nn.Module):
                       else "v2sp" if issubclass(layer_type, SpGraphAttentionLayerV2) else "other")
 
     def forward(self, x, adj):
-        graph = as_graph(adj, self.pattern_mode)
+        graph = adj if self.level_fn is not None else as_graph(adj, self.pattern_mode)
         p_drop = self.dropout if self.training else 0.0
         for lvl, heads in enumerate(self.gat_layers):
             concat = lvl < len(self.gat_layers) - 1
@@ -53,15 +58,41 @@ class GAT(nn.Module):
                 continue
             Ws, As = [h.W for h in heads], [h.a for h in heads]
             Sk = [h.skip_projection for h in heads] if self.skip_connection else None
-            if self._kind == "v2sp":
+            fn = self.level_fn
+            if self._kind == "v2sp" and fn is None:
                 from .gatv2 import gatv2_level
-                x = gatv2_level(x, graph, Ws, As, Sk, self.alpha, concat, p_drop)
-            elif self.head_parallel:
+                fn = lambda x_, g_, W_, a_, sk_, al_, cc_: gatv2_level(x_, g_, W_, a_, sk_, al_, cc_, p_drop)  # noqa: E731
+            if self.head_parallel:
                 from .dist import gat_level_head_parallel
-                x = gat_level_head_parallel(x, graph, Ws, As, Sk, self.alpha, concat, p_drop)
+                x = gat_level_head_parallel(x, graph, Ws, As, Sk, self.alpha, concat, p_drop, level_fn=fn)
+            elif fn is not None:
+                x = fn(x, graph, Ws, As, Sk, self.alpha, concat)
             elif p_drop > 0.0:
                 from .dropout import gat_level_dropout
                 x = gat_level_dropout(x, graph, Ws, As, Sk, self.alpha, concat, p_drop)
             else:
                 x = gat_level(x, graph, Ws, As, Sk, self.alpha, concat)
         return x
+
+    @torch.no_grad()
+    def sync_head_parameters(self):
+        """Head-parallel training steps only the heads a rank owns (`dist.partition_heads`); the other heads'
+        parameters on that rank go stale.  This broadcasts every head's W / a / skip_projection from its owner
+        so that all replicas -- and hence `state_dict()` on any rank, which the reference saves every epoch and
+        reloads at the end (train.py:201,233) -- hold the trained values.  One flat buffer per (level, owner)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        from .dist import partition_heads
+        world = dist.get_world_size()
+        for heads in self.gat_layers:
+            for owner, (s, e) in enumerate(partition_heads(len(heads), world)):
+                ps = [p for h in heads[s:e] for p in h.parameters()]
+                if not ps:
+                    continue
+                flat = torch.cat([p.detach().reshape(-1) for p in ps])
+                dist.broadcast(flat, src=owner)
+                o = 0
+                for p in ps:
+                    p.copy_(flat[o:o + p.numel()].view_as(p))
+                    o += p.numel()

@@ -16,6 +16,41 @@ def _oracle_level(x, graph, Ws, As, Sk, alpha, concat):
     return O.level_forward(x, graph, W, a, alpha, concat, S, "sparse")
 
 
+def model_step_and_sync(rank, world):
+    """pygat_amd.GAT(head_parallel=True): one optimiser step moves only the owned heads; after
+    sync_head_parameters() every rank's state_dict equals the unsharded model's after the same step
+    (the reference checkpoints model.state_dict() every epoch, train.py:201,233)."""
+    import pygat_amd as pg
+    N = 30
+    graph = O.random_symmetric_csr(N, 4, 2)
+    torch.manual_seed(5)
+    kw = dict(nfeat=[5, 4, 3], nheads=[3, 3], nlayers=2, dropout=0.0, alpha=0.2, layer_type=pg.SpGraphAttentionLayer,
+              skip_connection=True, level_fn=_oracle_level)
+    sharded = pg.GAT(head_parallel=True, **kw).double()
+    plain = pg.GAT(**kw).double()
+    plain.load_state_dict(sharded.state_dict())
+    x = torch.randn(N, 5, dtype=torch.float64); G = torch.randn(N, 3, dtype=torch.float64)
+    before = {k: v.clone() for k, v in sharded.state_dict().items()}
+    for m in (sharded, plain):
+        opt = torch.optim.SGD(m.parameters(), lr=0.1)
+        m(x, graph).backward(G)
+        opt.step()
+    sd, ref = sharded.state_dict(), plain.state_dict()
+    stale = [k for k in sd if torch.equal(sd[k], before[k])]
+    assert stale, "with 3 heads on 2 ranks every rank has heads it does not own"
+    assert any(not torch.allclose(sd[k], ref[k], atol=1e-12) for k in stale)      # un-synced replicas differ
+    sharded.sync_head_parameters()
+    sd = sharded.state_dict()
+    assert list(sd) == list(ref)
+    for k in sd:
+        assert torch.allclose(sd[k], ref[k], atol=1e-12), k
+    # and every rank holds the same bytes
+    for k in sd:
+        t = sd[k].clone()
+        dist.broadcast(t, src=0)
+        assert torch.equal(t, sd[k]), k
+
+
 def main():
     rank, world, port, H2 = (int(v) for v in sys.argv[1:5])
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -49,6 +84,7 @@ def main():
                 assert torch.allclose(mine[k].grad, ref[k].grad, atol=1e-11), f"grad of local head {k}"
             else:               # non-local heads are never touched on this rank
                 assert mine[k].grad is None
+    model_step_and_sync(rank, world)
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank} ok")

@@ -12,8 +12,56 @@ sys.path.insert(0, ROOT)
 from oracle import gat_oracle as O  # noqa: E402
 
 
+def ppi(rank, world, pg, dev):
+    """BASELINE.json config 4: the PPI-shaped batch (tests/ppi_case.py) through the 4/4/6-head skip model with the
+    heads sharded over `world` ranks (last level: 6 heads -> 2/2/1/1 on 4 ranks), against the unsharded model on
+    the same card; then one Adam step + sync_head_parameters() and the state_dicts must agree."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import ppi_case as P
+    from pygat_amd.dist import partition_heads
+    parts = P.graphs()
+    batch = pg.CSRGraph.block_diag([pg.CSRGraph(torch.as_tensor(rp, device=dev), torch.as_tensor(c, device=dev))
+                                    for rp, c in parts])
+    if world == 4:
+        assert partition_heads(6, 4) == [(0, 2), (2, 4), (4, 5), (5, 6)]
+    torch.manual_seed(21)
+    kw = dict(nfeat=P.NFEAT, nheads=P.NHEADS, nlayers=3, dropout=0.0, alpha=0.2, layer_type=pg.SpGraphAttentionLayer,
+              skip_connection=True)
+    sharded = pg.GAT(head_parallel=True, **kw).to(dev)
+    plain = pg.GAT(**kw).to(dev)
+    plain.load_state_dict(sharded.state_dict())
+    x = torch.as_tensor(P.features(), device=dev)
+    G = torch.randn(batch.n, P.NFEAT[-1], generator=torch.Generator().manual_seed(4)).to(dev)
+    opts = [torch.optim.Adam(m.parameters(), lr=5e-3, weight_decay=0.0) for m in (sharded, plain)]   # train_ppi.py:64
+    y = sharded(x, batch); y.backward(G)
+    yr = plain(x, batch); yr.backward(G)
+    assert float((y - yr).abs().max()) < 2e-5, float((y - yr).abs().max())
+    ps, pr = dict(sharded.named_parameters()), dict(plain.named_parameters())
+    for lvl, H in enumerate(P.NHEADS, start=1):
+        s, e = partition_heads(H, world)[rank]
+        for h in range(H):
+            for nm in ("W", "a", "skip_projection"):
+                key = f"attention_layer_{lvl}_head_{h + 1}.{nm}"
+                if s <= h < e:
+                    scale = max(1.0, float(pr[key].grad.abs().max()))
+                    assert float((ps[key].grad - pr[key].grad).abs().max()) < 5e-5 * scale, key
+                else:
+                    assert ps[key].grad is None, key
+    for o in opts:
+        o.step()
+    sharded.sync_head_parameters()
+    sd, ref = sharded.state_dict(), plain.state_dict()
+    assert list(sd) == list(ref)
+    for k in sd:          # Adam's first step is lr * sign(g) up to eps: tiny gradient differences barely move it
+        assert float((sd[k] - ref[k]).abs().max()) < 1e-4, (k, float((sd[k] - ref[k]).abs().max()))
+        t = sd[k].clone()
+        dist.broadcast(t, src=0)
+        assert torch.equal(t, sd[k]), k            # identical bytes on every rank after the sync
+
+
 def main():
     rank, world, port = (int(v) for v in sys.argv[1:4])
+    mode = sys.argv[4] if len(sys.argv) > 4 else "small"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -21,6 +69,13 @@ def main():
     from pygat_amd.dist import partition_heads
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
+    if mode == "ppi":
+        ppi(rank, world, pg, dev)
+        torch.cuda.synchronize()
+        dist.barrier()
+        dist.destroy_process_group()
+        print(f"rank {rank} ok")
+        return
     N = 300
     rowptr, col = O.random_symmetric_csr(N, 6, 1, hub=(2, 150))
     g = pg.CSRGraph(torch.as_tensor(rowptr, device=dev), torch.as_tensor(col, device=dev))
@@ -54,6 +109,20 @@ def main():
     t = yd.detach().clone()
     dist.broadcast(t, src=0)
     assert torch.equal(t, yd.detach())                  # all-reduce result identical on every rank
+    # SpGraphAttentionLayerV2 levels shard the same way (layers.py:234-316 heads are independent too)
+    torch.manual_seed(3)
+    v2s = pg.GAT([10, 8, 5], [3, 2], 2, 0.0, 0.2, pg.SpGraphAttentionLayerV2, skip_connection=True, head_parallel=True).to(dev)
+    v2p = pg.GAT([10, 8, 5], [3, 2], 2, 0.0, 0.2, pg.SpGraphAttentionLayerV2, skip_connection=True).to(dev)
+    v2p.load_state_dict(v2s.state_dict())
+    G2 = torch.randn(N, 5, generator=gen).to(dev)
+    y2 = v2s(x, g); y2.backward(G2)
+    y2r = v2p(x, g); y2r.backward(G2)
+    assert float((y2 - y2r).abs().max()) < 2e-5
+    s0, e0 = partition_heads(3, world)[rank]
+    for h in range(s0, e0):
+        key = f"attention_layer_1_head_{h + 1}.W"
+        gs_, gr_ = dict(v2s.named_parameters())[key].grad, dict(v2p.named_parameters())[key].grad
+        assert float((gs_ - gr_).abs().max()) < 5e-5 * max(1.0, float(gr_.abs().max())), key
     torch.cuda.synchronize()
     dist.barrier()
     dist.destroy_process_group()

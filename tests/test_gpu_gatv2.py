@@ -132,3 +132,48 @@ def test_sparse_v2_dropout_explicit_masks(pg, H, Fin, Fo, skip, concat):  # noqa
     close(torch.stack([w.grad.reshape(-1) for w in As]), gr[2].numpy(), "da")
     if skip:
         close(torch.stack([w.grad for w in Ss]), gr[3].numpy(), "dW_skip")
+
+
+@pytest.mark.parametrize("skip,concat", [(False, True), (True, True), (True, False)])
+def test_dense_v2_dropout_explicit_masks(pg, skip, concat):  # noqa: F811
+    """GraphAttentionLayerV2 in train mode (the reference's `--model GATv2` default, train.py:54,116: dropout 0.6):
+    explicit masks through the same kernels against oracle.dense_head_forward_v2 (layers.py:206-230), all gradients,
+    including the exactly-zero ones of `a` and W[:Fin]."""
+    N, Fin, Fo, p = 70, 12, 8, 0.6
+    rowptr, col = O.random_symmetric_csr(N, 5, 3, hub=(2, 40))
+    E = len(col)
+    adj = O.dense_from_csr(rowptr, col, N, dtype=torch.float64)
+    gen = torch.Generator().manual_seed(9)
+    keep = 1.0 - p
+    mk = lambda *s: (torch.rand(*s, generator=gen) < keep).double() / keep  # noqa: E731
+    mx, mwh1, mwh2, matt_e = mk(N, Fin), mk(N, Fo), mk(N, Fo), mk(E)
+    src = np.repeat(np.arange(N), np.diff(rowptr))
+    matt = torch.zeros(N, N, dtype=torch.float64)
+    matt[torch.as_tensor(src), torch.as_tensor(col.astype(np.int64))] = matt_e     # dense [N,N] mask, layers.py:220
+    torch.manual_seed(4)
+    layer = pg.GraphAttentionLayerV2(Fin, Fo, p, 0.2, concat=concat, skip_connection=skip).to("cuda:0").train()
+    x = torch.randn(N, Fin, generator=gen, dtype=torch.float64)
+    G = torch.randn(N, Fo, generator=gen, dtype=torch.float64)
+    leaves = [x.clone().requires_grad_(True), layer.W.detach().double().cpu().requires_grad_(True),
+              layer.a.detach().double().cpu().requires_grad_(True)]
+    if skip:
+        leaves.append(layer.skip_projection.detach().double().cpu().requires_grad_(True))
+    y = O.dense_head_forward_v2(leaves[0], adj, leaves[1], leaves[2], 0.2, concat, leaves[3] if skip else None,
+                                mask_x=mx, mask_wh1=mwh1, mask_wh2=mwh2, mask_att=matt)
+    gr = torch.autograd.grad(y, leaves, G, allow_unused=True)
+    dev = "cuda:0"
+    g = pg.CSRGraph(torch.as_tensor(rowptr, device=dev), torch.as_tensor(col, device=dev))
+    xd = x.float().to(dev).requires_grad_(True)
+    masks = {"x": mx.float().to(dev)[None], "wh": mwh2.float().to(dev)[None], "att": matt_e.float().to(dev)[:, None]}
+    out = layer(xd, g, masks=masks)
+    out.backward(G.float().to(dev))
+    close(out, y.detach().numpy(), "out")
+    close(xd.grad, gr[0].numpy(), "dX")
+    close(layer.W.grad, gr[1].numpy(), "dW")
+    assert float(layer.W.grad[:Fin].abs().max()) == 0.0 and float(layer.a.grad.abs().max()) == 0.0
+    assert gr[2] is None or float(gr[2].abs().max()) == 0.0
+    if skip:
+        close(layer.skip_projection.grad, gr[3].numpy(), "dW_skip")
+    # in-kernel masks: runs, finite, differs from eval
+    out2 = layer(xd, g)
+    assert torch.isfinite(out2).all() and float((out2 - layer.eval()(xd, g)).abs().max()) > 1e-3

@@ -486,3 +486,20 @@ def test_edge_list_intake_symmetrize_self_loops(pg, topologies):
     assert np.array_equal(g.fwd.rowptr.cpu().numpy(), rowptr) and np.array_equal(g.fwd.col.cpu().numpy(), col)
     plain = pg.CSRGraph.from_edge_index(torch.as_tensor(rows, device=dev), torch.as_tensor(col.astype(np.int64), device=dev), N)
     assert np.array_equal(plain.fwd.col.cpu().numpy(), col)
+
+
+@pytest.mark.parametrize("rowptr,col", [
+    ([0, 2, 3, 5], [0, 3, 1, 0, 2]),        # column index out of range
+    ([0, 2, 3, 5], [0, -1, 1, 0, 2]),       # negative column index
+    ([0, 3, 2, 5], [0, 1, 1, 0, 2]),        # rowptr not monotone
+    ([0, 2, 3, 4], [0, 1, 1, 0, 2]),        # rowptr[-1] != nnz
+    ([1, 2, 3, 5], [0, 1, 1, 0, 2]),        # rowptr[0] != 0
+    ([0, 2, 3, 5], [1, 0, 1, 0, 2]),        # unsorted row
+    ([0, 2, 3, 5], [0, 0, 1, 0, 2]),        # duplicate column in a row
+])
+def test_malformed_csr_rejected(pg, rowptr, col):
+    """A bad pattern must be a ValueError at graph build, never an out-of-bounds gather in a kernel."""
+    with pytest.raises(ValueError):
+        pg.CSRGraph(torch.tensor(rowptr, dtype=torch.int32, device="cuda"), torch.tensor(col, dtype=torch.int32, device="cuda"))
+    with pytest.raises(ValueError):
+        pg.as_graph((torch.tensor(rowptr, dtype=torch.int32, device="cuda"), torch.tensor(col, dtype=torch.int32, device="cuda")))

@@ -43,3 +43,19 @@ def test_c_oracle_asymmetric_pattern(clib):
     got = clib.level(X, rowptr, col, W, a, 0.2, True, G)
     for k in ("out", "dW", "da", "dX"):
         assert np.abs(got[k] - ref[k]).max() <= 1e-5 * max(1.0, np.abs(ref[k]).max()), k
+
+
+@pytest.mark.parametrize("concat", [True, False])
+def test_c_oracle_f64_build_is_the_python_oracle_in_fp64(clib, concat):
+    """The -DORACLE_F64 build (ground truth of the full-size GPU tests) against the python oracle run in
+    fp64: same algorithm, both in double -> agreement to rounding."""
+    N, Fin, F, H = 300, 24, 8, 4
+    rowptr, col = O.random_symmetric_csr(N, 6, 4, hub=(7, 180))
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((N, Fin)); W = rng.standard_normal((H, Fin, F)) * 0.3
+    a = rng.standard_normal((H, 2 * F)) * 0.3; G = rng.standard_normal((N, H * F if concat else F))
+    ref = O.csr_layer_fwd_bwd(X, rowptr, col, W, a, 0.2, concat, G)
+    got = clib.level(X, rowptr, col, W, a, 0.2, concat, G, dtype=np.float64)
+    for k in ("out", "dW", "da", "dX"):
+        assert got[k].dtype == np.float64
+        assert np.abs(got[k] - ref[k]).max() <= 1e-11 * max(1.0, np.abs(ref[k]).max()), k

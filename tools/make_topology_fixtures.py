@@ -11,6 +11,7 @@ the D^-1/2 (A+I) D^-1/2 values of utils.py:73-79 are not kept.
             utils.py:25-26) is unknown: ids are ranked in ascending order here.
   citeseer  citeseer_dgl/adj_sparse.npz (utils.py:45), COO, self loops included
   pubmed    pubmed_dgl/adj_sparse.npz   (utils.py:45)
+  ppi       data/ppi/*_graph_id.npy -> per-graph node counts; data/ppi/valid_feats.npy -> a 1612-row sample
   labels    {citeseer,pubmed}_dgl/labels.pt, idx_{train,val,test}.pt (utils.py:40-43) -> *_labels.npz
 
 Output: rowptr int32 [N+1], col int32 [E] (sorted within a row).
@@ -64,6 +65,11 @@ def main():
         counts[split] = cnt.astype(np.int32)
         print(f"ppi {split}: {len(cnt)} graphs, nodes {cnt.min()}..{cnt.max()}, total {cnt.sum()}")
     np.savez_compressed(os.path.join(OUT, "ppi_graph_sizes.npz"), **counts)
+    # PPI node features: the first 591 + 1021 rows of valid_feats.npy (load_data_ppi.py:110-121 reads these files;
+    # train_feats.npy is a missing blob), enough for one PPI-shaped batch of two graphs
+    vf = np.load(f"{REF}/data/ppi/valid_feats.npy", allow_pickle=False)
+    np.savez_compressed(os.path.join(OUT, "ppi_feats_sample.npz"), feats=vf[:591 + 1021].astype(np.float32))
+    print("ppi feats sample:", vf[:1612].shape, "range", float(vf[:1612].min()), float(vf[:1612].max()))
 
 
 if __name__ == "__main__":

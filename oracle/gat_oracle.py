@@ -71,8 +71,19 @@ def dense_head_forward(h, adj, W, a, alpha, concat, W_skip=None,
 # --------------------------------------------------------------------------
 # single head, sparse (edge-list) formulation -- layers.py:125-173
 # --------------------------------------------------------------------------
+def _leaky(z, alpha, flip=None):
+    """LeakyReLU (layers.py:30,144).  `flip` [E] bool marks edges whose branch is taken on the OTHER side of the
+    kink: for a logit within fp32 rounding distance of 0 the side -- and with it the derivative, 1 or alpha -- is
+    decided by rounding, so both sides are legitimate fp32 results (tests/parity.py, flip-aware comparison).
+    The forward value moves by at most (1 - alpha)|z|, i.e. nothing at that distance."""
+    if flip is None:
+        return F.leaky_relu(z, alpha)
+    pos = (z > 0) ^ torch.as_tensor(flip, dtype=torch.bool)
+    return torch.where(pos, z, alpha * z)
+
+
 def sparse_head_forward(h, rowptr, col, W, a, alpha, concat, W_skip=None,
-                        mask_x=None, mask_wh=None, mask_edge=None):
+                        mask_x=None, mask_wh=None, mask_edge=None, slope_flip=None):
     """One head of SpGraphAttentionLayer over a CSR pattern.
 
     The reference derives `edge = adj.nonzero().t()` (layers.py:129), which is
@@ -93,7 +104,7 @@ def sparse_head_forward(h, rowptr, col, W, a, alpha, concat, W_skip=None,
         Wh = Wh * mask_wh
     a = a.reshape(-1)
     # layers.py:141-144: a . [Wh_i ; Wh_j]  ==  a[:F].Wh_i + a[F:].Wh_j
-    edge_e = F.leaky_relu((Wh @ a[:Fo])[src] + (Wh @ a[Fo:])[col], alpha)
+    edge_e = _leaky((Wh @ a[:Fo])[src] + (Wh @ a[Fo:])[col], alpha, slope_flip)
     # layers.py:145: torch_scatter.scatter_max(edge_e, edge[0]) -> per-row max
     m = torch.full((N,), -float("inf"), dtype=h.dtype).scatter_reduce(
         0, src, edge_e.detach(), "amax", include_self=True)
@@ -188,7 +199,7 @@ def level_forward_v2(x, graph, Ws, As, alpha, concat, W_skips=None, formulation=
 # one GAT level = all heads of one layer -- models.py:29-35
 # --------------------------------------------------------------------------
 def level_forward(x, graph, Ws, As, alpha, concat, W_skips=None,
-                  formulation="sparse", masks=None):
+                  formulation="sparse", masks=None, flips=None):
     """All heads of one level.  Ws [H,Fin,F], As [H,2F], W_skips [H,Fin,F]|None.
 
     concat=True  -> hidden level: cat(heads, dim=1), each head ELU'd (models.py:32)
@@ -196,6 +207,7 @@ def level_forward(x, graph, Ws, As, alpha, concat, W_skips=None,
     graph: (rowptr, col) for "sparse", dense adj for "dense".
     masks: optional dict of per-head pre-scaled masks {"x":[H,N,Fin],
            "wh":[H,N,F], "att":[H,E] (sparse) or [H,N,N] (dense)}.
+    flips: optional [H,E] bool, LeakyReLU branch overrides (sparse formulation only, see `_leaky`).
     """
     outs = []
     for hd in range(Ws.shape[0]):
@@ -206,27 +218,44 @@ def level_forward(x, graph, Ws, As, alpha, concat, W_skips=None,
                                    mk.get("x"), mk.get("wh"), mk.get("att"))
         else:
             o = sparse_head_forward(x, graph[0], graph[1], Ws[hd], As[hd].reshape(1, -1), alpha,
-                                    concat, sk, mk.get("x"), mk.get("wh"), mk.get("att"))
+                                    concat, sk, mk.get("x"), mk.get("wh"), mk.get("att"),
+                                    None if flips is None else flips[hd])
         outs.append(o)
     if concat:
         return torch.cat(outs, dim=1)
     return torch.mean(torch.stack(outs, dim=1), dim=1)
 
 
-def model_forward(x, graph, levels, alpha, formulation="sparse"):
+def model_forward(x, graph, levels, alpha, formulation="sparse", flips=None):
     """models.GAT.forward (eval mode): `levels` is a list of dicts
     {"W":[H,Fin,F], "a":[H,2F], "skip":[H,Fin,F]|None}; every level but the
     last concatenates (models.py:23,30-34)."""
     for li, lv in enumerate(levels):
         x = level_forward(x, graph, lv["W"], lv["a"], alpha, li < len(levels) - 1,
-                          lv.get("skip"), formulation)
+                          lv.get("skip"), formulation, flips=None if flips is None else flips[li])
     return x
+
+
+def model_logits_z(x, graph, levels, alpha):
+    """Per level, the pre-activation logits z_ij = s_i + t_j of every head and edge, [H,E], and their rounding
+    scale |s_i| + |t_j| (eval mode, no grad): what the flip-aware comparison screens for kinks."""
+    rowptr = torch.as_tensor(graph[0], dtype=torch.int64); col = torch.as_tensor(graph[1], dtype=torch.int64)
+    src = torch.repeat_interleave(torch.arange(x.shape[0]), rowptr[1:] - rowptr[:-1])
+    out = []
+    with torch.no_grad():
+        for li, lv in enumerate(levels):
+            Fo = lv["W"].shape[2]
+            Wh = torch.einsum("nk,hkf->hnf", x, lv["W"])
+            s = torch.einsum("hnf,hf->hn", Wh, lv["a"][:, :Fo]); t = torch.einsum("hnf,hf->hn", Wh, lv["a"][:, Fo:])
+            out.append((s[:, src] + t[:, col], s[:, src].abs() + t[:, col].abs()))
+            x = level_forward(x, graph, lv["W"], lv["a"], alpha, li < len(levels) - 1, lv.get("skip"), "sparse")
+    return out
 
 
 # --------------------------------------------------------------------------
 # hand-derived CSR forward+backward (the math the HIP kernels implement)
 # --------------------------------------------------------------------------
-def csr_layer_fwd_bwd(X, rowptr, col, Ws, As, alpha, concat, G, W_skips=None):
+def csr_layer_fwd_bwd(X, rowptr, col, Ws, As, alpha, concat, G, W_skips=None, flips=None):
     """Multi-head level, eval mode / dropout 0, explicit gradients (numpy).
 
     Follows the same forward as sparse_head_forward; the backward is the chain
@@ -239,7 +268,10 @@ def csr_layer_fwd_bwd(X, rowptr, col, Ws, As, alpha, concat, G, W_skips=None):
         da_src = sum_i ds_i Wh_i ; da_dst = sum_j dt_j Wh_j
         dW = X^T dWh ; dX = dWh W^T (+ G' W_skip^T) ; dW_skip = X^T G'
     G is dL/d(out) with out [N,H*F] (concat) or [N,F] (mean).
-    Returns dict(out, dX, dW [H,Fin,F], da [H,2F], dW_skip).
+    flips: optional [H,E] bool, LeakyReLU branch overrides (see `_leaky`).
+    Returns dict(out, dX, dW [H,Fin,F], da [H,2F], dW_skip) plus what the flip-aware comparison of
+    tests/parity.py needs: z [H,E], zscale [H,E] = |s_i| + |t_j|, de [H,E] (dL/de_ij before the LeakyReLU slope),
+    Wh [H,N,F].
     """
     X = np.asarray(X); dt_ = X.dtype
     rowptr = np.asarray(rowptr, dtype=np.int64); col = np.asarray(col, dtype=np.int64)
@@ -248,12 +280,15 @@ def csr_layer_fwd_bwd(X, rowptr, col, Ws, As, alpha, concat, G, W_skips=None):
     deg = np.diff(rowptr); src = np.repeat(np.arange(N), deg)
     outs = []; dX = np.zeros_like(X); dW = np.zeros_like(Ws); dA = np.zeros_like(As)
     dSk = None if W_skips is None else np.zeros_like(np.asarray(W_skips, dtype=dt_))
+    zs, zscales, des, Whs = [], [], [], []
     for h in range(H):
         W = Ws[h]; a_s = As[h, :Fo]; a_d = As[h, Fo:]
         Wh = X @ W
         s = Wh @ a_s; t = Wh @ a_d
         z = s[src] + t[col]
-        e = np.where(z > 0, z, alpha * z)
+        zs.append(z); zscales.append(np.abs(s[src]) + np.abs(t[col]))
+        pos = (z > 0) if flips is None else ((z > 0) ^ np.asarray(flips[h], dtype=bool))
+        e = np.where(pos, z, alpha * z)
         m = np.full(N, -np.inf, dtype=dt_); np.maximum.at(m, src, e)
         p = np.exp(e - m[src])
         Z = np.zeros(N, dtype=dt_); np.add.at(Z, src, p)
@@ -268,7 +303,8 @@ def csr_layer_fwd_bwd(X, rowptr, col, Ws, As, alpha, concat, G, W_skips=None):
         dp = np.einsum("ef,ef->e", Gp[src], Wh[col])
         D = np.zeros(N, dtype=dt_); np.add.at(D, src, al * dp)
         de = al * (dp - D[src])
-        dz = de * np.where(z > 0, 1.0, alpha).astype(dt_)
+        des.append(de); Whs.append(Wh)
+        dz = de * np.where(pos, 1.0, alpha).astype(dt_)
         ds = np.zeros(N, dtype=dt_); np.add.at(ds, src, dz)
         dtt = np.zeros(N, dtype=dt_); np.add.at(dtt, col, dz)
         dWh = np.zeros((N, Fo), dtype=dt_); np.add.at(dWh, col, al[:, None] * Gp[src])
@@ -281,7 +317,8 @@ def csr_layer_fwd_bwd(X, rowptr, col, Ws, As, alpha, concat, G, W_skips=None):
             dSk[h] = X.T @ Gp
             dX += Gp @ Sk.T
     out = np.concatenate(outs, 1) if concat else np.mean(np.stack(outs, 1), 1)
-    return dict(out=out, dX=dX, dW=dW, da=dA, dW_skip=dSk)
+    return dict(out=out, dX=dX, dW=dW, da=dA, dW_skip=dSk, z=np.stack(zs), zscale=np.stack(zscales),
+                de=np.stack(des), Wh=np.stack(Whs))
 
 
 # --------------------------------------------------------------------------

@@ -15,7 +15,7 @@ from oracle import gat_oracle as O  # noqa: E402
 def ppi(rank, world, pg, dev):
     """BASELINE.json config 4: the PPI-shaped batch (tests/ppi_case.py) through the 4/4/6-head skip model with the
     heads sharded over `world` ranks (last level: 6 heads -> 2/2/1/1 on 4 ranks), against the unsharded model on
-    the same card; then one Adam step + sync_head_parameters() and the state_dicts must agree."""
+    the same card; then one optimiser step + sync_head_parameters() and the state_dicts must agree."""
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import ppi_case as P
     from pygat_amd.dist import partition_heads
@@ -32,7 +32,9 @@ def ppi(rank, world, pg, dev):
     plain.load_state_dict(sharded.state_dict())
     x = torch.as_tensor(P.features(), device=dev)
     G = torch.randn(batch.n, P.NFEAT[-1], generator=torch.Generator().manual_seed(4)).to(dev)
-    opts = [torch.optim.Adam(m.parameters(), lr=5e-3, weight_decay=0.0) for m in (sharded, plain)]   # train_ppi.py:64
+    # plain SGD: the step is linear in the gradient, so rounding differences between the sharded and the unsharded
+    # gradients stay rounding differences in the parameters (Adam's first step is lr * g / (|g| + 1e-8): sign-like)
+    opts = [torch.optim.SGD(m.parameters(), lr=1e-3) for m in (sharded, plain)]
     y = sharded(x, batch); y.backward(G)
     yr = plain(x, batch); yr.backward(G)
     assert float((y - yr).abs().max()) < 2e-5, float((y - yr).abs().max())
@@ -52,8 +54,8 @@ def ppi(rank, world, pg, dev):
     sharded.sync_head_parameters()
     sd, ref = sharded.state_dict(), plain.state_dict()
     assert list(sd) == list(ref)
-    for k in sd:          # Adam's first step is lr * sign(g) up to eps: tiny gradient differences barely move it
-        assert float((sd[k] - ref[k]).abs().max()) < 1e-4, (k, float((sd[k] - ref[k]).abs().max()))
+    for k in sd:
+        assert float((sd[k] - ref[k]).abs().max()) < 1e-5, (k, float((sd[k] - ref[k]).abs().max()))   # steps up to ~1 in size
         t = sd[k].clone()
         dist.broadcast(t, src=0)
         assert torch.equal(t, sd[k]), k            # identical bytes on every rank after the sync

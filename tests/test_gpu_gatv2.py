@@ -87,8 +87,9 @@ def test_v2_dropin_layers_and_model(pg, topologies):  # noqa: F811
     close(y, ref.numpy(), "GATv2_sparse model")
     y.sum().backward()
     assert all(p.grad is not None for p in m.parameters())
-    with pytest.raises(NotImplementedError):
-        pg.GraphAttentionLayerV2(Fin, Fo, 0.5, 0.2).cuda().train()(x.cuda(), adj.cuda())
+    # dense V2 in train mode (train.py:54,116 default for --model GATv2): runs (parity: test_dense_v2_dropout_explicit_masks)
+    yd = pg.GraphAttentionLayerV2(Fin, Fo, 0.5, 0.2).cuda().train()(x.cuda(), adj.cuda())
+    assert torch.isfinite(yd).all()
     # train-mode dropout of the sparse V2 layer: runs, differs between calls, has gradients
     m.dropout = 0.6
     for lay in m.modules():
@@ -171,7 +172,7 @@ def test_dense_v2_dropout_explicit_masks(pg, skip, concat):  # noqa: F811
     close(xd.grad, gr[0].numpy(), "dX")
     close(layer.W.grad, gr[1].numpy(), "dW")
     assert float(layer.W.grad[:Fin].abs().max()) == 0.0 and float(layer.a.grad.abs().max()) == 0.0
-    assert gr[2] is None or float(gr[2].abs().max()) == 0.0
+    assert gr[2] is None or float(gr[2].abs().max()) < 1e-10      # mathematically zero (uniform attention)
     if skip:
         close(layer.skip_projection.grad, gr[3].numpy(), "dW_skip")
     # in-kernel masks: runs, finite, differs from eval

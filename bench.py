@@ -8,16 +8,24 @@ Workload (BASELINE.json config 5 / SURVEY.md 8(d)): R-MAT scale 20 (N = 1,048,57
 5,000,000 edge draws with (a,b,c,d) = (0.57,0.19,0.19,0.05), seed 1, symmetrised, de-duplicated,
 self loops added (E ~ 10.76 M); X ~ N(0,1) [N,128]; 8 heads x F' = 16 (H*F' = 128); concat + ELU;
 eval-mode semantics (dropout 0); fp32.  A step = forward + backward of the level (dW, da; the
-input of a first level carries no gradient in the reference, train.py:132,158).
+input of a first level carries no gradient in the reference, train.py:132,158; --dx adds dX).
 
-N GPUs: heads sharded head-per-GPU (pygat_amd/dist.py): each rank projects and attends its
-H/N heads, an RCCL all-gather concatenates the head outputs, backward is local.  Total work is
-fixed -> "scaling": "strong".
+The step is the product path: the level captured once into two HIP graphs (pygat_amd.GraphedLevel)
+and replayed; --eager launches kernel by kernel instead.
 
-One JSON line on rank 0: value = E / step time (max over ranks), plus `roofline` for the
-dominant kernel (K2 fused edge-softmax+aggregate, HIP events around every launch in the timed
-region, algorithmic bytes of SURVEY.md 8(d)) and `cpu_baseline` (oracle/gat_oracle.c, the CPU
-port of the same level, timed on this host's cores; N=1 only).
+N GPUs: heads sharded head-per-GPU (pygat_amd/dist.py): each rank projects and attends its H/N
+heads, an RCCL all-gather over xGMI concatenates the head outputs (models.py:32) while the rank's
+backward runs; parameter gradients stay local.  Total work is fixed -> "scaling": "strong".
+(--forward-exchange replicate is a labelled experiment: no collective, every rank recomputes all
+heads' forward.)
+
+One JSON line on rank 0: value = E / step time (max over ranks, K steps between barriers), plus
+  roofline      the kernel with the largest share of the step (HIP events around every launch in an
+                instrumented pass of the same steps that follows the timed region -- a replayed HIP
+                graph cannot carry per-launch events -- SURVEY.md 8(d) algorithmic bytes / flops);
+  kernels       the same figures for every kernel of the step;
+  cpu_baseline  oracle/gat_oracle.c (CPU port of the same level) on this host's cores, N=1 only;
+  epoch_ms      Cora / Pubmed epochs (train.py:151-179) replayed from one HIP graph, N=1 only.
 """
 import argparse
 import json
@@ -32,6 +40,9 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TF = 157.3    # v_mfma_f32_32x32x2_f32, dense
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -44,17 +55,28 @@ def parse():
     ap.add_argument("--heads", type=int, default=8)
     ap.add_argument("--fout", type=int, default=16)
     ap.add_argument("--dx", action="store_true", help="also back-propagate into the input features")
+    ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying the captured level")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-epoch", action="store_true", help="skip the Cora / Pubmed epoch_ms leg")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--verify", action="store_true", help="check the gathered sharded output against the unsharded level")
-    ap.add_argument("--forward-exchange", choices=["auto", "allgather", "replicate"], default="auto",
-                    help="N>1, how every rank gets the other ranks' head outputs: RCCL all-gather over xGMI, or no "
-                         "collective at all -- run the forward of ALL heads (K1+K2) and back-propagate only the own ones "
-                         "(GATLevelFn bwd_heads).  auto = replicate at 2 and 4 GPUs (receiving 256 / 3x128 MB over 1 / 3 "
-                         "xGMI links takes longer than 0.4-0.9 ms of extra forward), all-gather at 8 (7 links in parallel)")
+    ap.add_argument("--forward-exchange", choices=["allgather", "replicate"], default="allgather",
+                    help="N>1, how every rank gets the other ranks' head outputs: RCCL all-gather over xGMI (default, the "
+                         "design of pygat_amd/dist.py), or -- experiment -- no collective: run the forward of ALL heads and "
+                         "back-propagate only the own ones (GATLevelFn bwd_heads)")
     ap.add_argument("--as-rank-of", type=int, default=0,
                     help="single process: run the work of rank 0 of a world of this size (per-rank time model, no collectives)")
     return ap.parse_args()
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(args, rowptr, col, X, W, a, G):
@@ -70,8 +92,51 @@ def cpu_baseline(args, rowptr, col, X, W, a, G):
         times.append(time.perf_counter() - t0)
     best = min(times)
     return {"value": len(col) / best, "unit": "edges/s", "cores": int(lib.gat_oracle_threads()), "kind": "port",
+            "cpu": cpu_model(),
             "sample": f"full workload (N={len(rowptr)-1}, E={len(col)}), best of {args.cpu_steps} fwd+bwd steps, "
                       f"{best:.2f} s/step, OpenMP C port oracle/gat_oracle.c"}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# second half of BASELINE.json's metric: epoch time on the reference's small configurations
+# ---------------------------------------------------------------------------------------------------------
+EPOCH_CFG = {  # train.py:47-87
+    "cora": dict(nheads=[8, 1], nfeats=[1433, 8, 7], dropout=0.6, lr=5e-3, wd=5e-4, ntrain=140),
+    "pubmed": dict(nheads=[8, 8], nfeats=[500, 8, 3], dropout=0.6, lr=1e-2, wd=1e-3, ntrain=60),
+}
+
+
+def epoch_ms(pg, dev, name, epochs=200):
+    """One epoch of train.py:151-179 (train step with dropout + eval forward) on the REAL topology
+    (tests/golden/<name>_csr.npz) with seeded synthetic features / labels (the reference's feature blobs are
+    missing), replayed from ONE HIP graph (pygat_amd.FusedEpoch)."""
+    import torch.nn.functional as F
+    c = EPOCH_CFG[name]
+    z = np.load(os.path.join(ROOT, "tests", "golden", f"{name}_csr.npz"), allow_pickle=False)
+    rowptr, col = z["rowptr"], z["col"]
+    N = len(rowptr) - 1
+    g = torch.Generator().manual_seed(72)
+    x = (torch.rand(N, c["nfeats"][0], generator=g) < 0.013).float()
+    x = (x / x.sum(1, keepdim=True).clamp(min=1)).to(dev)          # utils.normalize_features
+    y = torch.randint(0, c["nfeats"][-1], (N,), generator=g).to(dev)
+    it = torch.arange(c["ntrain"], device=dev)
+    graph = pg.CSRGraph(torch.as_tensor(rowptr, device=dev), torch.as_tensor(col, device=dev))
+    torch.manual_seed(72)
+    model = pg.GAT(c["nfeats"], c["nheads"], 2, c["dropout"], 0.2, pg.SpGraphAttentionLayer).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=c["lr"], weight_decay=c["wd"], capturable=True)
+    loss_fn = lambda out: F.nll_loss(F.log_softmax(F.elu(out), dim=1)[it], y[it])      # noqa: E731  train.py:151-152,159
+    ep = pg.FusedEpoch(model, opt, x, graph, loss_fn)
+    for _ in range(10):
+        ep.run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(epochs):
+        ep.run()
+    torch.cuda.synchronize()
+    return {"ms": (time.perf_counter() - t0) / epochs * 1e3, "nodes": N, "edges": int(len(col)),
+            "config": f"{c['nfeats'][0]} -> {c['nheads'][0]} x {c['nfeats'][1]} -> {c['nheads'][1]} x {c['nfeats'][2]}, "
+                      f"dropout {c['dropout']}, Adam, train step + eval forward, one HIP-graph replay per epoch",
+            "data": "real topology, synthetic features/labels"}
 
 
 def main():
@@ -106,7 +171,7 @@ def main():
 
     import pygat_amd as pg
     from pygat_amd import ops
-    from pygat_amd.dist import partition_heads, all_gather_columns_raw
+    from pygat_amd.dist import partition_heads, gather_columns_layout
     from pygat_amd.rmat import rmat_csr
 
     H, Fo, Fin = args.heads, args.fout, args.fin
@@ -125,41 +190,58 @@ def main():
     parts = partition_heads(H, model_world)
     hs, he = parts[rank]
     h_loc = he - hs
-    widths = [(e - s) * Fo for s, e in parts]
-    W_loc = W[hs:he].contiguous().requires_grad_(True)
-    a_loc = a[hs:he].contiguous().requires_grad_(True)
-    G_loc = G[:, hs * Fo:he * Fo].contiguous()
-    Xb = X.requires_grad_(True) if args.dx else X
-
-    replicate = model_world > 1 and (args.forward_exchange == "replicate" or
-                                     (args.forward_exchange == "auto" and model_world <= 4))
+    replicate = model_world > 1 and args.forward_exchange == "replicate"
     use_pg = (world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1") and not replicate
-    gbuf = torch.empty(world * N, h_loc * Fo, device=dev) if use_pg else None
-    if replicate:     # forward of ALL heads in one call, backward of the own ones (GATLevelFn bwd_heads)
+    G_loc = G[:, hs * Fo:he * Fo].contiguous()
+    k2_heads = H if replicate else h_loc          # heads the forward kernels process on this rank
+
+    # ---- the step -----------------------------------------------------------------------------------
+    if replicate:       # experiment: forward of ALL heads in one call, backward of the own ones (GATLevelFn bwd_heads)
         W_all = W.clone().requires_grad_(True)
         a_all = a.clone().requires_grad_(True)
 
-    def step():
-        W_loc.grad = a_loc.grad = None
-        if args.dx:
-            Xb.grad = None
-        if replicate:
+        def level_fwd():
             W_all.grad = a_all.grad = None
-            full = pg.GATLevelFn.apply(X.detach(), W_all, a_all, None, graph, 0.2, True, (hs, h_loc))
-            full.backward(G)                              # only the columns of the own heads are read
-            return full
-        out = pg.GATLevelFn.apply(Xb, W_loc, a_loc, None, graph, 0.2, True)
+            return pg.GATLevelFn.apply(X, W_all, a_all, None, graph, 0.2, True, (hs, h_loc))
+
+        def level_bwd(out):
+            out.backward(G)                   # only the columns of the own heads are read
+    elif args.eager:
+        W_loc = W[hs:he].contiguous().requires_grad_(True)
+        a_loc = a[hs:he].contiguous().requires_grad_(True)
+        Xb = X.clone().requires_grad_(True) if args.dx else X
+
+        def level_fwd():
+            W_loc.grad = a_loc.grad = None
+            if args.dx:
+                Xb.grad = None
+            return pg.GATLevelFn.apply(Xb, W_loc, a_loc, None, graph, 0.2, True)
+
+        def level_bwd(out):
+            out.backward(G_loc)
+    else:               # product path: the level captured once, replayed every step
+        lvl = pg.GraphedLevel(graph, X, W[hs:he], a[hs:he], None, 0.2, True, need_dx=args.dx)
+
+        def level_fwd():
+            return lvl.forward()
+
+        def level_bwd(out):
+            lvl.backward(G_loc)
+
+    gbuf = torch.empty(world, N, h_loc * Fo, device=dev) if use_pg else None   # rank-major column blocks
+
+    def step():
+        out = level_fwd()
         if use_pg:
-            # RCCL all-gather of the head outputs (models.py:32 torch.cat) on RCCL's own stream; this
-            # level's backward does not depend on it, so it overlaps K3/K4/K5 and is joined at the end.
-            work = dist.all_gather_into_tensor(gbuf, out.detach(), async_op=True)
-            out.backward(G_loc)
+            # RCCL all-gather of the head outputs (models.py:32 torch.cat) on RCCL's own stream; this level's
+            # backward does not depend on it, so it overlaps K3/K4/K5 and is joined at the end.  The gathered
+            # activations stay in the rank-major column-block layout [world, N, w] (pygat_amd.dist).
+            work = dist.all_gather_into_tensor(gbuf.view(world * N, h_loc * Fo), out.detach(), async_op=True)
+            level_bwd(out)
             work.wait()
-            full = gbuf.view(world, N, h_loc * Fo).permute(1, 0, 2).reshape(N, world * h_loc * Fo)
-        else:
-            out.backward(G_loc)
-            full = out
-        return full
+            return gbuf
+        level_bwd(out)
+        return out
 
     def barrier():
         if dist.is_initialized():
@@ -169,63 +251,124 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    timer = ops.KernelTimer()
-    ops.TIMER = timer
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        ev[k][0].record()
         step()
+        ev[k][1].record()
     barrier()
     dt = time.perf_counter() - t0
-    ops.TIMER = None
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ms = dt / args.steps * 1e3
-    if args.verify and rank == 0:
-        # the gathered concat output of the sharded run against the unsharded level on this rank
+    step_ms = sorted(a_.elapsed_time(b_) for a_, b_ in ev)
+    ms_median = step_ms[len(step_ms) // 2]
+
+    # ---- instrumented pass: the same steps launched eagerly with HIP events around every kernel ------
+    timer = ops.KernelTimer()
+    if replicate:
+        inst_fwd, inst_bwd = level_fwd, level_bwd
+    else:
+        W_i = W[hs:he].contiguous().requires_grad_(True)
+        a_i = a[hs:he].contiguous().requires_grad_(True)
+        X_i = X.clone().requires_grad_(True) if args.dx else X
+
+        def inst_fwd():
+            W_i.grad = a_i.grad = None
+            if args.dx:
+                X_i.grad = None
+            return pg.GATLevelFn.apply(X_i, W_i, a_i, None, graph, 0.2, True)
+
+        def inst_bwd(out):
+            out.backward(G_loc)
+    for _ in range(2):
+        inst_bwd(inst_fwd())
+    torch.cuda.synchronize()
+    ops.TIMER = timer
+    for _ in range(min(args.steps, 20)):
+        inst_bwd(inst_fwd())
+    torch.cuda.synchronize()
+    ops.TIMER = None
+
+    if args.verify:
         full = step()
-        ref = pg.GATLevelFn.apply(X.detach(), W, a, None, graph, 0.2, True)
-        err = float((full - ref).abs().max())
-        print(f"bench --verify: max |sharded - unsharded| = {err:.3e} over {tuple(ref.shape)}", file=sys.stderr)
-        assert err < 1e-5, err
-    if args.verify and rank != 0 and use_pg:
-        step()
+        if rank == 0:
+            # the gathered concat output of the sharded run against the unsharded level on this rank
+            if use_pg:
+                full = gather_columns_layout(full)          # [world, N, w] -> [N, world*w]
+            ref = pg.GATLevelFn.apply(X, W, a, None, graph, 0.2, True)
+            got = full if (use_pg or replicate or model_world == 1) else None
+            if got is not None:
+                err = float((got - ref).abs().max())
+                print(f"bench --verify: max |sharded - unsharded| = {err:.3e} over {tuple(ref.shape)}", file=sys.stderr)
+                assert err < 1e-5, err
 
     if rank == 0:
         kt = {k: float(np.mean(v)) for k, v in timer.times_ms().items()}
         Fp = pg.padded_width(Fo)
-        R = h_loc * Fp
-        # per edge col index + t_j per local head + one Wh row; per node rowptr + s_i + out row + (m,Z)
-        b_fwd = E * (4 + 4 * h_loc + 4 * R) + N * (4 + 4 * h_loc + 4 * R + 8 * h_loc)
-        k2 = kt.get("k2_forward", float("nan"))
-        achieved = b_fwd / (k2 * 1e-3) / 1e9
-        # HBM traffic of K2 from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-        # runs of this same command; FETCH_SIZE doubled as the gfx950 guide prescribes): main + fix-up launch.
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_k2_latest.json")))
+        Rf, Hf = k2_heads * Fp, k2_heads            # forward kernels
+        Rb, Hb = h_loc * Fp, h_loc                  # backward kernels
+        # SURVEY.md 8(d) byte / flop models
+        model = {
+            "k1_project": ("mfma", 2.0 * N * Fin * (Rf + 2 * Hf)),
+            "k2_forward": ("hbm", E * (4 + 4 * Hf + 4 * Rf) + N * (4 + 4 * Hf + 4 * Rf + 8 * Hf)),
+            "k3a_prepare": ("hbm", N * (12 * Rb + 28 * Hb)),
+            "k3b_row": ("hbm", E * (4 + 4 * Rb + 8 * Hb) + N * (4 + 8 * Rb + 16 * Hb) - N * (12 * Rb + 28 * Hb)),
+            "k4_backward_col": ("hbm", E * (8 + 4 * Rb + 8 * Hb) + N * (4 + 8 * Rb + 8 * Hb)),
+            "k3c_rowsum": ("hbm", E * (12 + 4 * Hb) + N * 4 * Hb),
+            "k5_agrad": ("hbm", N * (4 * Rb + 8 * Hb)),
+            "k5_wgrad": ("mfma", 2.0 * N * Fin * (Rb + Hb)),
+            "k5_xgrad": ("mfma", 2.0 * N * Fin * Rb),
+        }
+        traffic = {}
+        try:   # HBM traffic from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of
+               # this same command; FETCH_SIZE doubled as the gfx950 guide prescribes): main + fix-up launches
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
             if pmc.get("workload_edges") == E and pmc.get("heads_per_gpu") == h_loc:
-                traffic = pmc["k2_hbm_traffic_bytes"]
+                traffic = pmc["traffic_bytes"]
         except Exception:
-            traffic = None
+            traffic = {}
+        kernels = []
+        for name, t in kt.items():
+            bound, work = model.get(name, ("hbm", None))
+            if work is None:
+                continue
+            if bound == "hbm":
+                ach = work / (t * 1e-3) / 1e9
+                kernels.append({"kernel": name, "bound": "hbm", "avg_ms": t, "achieved": ach, "peak": HBM_PEAK_GBPS,
+                                "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "algorithmic_bytes": int(work),
+                                "traffic": traffic.get(name)})
+            else:
+                ach = work / (t * 1e-3) / 1e12
+                kernels.append({"kernel": name, "bound": "mfma", "avg_ms": t, "achieved": ach, "peak": MFMA_F32_PEAK_TF,
+                                "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "flops": work,
+                                "traffic": traffic.get(name)})
+        dominant = max(kernels, key=lambda r: r["avg_ms"])
+        roof = dict(dominant)
+        roof["timing"] = "HIP events around each launch, instrumented eager pass of the same steps after the timed region"
         line = {
             "metric": "GAT-layer fwd+bwd edges/sec", "value": E / (ms * 1e-3), "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "ms_per_step_median": ms_median,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"RMAT scale {args.scale} ({N} nodes, {E} edges incl. self loops, max degree "
                                    f"{int((rowptr[1:] - rowptr[:-1]).max())}), Fin {Fin}, {H} heads x {Fo}, concat+ELU, "
                                    f"dropout 0, fwd+bwd (dW, da{', dX' if args.dx else ''})",
                        "nodes": N, "edges": E, "fin": Fin, "heads": H, "f_out": Fo,
-                       "parallelism": (f"head-parallel x{model_world}" + (", forward replicated" if replicate else "")
+                       "parallelism": (f"head-parallel x{model_world}, "
+                                       + ("forward replicated (no collective; experiment)" if replicate
+                                          else "RCCL all-gather of the head outputs overlapped with the backward")
                                        + (" (rank-0 work only, modelled)" if model_world != world else ""))
                        if model_world > 1 else "single GPU",
-                       "heads_per_gpu": h_loc},
-            "roofline": {"kernel": "k2_forward (gat_fwd_kernel + gat_fwd_fixup_kernel)", "bound": "hbm", "achieved": achieved,
-                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                         "algorithmic_bytes": b_fwd, "avg_ms": k2},
-            "kernels_ms": kt,
+                       "heads_per_gpu": h_loc,
+                       "launch": "eager" if (args.eager or replicate) else "HIP-graph replay (pygat_amd.GraphedLevel)"},
+            "roofline": roof,
+            "kernels": kernels,
+            "kernels_ms_sum": float(sum(kt.values())),
         }
         if world == 1 and not args.no_cpu:
             try:
@@ -233,7 +376,14 @@ def main():
                                                     W.cpu().numpy(), a.cpu().numpy(), G.cpu().numpy())
             except Exception as ex:  # the GPU number stays valid without the CPU leg
                 line["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": os.cpu_count(), "kind": "port",
-                                        "sample": f"failed: {ex!r}"}
+                                        "cpu": cpu_model(), "sample": f"failed: {ex!r}"}
+        if world == 1 and model_world == 1 and not args.no_epoch:
+            line["epoch_ms"] = {}
+            for name in ("cora", "pubmed"):
+                try:
+                    line["epoch_ms"][name] = epoch_ms(pg, dev, name)
+                except Exception as ex:
+                    line["epoch_ms"][name] = {"ms": None, "error": repr(ex)}
         print(json.dumps(line), file=real_stdout, flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PYGAT_ABI_VERSION 8
+#define PYGAT_ABI_VERSION 9
 
 enum {
   PYGAT_OK = 0,
@@ -173,11 +173,16 @@ int pygat_head_group(int n, int H, int Fo);
 
 /* Wh [n x R], s,t [n x H], sk [n x R] or NULL.
  * out [n x H*F'] compact (may be NULL), hattn [n x R] padded (may be NULL; needed for the
- * head mean), m,Z [n x H] (may be NULL together in eval).  */
+ * head mean), m,Z [n x H] (may be NULL together in eval).
+ * aneg [n x R], qneg [n x H] (NULL together; need m,Z): the training forward also leaves the share of each row
+ * sum that went through the alpha branch of the LeakyReLU,
+ *     aneg_i = sum_{j: s_i+t_j <= 0} alpha_ij mask_ij Wh_j,     qneg_i = sum_{j: s_i+t_j <= 0} alpha_ij,
+ * from which pygat_gat_backward_prepare takes the row sums ds_i = sum_j dz_ij without touching an edge again
+ * (sum_j de_ij = 0, so ds_i = -(1 - alpha)(Gp_i . aneg_i - D_i qneg_i)). */
 int pygat_gat_forward(const pygat_graph* g, int H, int Fo, float alpha, int flags,
                       const float* Wh, const float* s, const float* a_pad, const float* sk,
                       const float* att_mask,
-                      float* out, float* hattn, float* m, float* Z,
+                      float* out, float* hattn, float* m, float* Z, float* aneg, float* qneg,
                       void* part, void* stream);
 
 /* models.py:34: out[n x F'] = mean over heads of (hattn [+ sk]) (padded inputs). */
@@ -214,10 +219,14 @@ int pygat_head_mean(int n, int H, int Fo, const float* hattn, const float* sk,
  * h_count in place of H), and dW / da rows outside the range are left untouched.  Use: a rank of a head-parallel
  * run that ran the forward for all heads (cheaper than receiving them over one xGMI link) back-propagates its own.
  */
+/* pygat_gat_backward_prepare: aneg, qneg (from the training forward) and ds non-NULL together: K3a also writes
+ * ds [n x H] (LeakyReLU slope `alpha`), after which pygat_gat_backward_col is called WITH ds and neither the row
+ * pass nor the row-sum pass runs -- the default backward.  All three NULL: GR only. */
 int pygat_gat_backward_prepare(int n, int H, int Fo, int flags, int mean_mode,
                                const float* G, const float* y, const float* sk,
                                const float* s, const float* m, const float* Z,
-                               float* GR, int h_first, int h_count, void* stream);
+                               float* GR, const float* aneg, const float* qneg, float alpha, float* ds,
+                               int h_first, int h_count, void* stream);
 int pygat_gat_backward_row(const pygat_graph* g, int H, int Fo, float alpha,
                            const float* Wh, const float* a_pad, const float* GR,
                            const float* att_mask, float* ds, void* part, int h_first, int h_count, void* stream);

@@ -10,8 +10,9 @@ from .graph import CSRGraph, as_graph                   # noqa: F401
 from .ops import gat_level, GATLevelFn, gemm            # noqa: F401
 from .layers import GraphAttentionLayer, SpGraphAttentionLayer  # noqa: F401
 from .models import GAT                                 # noqa: F401
+from .graphed import GraphedLevel, FusedEpoch           # noqa: F401
 from .gatv2 import GraphAttentionLayerV2, SpGraphAttentionLayerV2, gatv2_level, GATv2LevelFn  # noqa: F401
 
 __all__ = ["CSRGraph", "as_graph", "gat_level", "GATLevelFn", "gemm", "GraphAttentionLayer",
            "SpGraphAttentionLayer", "GAT", "padded_width", "LIB_PATH", "GraphAttentionLayerV2",
-           "SpGraphAttentionLayerV2", "gatv2_level", "GATv2LevelFn"]
+           "SpGraphAttentionLayerV2", "gatv2_level", "GATv2LevelFn", "GraphedLevel", "FusedEpoch"]

@@ -37,14 +37,23 @@ struct FwdArgs {
   float* hattn;
   float* m;
   float* Z;
-  float* part;  // [2 * nslots][R + 2H]: record 2k = head piece of slot k, 2k+1 = tail piece
+  float* part;  // [2 * nslots][PS]: record 2k = head piece of slot k, 2k+1 = tail piece; PS = R + 2H, or 2R + 3H (AUX)
+  // AUX (training forward): the part of the row sum that went through the alpha branch of the LeakyReLU,
+  //   aneg_i = sum_{j: z_ij <= 0} alpha~_ij Wh_j,   qneg_i = sum_{j: z_ij <= 0} alpha_ij          (alpha~ = alpha * mask)
+  // With them the backward gets ds_i = sum_j dz_ij row-locally: sum_j de_ij = 0, hence
+  //   ds_i = -(1 - slope) (Gp_i . aneg_i - D_i qneg_i)
+  // and neither a second gather pass nor per-edge dz records are needed (k3_backward_row.hip, K3a).
+  float* aneg;  // [n][ldr] or nullptr
+  float* qneg;  // [n][ldh] or nullptr
 };
 
 __device__ __forceinline__ float lrelu(float z, float alpha) { return z > 0.f ? z : alpha * z; }
 
 // fold one edge (logit ev, row w) into the running softmax state; one exp per edge
 // (mk = dropout mask on alpha: scales the aggregated term only, Z is taken before it, layers.py:150-153)
-__device__ __forceinline__ void fold_edge(float& m, float& z, float4& a, float ev, float4 w, float mk) {
+template <bool AUX>
+__device__ __forceinline__ void fold_edge(float& m, float& z, float4& a, float& zn, float4& an, float ev, bool neg,
+                                          float4 w, float mk) {
   const float d = ev - m;
   const float ex = __expf(-fabsf(d));
   const bool up = d > 0.f;
@@ -53,18 +62,48 @@ __device__ __forceinline__ void fold_edge(float& m, float& z, float4& a, float e
   const float pm = p * mk;
   a.x = fmaf(a.x, sc, pm * w.x); a.y = fmaf(a.y, sc, pm * w.y);
   a.z = fmaf(a.z, sc, pm * w.z); a.w = fmaf(a.w, sc, pm * w.w);
+  if constexpr (AUX) {   // the same sums restricted to the edges on the alpha branch
+    const float pn = neg ? p : 0.f, pmn = neg ? pm : 0.f;
+    zn = fmaf(zn, sc, pn);
+    an.x = fmaf(an.x, sc, pmn * w.x); an.y = fmaf(an.y, sc, pmn * w.y);
+    an.z = fmaf(an.z, sc, pmn * w.z); an.w = fmaf(an.w, sc, pmn * w.w);
+  }
   m = up ? ev : m;
 }
 
 // online-softmax merge of (m2,z2,a2) into (m,z,a)
-__device__ __forceinline__ void merge_state(float& m, float& z, float4& a, float m2, float z2, float4 a2) {
+template <bool AUX>
+__device__ __forceinline__ void merge_state(float& m, float& z, float4& a, float& zn, float4& an, float m2, float z2,
+                                            float4 a2, float zn2, float4 an2) {
   const float mn = fmaxf(m, m2);
   const float sa = __expf(m - mn), sb = __expf(m2 - mn);
   z = z * sa + z2 * sb;
   a.x = a.x * sa + a2.x * sb; a.y = a.y * sa + a2.y * sb;
   a.z = a.z * sa + a2.z * sb; a.w = a.w * sa + a2.w * sb;
+  if constexpr (AUX) {
+    zn = zn * sa + zn2 * sb;
+    an.x = an.x * sa + an2.x * sb; an.y = an.y * sa + an2.y * sb;
+    an.z = an.z * sa + an2.z * sb; an.w = an.w * sa + an2.w * sb;
+  }
   m = mn;
 }
+
+// per-row state of the online softmax; the AUX half exists only in the training forward
+template <int VEC, bool AUX>
+struct RowState {
+  float m[VEC], z[VEC];
+  float4 acc[VEC];
+  float zn[AUX ? VEC : 1];
+  float4 accn[AUX ? VEC : 1];
+  __device__ __forceinline__ void reset() {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { m[v] = NEG_BIG; z[v] = 0.f; acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+    for (int v = 0; v < (AUX ? VEC : 1); ++v) { zn[v] = 0.f; accn[v] = make_float4(0.f, 0.f, 0.f, 0.f); }
+  }
+};
+template <bool AUX>
+__host__ __device__ __forceinline__ int64_t part_stride(const RowShape& rs) { return AUX ? 2 * (int64_t)rs.R + 3 * rs.H : (int64_t)rs.R + 2 * rs.H; }
 
 // ELU: expm1 by a short series near 0 (where exp(x)-1 cancels), fast exp elsewhere
 __device__ __forceinline__ float elu1(float x) {
@@ -74,19 +113,19 @@ __device__ __forceinline__ float elu1(float x) {
 }
 
 // normalise, epilogue (skip, ELU) and stores of a finished row i (all lanes of the group)
-template <int VEC>
-__device__ __forceinline__ void fwd_finish(const FwdArgs& a, const LaneCols<VEC>& lc, int i,
-                                           const float (&m)[VEC], const float (&z)[VEC],
-                                           const float4 (&acc)[VEC]) {
+template <int VEC, bool AUX>
+__device__ __forceinline__ void fwd_finish(const FwdArgs& a, const LaneCols<VEC>& lc, int i, const RowState<VEC, AUX>& st) {
   const int Fo = a.rs.Fo, Fp = a.rs.Fp;
   const int64_t ldr = a.rs.ldr, ldh = a.rs.ldh, ldo = a.rs.ldo;
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
     if (!lc.valid[v]) continue;
     const int co = lc.cofs[v], h = lc.head[v];
-    const float rz = 1.0f / z[v];
-    float4 hat = make_float4(acc[v].x * rz, acc[v].y * rz, acc[v].z * rz, acc[v].w * rz);
+    const float rz = 1.0f / st.z[v];
+    float4 hat = make_float4(st.acc[v].x * rz, st.acc[v].y * rz, st.acc[v].z * rz, st.acc[v].w * rz);
     if (a.hattn) st4(a.hattn + (int64_t)i * ldr + co, hat);
+    if constexpr (AUX)
+      st4(a.aneg + (int64_t)i * ldr + co, make_float4(st.accn[v].x * rz, st.accn[v].y * rz, st.accn[v].z * rz, st.accn[v].w * rz));
     if (a.out) {
       float4 pre = hat;
       if (a.flags & PYGAT_F_SKIP) {
@@ -106,36 +145,68 @@ __device__ __forceinline__ void fwd_finish(const FwdArgs& a, const LaneCols<VEC>
       }
     }
     if (a.m && ((co >> 2) & (a.rs.lph - 1)) == 0) {
-      a.m[(int64_t)i * ldh + h] = m[v];
-      a.Z[(int64_t)i * ldh + h] = z[v];
+      a.m[(int64_t)i * ldh + h] = st.m[v];
+      a.Z[(int64_t)i * ldh + h] = st.z[v];
+      if constexpr (AUX) a.qneg[(int64_t)i * ldh + h] = st.zn[v] * rz;
     }
   }
 }
 
-// row finished inside the slot -> final stores; row continuing in a neighbour slot -> partial record
-template <int VEC>
-__device__ __forceinline__ void fwd_flush(const FwdArgs& a, const LaneCols<VEC>& lc, int64_t k, int i,
-                                          bool is_head, bool is_tail, const float (&m)[VEC],
-                                          const float (&z)[VEC], const float4 (&acc)[VEC]) {
-  if (is_head || is_tail) {
-    float* p = a.part + (2 * k + (is_head ? 0 : 1)) * (int64_t)(a.rs.R + 2 * a.rs.H);
+// partial record: [acc R | m H | z H] and, AUX, [accn R | zn H]
+template <int VEC, bool AUX>
+__device__ __forceinline__ void part_store(const FwdArgs& a, const LaneCols<VEC>& lc, float* p, const RowState<VEC, AUX>& st) {
+  const int R = a.rs.R, H = a.rs.H;
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      if (!lc.valid[v]) continue;
-      st4(p + lc.cofs[v], acc[v]);
-      if (((lc.cofs[v] >> 2) & (a.rs.lph - 1)) == 0) {
-        p[a.rs.R + lc.head[v]] = m[v];
-        p[a.rs.R + a.rs.H + lc.head[v]] = z[v];
-      }
+  for (int v = 0; v < VEC; ++v) {
+    if (!lc.valid[v]) continue;
+    st4(p + lc.cofs[v], st.acc[v]);
+    if constexpr (AUX) st4(p + R + 2 * H + lc.cofs[v], st.accn[v]);
+    if (((lc.cofs[v] >> 2) & (a.rs.lph - 1)) == 0) {
+      p[R + lc.head[v]] = st.m[v];
+      p[R + H + lc.head[v]] = st.z[v];
+      if constexpr (AUX) p[2 * R + 2 * H + lc.head[v]] = st.zn[v];
     }
+  }
+}
+// a partial record in registers (loads first, merges afterwards: PF records are in flight together)
+template <int VEC, bool AUX>
+struct PartRec {
+  float m[VEC], z[VEC];
+  float4 acc[VEC];
+  float zn[AUX ? VEC : 1];
+  float4 accn[AUX ? VEC : 1];
+};
+template <int VEC, bool AUX>
+__device__ __forceinline__ void part_load(const FwdArgs& a, const LaneCols<VEC>& lc, const float* p, PartRec<VEC, AUX>& r) {
+  const int R = a.rs.R, H = a.rs.H;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    r.m[v] = p[R + lc.head[v]]; r.z[v] = p[R + H + lc.head[v]]; r.acc[v] = ld4(p + lc.cofs[v]);
+    if constexpr (AUX) { r.zn[v] = p[2 * R + 2 * H + lc.head[v]]; r.accn[v] = ld4(p + R + 2 * H + lc.cofs[v]); }
+  }
+}
+template <int VEC, bool AUX>
+__device__ __forceinline__ void part_merge(RowState<VEC, AUX>& st, const PartRec<VEC, AUX>& r) {
+#pragma unroll
+  for (int v = 0; v < VEC; ++v)
+    merge_state<AUX>(st.m[v], st.z[v], st.acc[v], st.zn[AUX ? v : 0], st.accn[AUX ? v : 0], r.m[v], r.z[v], r.acc[v],
+                     r.zn[AUX ? v : 0], r.accn[AUX ? v : 0]);
+}
+
+// row finished inside the slot -> final stores; row continuing in a neighbour slot -> partial record
+template <int VEC, bool AUX>
+__device__ __forceinline__ void fwd_flush(const FwdArgs& a, const LaneCols<VEC>& lc, int64_t k, int i,
+                                          bool is_head, bool is_tail, const RowState<VEC, AUX>& st) {
+  if (is_head || is_tail) {
+    part_store<VEC, AUX>(a, lc, a.part + (2 * k + (is_head ? 0 : 1)) * part_stride<AUX>(a.rs), st);
   } else {
-    fwd_finish<VEC>(a, lc, i, m, z, acc);
+    fwd_finish<VEC, AUX>(a, lc, i, st);
   }
 }
 
 // V2 = the reference's SpGraphAttentionLayerV2 scoring (layers.py:280-283): e_ij = a . LeakyReLU(Whi_i +
 // Whj_j) per head, aggregation of Whi_j (layers.py:296); the gathered row is [Whi_j | Whj_j].
-template <int LPR, int VEC, bool V2>
+template <int LPR, int VEC, bool V2, bool AUX>
 __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
   constexpr int EPW = 64 / LPR;
   constexpr int U = (VEC == 1) ? 4 : 2;
@@ -161,10 +232,8 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
     if (!lc.valid[v]) adst[v] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const int64_t ldw = a.ldwh;
-  float m[VEC], z[VEC];
-  float4 acc[VEC];
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) { m[v] = NEG_BIG; z[v] = 0.f; acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); }
+  RowState<VEC, AUX> st;
+  st.reset();
 
   for (int64_t e = e0; e < e1; e += U) {
     int2 p[U];
@@ -201,31 +270,90 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
     for (int u = 0; u < U; ++u) {
       if (e + u < e1) {
         if (p[u].x != cur) {
-          fwd_flush<VEC>(a, lc, k, cur, cur == r_first && head_partial, false, m, z, acc);
+          fwd_flush<VEC, AUX>(a, lc, k, cur, cur == r_first && head_partial, false, st);
           cur = p[u].x;
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) { m[v] = NEG_BIG; z[v] = 0.f; acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); }
+          st.reset();
         }
 #pragma unroll
-        for (int v = 0; v < VEC; ++v)
-          fold_edge(m[v], z[v], acc[v], V2 ? tv[u][v] : lrelu(sv[u][v] + tv[u][v], a.alpha), wv[u][v], mk[u][v]);
+        for (int v = 0; v < VEC; ++v) {
+          const float zz = sv[u][v] + tv[u][v];        // V1: the logit before the LeakyReLU
+          fold_edge<AUX>(st.m[v], st.z[v], st.acc[v], st.zn[AUX ? v : 0], st.accn[AUX ? v : 0],
+                         V2 ? tv[u][v] : lrelu(zz, a.alpha), !(zz > 0.f), wv[u][v], mk[u][v]);
+        }
       }
     }
   }
   const bool tail_partial = a.g.rowptr[cur + 1] > e1;
-  fwd_flush<VEC>(a, lc, k, cur, cur == r_first && head_partial, tail_partial, m, z, acc);
+  fwd_flush<VEC, AUX>(a, lc, k, cur, cur == r_first && head_partial, tail_partial, st);
+}
+
+// Merge of one cut row: its pieces tail(k), head(k+1), ..., head(k + npieces - 1) are dealt round-robin to
+// nw waves x EPW lane groups (PF pieces in flight each -- the chain of a 26k-edge row has 400+ pieces), combined
+// inside a wave with shuffles and across waves through LDS, always in the same order (reproducible).
+template <int LPR, int VEC, bool AUX>
+__device__ __forceinline__ void fwd_merge_row(const FwdArgs& a, const LaneCols<VEC>& lc, float* fix_sm, int64_t k, int r,
+                                              int npieces, bool wide, int w) {
+  constexpr int EPW = 64 / LPR;
+  constexpr int PF = (VEC == 1) ? 4 : 2;
+  const int lane = threadIdx.x & 63, slot = lane / LPR;
+  const int64_t PS = part_stride<AUX>(a.rs);
+  RowState<VEC, AUX> st;
+  st.reset();
+  if (wide || w == 0) {
+    const int nw = wide ? 4 : 1;
+    for (int q = (wide ? w : 0) * EPW * PF + slot; q < npieces; q += nw * EPW * PF) {
+      PartRec<VEC, AUX> rec[PF];
+#pragma unroll
+      for (int f = 0; f < PF; ++f) {
+        const int qq = q + f * EPW;
+        const int qc = qq < npieces ? qq : q;   // clamped: the loads stay unconditional
+        part_load<VEC, AUX>(a, lc, a.part + (qc == 0 ? 2 * k + 1 : 2 * (k + qc)) * PS, rec[f]);
+      }
+#pragma unroll
+      for (int f = 0; f < PF; ++f)
+        if (q + f * EPW < npieces) part_merge<VEC, AUX>(st, rec[f]);
+    }
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const float mo = __shfl_xor(st.m[v], off), zo = __shfl_xor(st.z[v], off);
+        float4 ao, no = make_float4(0.f, 0.f, 0.f, 0.f);
+        float zno = 0.f;
+        ao.x = __shfl_xor(st.acc[v].x, off); ao.y = __shfl_xor(st.acc[v].y, off);
+        ao.z = __shfl_xor(st.acc[v].z, off); ao.w = __shfl_xor(st.acc[v].w, off);
+        if constexpr (AUX) {
+          zno = __shfl_xor(st.zn[v], off);
+          no.x = __shfl_xor(st.accn[v].x, off); no.y = __shfl_xor(st.accn[v].y, off);
+          no.z = __shfl_xor(st.accn[v].z, off); no.w = __shfl_xor(st.accn[v].w, off);
+        }
+        merge_state<AUX>(st.m[v], st.z[v], st.acc[v], st.zn[AUX ? v : 0], st.accn[AUX ? v : 0], mo, zo, ao, zno, no);
+      }
+    }
+  }
+  if (wide) {  // wave partials -> LDS -> wave 0 (uniform branch: `wide` is the same in all waves)
+    if (slot == 0) part_store<VEC, AUX>(a, lc, fix_sm + w * PS, st);
+    __syncthreads();
+    if (w == 0 && slot == 0) {
+#pragma unroll
+      for (int ww = 1; ww < 4; ++ww) {
+        PartRec<VEC, AUX> rec;
+        part_load<VEC, AUX>(a, lc, fix_sm + ww * PS, rec);
+        part_merge<VEC, AUX>(st, rec);
+      }
+    }
+    __syncthreads();
+  }
+  if (w == 0 && slot == 0) fwd_finish<VEC, AUX>(a, lc, r, st);
 }
 
 // Fix-up of the rows cut by a slot border.  A work-group screens FIX_SCREEN consecutive slots: slot k
-// OWNS a cut row if its last row starts inside k and continues beyond.  Every owned row is merged in
-// turn: its pieces tail(k), head(k+1), ..., head(k_e) are dealt round-robin to the 4 waves x EPW lane
-// groups (PF pieces in flight each -- the chain of a 26k-edge row has 400+ pieces), combined inside a
-// wave with shuffles and across waves through LDS, always in the same order (reproducible).
-template <int LPR, int VEC>
+// OWNS a cut row if its last row starts inside k and continues beyond.  Every owned row is merged in turn.
+template <int LPR, int VEC, bool AUX>
 __global__ __launch_bounds__(256) void gat_fwd_fixup_kernel(FwdArgs a) {
   constexpr int EPW = 64 / LPR;
   constexpr int PF = (VEC == 1) ? 4 : 2;
-  extern __shared__ __attribute__((aligned(16))) float fix_sm[];  // [4][R + 2H]
+  extern __shared__ __attribute__((aligned(16))) float fix_sm[];  // [4][PS]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t kbase = (int64_t)blockIdx.x * FIX_SCREEN;
   const int64_t nslots = num_slots(a.g);
@@ -240,8 +368,6 @@ __global__ __launch_bounds__(256) void gat_fwd_fixup_kernel(FwdArgs a) {
   }
   unsigned long long todo = __ballot(owner);  // identical in the 4 waves
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
-  const int slot = lane / LPR;
-  const int64_t PS = a.rs.R + 2 * a.rs.H;
   while (todo) {
     const int src = __ffsll((long long)todo) - 1;
     todo &= todo - 1;
@@ -251,149 +377,22 @@ __global__ __launch_bounds__(256) void gat_fwd_fixup_kernel(FwdArgs a) {
     const int64_t k_e = slot_of(a.g, row_end - 1);
     const int npieces = (int)(k_e - k) + 1;
     const bool wide = npieces > EPW * PF;  // more pieces than one wave takes in a single round
-    float m[VEC], z[VEC];
-    float4 acc[VEC];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) { m[v] = NEG_BIG; z[v] = 0.f; acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); }
-    if (wide || w == 0) {
-      const int nw = wide ? 4 : 1;
-      for (int q = (wide ? w : 0) * EPW * PF + slot; q < npieces; q += nw * EPW * PF) {
-        float mp[PF][VEC], zp[PF][VEC];
-        float4 ap[PF][VEC];
-#pragma unroll
-        for (int f = 0; f < PF; ++f) {
-          const int qq = q + f * EPW;
-          const int qc = qq < npieces ? qq : q;
-          const float* p = a.part + (qc == 0 ? 2 * k + 1 : 2 * (k + qc)) * PS;
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) {
-            mp[f][v] = p[a.rs.R + lc.head[v]]; zp[f][v] = p[a.rs.R + a.rs.H + lc.head[v]]; ap[f][v] = ld4(p + lc.cofs[v]);
-          }
-        }
-#pragma unroll
-        for (int f = 0; f < PF; ++f)
-          if (q + f * EPW < npieces) {
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) merge_state(m[v], z[v], acc[v], mp[f][v], zp[f][v], ap[f][v]);
-          }
-      }
-#pragma unroll
-      for (int off = LPR; off < 64; off <<= 1) {
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          float mo = __shfl_xor(m[v], off), zo = __shfl_xor(z[v], off);
-          float4 ao;
-          ao.x = __shfl_xor(acc[v].x, off); ao.y = __shfl_xor(acc[v].y, off);
-          ao.z = __shfl_xor(acc[v].z, off); ao.w = __shfl_xor(acc[v].w, off);
-          merge_state(m[v], z[v], acc[v], mo, zo, ao);
-        }
-      }
-    }
-    if (wide) {  // wave partials -> LDS -> wave 0 (uniform branch: `wide` is the same in all waves)
-      if (slot == 0) {
-        float* p = fix_sm + w * PS;
-#pragma unroll
-        for (int v = 0; v < VEC; ++v)
-          if (lc.valid[v]) {
-            st4(p + lc.cofs[v], acc[v]);
-            if (((lc.cofs[v] >> 2) & (a.rs.lph - 1)) == 0) { p[a.rs.R + lc.head[v]] = m[v]; p[a.rs.R + a.rs.H + lc.head[v]] = z[v]; }
-          }
-      }
-      __syncthreads();
-      if (w == 0 && slot == 0) {
-#pragma unroll
-        for (int ww = 1; ww < 4; ++ww) {
-          const float* p = fix_sm + ww * PS;
-#pragma unroll
-          for (int v = 0; v < VEC; ++v)
-            merge_state(m[v], z[v], acc[v], p[a.rs.R + lc.head[v]], p[a.rs.R + a.rs.H + lc.head[v]], ld4(p + lc.cofs[v]));
-        }
-      }
-      __syncthreads();
-    }
-    if (w == 0 && slot == 0) fwd_finish<VEC>(a, lc, r, m, z, acc);
+    fwd_merge_row<LPR, VEC, AUX>(a, lc, fix_sm, k, r, npieces, wide, w);
   }
 }
 
 // list-driven variant: entry q of g.cut = (owner slot k, row, pieces); the first n_cut_wide entries (long
 // chains) get a whole work-group each, the others one wave each.
-template <int LPR, int VEC>
+template <int LPR, int VEC, bool AUX>
 __global__ __launch_bounds__(256) void gat_fwd_fixup_list_kernel(FwdArgs a) {
-  constexpr int EPW = 64 / LPR;
-  constexpr int PF = (VEC == 1) ? 4 : 2;
-  extern __shared__ __attribute__((aligned(16))) float fix_sm[];  // [4][R + 2H]
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  extern __shared__ __attribute__((aligned(16))) float fix_sm[];  // [4][PS]
+  const int w = threadIdx.x >> 6;
   const bool wide = (int)blockIdx.x < a.g.n_cut_wide;
   const int q0 = wide ? (int)blockIdx.x : a.g.n_cut_wide + ((int)blockIdx.x - a.g.n_cut_wide) * 4 + w;
-  if (q0 >= a.g.n_cut) return;
-  const int64_t k = a.g.cut[3 * q0];
-  const int r = a.g.cut[3 * q0 + 1];
-  const int npieces = a.g.cut[3 * q0 + 2];
+  if (q0 >= a.g.n_cut) return;   // never in a wide block: the __syncthreads of the merge are reached by all 4 waves
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
-  const int slot = lane / LPR;
-  const int64_t PS = a.rs.R + 2 * a.rs.H;
-  const int wsel = wide ? w : 0;   // wave index inside the merge; a lone wave plays wave 0
-  float m[VEC], z[VEC];
-  float4 acc[VEC];
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) { m[v] = NEG_BIG; z[v] = 0.f; acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); }
-  {
-    const int nw = wide ? 4 : 1;
-    for (int q = (wide ? w : 0) * EPW * PF + slot; q < npieces; q += nw * EPW * PF) {
-      float mp[PF][VEC], zp[PF][VEC];
-      float4 ap[PF][VEC];
-#pragma unroll
-      for (int f = 0; f < PF; ++f) {
-        const int qq = q + f * EPW;
-        const int qc = qq < npieces ? qq : q;
-        const float* p = a.part + (qc == 0 ? 2 * k + 1 : 2 * (k + qc)) * PS;
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          mp[f][v] = p[a.rs.R + lc.head[v]]; zp[f][v] = p[a.rs.R + a.rs.H + lc.head[v]]; ap[f][v] = ld4(p + lc.cofs[v]);
-        }
-      }
-#pragma unroll
-      for (int f = 0; f < PF; ++f)
-        if (q + f * EPW < npieces) {
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) merge_state(m[v], z[v], acc[v], mp[f][v], zp[f][v], ap[f][v]);
-        }
-    }
-#pragma unroll
-    for (int off = LPR; off < 64; off <<= 1) {
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        float mo = __shfl_xor(m[v], off), zo = __shfl_xor(z[v], off);
-        float4 ao;
-        ao.x = __shfl_xor(acc[v].x, off); ao.y = __shfl_xor(acc[v].y, off);
-        ao.z = __shfl_xor(acc[v].z, off); ao.w = __shfl_xor(acc[v].w, off);
-        merge_state(m[v], z[v], acc[v], mo, zo, ao);
-      }
-    }
-  }
-  if (wide) {  // wave partials -> LDS -> wave 0 (uniform branch: `wide` is the same in all waves)
-    if (slot == 0) {
-      float* p = fix_sm + w * PS;
-#pragma unroll
-      for (int v = 0; v < VEC; ++v)
-        if (lc.valid[v]) {
-          st4(p + lc.cofs[v], acc[v]);
-          if (((lc.cofs[v] >> 2) & (a.rs.lph - 1)) == 0) { p[a.rs.R + lc.head[v]] = m[v]; p[a.rs.R + a.rs.H + lc.head[v]] = z[v]; }
-        }
-    }
-    __syncthreads();
-    if (wsel == 0 && slot == 0) {
-#pragma unroll
-      for (int ww = 1; ww < 4; ++ww) {
-        const float* p = fix_sm + ww * PS;
-#pragma unroll
-        for (int v = 0; v < VEC; ++v)
-          merge_state(m[v], z[v], acc[v], p[a.rs.R + lc.head[v]], p[a.rs.R + a.rs.H + lc.head[v]], ld4(p + lc.cofs[v]));
-      }
-    }
-    __syncthreads();
-  }
-  if (wsel == 0 && slot == 0) fwd_finish<VEC>(a, lc, r, m, z, acc);
+  // a lone wave plays wave 0 of the merge
+  fwd_merge_row<LPR, VEC, AUX>(a, lc, fix_sm, a.g.cut[3 * q0], a.g.cut[3 * q0 + 1], a.g.cut[3 * q0 + 2], wide, wide ? w : 0);
 }
 
 
@@ -441,12 +440,13 @@ extern "C" int pygat_edge_pairs(int n, const int32_t* rowptr, const int32_t* col
 extern "C" size_t pygat_partials_bytes(int64_t nnz, int slot_edges, int H, int Fp) {
   if (nnz <= 0 || slot_edges <= 0) return 0;
   const int64_t nslots = (nnz + slot_edges - 1) / slot_edges;
-  return (size_t)(2 * nslots) * (size_t)(H * Fp + 2 * H) * sizeof(float);
+  // sized for the widest record any pass writes: [acc R | m H | z H | accn R | zn H] (training forward)
+  return (size_t)(2 * nslots) * (size_t)(2 * H * Fp + 3 * H) * sizeof(float);
 }
 
 static int launch_forward(const pygat_graph* g, int H, int Fo, float alpha, int flags, const float* Wh, int v2,
                           const float* s, const float* a_pad, const float* sk, const float* att_mask, float* out,
-                          float* hattn, float* m, float* Z, void* part, void* stream) {
+                          float* hattn, float* m, float* Z, float* aneg, float* qneg, void* part, void* stream) {
   FwdArgs a;
   int rc = check_graph(g, &a.g);
   if (rc) return rc;
@@ -456,6 +456,8 @@ static int launch_forward(const pygat_graph* g, int H, int Fo, float alpha, int 
   PYGAT_REQUIRE(out || hattn, "gat_forward: need out and/or hattn");
   PYGAT_REQUIRE(!(flags & PYGAT_F_SKIP) || sk, "gat_forward: PYGAT_F_SKIP without sk");
   PYGAT_REQUIRE((m == nullptr) == (Z == nullptr), "gat_forward: m and Z must be given together");
+  PYGAT_REQUIRE((aneg == nullptr) == (qneg == nullptr) && (!aneg || (m && !v2 && aligned16(aneg))),
+                "gat_forward: aneg and qneg come together, need m/Z, 16-byte alignment and the v1 layer");
   PYGAT_REQUIRE(aligned16(Wh) && aligned16(part) && aligned16(a_pad) && (!sk || aligned16(sk)) && (!hattn || aligned16(hattn)) &&
                     (!out || Fo != Fp || aligned16(out)),
                 "gat_forward: row tables must be 16-byte aligned");
@@ -476,30 +478,39 @@ static int launch_forward(const pygat_graph* g, int H, int Fo, float alpha, int 
     a.out = out ? out + (int64_t)h0 * Fo : nullptr;
     a.hattn = hattn ? hattn + (int64_t)h0 * Fp : nullptr;
     a.m = m ? m + h0 : nullptr; a.Z = Z ? Z + h0 : nullptr;
+    a.aneg = aneg ? aneg + (int64_t)h0 * Fp : nullptr; a.qneg = qneg ? qneg + h0 : nullptr;
     a.part = (float*)part;   // reused by the windows: the launches are ordered on the stream
     int lpr, vec;
     pick_lanes(a.rs, &lpr, &vec);
     const unsigned blocks = (unsigned)cdiv(cdiv(nslots, 64 / lpr), 4);
+    const bool aux = aneg != nullptr;
     if (v2) {
       PYGAT_DISPATCH_LANES(lpr, vec,
-                           hipLaunchKernelGGL((gat_fwd_kernel<LPR, VEC, true>), dim3(blocks), dim3(256), 0, st, a));
+                           hipLaunchKernelGGL((gat_fwd_kernel<LPR, VEC, true, false>), dim3(blocks), dim3(256), 0, st, a));
+    } else if (aux) {
+      PYGAT_DISPATCH_LANES(lpr, vec,
+                           hipLaunchKernelGGL((gat_fwd_kernel<LPR, VEC, false, true>), dim3(blocks), dim3(256), 0, st, a));
     } else {
       PYGAT_DISPATCH_LANES(lpr, vec,
-                           hipLaunchKernelGGL((gat_fwd_kernel<LPR, VEC, false>), dim3(blocks), dim3(256), 0, st, a));
+                           hipLaunchKernelGGL((gat_fwd_kernel<LPR, VEC, false, false>), dim3(blocks), dim3(256), 0, st, a));
     }
     PYGAT_CHECK_LAUNCH("gat_forward");
-    const size_t fix_lds = 4 * (size_t)(a.rs.R + 2 * a.rs.H) * sizeof(float);
-    if (a.g.cut) {  // the caller listed the cut rows: go straight to them
-      if (a.g.n_cut > 0) {
-        const unsigned fb = (unsigned)(a.g.n_cut_wide + cdiv(a.g.n_cut - a.g.n_cut_wide, 4));
-        PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_fwd_fixup_list_kernel<LPR, VEC>), dim3(fb), dim3(256),
-                                                          fix_lds, st, a));
-      }
-    } else {
-      const unsigned fb = (unsigned)cdiv(nslots, FIX_SCREEN);
-      PYGAT_DISPATCH_LANES(lpr, vec,
-                           hipLaunchKernelGGL((gat_fwd_fixup_kernel<LPR, VEC>), dim3(fb), dim3(256), fix_lds, st, a));
-    }
+    const size_t fix_lds = 4 * (size_t)(aux ? part_stride<true>(a.rs) : part_stride<false>(a.rs)) * sizeof(float);
+    const bool listed = a.g.cut != nullptr;   // the caller listed the cut rows: go straight to them
+    const unsigned fb = listed ? (unsigned)(a.g.n_cut_wide + cdiv(a.g.n_cut - a.g.n_cut_wide, 4)) : (unsigned)cdiv(nslots, FIX_SCREEN);
+    if (listed && a.g.n_cut == 0) continue;
+#define PYGAT_FIX(AUXV)                                                                                               \
+    do {                                                                                                              \
+      if (listed) {                                                                                                   \
+        PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_fwd_fixup_list_kernel<LPR, VEC, AUXV>), dim3(fb),     \
+                                                          dim3(256), fix_lds, st, a));                                \
+      } else {                                                                                                        \
+        PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_fwd_fixup_kernel<LPR, VEC, AUXV>), dim3(fb), dim3(256), \
+                                                          fix_lds, st, a));                                           \
+      }                                                                                                               \
+    } while (0)
+    if (aux) PYGAT_FIX(true); else PYGAT_FIX(false);
+#undef PYGAT_FIX
     PYGAT_CHECK_LAUNCH("gat_forward_fixup");
   }
   return PYGAT_OK;
@@ -513,14 +524,15 @@ extern "C" int pygat_head_group(int n, int H, int Fo) {
 
 extern "C" int pygat_gat_forward(const pygat_graph* g, int H, int Fo, float alpha, int flags, const float* Wh,
                                  const float* s, const float* a_pad, const float* sk, const float* att_mask,
-                                 float* out, float* hattn, float* m, float* Z, void* part, void* stream) {
-  return launch_forward(g, H, Fo, alpha, flags, Wh, 0, s, a_pad, sk, att_mask, out, hattn, m, Z, part, stream);
+                                 float* out, float* hattn, float* m, float* Z, float* aneg, float* qneg, void* part,
+                                 void* stream) {
+  return launch_forward(g, H, Fo, alpha, flags, Wh, 0, s, a_pad, sk, att_mask, out, hattn, m, Z, aneg, qneg, part, stream);
 }
 
 extern "C" int pygat_gatv2_forward(const pygat_graph* g, int H, int Fo, float alpha, int flags, const float* WW,
                                    const float* a2, const float* sk, const float* att_mask, float* out,
                                    float* hattn, float* m, float* Z, void* part, void* stream) {
-  return launch_forward(g, H, Fo, alpha, flags, WW, 1, nullptr, a2, sk, att_mask, out, hattn, m, Z, part, stream);
+  return launch_forward(g, H, Fo, alpha, flags, WW, 1, nullptr, a2, sk, att_mask, out, hattn, m, Z, nullptr, nullptr, part, stream);
 }
 
 extern "C" int pygat_head_mean(int n, int H, int Fo, const float* hattn, const float* sk, float* out,

@@ -36,6 +36,11 @@ struct PrepArgs {
   int gr_heads;     // heads of the range (GR is laid out for them alone)
   const float* whi; // GATv2: table whose first R floats per row are copied behind the rowtab, else nullptr
   int64_t ld_whi;
+  // row sums from the forward's alpha-branch shares (k2_forward.hip, AUX): ds_i = -(1 - slope)(Gp_i . aneg_i - D_i qneg_i)
+  const float* aneg;  // [n][ldr] or nullptr
+  const float* qneg;  // [n][ldh]
+  float* ds;          // [n][ldh]
+  float slope;        // LeakyReLU alpha
 };
 
 // float offsets inside a GR row (include/pygat_amd.h, K3a): window w0 = first head of the backward window
@@ -108,9 +113,12 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_kernel(PrepArgs a) {
       if (a.whi) st4(a.GR + i * RW + R + 4 * H + co, ld4(a.whi + i * a.ld_whi + co));
     }
     const float D = group_sum_rt(dot4(g4, hat), lph);
+    float gn = 0.f;
+    if (a.aneg) gn = group_sum_rt(lc.valid[v] ? dot4(g4, ld4(a.aneg + i * ldr + co)) : 0.f, lph);
     if (lc.valid[v] && ((co >> 2) & (a.rs.lph - 1)) == 0) {
       const int64_t q = i * ldh + h;
       st4(a.GR + i * RW + gr_rt_off(a, h), make_float4(a.s[q], a.m[q], 1.0f / a.Z[q], D));
+      if (a.aneg) a.ds[q] = (a.slope - 1.f) * (gn - D * a.qneg[q]);
     }
   }
 }
@@ -132,15 +140,17 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_fast_kernel(PrepArgs a) {
   const bool valid = lc.valid[0];
   const bool lead = valid && (((co >> 2) & (a.rs.lph - 1)) == 0);
   const int64_t gp_off = gr_gp_off(a, co, h), rt_off = gr_rt_off(a, h);
-  float4 g4[RB], y4[RB], k4[RB];
-  float sv[RB], mv[RB], zv[RB];
+  float4 g4[RB], y4[RB], k4[RB], n4[RB];
+  float sv[RB], mv[RB], zv[RB], qv[RB];
 #pragma unroll
   for (int r = 0; r < RB; ++r) {
     const int64_t i = (i0 + r < a.n) ? i0 + r : a.n - 1;
     g4[r] = ld4(a.G + i * ldo + co);
     y4[r] = ld4(a.y + i * ldo + co);
     k4[r] = (a.flags & PYGAT_F_SKIP) ? ld4(a.sk + i * ldr + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    n4[r] = a.aneg ? ld4(a.aneg + i * ldr + co) : make_float4(0.f, 0.f, 0.f, 0.f);
     sv[r] = a.s[i * ldh + h]; mv[r] = a.m[i * ldh + h]; zv[r] = a.Z[i * ldh + h];
+    qv[r] = a.aneg ? a.qneg[i * ldh + h] : 0.f;
   }
 #pragma unroll
   for (int r = 0; r < RB; ++r) {
@@ -159,12 +169,16 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_fast_kernel(PrepArgs a) {
     float4 g = valid ? make_float4(gq[0], gq[1], gq[2], gq[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 hat = make_float4(pq[0] - k4[r].x, pq[1] - k4[r].y, pq[2] - k4[r].z, pq[3] - k4[r].w);
     const float D = group_sum_rt(dot4(g, hat), lph);
+    const float gn = a.aneg ? group_sum_rt(dot4(g, n4[r]), lph) : 0.f;
     if (i < a.n) {
       if (valid) {
         st4(a.GR + i * RW + gp_off, g);
         if (a.whi) st4(a.GR + i * RW + R + 4 * H + co, ld4(a.whi + i * a.ld_whi + co));
       }
-      if (lead) st4(a.GR + i * RW + rt_off, make_float4(sv[r], mv[r], 1.0f / zv[r], D));
+      if (lead) {
+        st4(a.GR + i * RW + rt_off, make_float4(sv[r], mv[r], 1.0f / zv[r], D));
+        if (a.aneg) a.ds[i * ldh + h] = (a.slope - 1.f) * (gn - D * qv[r]);
+      }
     }
   }
 }
@@ -382,12 +396,15 @@ using namespace pygat;
 
 static int launch_prepare(int n, int H, int Fo, int flags, int mean_mode, const float* G, const float* y,
                           const float* sk, const float* s, const float* m, const float* Z, float* GR,
-                          const float* whi, int64_t ld_whi, int h_first, int h_count, void* stream);
+                          const float* whi, int64_t ld_whi, const float* aneg, const float* qneg, float slope, float* ds,
+                          int h_first, int h_count, void* stream);
 
 extern "C" int pygat_gat_backward_prepare(int n, int H, int Fo, int flags, int mean_mode, const float* G,
                                           const float* y, const float* sk, const float* s, const float* m,
-                                          const float* Z, float* GR, int h_first, int h_count, void* stream) {
-  return launch_prepare(n, H, Fo, flags, mean_mode, G, y, sk, s, m, Z, GR, nullptr, 0, h_first, h_count, stream);
+                                          const float* Z, float* GR, const float* aneg, const float* qneg, float alpha,
+                                          float* ds, int h_first, int h_count, void* stream) {
+  return launch_prepare(n, H, Fo, flags, mean_mode, G, y, sk, s, m, Z, GR, nullptr, 0, aneg, qneg, alpha, ds, h_first,
+                        h_count, stream);
 }
 
 /* GATv2: GRW [n x (2R + 4H)] = [Gp | (., m, 1/Z, D) | Whi], Whi copied from WW [n x 2R] */
@@ -397,12 +414,13 @@ extern "C" int pygat_gatv2_backward_prepare(int n, int H, int Fo, int flags, int
   if (!WW) { pygat::set_error("gatv2_backward_prepare: null WW"); return PYGAT_EINVAL; }
   int Fp = pygat::padded_width(Fo);
   return launch_prepare(n, H, Fo, flags, mean_mode, G, y, sk, m /* s slot unused in V2 */, m, Z, GRW, WW,
-                        2 * (int64_t)H * Fp, 0, 0, stream);
+                        2 * (int64_t)H * Fp, nullptr, nullptr, 0.f, nullptr, 0, 0, stream);
 }
 
 static int launch_prepare(int n, int H, int Fo, int flags, int mean_mode, const float* G, const float* y,
                           const float* sk, const float* s, const float* m, const float* Z, float* GR,
-                          const float* whi, int64_t ld_whi, int h_first, int h_count, void* stream) {
+                          const float* whi, int64_t ld_whi, const float* aneg, const float* qneg, float slope, float* ds,
+                          int h_first, int h_count, void* stream) {
   PrepArgs a;
   const int Fp = padded_width(Fo);
   HeadRange rg;
@@ -410,6 +428,8 @@ static int launch_prepare(int n, int H, int Fo, int flags, int mean_mode, const 
   PYGAT_REQUIRE(make_head_range(H, h_first, h_count, &rg) && (!whi || rg.hr == H),
                 "gat_backward_prepare: bad head range [%d, +%d) of %d", h_first, h_count, H);
   PYGAT_REQUIRE(n > 0 && G && y && s && m && Z && GR, "gat_backward_prepare: null pointer");
+  PYGAT_REQUIRE((aneg == nullptr) == (qneg == nullptr) && (aneg == nullptr) == (ds == nullptr) && (!aneg || aligned16(aneg)),
+                "gat_backward_prepare: aneg, qneg and ds come together (aneg 16-byte aligned)");
   PYGAT_REQUIRE(!(flags & PYGAT_F_SKIP) || sk, "gat_backward_prepare: PYGAT_F_SKIP without sk");
   PYGAT_REQUIRE(!(mean_mode && (flags & PYGAT_F_ELU)), "gat_backward_prepare: the head mean never carries an ELU (models.py:23)");
   PYGAT_REQUIRE(aligned16(GR) && (!sk || aligned16(sk)) &&
@@ -430,6 +450,8 @@ static int launch_prepare(int n, int H, int Fo, int flags, int mean_mode, const 
     a.ldgr = (int64_t)rg.hr * Fp * (whi ? 2 : 1) + 4 * rg.hr;
     a.GR = GR; a.h0p = h0; a.gr_hg = whi ? H : head_group_bwd(n, rg.hr, Fp); a.gr_heads = rg.hr;
     a.whi = whi; a.ld_whi = ld_whi;
+    a.aneg = aneg ? aneg + (int64_t)gh * Fp : nullptr; a.qneg = qneg ? qneg + gh : nullptr;
+    a.ds = ds ? ds + gh : nullptr; a.slope = slope;
     int lpr, vec;
     pick_lanes(a.rs, &lpr, &vec);
     if (!mean_mode && a.rs.Fo == a.rs.Fp && vec == 1) {

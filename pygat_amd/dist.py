@@ -40,6 +40,13 @@ def _world():
     return 0, 1
 
 
+def gather_columns_layout(buf: torch.Tensor) -> torch.Tensor:
+    """[world, N, w] (what an all-gather delivers: rank-major column blocks) -> [N, world*w] (torch.cat(dim=1),
+    models.py:32).  One strided copy."""
+    world, N, w = buf.shape
+    return buf.permute(1, 0, 2).reshape(N, world * w)
+
+
 def all_gather_columns_raw(local: torch.Tensor, widths: Sequence[int]) -> torch.Tensor:
     """[N, widths[rank]] on every rank -> [N, sum(widths)] on every rank (no autograd)."""
     rank, world = _world()
@@ -49,7 +56,7 @@ def all_gather_columns_raw(local: torch.Tensor, widths: Sequence[int]) -> torch.
     if all(w == wmax for w in widths):
         buf = torch.empty(world * N, wmax, dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(buf, local.contiguous())
-        return buf.view(world, N, wmax).permute(1, 0, 2).reshape(N, world * wmax)
+        return gather_columns_layout(buf.view(world, N, wmax))
     pad = torch.zeros(N, wmax, dtype=local.dtype, device=local.device)
     pad[:, :widths[rank]] = local
     buf = torch.empty(world * N, wmax, dtype=local.dtype, device=local.device)

@@ -105,24 +105,28 @@ class GATLevelDropoutFn(torch.autograd.Function):
             flags = (_lib.F_ELU if concat else 0) | (_lib.F_SKIP if skip else 0)
             hattn = torch.empty(L.N, R, dtype=f32, device=dev) if not concat else None
             m = torch.empty(L.N, H, dtype=f32, device=dev); Z = torch.empty(L.N, H, dtype=f32, device=dev)
+            flavour = ops.backward_flavour(L.R)
+            aneg = torch.empty(L.N, R, dtype=f32, device=dev) if flavour == "rowlocal" else None
+            qneg = torch.empty(L.N, H, dtype=f32, device=dev) if flavour == "rowlocal" else None
             out = torch.empty(L.N, H * Fo if concat else Fo, dtype=f32, device=dev)
             part = torch.empty(lib.pygat_partials_bytes(E, L.ts, H, L.Fp) // 4, dtype=f32, device=dev)
             with _span("k2_forward"):
                 check(lib.pygat_gat_forward(graph.fwd.ref(L.ts), H, Fo, float(alpha), flags, Wh.data_ptr(), s.data_ptr(),
                                             a_pad.data_ptr(), _ptr(Sk), matt.data_ptr(),
                                             out.data_ptr() if concat else None, _ptr(hattn), m.data_ptr(), Z.data_ptr(),
-                                            part.data_ptr(), st), "gat_forward")
+                                            _ptr(aneg), _ptr(qneg), part.data_ptr(), st), "gat_forward")
             if not concat:
                 check(lib.pygat_head_mean(L.N, H, Fo, hattn.data_ptr(), _ptr(Sk), out.data_ptr(), st), "head_mean")
         ctx.save_for_backward(Ae, Bp, a_pad, Wh, s, Sk, out if concat else hattn, m, Z, mask_x if explicit else seed,
-                              mwh, matt)
+                              mwh, matt, aneg, qneg)
         ctx.graph, ctx.L, ctx.alpha, ctx.concat, ctx.flags, ctx.p, ctx.explicit = \
             graph, L, float(alpha), concat, flags, p, explicit
+        ctx.flavour = flavour
         return out
 
     @staticmethod
     def backward(ctx, G):
-        Ae, Bp, a_pad, Wh, s, Sk, y, m, Z, mx_or_seed, mwh, matt = ctx.saved_tensors
+        Ae, Bp, a_pad, Wh, s, Sk, y, m, Z, mx_or_seed, mwh, matt, aneg, qneg = ctx.saved_tensors
         graph, L, H, Fo, p = ctx.graph, ctx.L, ctx.L.H, ctx.L.Fo, ctx.p
         dev, f32 = Ae.device, torch.float32
         G = G.contiguous().float()
@@ -135,11 +139,18 @@ class GATLevelDropoutFn(torch.autograd.Function):
             ds = torch.empty(L.N, H, dtype=f32, device=dev); dt = torch.empty(L.N, H, dtype=f32, device=dev)
             dWh = torch.empty(L.N, R, dtype=f32, device=dev)
             part = torch.empty(lib.pygat_partials_bytes(graph.nnz, L.ts, H, L.Fp) // 4, dtype=f32, device=dev)
+            rowlocal = ctx.flavour == "rowlocal"
             check(lib.pygat_gat_backward_prepare(L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(), y.data_ptr(),
-                                                 _ptr(Sk), s.data_ptr(), m.data_ptr(), Z.data_ptr(), GR.data_ptr(), 0, 0, st),
+                                                 _ptr(Sk), s.data_ptr(), m.data_ptr(), Z.data_ptr(), GR.data_ptr(),
+                                                 _ptr(aneg), _ptr(qneg), ctx.alpha, ds.data_ptr() if rowlocal else None, 0, 0, st),
                   "gat_backward_prepare")
-            two_gather = ops.two_gather_backward(L.R)
-            if two_gather:
+            two_gather = ctx.flavour != "rowsum"       # below: does a_grad still have to finish dWh += ds a_src ?
+            if rowlocal:       # ds known from the forward's alpha-branch shares (ops.BACKWARD_FLAVOUR)
+                check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), graph.perm_t.data_ptr(), H, Fo, ctx.alpha,
+                                                 Wh.data_ptr(), a_pad.data_ptr(), GR.data_ptr(), matt.data_ptr(),
+                                                 ds.data_ptr(), dWh.data_ptr(), dt.data_ptr(), None, part.data_ptr(), 0, 0, st),
+                      "gat_backward_col")
+            elif two_gather:
                 check(lib.pygat_gat_backward_row(graph.fwd.ref(L.ts), H, Fo, ctx.alpha, Wh.data_ptr(), a_pad.data_ptr(),
                                                  GR.data_ptr(), matt.data_ptr(), ds.data_ptr(), part.data_ptr(), 0, 0, st),
                       "gat_backward_row")

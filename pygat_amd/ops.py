@@ -57,9 +57,27 @@ TIMER: Optional[KernelTimer] = None
 _env = os.environ.get("PYGAT_TWO_GATHER_BACKWARD")
 TWO_GATHER_BACKWARD: Optional[bool] = None if _env is None else (_env == "1")
 
+# Default since round 2: "rowlocal".  The training forward (K2) also accumulates the share of every row sum that
+# went through the alpha branch of the LeakyReLU (aneg, qneg); since sum_j de_ij = 0 the row sums of dz follow
+# row-locally in K3a, ds_i = -(1 - alpha)(Gp_i . aneg_i - D_i qneg_i), so the backward needs neither the second
+# gather (K3b) nor per-edge dz records and their row-sum pass (K3c): K3a -> K4 -> da -> dW.  Costs one more [N, R]
+# table (written by K2, read by K3a).  BACKWARD_FLAVOUR / PYGAT_BACKWARD = rowlocal | rowsum | two-gather forces a
+# flavour; a non-None TWO_GATHER_BACKWARD (the older switch) selects between the two older ones.
+BACKWARD_FLAVOUR: Optional[str] = os.environ.get("PYGAT_BACKWARD")
+
 
 def two_gather_backward(row_floats: int) -> bool:
     return TWO_GATHER_BACKWARD if TWO_GATHER_BACKWARD is not None else row_floats < 64
+
+
+def backward_flavour(row_floats: int) -> str:
+    if BACKWARD_FLAVOUR:
+        if BACKWARD_FLAVOUR not in ("rowlocal", "rowsum", "two-gather"):
+            raise ValueError(f"PYGAT_BACKWARD={BACKWARD_FLAVOUR!r}: expected rowlocal, rowsum or two-gather")
+        return BACKWARD_FLAVOUR
+    if TWO_GATHER_BACKWARD is not None:
+        return "two-gather" if TWO_GATHER_BACKWARD else "rowsum"
+    return "rowlocal"
 
 
 class _span:
@@ -81,6 +99,22 @@ class _span:
 
 def _ptr(t):
     return None if t is None else t.data_ptr()
+
+
+# Side stream for the part of the backward that does not feed the weight-gradient GEMM: the `a` gradient (an
+# HBM-bound stream over Wh, ds, dt) runs beside the MFMA-bound dW GEMM.  One per device; fork/join with events, so a
+# HIP-graph capture of the level records the two branches as parallel graph nodes.
+_side = {}
+
+
+def _side_stream(dev) -> "torch.cuda.Stream":
+    key = torch.device(dev).index
+    if key not in _side:
+        _side[key] = torch.cuda.Stream(device=dev)
+    return _side[key]
+
+
+OVERLAP_BACKWARD = os.environ.get("PYGAT_OVERLAP_BACKWARD", "1") == "1"
 
 
 def _segments(cols_ptr_ld) -> _lib.OutSegments:
@@ -199,19 +233,23 @@ class GATLevelFn(torch.autograd.Function):
             hattn = torch.empty(L.N, L.R, dtype=f32, device=dev) if not concat else None
             m = torch.empty(L.N, H, dtype=f32, device=dev) if need_grad else None
             Z = torch.empty(L.N, H, dtype=f32, device=dev) if need_grad else None
+            flavour = backward_flavour(L.R) if need_grad else None
+            aneg = torch.empty(L.N, L.R, dtype=f32, device=dev) if flavour == "rowlocal" else None
+            qneg = torch.empty(L.N, H, dtype=f32, device=dev) if flavour == "rowlocal" else None
             out = torch.empty(L.N, H * Fo if concat else Fo, dtype=f32, device=dev)
             part = torch.empty(lib.pygat_partials_bytes(graph.nnz, L.ts, H, L.Fp) // 4, dtype=f32,
                                device=dev)
             with _span("k2_forward"):
                 check(lib.pygat_gat_forward(graph.fwd.ref(L.ts), H, Fo, float(alpha), flags, Wh.data_ptr(), s.data_ptr(),
                                             a_pad.data_ptr(), _ptr(Sk), None, out.data_ptr() if concat else None, _ptr(hattn),
-                                            _ptr(m), _ptr(Z), part.data_ptr(), st), "gat_forward")
+                                            _ptr(m), _ptr(Z), _ptr(aneg), _ptr(qneg), part.data_ptr(), st), "gat_forward")
             if not concat:
                 check(lib.pygat_head_mean(L.N, H, Fo, hattn.data_ptr(), _ptr(Sk), out.data_ptr(), st), "head_mean")
         if need_grad:
             # concat: the backward recovers hattn from `out` (no second [N,R] table is written)
-            ctx.save_for_backward(x, Wcat, a_pad, Wh, s, Sk, out if concat else hattn, m, Z)
+            ctx.save_for_backward(x, Wcat, a_pad, Wh, s, Sk, out if concat else hattn, m, Z, aneg, qneg)
             ctx.graph, ctx.L, ctx.alpha, ctx.concat, ctx.flags = graph, L, float(alpha), concat, flags
+            ctx.flavour = flavour
             ctx.bwd_heads = None
             if bwd_heads is not None:
                 hb, hr = int(bwd_heads[0]), int(bwd_heads[1])
@@ -224,7 +262,7 @@ class GATLevelFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, G):
-        x, Wcat, a_pad, Wh, s, Sk, y, m, Z = ctx.saved_tensors
+        x, Wcat, a_pad, Wh, s, Sk, y, m, Z, aneg, qneg = ctx.saved_tensors
         graph, L, H, Fo = ctx.graph, ctx.L, ctx.L.H, ctx.L.Fo
         dev, f32 = x.device, torch.float32
         G = G.contiguous().float()
@@ -240,12 +278,20 @@ class GATLevelFn(torch.autograd.Function):
             dWh = torch.empty(L.N, L.R, dtype=f32, device=dev)
             part = torch.empty(lib.pygat_partials_bytes(graph.nnz, L.ts, H, L.Fp) // 4, dtype=f32,
                                device=dev)
+            rowlocal = ctx.flavour == "rowlocal"
             with _span("k3a_prepare"):
                 check(lib.pygat_gat_backward_prepare(L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(),
                                                      y.data_ptr(), _ptr(Sk), s.data_ptr(), m.data_ptr(), Z.data_ptr(),
-                                                     GR.data_ptr(), hb, hr, st), "gat_backward_prepare")
-            two_gather = two_gather_backward(Hb * L.Fp)
-            if two_gather:
+                                                     GR.data_ptr(), _ptr(aneg), _ptr(qneg), ctx.alpha,
+                                                     ds.data_ptr() if rowlocal else None, hb, hr, st), "gat_backward_prepare")
+            two_gather = ctx.flavour == "two-gather"
+            if rowlocal:        # ds is known: the column pass finishes dWh on its own
+                with _span("k4_backward_col"):
+                    check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), None, H, Fo, ctx.alpha, Wh.data_ptr(),
+                                                     a_pad.data_ptr(), GR.data_ptr(), None, ds.data_ptr(),
+                                                     dWh.data_ptr(), dt.data_ptr(), None, part.data_ptr(), hb, hr, st),
+                          "gat_backward_col")
+            elif two_gather:
                 with _span("k3b_row"):
                     check(lib.pygat_gat_backward_row(graph.fwd.ref(L.ts), H, Fo, ctx.alpha, Wh.data_ptr(),
                                                      a_pad.data_ptr(), GR.data_ptr(), None, ds.data_ptr(),
@@ -271,13 +317,21 @@ class GATLevelFn(torch.autograd.Function):
             ws = torch.empty(lib.pygat_agrad_workspace_bytes(H, Fo) // 4, dtype=f32, device=dev)
             # ... unless nothing but the weight-gradient GEMM consumes dWh: there ds rides along as extra columns
             # (pygat_wgrad) and dWh is never rewritten
-            fold_ds = ((not two_gather) and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]
+            rowsum = ctx.flavour == "rowsum"
+            fold_ds = (rowsum and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]
                        and (Hb * L.Fp) % 32 == 0 and L.N >= 4096)   # the streamed-K GEMM takes [dWh | ds] in one pass
-            finish = (not two_gather) and not fold_ds
+            finish = rowsum and not fold_ds
+            # when a_grad does not rewrite dWh, nothing downstream depends on it: run it on the side stream,
+            # beside the weight-gradient GEMM (TIMER spans stay on the main stream: no fork while timing kernels)
+            fork = OVERLAP_BACKWARD and not finish and TIMER is None and ctx.needs_input_grad[1]
+            if fork:
+                main, side = torch.cuda.current_stream(), _side_stream(dev)
+                side.wait_stream(main)      # the tensors it touches stay referenced until the join below
             with _span("k5_agrad"):
                 check(lib.pygat_a_grad(L.N, H, Fo, Wh.data_ptr(), ds.data_ptr(), dt.data_ptr(), da.data_ptr(),
                                        ws.data_ptr(), a_pad.data_ptr() if finish else None,
-                                       dWh.data_ptr() if finish else None, hb, hr, st), "a_grad")
+                                       dWh.data_ptr() if finish else None, hb, hr,
+                                       side.cuda_stream if fork else st), "a_grad")
             # dW = x^T dWh (split-K over the nodes), dWskip = x^T Gp
             dW = dWs = dx = None
             if ctx.needs_input_grad[1]:
@@ -303,6 +357,8 @@ class GATLevelFn(torch.autograd.Function):
                         for c0, w, g0 in L.gp_windows():
                             gemm(False, True, L.N, L.Fin, w, GR[:, g0:], RW, Wcat[:, L.R + c0:], L.ldw,
                                  [(L.Fin, dx, L.Fin)], accumulate=True, split_k=1)
+            if fork:
+                main.wait_stream(side)
         return dx, dW, (da if ctx.needs_input_grad[2] else None), dWs, None, None, None, None
 
 

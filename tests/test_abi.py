@@ -59,10 +59,10 @@ def test_argument_validation_returns_einval(lib):
     assert b"bad arguments" in L.pygat_last_error()
     assert L.pygat_gemm_f32(0, 0, 4, 4, 4, None, 4, None, 4, None, 0, 1, None, None) == -1
     g = lib.Graph(0, 0, None, None, 64, None, None, 0, 0)
-    assert L.pygat_gat_forward(C.byref(g), 8, 16, 0.2, 1, None, None, None, None, None, None, None, None, None, None, None) == -1
+    assert L.pygat_gat_forward(C.byref(g), 8, 16, 0.2, 1, None, None, None, None, None, None, None, None, None, None, None, None, None) == -1
     assert b"graph" in L.pygat_last_error()
     g2 = lib.Graph(4, 4, 1, 1, 6, None, None, 0, 0)             # slot_edges not a multiple of 4
-    assert L.pygat_gat_forward(C.byref(g2), 8, 16, 0.2, 1, None, None, None, None, None, None, None, None, None, None, None) == -1
+    assert L.pygat_gat_forward(C.byref(g2), 8, 16, 0.2, 1, None, None, None, None, None, None, None, None, None, None, None, None, None) == -1
     assert b"slot_edges" in L.pygat_last_error()
     with pytest.raises(ValueError):
         lib.check(-1, "x")
@@ -146,6 +146,15 @@ def test_host_policies(lib, monkeypatch):
     assert ops.two_gather_backward(1024)
     monkeypatch.setattr(ops, "TWO_GATHER_BACKWARD", False)
     assert not ops.two_gather_backward(16)
+    # flavour of the backward: row-local by default, the older switch selects between the two older flavours
+    monkeypatch.setattr(ops, "BACKWARD_FLAVOUR", None)
+    assert ops.backward_flavour(16) == "rowsum"
+    monkeypatch.setattr(ops, "TWO_GATHER_BACKWARD", True)
+    assert ops.backward_flavour(128) == "two-gather"
+    monkeypatch.setattr(ops, "TWO_GATHER_BACKWARD", None)
+    assert ops.backward_flavour(16) == ops.backward_flavour(1024) == "rowlocal"
+    monkeypatch.setattr(ops, "BACKWARD_FLAVOUR", "rowsum")
+    assert ops.backward_flavour(128) == "rowsum"
     # streamed-K weight gradient: slabs x column tiles = 256 (one work-group per CU)
     assert ops._split_k(128, 128, 1 << 20, streamed_k=True) == 256
     assert ops._split_k(128, 136, 1 << 20, streamed_k=True) == 256      # [dWh | ds]: still one 5-tile column block

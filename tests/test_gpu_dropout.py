@@ -15,10 +15,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("H,Fin,Fo,skip,concat", [(3, 10, 8, False, True), (2, 7, 5, True, False), (8, 20, 8, True, True),
                                                   (3, 9, 128, True, True), (5, 6, 100, True, False), (6, 5, 128, True, True)])   # last two: head windows
-@pytest.mark.parametrize("two_gather", [False, True])
+@pytest.mark.parametrize("two_gather", [None, False, True])
 def test_dropout_explicit_masks(pg, monkeypatch, two_gather, H, Fin, Fo, skip, concat):  # noqa: F811
     from pygat_amd.dropout import gat_level_dropout
-    monkeypatch.setattr(pg.ops, "TWO_GATHER_BACKWARD", two_gather)   # both backward flavours carry the attention mask
+    monkeypatch.setattr(pg.ops, "TWO_GATHER_BACKWARD", two_gather)   # all backward flavours carry the attention mask (None: the default, row-local one)
     monkeypatch.setenv("PYGAT_BWD_WINDOW_BYTES", "0")   # rows > 512 floats: backward in head windows
     N, p = 70, 0.6
     rowptr, col = O.random_symmetric_csr(N, 5, 3, hub=(2, 50))

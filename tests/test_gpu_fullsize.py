@@ -12,6 +12,8 @@ import numpy as np
 import pytest
 import torch
 
+from parity import close_fwd, close_grad
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -40,26 +42,40 @@ def run(w, X, W, a, G):
     return out.detach(), Wd.grad, ad.grad
 
 
-def test_fullsize_against_c_oracle(world):
-    w = world
+def c_refs(X, rowptr, col, W, a, G):
+    """(fp64 ground truth, fp32 port) of the level from the two builds of oracle/gat_oracle.c."""
     subprocess.run(["make", "-B", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
     from oracle import c_oracle
+    args = (X.cpu().numpy(), rowptr.cpu().numpy(), col.cpu().numpy(), W.detach().cpu().numpy(), a.detach().cpu().numpy(), 0.2,
+            True, G.cpu().numpy())
+    tp = c_oracle.transpose_pattern(args[1], args[2])
+    return (c_oracle.level(*args, want_dx=False, tp=tp, dtype=np.float64), c_oracle.level(*args, want_dx=False, tp=tp))
+
+
+@pytest.mark.parametrize("flavour", ["rowlocal", "rowsum", "two-gather"])
+def test_fullsize_against_c_oracle(world, monkeypatch, flavour):
+    """SURVEY.md 8(c) at full size, against the fp64 build of the C oracle: forward within 1e-5 ABSOLUTE; gradients
+    within max(1e-5, 4 x the error of the fp32 build against the same fp64 truth).  (86 M logits: both fp32 sides
+    take the other LeakyReLU branch at a few hundred near-zero ones; the rule prices that too.)"""
+    w = world
+    monkeypatch.setattr(w["pg"].ops, "BACKWARD_FLAVOUR", flavour)
     out, dW, da = run(w, w["X"], w["W"], w["a"], w["G"])
-    ref = c_oracle.level(w["X"].cpu().numpy(), w["rowptr"].cpu().numpy(), w["col"].cpu().numpy(), w["W"].cpu().numpy(),
-                         w["a"].cpu().numpy(), 0.2, True, w["G"].cpu().numpy(), want_dx=False)
-    # both sides are fp32 here (the C port accumulates rows in fp32): 1e-5 on the outputs, and on the
-    # gradients relative to their magnitude (sums over up to 10^6 nodes)
-    o = out.cpu().numpy()
-    assert np.isfinite(o).all()
-    assert np.abs(o - ref["out"]).max() <= 1e-5 * max(1.0, np.abs(ref["out"]).max())
-    for got, want, name in ((dW, ref["dW"], "dW"), (da, ref["da"], "da")):
-        got = got.cpu().numpy()
-        assert np.abs(got - want).max() <= 2e-4 * np.abs(want).max(), name
+    if "refs" not in w:
+        w["refs"] = c_refs(w["X"], w["rowptr"], w["col"], w["W"], w["a"], w["G"])
+    r64, r32 = w["refs"]
+    e = close_fwd(out, r64["out"], "out")
+    e32 = float(np.abs(r32["out"].astype(np.float64) - r64["out"]).max())
+    msg = [f"fullsize[{flavour}]: out err {e:.2e} (fp32 oracle {e32:.2e}, max |out| {np.abs(r64['out']).max():.3g})"]
+    for got, name in ((dW, "dW"), (da, "da")):
+        err, own = close_grad(got, r64[name], r32[name], name)
+        msg.append(f"{name} err {err:.2e} (fp32 oracle {own:.2e}, max |{name}| {np.abs(r64[name]).max():.3g})")
+    print("; ".join(msg))
 
 
 def test_fullsize_properties(world, monkeypatch):
     w = world
     pg, graph, H, Fo = w["pg"], w["graph"], w["H"], w["Fo"]
+    monkeypatch.setattr(pg.ops, "BACKWARD_FLAVOUR", None)
     monkeypatch.setattr(pg.ops, "TWO_GATHER_BACKWARD", True)
     out1, dW1, da1 = run(w, w["X"], w["W"], w["a"], w["G"])
     out2, dW2, da2 = run(w, w["X"], w["W"], w["a"], w["G"])
@@ -72,7 +88,15 @@ def test_fullsize_properties(world, monkeypatch):
     assert torch.equal(out3, out1) and torch.equal(dW3f, dW4f) and torch.equal(da3f, da4f)
     assert float((dW3f - dW1).abs().max()) <= 1e-5 * float(dW1.abs().max())
     assert float((da3f - da1).abs().max()) <= 1e-5 * float(da1.abs().max())
-    dW1, da1 = dW3f, da3f
+    # the default backward (row sums from the forward's alpha-branch shares): bitwise reproducible, same results up to
+    # rounding
+    monkeypatch.setattr(pg.ops, "TWO_GATHER_BACKWARD", None)
+    out5, dW5, da5 = run(w, w["X"], w["W"], w["a"], w["G"])
+    out6, dW6, da6 = run(w, w["X"], w["W"], w["a"], w["G"])
+    assert torch.equal(out5, out1) and torch.equal(dW5, dW6) and torch.equal(da5, da6)
+    assert float((dW5 - dW1).abs().max()) <= 1e-5 * float(dW1.abs().max())
+    assert float((da5 - da1).abs().max()) <= 1e-5 * float(da1.abs().max())
+    dW1, da1 = dW5, da5
     _, dW3, da3 = run(w, w["X"], w["W"], w["a"], 2.0 * w["G"])
     assert torch.allclose(dW3, 2 * dW1, rtol=1e-5, atol=1e-6 * float(dW1.abs().max()))   # backward linear in G
     assert torch.allclose(da3, 2 * da1, rtol=1e-5, atol=1e-6 * float(da1.abs().max()))
@@ -93,8 +117,6 @@ def test_wide_rows_at_scale_against_c_oracle():
     Forward, dW and da against the C oracle."""
     import pygat_amd as pg
     from pygat_amd.rmat import rmat_csr
-    from oracle import c_oracle
-    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
     dev = torch.device("cuda", 0)
     rowptr, col = rmat_csr(18, 1_250_000, seed=3, device=dev)
     graph = pg.CSRGraph(rowptr, col)
@@ -108,11 +130,8 @@ def test_wide_rows_at_scale_against_c_oracle():
     out = pg.GATLevelFn.apply(X, W, a, None, graph, 0.2, True)
     out.backward(G)
     torch.cuda.synchronize()
-    ref = c_oracle.level(X.cpu().numpy(), rowptr.cpu().numpy(), col.cpu().numpy(), W.detach().cpu().numpy(),
-                         a.detach().cpu().numpy(), 0.2, True, G.cpu().numpy(), want_dx=False)
-    o = out.detach().cpu().numpy()
-    assert np.isfinite(o).all()
-    assert np.abs(o - ref["out"]).max() <= 1e-5 * max(1.0, np.abs(ref["out"]).max())
-    for got, want, name in ((W.grad, ref["dW"], "dW"), (a.grad, ref["da"], "da")):
-        got = got.cpu().numpy()
-        assert np.abs(got - want).max() <= 2e-4 * np.abs(want).max(), name
+    r64, r32 = c_refs(X, rowptr, col, W, a, G)
+    close_fwd(out, r64["out"], "out")
+    for got, name in ((W.grad, "dW"), (a.grad, "da")):
+        err, own = close_grad(got, r64[name], r32[name], name)
+        print(f"wide rows: {name} err {err:.2e} (fp32 oracle {own:.2e}, max {np.abs(r64[name]).max():.3g})")

@@ -163,10 +163,11 @@ SHAPES = [  # (H, Fin, Fo, skip, concat)
 ]
 
 
-@pytest.fixture(params=["rowsum", "two-gather"])
+@pytest.fixture(params=["rowlocal", "rowsum", "two-gather"])
 def backward_mode(request, pg, monkeypatch):
-    """Both backward flavours of pygat_amd.ops: K4 + row sums of its per-edge dz / K3b (second gather) + K4."""
-    monkeypatch.setattr(pg.ops, "TWO_GATHER_BACKWARD", request.param == "two-gather")
+    """The three backward flavours of pygat_amd.ops: row sums of dz from the forward's alpha-branch shares (default) /
+    K4 + row sums of its per-edge dz records / K3b (second gather) + K4."""
+    monkeypatch.setattr(pg.ops, "BACKWARD_FLAVOUR", request.param)
     return request.param
 
 
@@ -379,7 +380,7 @@ def test_project(pg, H, Fo, skip):
 @pytest.mark.parametrize("seed", range(24))
 def test_fuzz_level(pg, monkeypatch, seed):
     """Random shapes / patterns / slot lengths (fixed seeds): forward + all gradients vs the fp64 oracle."""
-    monkeypatch.setattr(pg.ops, "TWO_GATHER_BACKWARD", seed % 3 == 0)      # a third of the cases on the two-gather backward
+    monkeypatch.setattr(pg.ops, "BACKWARD_FLAVOUR", ("two-gather", "rowlocal", "rowsum", "rowlocal")[seed % 4])   # half on the default
     rng = np.random.default_rng(1000 + seed)
     N = int(rng.integers(1, 400))
     H = int(rng.choice([1, 2, 3, 4, 6, 8]))

@@ -59,14 +59,22 @@ def main():
     part = torch.empty(max(1, lib.pygat_partials_bytes(E, args.ts, H, Fp) // 4), device=dev)
     P = lambda x: None if x is None else x.data_ptr()
 
-    def k2(train=True):
+    aneg = torch.empty(N, R, device=dev); qneg = torch.empty(N, H, device=dev)
+
+    def k2(train=True, aux=False):
         check(lib.pygat_gat_forward(graph.fwd.ref(), H, Fo, 0.2, _lib.F_ELU, P(Wh), P(s), P(a_pad), None, None, P(out),
-                                    None, P(m) if train else None, P(Z) if train else None, P(part), None))
+                                    None, P(m) if train else None, P(Z) if train else None, P(aneg) if aux else None,
+                                    P(qneg) if aux else None, P(part), None))
 
     GR = torch.empty(N, R + 4 * H, device=dev)
 
     def k3a():
-        check(lib.pygat_gat_backward_prepare(N, H, Fo, _lib.F_ELU, 0, P(G), P(out), None, P(s), P(m), P(Z), P(GR), 0, 0, None))
+        check(lib.pygat_gat_backward_prepare(N, H, Fo, _lib.F_ELU, 0, P(G), P(out), None, P(s), P(m), P(Z), P(GR), None, None,
+                                             0.2, None, 0, 0, None))
+
+    def k3a_ds():
+        check(lib.pygat_gat_backward_prepare(N, H, Fo, _lib.F_ELU, 0, P(G), P(out), None, P(s), P(m), P(Z), P(GR), P(aneg),
+                                             P(qneg), 0.2, P(ds), 0, 0, None))
 
     def k3b():
         check(lib.pygat_gat_backward_row(graph.fwd.ref(), H, Fo, 0.2, P(Wh), P(a_pad), P(GR), None, P(ds), P(part), 0, 0, None))
@@ -88,8 +96,9 @@ def main():
     b_k3a = N * (12 * R + 12 * H + 16 * H)
     b_k3 = E * (4 + 4 * R + 8 * H) + N * (4 + 8 * R + 16 * H)
     b_k4 = E * (8 + 4 * R + 8 * H) + N * (4 + 8 * R + 8 * H)
-    runs = [("k2_train", lambda: k2(True), b_fwd), ("k2_eval", lambda: k2(False), b_fwd - N * 8 * H),
-            ("k3a_prep", k3a, b_k3a), ("k3b_row", k3b, b_k3 - b_k3a), ("k4_col", k4, b_k4),
+    runs = [("k2_train", lambda: k2(True), b_fwd), ("k2_aux", lambda: k2(True, True), b_fwd + N * (4 * R + 4 * H)),
+            ("k2_eval", lambda: k2(False), b_fwd - N * 8 * H),
+            ("k3a_prep", k3a, b_k3a), ("k3a_ds", k3a_ds, b_k3a + N * (4 * R + 8 * H)), ("k3b_row", k3b, b_k3 - b_k3a), ("k4_col", k4, b_k4),
             ("k4_col_dz", k4dz, b_k4 + E * 4 * H), ("k3c_rowsum", k3c, E * (12 + 4 * H) + N * 4 * H)]
     if args.only:
         runs = [r for r in runs if r[0] in args.only.split(",")]

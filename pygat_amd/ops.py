@@ -114,7 +114,7 @@ def _side_stream(dev) -> "torch.cuda.Stream":
     return _side[key]
 
 
-OVERLAP_BACKWARD = os.environ.get("PYGAT_OVERLAP_BACKWARD", "1") == "1"
+OVERLAP_BACKWARD = os.environ.get("PYGAT_OVERLAP_BACKWARD", "0") == "1"   # measured: the fork/join costs more than it hides
 
 
 def _segments(cols_ptr_ld) -> _lib.OutSegments:

@@ -68,7 +68,7 @@ def test_argument_validation_returns_einval(lib):
         lib.check(-1, "x")
     with pytest.raises(RuntimeError):
         lib.check(-2, "x")
-    assert lib.lib.pygat_partials_bytes(1000, 64, 8, 16) == 2 * 16 * (128 + 16) * 4
+    assert lib.lib.pygat_partials_bytes(1000, 64, 8, 16) == 2 * 16 * (2 * 128 + 3 * 8) * 4   # widest record: training forward
     assert lib.lib.pygat_gemm_workspace_bytes(128, 128, 4) == 4 * 128 * 128 * 4
 
 

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from parity import close_fwd, close_grad
+from parity import close_grad
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -54,17 +54,20 @@ def c_refs(X, rowptr, col, W, a, G):
 
 @pytest.mark.parametrize("flavour", ["rowlocal", "rowsum", "two-gather"])
 def test_fullsize_against_c_oracle(world, monkeypatch, flavour):
-    """SURVEY.md 8(c) at full size, against the fp64 build of the C oracle: forward within 1e-5 ABSOLUTE; gradients
-    within max(1e-5, 4 x the error of the fp32 build against the same fp64 truth).  (86 M logits: both fp32 sides
-    take the other LeakyReLU branch at a few hundred near-zero ones; the rule prices that too.)"""
+    """SURVEY.md 8(c) at full size, against the fp64 build of the C oracle: forward AND gradients within
+    max(1e-5, 4 x the error of the fp32 build against the same fp64 truth).  The outputs reach |11| here (X ~ N(0,1),
+    134 M of them): one fp32 ulp is 1e-6 there and a K = 128 fp32 projection alone is ~1e-5 off at the worst element
+    -- in the fp32 oracle as much as on the GPU -- so the absolute 1e-5 of the north star (stated for the
+    reference's row-normalised datasets, |out| < 1, where tests/test_gpu_parity.py holds it) cannot be the bar for
+    this synthetic input.  (86 M logits: both fp32 sides also take the other LeakyReLU branch at a few hundred
+    near-zero ones; the rule prices that too.)"""
     w = world
     monkeypatch.setattr(w["pg"].ops, "BACKWARD_FLAVOUR", flavour)
     out, dW, da = run(w, w["X"], w["W"], w["a"], w["G"])
     if "refs" not in w:
         w["refs"] = c_refs(w["X"], w["rowptr"], w["col"], w["W"], w["a"], w["G"])
     r64, r32 = w["refs"]
-    e = close_fwd(out, r64["out"], "out")
-    e32 = float(np.abs(r32["out"].astype(np.float64) - r64["out"]).max())
+    e, e32 = close_grad(out, r64["out"], r32["out"], "out")
     msg = [f"fullsize[{flavour}]: out err {e:.2e} (fp32 oracle {e32:.2e}, max |out| {np.abs(r64['out']).max():.3g})"]
     for got, name in ((dW, "dW"), (da, "da")):
         err, own = close_grad(got, r64[name], r32[name], name)
@@ -131,7 +134,8 @@ def test_wide_rows_at_scale_against_c_oracle():
     out.backward(G)
     torch.cuda.synchronize()
     r64, r32 = c_refs(X, rowptr, col, W, a, G)
-    close_fwd(out, r64["out"], "out")
+    e, e32 = close_grad(out, r64["out"], r32["out"], "out")
+    print(f"wide rows: out err {e:.2e} (fp32 oracle {e32:.2e}, max {np.abs(r64['out']).max():.3g})")
     for got, name in ((W.grad, "dW"), (a.grad, "da")):
         err, own = close_grad(got, r64[name], r32[name], name)
         print(f"wide rows: {name} err {err:.2e} (fp32 oracle {own:.2e}, max {np.abs(r64[name]).max():.3g})")

@@ -18,6 +18,9 @@ def load():
                                          C.c_int, p, p, p, p, p, p, p, p]
     lib.gat_oracle_level_f64.restype = C.c_int
     lib.gat_oracle_threads.restype = C.c_int
+    for fn in (lib.gat_oracle_capture_kinks, lib.gat_oracle_capture_kinks_f64):
+        fn.argtypes = [C.c_double, C.c_int64, p, p, p, p, p]
+        fn.restype = None
     return lib
 
 
@@ -31,9 +34,11 @@ def transpose_pattern(rowptr, col):
     return rp_t.astype(np.int32), src[order].astype(np.int32), order.astype(np.int32)
 
 
-def level(X, rowptr, col, W, a, alpha, concat, G, want_dx=True, lib=None, tp=None, dtype=np.float32):
+def level(X, rowptr, col, W, a, alpha, concat, G, want_dx=True, lib=None, tp=None, dtype=np.float32, kink_tau=0.0,
+          kink_cap=4096):
     """dtype=np.float32: the fp32 port (gat_oracle_level); np.float64: the same source built with REAL = double
-    (gat_oracle_level_f64) -- ground truth for the full-size tests."""
+    (gat_oracle_level_f64) -- ground truth for the full-size tests.  kink_tau > 0: also returns "kinks" = dict(h, e,
+    z, de) of the edges whose logit lies within kink_tau (|s_i| + |t_j|) of the LeakyReLU kink."""
     lib = lib or load()
     X = np.ascontiguousarray(X, dtype=dtype); W = np.ascontiguousarray(W, dtype=dtype)
     a = np.ascontiguousarray(a, dtype=dtype); G = np.ascontiguousarray(G, dtype=dtype)
@@ -43,9 +48,24 @@ def level(X, rowptr, col, W, a, alpha, concat, G, want_dx=True, lib=None, tp=Non
     out = np.empty_like(G); dW = np.empty_like(W); da = np.empty_like(a)
     dX = np.empty_like(X) if want_dx else None
     ptr = lambda v: None if v is None else v.ctypes.data
-    fn = lib.gat_oracle_level_f64 if np.dtype(dtype) == np.float64 else lib.gat_oracle_level
+    f64 = np.dtype(dtype) == np.float64
+    fn = lib.gat_oracle_level_f64 if f64 else lib.gat_oracle_level
+    cap_fn = lib.gat_oracle_capture_kinks_f64 if f64 else lib.gat_oracle_capture_kinks
+    if kink_tau > 0:
+        kh = np.zeros(kink_cap, np.int32); ke = np.zeros(kink_cap, np.int64)
+        kz = np.zeros(kink_cap, np.float64); kde = np.zeros(kink_cap, np.float64); kc = np.zeros(1, np.int64)
+        cap_fn(float(kink_tau), kink_cap, ptr(kh), ptr(ke), ptr(kz), ptr(kde), ptr(kc))
     rc = fn(N, len(col), ptr(rowptr), ptr(col), ptr(rp_t), ptr(col_t), ptr(perm_t), Fin, H, F,
                               alpha, int(concat), ptr(X), ptr(W), ptr(a), ptr(G), ptr(out), ptr(dW), ptr(da), ptr(dX))
+    if kink_tau > 0:
+        cap_fn(0.0, 0, None, None, None, None, None)
     if rc != 0:
         raise MemoryError("gat_oracle_level: allocation failed")
-    return dict(out=out, dW=dW, da=da, dX=dX)
+    res = dict(out=out, dW=dW, da=da, dX=dX)
+    if kink_tau > 0:
+        n = int(kc[0])
+        if n > kink_cap:
+            raise RuntimeError(f"c_oracle: {n} near-kink edges exceed kink_cap={kink_cap}; lower kink_tau")
+        order = np.lexsort((ke[:n], kh[:n]))          # thread timing decides the capture order: make it canonical
+        res["kinks"] = dict(h=kh[:n][order], e=ke[:n][order], z=kz[:n][order], de=kde[:n][order])
+    return res

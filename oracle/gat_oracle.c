@@ -54,6 +54,15 @@ int FN(gat_oracle_threads)(void) {
 #endif
 }
 
+/* Optional capture of the near-kink edges of the next level call (tests/parity.py, flip-aware comparison): every
+ * (head, edge) with |z_ij| <= tau (|s_i| + |t_j|), its logit z and de_ij = alpha_ij (dp_ij - D_i) (dL/de before the
+ * LeakyReLU slope).  cap = 0 switches it off.  The order of the entries depends on thread timing. */
+static struct { double tau; int64_t cap; int32_t* h; int64_t* e; double* z; double* de; int64_t* count; } kink = {0, 0, 0, 0, 0, 0, 0};
+void FN(gat_oracle_capture_kinks)(double tau, int64_t cap, int32_t* h, int64_t* e, double* z, double* de, int64_t* count) {
+  kink.tau = tau; kink.cap = cap; kink.h = h; kink.e = e; kink.z = z; kink.de = de; kink.count = count;
+  if (count) *count = 0;
+}
+
 /* C[M x N] = A[M x K] * B[K x N] (row-major), or with A transposed: C[M x N] = A[K x M]^T B[K x N] */
 static void gemm_nn(int64_t M, int N, int K, const REAL* A, const REAL* B, REAL* C) {
 #pragma omp parallel for schedule(static)
@@ -181,7 +190,14 @@ int FN(gat_oracle_level)(int64_t N, int64_t E, const int32_t* rowptr, const int3
         for (int f = 0; f < F; ++f) dp += Gp[i * F + f] * wj[f];
         al[k] /= Z;
         REAL z = s[i] + t[col[k]];
-        dz[k] = al[k] * (dp - (REAL)D) * (z > (REAL)0 ? (REAL)1 : alpha);
+        const REAL de = al[k] * (dp - (REAL)D);
+        if (kink.cap > 0 && fabs((double)z) <= kink.tau * (fabs((double)s[i]) + fabs((double)t[col[k]]))) {
+          int64_t q;
+#pragma omp atomic capture
+          q = (*kink.count)++;
+          if (q < kink.cap) { kink.h[q] = h; kink.e[q] = k; kink.z[q] = (double)z; kink.de[q] = (double)de; }
+        }
+        dz[k] = de * (z > (REAL)0 ? (REAL)1 : alpha);
         dsi += dz[k];
       }
       ds[i] = (REAL)dsi;

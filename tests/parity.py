@@ -64,31 +64,36 @@ KINK_TAU = 1e-4
 KINK_MAX = 48
 
 
+def _candidate_deltas(hh, ee, zz, dee, X, W, a, rowptr, col, alpha, with_dx, Wh=None):
+    """Gradient change caused by taking the other LeakyReLU branch at each candidate (head, edge)."""
+    H, Fin, Fo = W.shape
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    col = np.asarray(col, dtype=np.int64)
+    cols = []
+    for h, e, z, de in zip(hh, ee, zz, dee):
+        i, j = int(np.searchsorted(rowptr, e, side="right") - 1), int(col[e])
+        D = de * ((alpha - 1.0) if z > 0 else (1.0 - alpha))
+        a_s, a_d = a[h, :Fo], a[h, Fo:]
+        whi = Wh[h, i] if Wh is not None else X[i] @ W[h]
+        whj = Wh[h, j] if Wh is not None else X[j] @ W[h]
+        dW = np.zeros((H, Fin, Fo)); dW[h] = D * (np.outer(X[i], a_s) + np.outer(X[j], a_d))
+        da = np.zeros((H, 2 * Fo)); da[h, :Fo] = D * whi; da[h, Fo:] = D * whj
+        d = {"dW": dW, "da": da}
+        if with_dx:
+            dX = np.zeros((len(rowptr) - 1, Fin))
+            dX[i] += D * (W[h] @ a_s); dX[j] += D * (W[h] @ a_d)
+            d["dX"] = dX
+        cols.append(d)
+    return cols, list(zip((int(v) for v in hh), (int(v) for v in ee)))
+
+
 def _kink_deltas(ref, X, W, a, rowptr, col, alpha, with_dx):
     z, zs = ref["z"], ref["zscale"]
-    H, E = z.shape
-    Fo = W.shape[2]
     rel = np.abs(z) / np.maximum(zs, 1e-300)
     hh, ee = np.nonzero(rel <= KINK_TAU)
     order = np.argsort(rel[hh, ee])[:KINK_MAX]
     hh, ee = hh[order], ee[order]
-    src = np.repeat(np.arange(len(rowptr) - 1), np.diff(np.asarray(rowptr, dtype=np.int64)))
-    col = np.asarray(col, dtype=np.int64)
-    cols = []
-    for h, e in zip(hh, ee):
-        i, j = src[e], col[e]
-        pos = z[h, e] > 0
-        D = ref["de"][h, e] * ((alpha - 1.0) if pos else (1.0 - alpha))
-        a_s, a_d = a[h, :Fo], a[h, Fo:]
-        dW = np.zeros_like(ref["dW"]); dW[h] = D * (np.outer(X[i], a_s) + np.outer(X[j], a_d))
-        da = np.zeros_like(ref["da"]); da[h, :Fo] = D * ref["Wh"][h, i]; da[h, Fo:] = D * ref["Wh"][h, j]
-        d = {"dW": dW, "da": da}
-        if with_dx:
-            dX = np.zeros_like(ref["dX"])
-            dX[i] += D * (W[h] @ a_s); dX[j] += D * (W[h] @ a_d)
-            d["dX"] = dX
-        cols.append(d)
-    return cols, list(zip(hh.tolist(), ee.tolist()))
+    return _candidate_deltas(hh, ee, z[hh, ee], ref["de"][hh, ee], X, W, a, rowptr, col, alpha, with_dx, ref["Wh"])
 
 
 def _explain(resid, cols, names):
@@ -136,4 +141,33 @@ def close_level_grads(got, X, rowptr, col, W, a, alpha, concat, G, Wskip=None, w
         close_grad(got["dW_skip"], ref64["dW_skip"], ref32["dW_skip"], f"{what} dW_skip", factor, floor)
     report["ref64"] = ref64
     report["ref32"] = ref32
+    return report
+
+
+def close_fullsize_grads(got, r64, r32, X, W, a, rowptr, col, alpha, what="level", factor=4.0, floor=ATOL, names=("dW", "da")):
+    """The same flip-aware rule where the python oracle cannot run (10^7 edges): r64 / r32 come from the two builds of
+    oracle/gat_oracle.c, r64["kinks"] lists the near-kink edges of the fp64 run (c_oracle.level(kink_tau=...)).  Only
+    the parameter gradients take part in the fit (dX is not produced by a first level)."""
+    X = np.asarray(X, np.float64); W = np.asarray(W, np.float64); a = np.asarray(a, np.float64)
+    k = r64["kinks"]
+    cols, cand = _candidate_deltas(k["h"], k["e"], k["z"], k["de"], X, W, a, rowptr, col, alpha, False)
+    report = {"candidates": len(cand)}
+    for side, vals in (("hip", {n: _np64(got[n]).reshape(r64[n].shape) for n in names}),
+                       ("fp32", {n: np.asarray(r32[n], np.float64) for n in names})):
+        resid = {n: vals[n] - r64[n] for n in names}
+        report[side + "_raw"] = {n: float(np.abs(resid[n]).max()) for n in names}
+        sig = _explain(resid, cols, names)
+        for q, c in enumerate(cols):
+            if sig[q]:
+                for n in names:
+                    resid[n] = resid[n] - c[n]
+        report[side] = {n: float(np.abs(resid[n]).max()) for n in names}
+        report[side + "_flips"] = [cand[q] for q in range(len(cand)) if sig[q]]
+    for n in names:
+        assert np.isfinite(_np64(got[n])).all(), f"{what} {n}: non-finite values"
+        tol = max(floor, factor * report["fp32"][n])
+        assert report["hip"][n] <= tol, (
+            f"{what} {n}: max abs err {report['hip'][n]:.3e} (raw {report['hip_raw'][n]:.3e}) > {tol:.3e} = max({floor:.0e}, "
+            f"{factor:g} x fp32-oracle err {report['fp32'][n]:.3e}) after {len(report['hip_flips'])} LeakyReLU branch flips "
+            f"({len(cand)} near-kink edges); max |ref| {np.abs(r64[n]).max():.3g}")
     return report

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from parity import close_grad
+from parity import close_fullsize_grads, close_grad
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,14 +42,26 @@ def run(w, X, W, a, G):
     return out.detach(), Wd.grad, ad.grad
 
 
+KINK_TAU = 4e-6     # near-kink band of the full-size runs: ~60 ulp of |s| + |t| (a few hundred of 86 M logits)
+
+
 def c_refs(X, rowptr, col, W, a, G):
-    """(fp64 ground truth, fp32 port) of the level from the two builds of oracle/gat_oracle.c."""
+    """(fp64 ground truth incl. its near-kink edges, fp32 port) of the level from the two builds of oracle/gat_oracle.c."""
     subprocess.run(["make", "-B", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
     from oracle import c_oracle
     args = (X.cpu().numpy(), rowptr.cpu().numpy(), col.cpu().numpy(), W.detach().cpu().numpy(), a.detach().cpu().numpy(), 0.2,
             True, G.cpu().numpy())
     tp = c_oracle.transpose_pattern(args[1], args[2])
-    return (c_oracle.level(*args, want_dx=False, tp=tp, dtype=np.float64), c_oracle.level(*args, want_dx=False, tp=tp))
+    return (c_oracle.level(*args, want_dx=False, tp=tp, dtype=np.float64, kink_tau=KINK_TAU, kink_cap=1 << 16),
+            c_oracle.level(*args, want_dx=False, tp=tp))
+
+
+def check_grads(got_dW, got_da, r64, r32, X, rowptr, col, W, a, what):
+    rep = close_fullsize_grads({"dW": got_dW, "da": got_da}, r64, r32, X.cpu().numpy(), W.detach().cpu().numpy(),
+                               a.detach().cpu().numpy(), rowptr.cpu().numpy(), col.cpu().numpy(), 0.2, what=what)
+    return (f"{rep['candidates']} near-kink edges, branch flips: hip {len(rep['hip_flips'])}, fp32 oracle {len(rep['fp32_flips'])}; "
+            + "; ".join(f"{n} err {rep['hip'][n]:.2e} (raw {rep['hip_raw'][n]:.2e}; fp32 oracle {rep['fp32'][n]:.2e}, raw "
+                        f"{rep['fp32_raw'][n]:.2e}; max |{n}| {np.abs(r64[n]).max():.3g})" for n in ("dW", "da")))
 
 
 @pytest.mark.parametrize("flavour", ["rowlocal", "rowsum", "two-gather"])
@@ -68,11 +80,8 @@ def test_fullsize_against_c_oracle(world, monkeypatch, flavour):
         w["refs"] = c_refs(w["X"], w["rowptr"], w["col"], w["W"], w["a"], w["G"])
     r64, r32 = w["refs"]
     e, e32 = close_grad(out, r64["out"], r32["out"], "out")
-    msg = [f"fullsize[{flavour}]: out err {e:.2e} (fp32 oracle {e32:.2e}, max |out| {np.abs(r64['out']).max():.3g})"]
-    for got, name in ((dW, "dW"), (da, "da")):
-        err, own = close_grad(got, r64[name], r32[name], name)
-        msg.append(f"{name} err {err:.2e} (fp32 oracle {own:.2e}, max |{name}| {np.abs(r64[name]).max():.3g})")
-    print("; ".join(msg))
+    print(f"fullsize[{flavour}]: out err {e:.2e} (fp32 oracle {e32:.2e}, max |out| {np.abs(r64['out']).max():.3g}); "
+          + check_grads(dW, da, r64, r32, w["X"], w["rowptr"], w["col"], w["W"], w["a"], f"fullsize[{flavour}]"))
 
 
 def test_fullsize_properties(world, monkeypatch):
@@ -96,7 +105,9 @@ def test_fullsize_properties(world, monkeypatch):
     monkeypatch.setattr(pg.ops, "TWO_GATHER_BACKWARD", None)
     out5, dW5, da5 = run(w, w["X"], w["W"], w["a"], w["G"])
     out6, dW6, da6 = run(w, w["X"], w["W"], w["a"], w["G"])
-    assert torch.equal(out5, out1) and torch.equal(dW5, dW6) and torch.equal(da5, da6)
+    # (its forward is the AUX instantiation of K2: same sums, its own instruction schedule -- equal up to rounding)
+    assert torch.equal(out5, out6) and torch.equal(dW5, dW6) and torch.equal(da5, da6)
+    assert float((out5 - out1).abs().max()) <= 2e-6 * float(out1.abs().max())
     assert float((dW5 - dW1).abs().max()) <= 1e-5 * float(dW1.abs().max())
     assert float((da5 - da1).abs().max()) <= 1e-5 * float(da1.abs().max())
     dW1, da1 = dW5, da5
@@ -136,6 +147,4 @@ def test_wide_rows_at_scale_against_c_oracle():
     r64, r32 = c_refs(X, rowptr, col, W, a, G)
     e, e32 = close_grad(out, r64["out"], r32["out"], "out")
     print(f"wide rows: out err {e:.2e} (fp32 oracle {e32:.2e}, max {np.abs(r64['out']).max():.3g})")
-    for got, name in ((W.grad, "dW"), (a.grad, "da")):
-        err, own = close_grad(got, r64[name], r32[name], name)
-        print(f"wide rows: {name} err {err:.2e} (fp32 oracle {own:.2e}, max {np.abs(r64[name]).max():.3g})")
+    print("wide rows: " + check_grads(W.grad, a.grad, r64, r32, X, rowptr, col, W, a, "wide rows"))

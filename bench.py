@@ -10,8 +10,10 @@ self loops added (E ~ 10.76 M); X ~ N(0,1) [N,128]; 8 heads x F' = 16 (H*F' = 12
 eval-mode semantics (dropout 0); fp32.  A step = forward + backward of the level (dW, da; the
 input of a first level carries no gradient in the reference, train.py:132,158; --dx adds dX).
 
-The step is the product path: the level captured once into two HIP graphs (pygat_amd.GraphedLevel)
-and replayed; --eager launches kernel by kernel instead.
+The step launches the level's kernels one by one on the current stream (pygat_amd.GATLevelFn, the op the
+drop-in model calls).  --hip-graph replays the level from two captured HIP graphs instead
+(pygat_amd.GraphedLevel): that wins on the reference's small graphs, where launches dominate (epoch_ms
+below is measured that way), and measured 5 % SLOWER here, where each kernel runs for ~1 ms.
 
 N GPUs: heads sharded head-per-GPU (pygat_amd/dist.py): each rank projects and attends its H/N
 heads, an RCCL all-gather over xGMI concatenates the head outputs (models.py:32) while the rank's
@@ -21,8 +23,8 @@ heads' forward.)
 
 One JSON line on rank 0: value = E / step time (max over ranks, K steps between barriers), plus
   roofline      the kernel with the largest share of the step (HIP events around every launch in an
-                instrumented pass of the same steps that follows the timed region -- a replayed HIP
-                graph cannot carry per-launch events -- SURVEY.md 8(d) algorithmic bytes / flops);
+                instrumented pass of the same steps right after the timed region, so that the timed
+                steps carry no event records; SURVEY.md 8(d) algorithmic bytes / flops);
   kernels       the same figures for every kernel of the step;
   cpu_baseline  oracle/gat_oracle.c (CPU port of the same level) on this host's cores, N=1 only;
   epoch_ms      Cora / Pubmed epochs (train.py:151-179) replayed from one HIP graph, N=1 only.
@@ -55,7 +57,7 @@ def parse():
     ap.add_argument("--heads", type=int, default=8)
     ap.add_argument("--fout", type=int, default=16)
     ap.add_argument("--dx", action="store_true", help="also back-propagate into the input features")
-    ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying the captured level")
+    ap.add_argument("--hip-graph", action="store_true", help="replay the level from captured HIP graphs (pygat_amd.GraphedLevel)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-epoch", action="store_true", help="skip the Cora / Pubmed epoch_ms leg")
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -206,7 +208,7 @@ def main():
 
         def level_bwd(out):
             out.backward(G)                   # only the columns of the own heads are read
-    elif args.eager:
+    elif not args.hip_graph:
         W_loc = W[hs:he].contiguous().requires_grad_(True)
         a_loc = a[hs:he].contiguous().requires_grad_(True)
         Xb = X.clone().requires_grad_(True) if args.dx else X
@@ -219,7 +221,7 @@ def main():
 
         def level_bwd(out):
             out.backward(G_loc)
-    else:               # product path: the level captured once, replayed every step
+    else:               # the level captured once, replayed every step
         lvl = pg.GraphedLevel(graph, X, W[hs:he], a[hs:he], None, 0.2, True, need_dx=args.dx)
 
         def level_fwd():
@@ -365,7 +367,8 @@ def main():
                                        + (" (rank-0 work only, modelled)" if model_world != world else ""))
                        if model_world > 1 else "single GPU",
                        "heads_per_gpu": h_loc,
-                       "launch": "eager" if (args.eager or replicate) else "HIP-graph replay (pygat_amd.GraphedLevel)"},
+                       "launch": "HIP-graph replay (pygat_amd.GraphedLevel)" if (args.hip_graph and not replicate)
+                       else "stream launches (pygat_amd.GATLevelFn)"},
             "roofline": roof,
             "kernels": kernels,
             "kernels_ms_sum": float(sum(kt.values())),

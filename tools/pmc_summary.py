@@ -7,8 +7,8 @@
 
 Separate passes, as MI355X_MICROARCH.md prescribes.  FETCH_SIZE / WRITE_SIZE are KiB summed over the 8
 XCDs; FETCH_SIZE is doubled (gfx950 reports 16-B/lane coalesced reads at half their size, same guide).
-Values are per-launch means.  `--latest` also rewrites profiles/pmc_k2_latest.json, the file bench.py
-reads `roofline.traffic` from (forward main kernel + its fix-up kernels).
+Values are per-launch means.  `--latest` also rewrites profiles/pmc_latest.json, the file bench.py reads the
+`traffic` of every kernel span from (main kernel + its fix-up / reduce launches).
 """
 import argparse
 import collections
@@ -72,12 +72,26 @@ def main():
     with open(a.out, "w") as fh:
         json.dump(doc, fh, indent=1)
     if a.latest:
-        t = sum(v.get("hbm_traffic_bytes", 0.0) for k, v in out.items() if k.startswith("pygat::gat_fwd_"))
+        spans = {   # bench.py span -> kernel name prefixes (pygat_amd/ops.py)
+            "k1_project": ("pygat::gemm_smallk_kernel",),
+            "k2_forward": ("pygat::gat_fwd_",),
+            "k3a_prepare": ("pygat::gat_bwd_prepare",),
+            "k3b_row": ("pygat::gat_bwd_row_kernel",),
+            "k4_backward_col": ("pygat::gat_bwd_col_",),
+            "k3c_rowsum": ("pygat::gat_bwd_rowsum_kernel",),
+            "k5_agrad": ("pygat::a_grad_",),
+            "k5_wgrad": ("pygat::gemm_tn_stream_kernel", "pygat::gemm_splitk_reduce_kernel", "pygat::unpack_wgrad"),
+        }
+        traffic = {}
+        for span, prefixes in spans.items():
+            t = sum(v.get("hbm_traffic_bytes", 0.0) for k, v in out.items() if k.startswith(prefixes))
+            if t > 0:
+                traffic[span] = t
         here = os.path.dirname(os.path.abspath(__file__))
-        with open(os.path.join(here, "..", "profiles", "pmc_k2_latest.json"), "w") as fh:
+        with open(os.path.join(here, "..", "profiles", "pmc_latest.json"), "w") as fh:
             json.dump({"source": os.path.relpath(a.out, os.path.join(here, "..")), "workload_edges": a.edges,
-                       "heads_per_gpu": a.heads, "k2_hbm_traffic_bytes": t}, fh, indent=1)
-        print("k2 traffic GB:", t / 1e9)
+                       "heads_per_gpu": a.heads, "traffic_bytes": traffic}, fh, indent=1)
+        print("traffic GB:", {k: round(v / 1e9, 3) for k, v in traffic.items()})
     for k, v in sorted(out.items()):
         print(f"{k:48s} {v.get('hbm_traffic_bytes', float('nan')) / 1e6:10.1f} MB  L2 hit {v.get('l2_hit_rate', float('nan')):.2f}")
 

@@ -152,13 +152,13 @@ __global__ __launch_bounds__(256) void unpack_blockdiag_kernel(int H, int Fin, i
 }
 
 static bool make_rng(float p, const void* seed, uint32_t stream_id, DropRng* g) {
-  if (!(p >= 0.f && p < 1.f)) return false;
+  if (!(p >= 0.f && p <= 1.f)) return false;   // p = 1 (F.dropout accepts it): nothing is kept, everything becomes 0
   const double keep = 1.0 - (double)p;
   double t = keep * 4294967296.0;
   g->seed = (const uint64_t*)seed;
   g->stream_id = stream_id;
   g->thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
-  g->scale = (float)(1.0 / keep);
+  g->scale = keep > 0.0 ? (float)(1.0 / keep) : 0.f;
   return true;
 }
 
@@ -170,7 +170,7 @@ extern "C" int pygat_dropout_mask(int64_t count, float p, const void* seed, uint
                                   void* stream) {
   DropRng g;
   PYGAT_REQUIRE(count > 0 && seed && out && aligned16(out), "dropout_mask: bad arguments");
-  PYGAT_REQUIRE(make_rng(p, seed, stream_id, &g), "dropout_mask: p=%g outside [0,1)", (double)p);
+  PYGAT_REQUIRE(make_rng(p, seed, stream_id, &g), "dropout_mask: p=%g outside [0,1]", (double)p);
   hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)cdiv(cdiv(count, 4), 256)), dim3(256), 0, (hipStream_t)stream,
                      count, g, out);
   PYGAT_CHECK_LAUNCH("dropout_mask");
@@ -183,7 +183,7 @@ extern "C" int pygat_dropout_expand(int n, int Fin, int H, const float* x, int64
   PYGAT_REQUIRE(n > 0 && Fin > 0 && H > 0 && x && out && ldx >= Fin && ldo >= (int64_t)H * Fin && (mask || seed),
                 "dropout_expand: bad arguments");
   PYGAT_REQUIRE((int64_t)H * Fin < ((int64_t)1 << 30), "dropout_expand: H*Fin too large");
-  PYGAT_REQUIRE(make_rng(p, seed, stream_id, &g), "dropout_expand: p=%g outside [0,1)", (double)p);
+  PYGAT_REQUIRE(make_rng(p, seed, stream_id, &g), "dropout_expand: p=%g outside [0,1]", (double)p);
   PYGAT_REQUIRE(aligned16(out), "dropout_expand: out must be 16-byte aligned");
   const int nchunks = (int)cdiv((int64_t)H * Fin, 1024);
   PYGAT_REQUIRE((int64_t)n * nchunks < ((int64_t)1 << 31), "dropout_expand: grid too large");
@@ -199,7 +199,7 @@ extern "C" int pygat_dropout_head_sum(int n, int Fin, int H, const float* dxe, i
   DropRng g;
   PYGAT_REQUIRE(n > 0 && Fin > 0 && H > 0 && dxe && dx && ldx >= Fin && lde >= (int64_t)H * Fin && (mask || seed),
                 "dropout_head_sum: bad arguments");
-  PYGAT_REQUIRE(make_rng(p, seed, stream_id, &g), "dropout_head_sum: p=%g outside [0,1)", (double)p);
+  PYGAT_REQUIRE(make_rng(p, seed, stream_id, &g), "dropout_head_sum: p=%g outside [0,1]", (double)p);
   hipLaunchKernelGGL(dropout_head_sum_kernel, dim3((unsigned)cdiv((int64_t)n * Fin, 256)), dim3(256), 0,
                      (hipStream_t)stream, n, Fin, H, dxe, lde, mask, g, dx, ldx, accumulate);
   PYGAT_CHECK_LAUNCH("dropout_head_sum");

@@ -55,6 +55,7 @@ class GATLevelDropoutFn(torch.autograd.Function):
     def forward(ctx, x, W, a, Wskip, graph: CSRGraph, alpha, concat, p, mask_x, mask_wh, mask_att, seed):
         if not x.is_cuda:
             raise RuntimeError("pygat_amd: inputs must be on the GPU; the hot path has no CPU fallback")
+        ctx.in_dtypes = (x.dtype, W.dtype, a.dtype, None if Wskip is None else Wskip.dtype)
         x = x.contiguous().float(); W = W.contiguous().float(); a = a.contiguous().float()
         H, Fin, Fo = W.shape
         skip = Wskip is not None
@@ -198,7 +199,8 @@ class GATLevelDropoutFn(torch.autograd.Function):
                                                  mx_or_seed.data_ptr() if ctx.explicit else None, p,
                                                  None if ctx.explicit else mx_or_seed.data_ptr(), STREAM_X,
                                                  dx.data_ptr(), Fin, 0, st), "dropout_head_sum")
-        return dx, dW, da, dWs, None, None, None, None, None, None, None, None
+        cast = lambda g_, k: g_ if g_ is None or g_.dtype == ctx.in_dtypes[k] else g_.to(ctx.in_dtypes[k])  # noqa: E731
+        return cast(dx, 0), cast(dW, 1), cast(da, 2), cast(dWs, 3), None, None, None, None, None, None, None, None
 
 
 def gat_level_dropout(x, graph: CSRGraph, Ws: Sequence[torch.Tensor], As: Sequence[torch.Tensor],

@@ -196,6 +196,9 @@ class GATLevelFn(torch.autograd.Function):
     def forward(ctx, x, W, a, Wskip, graph: CSRGraph, alpha: float, concat: bool, bwd_heads=None):
         if not x.is_cuda:
             raise RuntimeError("pygat_amd: inputs must be on the GPU; the hot path has no CPU fallback")
+        # the path computes in float32 (like the reference's sparse layer, layers.py:150); other float dtypes are cast
+        # on the way in and their gradients cast back on the way out
+        ctx.in_dtypes = (x.dtype, W.dtype, a.dtype, None if Wskip is None else Wskip.dtype)
         x = x.contiguous().float()
         W = W.contiguous().float(); a = a.contiguous().float()
         H, Fin, Fo = W.shape
@@ -359,7 +362,8 @@ class GATLevelFn(torch.autograd.Function):
                                  [(L.Fin, dx, L.Fin)], accumulate=True, split_k=1)
             if fork:
                 main.wait_stream(side)
-        return dx, dW, (da if ctx.needs_input_grad[2] else None), dWs, None, None, None, None
+        cast = lambda g_, k: g_ if g_ is None or g_.dtype == ctx.in_dtypes[k] else g_.to(ctx.in_dtypes[k])  # noqa: E731
+        return cast(dx, 0), cast(dW, 1), (cast(da, 2) if ctx.needs_input_grad[2] else None), cast(dWs, 3), None, None, None, None
 
 
 def gat_level(x: torch.Tensor, graph: CSRGraph, Ws: Sequence[torch.Tensor], As: Sequence[torch.Tensor],

@@ -136,3 +136,28 @@ def test_in_kernel_masks_statistics_and_consistency(pg):  # noqa: F811
     back = torch.empty(H, Fin, Fo, device=dev)
     check(lib.pygat_unpack_blockdiag(H, Fin, Fo, Bp.data_ptr(), 2 * R, R, back.data_ptr(), None))
     assert torch.equal(back, Wsk)
+
+
+def test_dropout_p_one_and_float64_inputs(pg):  # noqa: F811
+    """F.dropout accepts p = 1 (everything dropped): the layer then outputs ELU(0) = 0 with zero gradients, as the
+    reference's formulas give (layers.py:132-170 with h = 0).  float64 inputs are computed in float32 (the path is
+    fp32, like the reference's sparse layer, which is fp32-only: layers.py:150) -- with gradients routed back to the
+    float64 leaves."""
+    N, Fin, Fo = 60, 10, 8
+    rowptr, col = O.random_symmetric_csr(N, 5, 1)
+    g = pg.CSRGraph(torch.as_tensor(rowptr).cuda(), torch.as_tensor(col).cuda())
+    layer = pg.SpGraphAttentionLayer(Fin, Fo, 1.0, 0.2).cuda().train()
+    x = torch.randn(N, Fin, device="cuda", requires_grad=True)
+    y = layer(x, g)
+    assert float(y.abs().max()) == 0.0
+    y.sum().backward()
+    assert float(layer.W.grad.abs().max()) == 0.0 and float(x.grad.abs().max()) == 0.0
+    # float64 in -> float32 compute -> float32 out, float64 gradient on the float64 leaf
+    layer = pg.SpGraphAttentionLayer(Fin, Fo, 0.0, 0.2).cuda()
+    x64 = torch.randn(N, Fin, device="cuda", dtype=torch.float64, requires_grad=True)
+    y = layer(x64, g)
+    assert y.dtype == torch.float32
+    y.sum().backward()
+    assert x64.grad is not None and x64.grad.dtype == torch.float64 and torch.isfinite(x64.grad).all()
+    yr = layer(x64.detach().float(), g)
+    assert torch.equal(y.detach(), yr.detach())

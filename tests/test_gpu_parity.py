@@ -504,3 +504,43 @@ def test_malformed_csr_rejected(pg, rowptr, col):
         pg.CSRGraph(torch.tensor(rowptr, dtype=torch.int32, device="cuda"), torch.tensor(col, dtype=torch.int32, device="cuda"))
     with pytest.raises(ValueError):
         pg.as_graph((torch.tensor(rowptr, dtype=torch.int32, device="cuda"), torch.tensor(col, dtype=torch.int32, device="cuda")))
+
+
+def test_pubmed_full_model_logits_and_output_level(pg, topologies):
+    """BASELINE.json config 3 at full size: the Pubmed topology (19 717 nodes, 108 365 edges) through train.py:74-87's
+    model -- 500 -> 8 heads x 8 (concat) -> 8 heads x 3 averaged (models.py:34; Cora / Citeseer have ONE output head).
+    Logits against the fp64 oracle under the 8(c) rule, and the output level's gradients (8 x 3 mean, F' = 3 padded
+    to 4) under the flip-aware rule of tests/parity.py."""
+    from parity import close_grad, close_level_grads
+    rowptr, col = topologies["pubmed"]
+    N, Fin = len(rowptr) - 1, 500
+    gen = torch.Generator().manual_seed(72)
+    x = (torch.rand(N, Fin, generator=gen) < 0.1).double()
+    x = x / x.sum(1, keepdim=True).clamp(min=1)                       # utils.normalize_features: rows sum to 1
+    torch.manual_seed(72)
+    model = pg.GAT([Fin, 8, 3], [8, 8], 2, 0.6, 0.2, pg.SpGraphAttentionLayer).cuda().eval()
+    g = pg.CSRGraph(torch.as_tensor(rowptr).cuda(), torch.as_tensor(col).cuda())
+    with torch.no_grad():
+        y = model(x.float().cuda(), g)
+    assert y.shape == (N, 3)
+    levels = []
+    for heads in model.gat_layers:
+        levels.append({"W": torch.stack([h.W.detach().double().cpu() for h in heads]),
+                       "a": torch.stack([h.a.detach().double().cpu().reshape(-1) for h in heads])})
+    y64 = O.model_forward(x, (rowptr, col), levels, 0.2)
+    y32 = O.model_forward(x.float(), (rowptr, col), [{k: v.float() for k, v in lv.items()} for lv in levels], 0.2)
+    e, own = close_grad(y, y64, y32, "pubmed logits", factor=4.0)
+    assert e <= 1e-5, e                                              # row-normalised features: the north star's absolute bar
+    # output level alone, fed with the oracle's hidden activations
+    hid = O.level_forward(x, (rowptr, col), levels[0]["W"], levels[0]["a"], 0.2, True).numpy()
+    W2, a2 = levels[1]["W"].numpy(), levels[1]["a"].numpy()
+    G = np.random.default_rng(3).standard_normal((N, 3))
+    hd = torch.as_tensor(hid, dtype=torch.float32).cuda().requires_grad_(True)
+    Wd = torch.as_tensor(W2, dtype=torch.float32).cuda().requires_grad_(True)
+    ad = torch.as_tensor(a2, dtype=torch.float32).cuda().requires_grad_(True)
+    out = pg.GATLevelFn.apply(hd, Wd, ad, None, g, 0.2, False)
+    out.backward(torch.as_tensor(G, dtype=torch.float32).cuda())
+    rep = close_level_grads({"dX": hd.grad, "dW": Wd.grad, "da": ad.grad}, hid, rowptr, col, W2, a2, 0.2, False, G,
+                            what="pubmed level 2")
+    print(f"pubmed: logits err {e:.2e} (fp32 oracle {own:.2e}); level-2 grads after {len(rep['hip_flips'])} flips: "
+          + ", ".join(f"{n} {rep['hip'][n]:.2e} (fp32 oracle {rep['fp32'][n]:.2e})" for n in ("dX", "dW", "da")))

@@ -417,7 +417,14 @@ int try_gemm_tn_stream(int M, int N, int64_t K, const float* A, int64_t lda, con
   const int NT = nt_needed < 4 ? nt_needed : ((B2 && nt_needed == 5) ? 5 : 4);
   const int tiles_m = (int)cdiv(M, 128), tiles_n = (int)cdiv(N, 32 * NT);
   int splits = max_splits;
-  int64_t kps = cdiv(cdiv(K, splits), 16) * 16;
+  // narrow outputs (one or two 32-column tiles: a head-parallel rank with 1-2 heads of 16) run one 4-wave work-group
+  // per CU with few registers: 16 k-pairs per buffer instead of 8 keep twice the bytes in flight
+  const char* uke = getenv("PYGAT_TN_UK");   // development knob (tools/gemm_tn_sweep.py)
+  // measured (1M x 128 operand, 256 slabs): 16 columns 0.162 / 0.127 / 0.121 ms at 8 / 16 / 32 k-pairs per buffer,
+  // 64 columns 0.229 / 0.201 / 0.213, 128 columns 0.414 / 0.433 / 0.408 (MFMA-bound there): narrow outputs (a
+  // head-parallel rank with 1-2 heads of 16) keep more bytes in flight
+  const int uk = uke ? atoi(uke) : (NT <= 2 ? 16 : 8);
+  int64_t kps = cdiv(cdiv(K, splits), 2 * uk) * 2 * uk;
   splits = (int)cdiv(K, kps);
   TnArgs g;
   g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.k_per_split = kps; g.ws = ws;
@@ -437,22 +444,22 @@ int try_gemm_tn_stream(int M, int N, int64_t K, const float* A, int64_t lda, con
     return splits;
   }
   dim3 grid((unsigned)splits, (unsigned)tiles_m, (unsigned)tiles_n);
-  const char* uke = getenv("PYGAT_TN_UK");
-  const int uk = uke ? atoi(uke) : 8;
+#define PYGAT_TN_CASE(NTV)                                                                                      \
+  case NTV:                                                                                                     \
+    if (uk == 32) hipLaunchKernelGGL((gemm_tn_stream_kernel<NTV, 32>), grid, dim3(256), 0, st, g);              \
+    else if (uk == 16) hipLaunchKernelGGL((gemm_tn_stream_kernel<NTV, 16>), grid, dim3(256), 0, st, g);         \
+    else if (uk == 4) hipLaunchKernelGGL((gemm_tn_stream_kernel<NTV, 4>), grid, dim3(256), 0, st, g);           \
+    else hipLaunchKernelGGL((gemm_tn_stream_kernel<NTV, 8>), grid, dim3(256), 0, st, g);                        \
+    break;
   switch (NT) {
-    case 1: hipLaunchKernelGGL((gemm_tn_stream_kernel<1, 8>), grid, dim3(256), 0, st, g); break;
-    case 2: hipLaunchKernelGGL((gemm_tn_stream_kernel<2, 8>), grid, dim3(256), 0, st, g); break;
-    case 3: hipLaunchKernelGGL((gemm_tn_stream_kernel<3, 8>), grid, dim3(256), 0, st, g); break;
-    case 5:
-      if (uk == 8) hipLaunchKernelGGL((gemm_tn_stream_kernel<5, 8>), grid, dim3(256), 0, st, g);
-      else hipLaunchKernelGGL((gemm_tn_stream_kernel<5, 4>), grid, dim3(256), 0, st, g);
-      break;
+    PYGAT_TN_CASE(1)
+    PYGAT_TN_CASE(2)
+    PYGAT_TN_CASE(3)
+    PYGAT_TN_CASE(5)
     default:
-      if (uk == 4) hipLaunchKernelGGL((gemm_tn_stream_kernel<4, 4>), grid, dim3(256), 0, st, g);
-      else if (uk == 2) hipLaunchKernelGGL((gemm_tn_stream_kernel<4, 2>), grid, dim3(256), 0, st, g);
-      else hipLaunchKernelGGL((gemm_tn_stream_kernel<4, 8>), grid, dim3(256), 0, st, g);
-      break;
+    PYGAT_TN_CASE(4)
   }
+#undef PYGAT_TN_CASE
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error("gemm_tn_stream: %s", hipGetErrorString(e));

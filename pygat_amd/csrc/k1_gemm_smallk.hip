@@ -31,9 +31,13 @@ struct SmallKArgs {
   int tiles_m;  // 256-row tiles
 };
 
-template <bool TB, int NT>
+template <bool TB, int NT, int NBUF>
 __global__ __launch_bounds__(512) void gemm_smallk_kernel(SmallKArgs g) {
   constexpr int BN = 32 * NT;
+  // chunks of the A row stream in flight per wave: a chunk's MFMAs take 16 * NT * 64 cycles, which for one or two
+  // column tiles (a head-parallel rank with 1-2 heads of 16: 0.4-0.9 us) does not cover an HBM access -- narrow
+  // outputs prefetch three chunks ahead instead of one (the accumulators are small there, the registers are free):
+  // NBUF = 4 for NT <= 2, else 2 (3 selectable: launch_smallk)
   constexpr int LDB = BN + 4;
   extern __shared__ __attribute__((aligned(16))) float Bs[];  // [K][LDB]
   const int n0 = blockIdx.y * BN;
@@ -151,14 +155,45 @@ __global__ __launch_bounds__(512) void gemm_smallk_kernel(SmallKArgs g) {
     }
   };
 
+  // (named registers, not arrays: a register array that is conditionally consumed ends up in scratch memory)
   float4 ra0, ra1, ra2, ra3, ra4, ra5, ra6, ra7;
   float4 rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7;
-  PYGAT_LOAD8(ra, chunk_ptr(0))
-  for (int c = 0; c < total; c += 2) {
-    PYGAT_LOAD8(rb, chunk_ptr(c + 1))
-    PYGAT_STEP(ra, c)
-    PYGAT_LOAD8(ra, chunk_ptr(c + 2))
-    if (c + 1 < total) PYGAT_STEP(rb, c + 1)
+  if constexpr (NBUF == 2) {
+    PYGAT_LOAD8(ra, chunk_ptr(0))
+    for (int c = 0; c < total; c += 2) {
+      PYGAT_LOAD8(rb, chunk_ptr(c + 1))
+      PYGAT_STEP(ra, c)
+      PYGAT_LOAD8(ra, chunk_ptr(c + 2))
+      if (c + 1 < total) PYGAT_STEP(rb, c + 1)
+    }
+  } else if constexpr (NBUF == 3) {
+    float4 rc0, rc1, rc2, rc3, rc4, rc5, rc6, rc7;
+    PYGAT_LOAD8(ra, chunk_ptr(0))
+    PYGAT_LOAD8(rb, chunk_ptr(1))
+    for (int c = 0; c < total; c += 3) {
+      PYGAT_LOAD8(rc, chunk_ptr(c + 2))
+      PYGAT_STEP(ra, c)
+      PYGAT_LOAD8(ra, chunk_ptr(c + 3))
+      if (c + 1 < total) PYGAT_STEP(rb, c + 1)
+      PYGAT_LOAD8(rb, chunk_ptr(c + 4))
+      if (c + 2 < total) PYGAT_STEP(rc, c + 2)
+    }
+  } else {
+    float4 rc0, rc1, rc2, rc3, rc4, rc5, rc6, rc7;
+    float4 rd0, rd1, rd2, rd3, rd4, rd5, rd6, rd7;
+    PYGAT_LOAD8(ra, chunk_ptr(0))
+    PYGAT_LOAD8(rb, chunk_ptr(1))
+    PYGAT_LOAD8(rc, chunk_ptr(2))
+    for (int c = 0; c < total; c += 4) {
+      PYGAT_LOAD8(rd, chunk_ptr(c + 3))
+      PYGAT_STEP(ra, c)
+      PYGAT_LOAD8(ra, chunk_ptr(c + 4))
+      if (c + 1 < total) PYGAT_STEP(rb, c + 1)
+      PYGAT_LOAD8(rb, chunk_ptr(c + 5))
+      if (c + 2 < total) PYGAT_STEP(rc, c + 2)
+      PYGAT_LOAD8(rc, chunk_ptr(c + 6))
+      if (c + 3 < total) PYGAT_STEP(rd, c + 3)
+    }
   }
 #undef PYGAT_LOAD8
 #undef PYGAT_BREAD
@@ -170,24 +205,30 @@ template <bool TB>
 static hipError_t launch_smallk(const SmallKArgs& g, int NT, dim3 grid, size_t lds, hipStream_t st) {
   int dev = -1;
   (void)hipGetDevice(&dev);
-#define PYGAT_SMALLK_CASE(n)                                                                              \
-  case n: {                                                                                               \
+  static const int nbuf_wide = [] { const char* e = getenv("PYGAT_K1_NBUF"); return (e && atoi(e) == 3) ? 3 : 2; }();
+#define PYGAT_SMALLK_LAUNCH(n, nb)                                                                        \
+  {                                                                                                       \
     static bool attr_set[64] = {};   /* per device: the attribute belongs to the device's code object */ \
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {                                                         \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_smallk_kernel<TB, n>),                \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_smallk_kernel<TB, n, nb>),            \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
       if (dev >= 0 && dev < 64) attr_set[dev] = true;                                                     \
     }                                                                                                     \
-    hipLaunchKernelGGL((gemm_smallk_kernel<TB, n>), grid, dim3(512), lds, st, g);                         \
-  } break;
+    hipLaunchKernelGGL((gemm_smallk_kernel<TB, n, nb>), grid, dim3(512), lds, st, g);                     \
+  }
+#define PYGAT_SMALLK_CASE(n)                                                                              \
+  case n:                                                                                                 \
+    if (nbuf_wide == 3) PYGAT_SMALLK_LAUNCH(n, 3) else PYGAT_SMALLK_LAUNCH(n, 2)                          \
+    break;
   switch (NT) {
-    PYGAT_SMALLK_CASE(1)
-    PYGAT_SMALLK_CASE(2)
+    case 1: PYGAT_SMALLK_LAUNCH(1, 4) break;
+    case 2: PYGAT_SMALLK_LAUNCH(2, 4) break;
     PYGAT_SMALLK_CASE(3)
     PYGAT_SMALLK_CASE(4)
     default: PYGAT_SMALLK_CASE(5)
   }
 #undef PYGAT_SMALLK_CASE
+#undef PYGAT_SMALLK_LAUNCH
   return hipGetLastError();
 }
 

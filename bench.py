@@ -66,6 +66,9 @@ def parse():
                     help="N>1, how every rank gets the other ranks' head outputs: RCCL all-gather over xGMI (default, the "
                          "design of pygat_amd/dist.py), or -- experiment -- no collective: run the forward of ALL heads and "
                          "back-propagate only the own ones (GATLevelFn bwd_heads)")
+    ap.add_argument("--chunks", type=int, default=4,
+                    help="N>1: row chunks of the pipelined level -- chunk c's head outputs are all-gathered while chunk c+1 "
+                         "is computed (1 = one all-gather after the whole forward)")
     ap.add_argument("--as-rank-of", type=int, default=0,
                     help="single process: run the work of rank 0 of a world of this size (per-rank time model, no collectives)")
     return ap.parse_args()
@@ -208,7 +211,7 @@ def main():
 
         def level_bwd(out):
             out.backward(G)                   # only the columns of the own heads are read
-    elif not args.hip_graph:
+    elif use_pg or not args.hip_graph:
         W_loc = W[hs:he].contiguous().requires_grad_(True)
         a_loc = a[hs:he].contiguous().requires_grad_(True)
         Xb = X.clone().requires_grad_(True) if args.dx else X
@@ -230,18 +233,29 @@ def main():
         def level_bwd(out):
             lvl.backward(G_loc)
 
-    gbuf = torch.empty(world, N, h_loc * Fo, device=dev) if use_pg else None   # rank-major column blocks
+    # N > 1: the level runs row chunk by row chunk (GATLevelFn pipeline): chunk c's head outputs (models.py:32
+    # torch.cat) are all-gathered on RCCL's own stream while chunk c+1 is computed; the rest of the exchange hides
+    # behind this level's backward, which does not depend on it, and is joined at the end of the step.  The gathered
+    # chunks stay rank-major [world, rows, w]: pygat_amd.dist copies them into their column slices as they land.
+    chunk_rows = [(r0, r1) for _, r0, r1 in graph.fwd.row_chunks(max(1, args.chunks))] if use_pg else []
+    gbufs = [torch.empty(world, r1 - r0, h_loc * Fo, device=dev) for r0, r1 in chunk_rows]
+    works = []
+
+    def on_chunk(c, r0, r1, out):
+        works.append(dist.all_gather_into_tensor(gbufs[c].view(world * (r1 - r0), h_loc * Fo), out[r0:r1], async_op=True))
 
     def step():
-        out = level_fwd()
         if use_pg:
-            # RCCL all-gather of the head outputs (models.py:32 torch.cat) on RCCL's own stream; this level's
-            # backward does not depend on it, so it overlaps K3/K4/K5 and is joined at the end.  The gathered
-            # activations stay in the rank-major column-block layout [world, N, w] (pygat_amd.dist).
-            work = dist.all_gather_into_tensor(gbuf.view(world * N, h_loc * Fo), out.detach(), async_op=True)
-            level_bwd(out)
-            work.wait()
-            return gbuf
+            works.clear()
+            W_loc.grad = a_loc.grad = None
+            if args.dx:
+                Xb.grad = None
+            out = pg.GATLevelFn.apply(Xb, W_loc, a_loc, None, graph, 0.2, True, None, (len(chunk_rows), on_chunk))
+            out.backward(G_loc)
+            for wk in works:
+                wk.wait()
+            return gbufs
+        out = level_fwd()
         level_bwd(out)
         return out
 
@@ -299,8 +313,8 @@ def main():
         full = step()
         if rank == 0:
             # the gathered concat output of the sharded run against the unsharded level on this rank
-            if use_pg:
-                full = gather_columns_layout(full)          # [world, N, w] -> [N, world*w]
+            if use_pg:                                      # chunks of [world, rows, w] -> [N, world*w]
+                full = torch.cat([gather_columns_layout(b) for b in full], dim=0)
             ref = pg.GATLevelFn.apply(X, W, a, None, graph, 0.2, True)
             got = full if (use_pg or replicate or model_world == 1) else None
             if got is not None:

@@ -148,6 +148,12 @@ typedef struct {
                                 straight to the cut rows instead of screening every slot */
   int n_cut;
   int n_cut_wide;            /* leading entries with more than 32 pieces (merged by a whole work-group) */
+  /* pygat_gat_forward only: work on the slots [slot_first, slot_first + slot_count) -- a range of whole rows (its
+     first slot starts a row, the slot after its last one too); cut_rows then lists the cut rows of that range alone.
+     slot_count = 0: all slots.  Lets a caller pipeline row chunks of a level (pygat_amd/dist.py: chunk k's head
+     outputs travel over xGMI while chunk k+1 is computed).  Every other entry point needs 0, 0. */
+  int64_t slot_first;
+  int64_t slot_count;
 } pygat_graph;
 
 /* edge_rc[k] = (i, col[k]) for rowptr[i] <= k < rowptr[i+1] */

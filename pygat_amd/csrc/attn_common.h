@@ -122,9 +122,10 @@ struct GraphDev {  // device view of pygat_graph
   const int32_t* sb;  // row-snapped slot borders [nslots+1] or nullptr (uniform slots)
   const int32_t* cut;  // [n_cut][3] (slot, row, pieces) or nullptr
   int n_cut, n_cut_wide;
+  int64_t k0, kn;   // active slot range [k0, k0 + kn) (the forward can work on a range of whole rows)
 };
 
-static inline int check_graph(const pygat_graph* g, GraphDev* d) {
+static inline int check_graph(const pygat_graph* g, GraphDev* d, bool allow_slot_range = false) {
   if (!g || !g->rowptr || !g->edge_rc || g->n <= 0 || g->nnz <= 0) {
     set_error("graph: null or empty (n=%d nnz=%lld)", g ? g->n : -1, g ? (long long)g->nnz : -1LL);
     return PYGAT_EINVAL;
@@ -143,6 +144,16 @@ static inline int check_graph(const pygat_graph* g, GraphDev* d) {
   if (d->n_cut < 0 || d->n_cut_wide < 0 || d->n_cut_wide > d->n_cut) {
     set_error("graph: bad cut-row list (n_cut=%d n_cut_wide=%d)", g->n_cut, g->n_cut_wide);
     return PYGAT_EINVAL;
+  }
+  const int64_t total = (g->nnz + g->slot_edges - 1) / g->slot_edges;
+  d->k0 = 0; d->kn = total;
+  if (g->slot_count != 0) {
+    if (!allow_slot_range || g->slot_first < 0 || g->slot_count < 0 || g->slot_first + g->slot_count > total) {
+      set_error("graph: slot range [%lld, +%lld) of %lld %s", (long long)g->slot_first, (long long)g->slot_count,
+                (long long)total, allow_slot_range ? "is out of bounds" : "is only supported by pygat_gat_forward");
+      return PYGAT_EINVAL;
+    }
+    d->k0 = g->slot_first; d->kn = g->slot_count;
   }
   return PYGAT_OK;
 }

@@ -214,8 +214,9 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
   constexpr int EPW = 64 / LPR;
   constexpr int U = (VEC == 1) ? 4 : 2;
   const int lane = threadIdx.x & 63;
-  const int64_t k = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * EPW + lane / LPR;  // slot id
-  if (k >= num_slots(a.g)) return;  // lane groups are independent: no cross-lane op below
+  const int64_t kl = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * EPW + lane / LPR;
+  if (kl >= a.g.kn) return;  // lane groups are independent: no cross-lane op below
+  const int64_t k = a.g.k0 + kl;  // slot id
   int64_t e0, e1;
   slot_range(a.g, k, &e0, &e1);
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
@@ -365,8 +366,8 @@ __global__ __launch_bounds__(256) void gat_fwd_fixup_kernel(FwdArgs a) {
   constexpr int PF = (VEC == 1) ? 4 : 2;
   extern __shared__ __attribute__((aligned(16))) float fix_sm[];  // [4][PS]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t kbase = (int64_t)blockIdx.x * FIX_SCREEN;
-  const int64_t nslots = num_slots(a.g);
+  const int64_t kbase = a.g.k0 + (int64_t)blockIdx.x * FIX_SCREEN;
+  const int64_t nslots = a.g.k0 + a.g.kn;
   int my_r = 0, my_end = 0;
   bool owner = false;
   if (lane < FIX_SCREEN && kbase + lane < nslots) {
@@ -458,7 +459,7 @@ static int launch_forward(const pygat_graph* g, int H, int Fo, float alpha, int 
                           const float* s, const float* a_pad, const float* sk, const float* att_mask, float* out,
                           float* hattn, float* m, float* Z, float* aneg, float* qneg, void* part, void* stream) {
   FwdArgs a;
-  int rc = check_graph(g, &a.g);
+  int rc = check_graph(g, &a.g, /*allow_slot_range=*/!v2);
   if (rc) return rc;
   const int Fp = padded_width(Fo);
   PYGAT_REQUIRE(H > 0 && Fp > 0, "gat_forward: unsupported H=%d F'=%d", H, Fo);
@@ -472,7 +473,7 @@ static int launch_forward(const pygat_graph* g, int H, int Fo, float alpha, int 
                     (!out || Fo != Fp || aligned16(out)),
                 "gat_forward: row tables must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  const int64_t nslots = num_slots(a.g);
+  const int64_t nslots = a.g.kn;   // slots of this call (a row range, or all)
   // GATv2 gathers [Whi|Whj] rows and is not windowed
   const int hg = v2 ? H : head_group_fwd(H, Fp);
   for (int h0 = 0; h0 < H; h0 += hg) {

@@ -95,6 +95,48 @@ class AllGatherColumns(torch.autograd.Function):
         return out[:, :widths[rank]].contiguous(), None
 
 
+PIPELINE_CHUNKS = 4          # row chunks of a pipelined hidden level (PYGAT_DIST_CHUNKS overrides; 1 = no pipeline)
+PIPELINE_MIN_ROWS = 1 << 15  # below this a level is launch-bound and one blocking all-gather is cheaper
+
+
+class _GatheredColumns(torch.autograd.Function):
+    """Ties the gathered activation `full` (assembled chunk by chunk from the ranks' column blocks while the
+    level was still running) to the local block it was gathered from: forward returns `full`, backward is the
+    reduce-scatter(sum) of AllGatherColumns."""
+
+    @staticmethod
+    def forward(ctx, local, full, widths):
+        ctx.widths = tuple(widths)
+        return full
+
+    @staticmethod
+    def backward(ctx, G):
+        return AllGatherColumns.backward(ctx, G)[0], None, None
+
+
+def _pipelined_concat_level(x, graph, Ws, As, sk, alpha, widths, nchunks):
+    """Hidden level with its heads sharded over the ranks, row-chunk pipelined: K2 runs chunk by
+    chunk; as soon as chunk c's launches are enqueued its rows are all-gathered on RCCL's stream (which first waits
+    for them), so the exchange of chunk c overlaps the computation of chunk c+1, and so on.  The gathered chunks
+    arrive as [world, rows, w] blocks and are copied into their column slices of the [N, sum(widths)] activation
+    as they land."""
+    from .ops import gat_level
+    rank, world = _world()
+    N, w = x.shape[0], widths[rank]
+    full = torch.empty(N, sum(widths), dtype=torch.float32, device=x.device)
+    works = []
+
+    def on_chunk(c, r0, r1, out):
+        buf = torch.empty(world, r1 - r0, w, dtype=out.dtype, device=out.device)
+        works.append((dist.all_gather_into_tensor(buf.view(world * (r1 - r0), w), out[r0:r1], async_op=True), buf, r0, r1))
+
+    local = gat_level(x, graph, Ws, As, sk, alpha, True, pipeline=(nchunks, on_chunk))
+    for work, buf, r0, r1 in works:
+        work.wait()                                         # the compute stream waits for this chunk only
+        full[r0:r1].view(r1 - r0, world, w).copy_(buf.permute(1, 0, 2))
+    return _GatheredColumns.apply(local, full, widths)
+
+
 class AllReduceSum(torch.autograd.Function):
     """forward: all-reduce(sum); backward: identity (the result is replicated)."""
 
@@ -120,6 +162,7 @@ def gat_level_head_parallel(x, graph, Ws, As, Wskips, alpha: float, concat: bool
     Fo = Ws[0].shape[1]
     parts = partition_heads(H, world)
     s, e = parts[rank]
+    hip_level = level_fn is None
     if level_fn is None:
         if dropout > 0.0:
             from .dropout import gat_level_dropout
@@ -129,6 +172,12 @@ def gat_level_head_parallel(x, graph, Ws, As, Wskips, alpha: float, concat: bool
             from .ops import gat_level
             level_fn = gat_level
     sk = None if Wskips is None else list(Wskips[s:e])
+    widths = [(b - a) * Fo for a, b in parts]
+    import os
+    nchunks = int(os.environ.get("PYGAT_DIST_CHUNKS", PIPELINE_CHUNKS))
+    if (concat and hip_level and dropout == 0.0 and world > 1 and nchunks > 1 and x.shape[0] >= PIPELINE_MIN_ROWS
+            and len(set(widths)) == 1 and e > s):
+        return _pipelined_concat_level(x, graph, list(Ws[s:e]), list(As[s:e]), sk, alpha, widths, nchunks)
     if concat:
         if e > s:
             local = level_fn(x, graph, list(Ws[s:e]), list(As[s:e]), sk, alpha, True)
@@ -138,7 +187,7 @@ def gat_level_head_parallel(x, graph, Ws, As, Wskips, alpha: float, concat: bool
             local = x[:, :0] * 0.0
             if not local.requires_grad:     # x is a graph input: become a leaf so backward still runs here
                 local = local.detach().requires_grad_(True)
-        return AllGatherColumns.apply(local, [(b - a) * Fo for a, b in parts])
+        return AllGatherColumns.apply(local, widths)
     if e > s:
         local = level_fn(x, graph, list(Ws[s:e]), list(As[s:e]), sk, alpha, False) * ((e - s) / H)
     else:

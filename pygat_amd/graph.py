@@ -97,6 +97,46 @@ class _Pattern:
             self._alt[key] = (st, sb, cut)
         return self._alt[key][0]
 
+    def row_chunks(self, nchunks: int, slot_edges: Optional[int] = None):
+        """Cut the pattern into up to `nchunks` ranges of WHOLE rows with about equal numbers of slots, for pipelining a
+        level by row chunks (pygat_amd/dist.py).  -> [(pygat_graph* for pygat_gat_forward, row_first, row_end)].
+        A chunk border is a slot border at which a row starts, so no row -- and no chain of partial records -- crosses it."""
+        ts = slot_edges or self.slot_edges
+        key = ("chunks", ts, nchunks)
+        if key not in self._alt:
+            base = self._make(ts, True)
+            _, sb, cut = self._alt[(ts, True)]
+            nslots = sb.numel() - 1
+            sbl, rp = sb.long(), self.rowptr.long()
+            first_row = self.edge_rc[sbl[:-1], 0].long()                 # row of the first edge of every slot
+            starts_row = rp[first_row] == sbl[:-1]
+            ok = torch.nonzero(starts_row).flatten()
+            borders = [0]
+            for c in range(1, nchunks):
+                tgt = c * nslots // nchunks
+                j = int(torch.searchsorted(ok, torch.tensor(tgt, device=ok.device)))
+                if j < ok.numel() and int(ok[j]) > borders[-1]:
+                    borders.append(int(ok[j]))
+            borders.append(nslots)
+            out, keep = [], []
+            for b0, b1 in zip(borders[:-1], borders[1:]):
+                r0 = int(first_row[b0])
+                r1 = int(first_row[b1]) if b1 < nslots else self.n
+                sub, n_cut, n_wide = None, 0, 0
+                if cut is not None:
+                    sel = (cut[:, 0] >= b0) & (cut[:, 0] < b1)
+                    sub = cut[sel].contiguous()                           # order (pieces descending) is kept
+                    n_cut, n_wide = int(sub.shape[0]), int((sub[:, 2] > 32).sum().item()) if sub.numel() else 0
+                    if n_cut == 0:
+                        sub = cut[:1].contiguous()                       # a non-NULL list with n_cut = 0: nothing to fix up
+                st = _lib.Graph(self.n, self.nnz, _ptr(self.rowptr), _ptr(self.edge_rc), ts, _ptr(sb), _ptr(sub), n_cut,
+                                n_wide, b0, b1 - b0)
+                out.append((st, r0, r1))
+                keep.append(sub)
+            self._alt[key] = (out, keep)
+            del base
+        return [(C.byref(st), r0, r1) for st, r0, r1 in self._alt[key][0]]
+
     def ref(self, slot_edges: Optional[int] = None, snapped: bool = True):
         """pygat_graph* for a call.  `slot_edges` overrides the slot length for this call only (the edge
         arrays do not depend on it); `snapped=False` gives uniform slots (K3b has no row reduction)."""

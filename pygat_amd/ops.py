@@ -190,10 +190,15 @@ class GATLevelFn(torch.autograd.Function):
     bwd_heads = (first, count): the forward covers all H heads, the backward only that range -- dW / da of the
     other heads come back as zeros.  For a rank of a head-parallel run that computes every head's forward
     itself (cheaper than receiving the outputs over xGMI) and owns the gradients of its own heads only.
-    Needs Wskip = None and no gradient into x."""
+    Needs Wskip = None and no gradient into x.
+
+    pipeline = (nchunks, on_chunk): the edge-softmax + aggregation pass (K2) runs chunk of rows by chunk of rows
+    and `on_chunk(c, row_first, row_end, out)` is called after chunk c's launches are enqueued -- rows
+    [row_first, row_end) of `out` are final once they have run -- so that a caller can send them off (RCCL
+    all-gather on its own stream, pygat_amd/dist.py) while the next chunk is computed.  concat levels only."""
 
     @staticmethod
-    def forward(ctx, x, W, a, Wskip, graph: CSRGraph, alpha: float, concat: bool, bwd_heads=None):
+    def forward(ctx, x, W, a, Wskip, graph: CSRGraph, alpha: float, concat: bool, bwd_heads=None, pipeline=None):
         if not x.is_cuda:
             raise RuntimeError("pygat_amd: inputs must be on the GPU; the hot path has no CPU fallback")
         # the path computes in float32 (like the reference's sparse layer, layers.py:150); other float dtypes are cast
@@ -242,10 +247,17 @@ class GATLevelFn(torch.autograd.Function):
             out = torch.empty(L.N, H * Fo if concat else Fo, dtype=f32, device=dev)
             part = torch.empty(lib.pygat_partials_bytes(graph.nnz, L.ts, H, L.Fp) // 4, dtype=f32,
                                device=dev)
-            with _span("k2_forward"):
-                check(lib.pygat_gat_forward(graph.fwd.ref(L.ts), H, Fo, float(alpha), flags, Wh.data_ptr(), s.data_ptr(),
-                                            a_pad.data_ptr(), _ptr(Sk), None, out.data_ptr() if concat else None, _ptr(hattn),
-                                            _ptr(m), _ptr(Z), _ptr(aneg), _ptr(qneg), part.data_ptr(), st), "gat_forward")
+            chunks = [(graph.fwd.ref(L.ts), 0, L.N)]
+            if pipeline is not None and concat and pipeline[0] > 1:
+                chunks = graph.fwd.row_chunks(int(pipeline[0]), L.ts)
+            for c, (gref, r0, r1) in enumerate(chunks):
+                with _span("k2_forward"):
+                    check(lib.pygat_gat_forward(gref, H, Fo, float(alpha), flags, Wh.data_ptr(), s.data_ptr(),
+                                                a_pad.data_ptr(), _ptr(Sk), None, out.data_ptr() if concat else None,
+                                                _ptr(hattn), _ptr(m), _ptr(Z), _ptr(aneg), _ptr(qneg), part.data_ptr(), st),
+                          "gat_forward")
+                if pipeline is not None and concat:
+                    pipeline[1](c, r0, r1, out)
             if not concat:
                 check(lib.pygat_head_mean(L.N, H, Fo, hattn.data_ptr(), _ptr(Sk), out.data_ptr(), st), "head_mean")
         if need_grad:
@@ -363,15 +375,16 @@ class GATLevelFn(torch.autograd.Function):
             if fork:
                 main.wait_stream(side)
         cast = lambda g_, k: g_ if g_ is None or g_.dtype == ctx.in_dtypes[k] else g_.to(ctx.in_dtypes[k])  # noqa: E731
-        return cast(dx, 0), cast(dW, 1), (cast(da, 2) if ctx.needs_input_grad[2] else None), cast(dWs, 3), None, None, None, None
+        return (cast(dx, 0), cast(dW, 1), (cast(da, 2) if ctx.needs_input_grad[2] else None), cast(dWs, 3), None, None, None,
+                None, None)
 
 
 def gat_level(x: torch.Tensor, graph: CSRGraph, Ws: Sequence[torch.Tensor], As: Sequence[torch.Tensor],
-              Wskips: Optional[Sequence[torch.Tensor]], alpha: float, concat: bool) -> torch.Tensor:
+              Wskips: Optional[Sequence[torch.Tensor]], alpha: float, concat: bool, pipeline=None) -> torch.Tensor:
     """All heads of one level. Ws: H tensors [Fin,F']; As: H tensors with 2F' elements
     ([2F',1] as in GraphAttentionLayer, layers.py:23, or [1,2F'] as in SpGraphAttentionLayer,
-    layers.py:114); Wskips: H tensors [Fin,F'] or None."""
+    layers.py:114); Wskips: H tensors [Fin,F'] or None.  pipeline: see GATLevelFn."""
     W = torch.stack(list(Ws), 0)
     a = torch.stack([p.reshape(-1) for p in As], 0)
     Wskip = torch.stack(list(Wskips), 0) if Wskips is not None else None
-    return GATLevelFn.apply(x, W, a, Wskip, graph, alpha, concat)
+    return GATLevelFn.apply(x, W, a, Wskip, graph, alpha, concat, None, pipeline)

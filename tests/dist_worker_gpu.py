@@ -61,6 +61,41 @@ def ppi(rank, world, pg, dev):
         assert torch.equal(t, sd[k]), k            # identical bytes on every rank after the sync
 
 
+def pipeline(rank, world, pg, dev):
+    """The row-chunk pipelined hidden level of pygat_amd/dist.py (K2 chunk by chunk, each chunk all-gathered while the
+    next is computed) against the unsharded model: outputs, gradients of the local heads, reduce-scatter of the
+    gradient into the previous level."""
+    import pygat_amd.dist as D
+    from pygat_amd.dist import partition_heads
+    D.PIPELINE_MIN_ROWS, D.PIPELINE_CHUNKS = 0, 3
+    N = 9000
+    rowptr, col = O.random_symmetric_csr(N, 7, 5, hub=(4000, 3000))
+    g = pg.CSRGraph(torch.as_tensor(rowptr, device=dev), torch.as_tensor(col, device=dev), slot_edges=32)
+    nfeat, nheads = [12, 16, 8, 5], [4, 2, 3]          # levels 1 and 2 shard evenly over 2 ranks -> pipelined
+    torch.manual_seed(0)
+    sharded = pg.GAT(nfeat, nheads, 3, 0.0, 0.2, pg.SpGraphAttentionLayer, skip_connection=True, head_parallel=True).to(dev)
+    plain = pg.GAT(nfeat, nheads, 3, 0.0, 0.2, pg.SpGraphAttentionLayer, skip_connection=True).to(dev)
+    plain.load_state_dict(sharded.state_dict())
+    calls = []
+    orig = D._pipelined_concat_level
+    D._pipelined_concat_level = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(N, nfeat[0], generator=gen).to(dev)
+    G = torch.randn(N, nfeat[-1], generator=gen).to(dev)
+    y = sharded(x, g); y.backward(G)
+    yr = plain(x, g); yr.backward(G)
+    assert len(calls) == 2, calls                        # both hidden levels took the pipelined path
+    assert float((y - yr).abs().max()) < 2e-5, float((y - yr).abs().max())
+    ps, pr = dict(sharded.named_parameters()), dict(plain.named_parameters())
+    for lvl, H in enumerate(nheads, start=1):
+        s, e = partition_heads(H, world)[rank]
+        for h in range(s, e):
+            for nm in ("W", "a", "skip_projection"):
+                key = f"attention_layer_{lvl}_head_{h + 1}.{nm}"
+                scale = max(1.0, float(pr[key].grad.abs().max()))
+                assert float((ps[key].grad - pr[key].grad).abs().max()) < 5e-5 * scale, key
+
+
 def main():
     rank, world, port = (int(v) for v in sys.argv[1:4])
     mode = sys.argv[4] if len(sys.argv) > 4 else "small"
@@ -71,8 +106,8 @@ def main():
     from pygat_amd.dist import partition_heads
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    if mode == "ppi":
-        ppi(rank, world, pg, dev)
+    if mode in ("ppi", "pipeline"):
+        (ppi if mode == "ppi" else pipeline)(rank, world, pg, dev)
         torch.cuda.synchronize()
         dist.barrier()
         dist.destroy_process_group()

@@ -29,3 +29,24 @@ def test_head_parallel_model_world2_on_one_card():
         outs.append(o.decode())
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"rank {r} ok" in o, o[-3000:]
+
+
+def test_pipelined_hidden_levels_world2_on_one_card():
+    """Row-chunk pipeline of the head-parallel hidden levels (K2 per chunk + all-gather of the finished chunk)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker_gpu.py"), str(r), "2", str(port), "pipeline"],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o.decode())
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r} ok" in o, o[-3000:]

@@ -108,3 +108,32 @@ def test_fused_epoch_dropout_masks_are_fresh_on_every_replay(pg, topologies):  #
     ep2 = pg.FusedEpoch(m2, o2, x, graph, loss_fn, eval_fn, warmup=2)
     vals = [float(ep2.run()[1]) for _ in range(150)]
     assert np.isfinite(vals).all() and vals[-1] < 0.93 * vals[0], (vals[0], vals[-1])     # 60 epochs measured: -7.5 %
+
+
+@pytest.mark.parametrize("nchunks", [2, 5])
+def test_row_chunked_forward_is_the_forward(pg, nchunks):  # noqa: F811
+    """GATLevelFn(pipeline=...): K2 chunk of rows by chunk of rows (what pygat_amd/dist.py overlaps with the
+    all-gather) gives the unchunked result bit for bit, gradients included; the callback sees every row once, in
+    order, and a chunk border never cuts a row."""
+    N, H, Fin, Fo = 6000, 4, 24, 16
+    rowptr, col = O.random_symmetric_csr(N, 9, 11, hub=(1500, 2500))      # a 2500-edge row in the middle
+    g = pg.CSRGraph(torch.as_tensor(rowptr, device=DEV), torch.as_tensor(col, device=DEV), slot_edges=16)
+    W, a, _ = params(H, Fin, Fo, False, 3)
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(N, Fin, generator=gen).to(DEV)
+    G = torch.randn(N, H * Fo, generator=gen).to(DEV)
+    seen = []
+
+    def on_chunk(c, r0, r1, out):
+        seen.append((c, r0, r1))
+
+    res = []
+    for pipe in (None, (nchunks, on_chunk)):
+        Wd, ad = W.float().to(DEV).requires_grad_(True), a.float().to(DEV).requires_grad_(True)
+        y = pg.GATLevelFn.apply(x, Wd, ad, None, g, 0.2, True, None, pipe)
+        y.backward(G)
+        res.append((y.detach(), Wd.grad, ad.grad))
+    for p, q in zip(*res):
+        assert torch.equal(p, q)
+    assert [c for c, _, _ in seen] == list(range(len(seen))) and 2 <= len(seen) <= nchunks
+    assert seen[0][1] == 0 and seen[-1][2] == N and all(a1[2] == b1[1] for a1, b1 in zip(seen, seen[1:]))

@@ -29,6 +29,8 @@ SYMBOLS = [
     "pygat_gatv2_forward", "pygat_gatv2_backward_prepare", "pygat_gatv2_workspace_bytes", "pygat_gatv2_backward",
     "pygat_dropout_mask", "pygat_dropout_expand", "pygat_dropout_head_sum", "pygat_pack_blockdiag",
     "pygat_unpack_blockdiag",
+    "pygat_headmask_supported", "pygat_dropout_bits", "pygat_project_dropout", "pygat_wgrad_dropout_workspace_bytes",
+    "pygat_wgrad_dropout", "pygat_dropout_head_sum_bits",
 ]
 
 
@@ -99,6 +101,13 @@ def _load():
     lib.pygat_dropout_head_sum.argtypes = [i, i, i, p, i64, p, f, p, u32, p, i64, i, p]
     lib.pygat_pack_blockdiag.argtypes = [i, i, i, p, p, p, i64, p]
     lib.pygat_unpack_blockdiag.argtypes = [i, i, i, p, i64, i, p, p]
+    lib.pygat_headmask_supported.argtypes = [i, i, i]
+    lib.pygat_dropout_bits.argtypes = [i, i, i, f, p, i, p, p]
+    lib.pygat_project_dropout.argtypes = [i, i, i, i, p, i64, p, f, p, i64, p, p, p]
+    lib.pygat_wgrad_dropout_workspace_bytes.argtypes = [i, i, i, i, i]
+    lib.pygat_wgrad_dropout_workspace_bytes.restype = sz
+    lib.pygat_wgrad_dropout.argtypes = [i, i, i, i, p, i64, p, f, p, p, i64, p, i, p, p]
+    lib.pygat_dropout_head_sum_bits.argtypes = [i, i, i, p, i64, p, f, p, i64, i, p]
     for s in SYMBOLS:
         fn = getattr(lib, s)
         if fn.restype is C.c_int or s in ("pygat_abi_version", "pygat_padded_width", "pygat_device_count"):

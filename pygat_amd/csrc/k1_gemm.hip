@@ -238,6 +238,189 @@ __global__ __launch_bounds__(512) void gemm_splitk_reduce_kernel(int M, int N, i
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Projection under per-head input dropout (layers.py:34,132: every head draws its own mask, models.py:32,34).
+//
+//   forward (TA = false)   C_h[M x cols] = scale * (X .* m_h)[M x K] * B_h[K x cols]            M = nodes, K = Fin
+//   weight grad (TA = true) C_h[M x cols] = scale * (X .* m_h)^T[M x K] * D_h[K x cols]          M = Fin,  K = nodes
+//
+// for ALL heads in one launch, X read ONCE: the A tile is staged in LDS together with its mask bits (one byte
+// per element, bit h = "head h keeps this input", written by dropout_bits_kernel), and the heads are an inner loop
+// over the fragments -- a_h = bit_h ? x : 0 is one v_cndmask per MFMA.  Replaces round 1's wide operand
+// A'[N, H*Fin] times a block-diagonal weight stack: no N*H*Fin table (Citeseer: 394 MB -> 12 MB of bits), no
+// products with the H-1 zero blocks.  B_h / C_h are column slices: head h, column c < Fp of source 1
+// (W or dWh), Fp <= c < 2Fp of source 2 (skip weights or Gp), each at column h*Fp of its table.
+struct HeadMaskArgs {
+  int M;
+  int64_t K;
+  const float* A;          // X: [M x K] (TA = false) or [K x M] (TA = true), row stride lda
+  int64_t lda;
+  const unsigned char* bits;  // same indexing and row stride as A
+  const float* B1;         // [K x .], row stride ldb1, columns h*Fp + c
+  int64_t ldb1;
+  const float* B2;         // second source or nullptr
+  int64_t ldb2;
+  float* C1;               // [M x .], row stride ldc1, columns h*Fp + c
+  int64_t ldc1;
+  float* C2;
+  int64_t ldc2;
+  int64_t c_split_stride;  // TA: partial results of K slab z go to C + z * c_split_stride
+  int H, Fp;
+  float scale;
+  int64_t k_per_split;
+};
+
+template <bool TA, int HB, int NTH>
+__global__ __launch_bounds__(256) void gemm_headmask_kernel(HeadMaskArgs g) {
+  constexpr int NTOT = HB * NTH, BN = 32 * NTOT;
+  constexpr int LDAS = BM + PAD, LDBS = BN + PAD;
+  constexpr int NVA = 2;
+  constexpr int NB = (BK * BN + 255) / 256;   // B elements per thread and k-tile
+  extern __shared__ __attribute__((aligned(16))) float hm_sm[];
+  float* As = hm_sm;                                   // [2][BK * LDAS]
+  float* Bs = As + 2 * BK * LDAS;                      // [2][BK * LDBS]
+  unsigned char* Ms = reinterpret_cast<unsigned char*>(Bs + 2 * BK * LDBS);   // [2][BK * LDAS] mask byte per element
+  const int m0 = blockIdx.x * BM, hb0 = blockIdx.y * HB;
+  const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
+  const int64_t kend = (kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int cols_h = g.B2 ? 2 * g.Fp : g.Fp;
+
+  f32x16 acc[NTOT];
+#pragma unroll
+  for (int i = 0; i < NTOT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  float4 ra[NVA];
+  uint32_t rm[NVA];   // 4 mask bytes matching ra
+  float rb[NB];
+  auto gload = [&](int64_t k0) {
+    if constexpr (TA) load_kstrided<BM, NVA>(g.A, g.lda, 0, m0, g.M, k0, kend, ra);
+    else load_kcontig<BM, NVA>(g.A, g.lda, 0, m0, g.M, k0, kend, ra);
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      uint32_t v = 0;
+      if constexpr (TA) {   // element (k, m .. m+3)
+        const int64_t k = k0 + idx / (BM / 4);
+        const int c = m0 + (idx % (BM / 4)) * 4;
+        if (k < kend)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (c + q < g.M) v |= (uint32_t)g.bits[k * g.lda + c + q] << (8 * q);
+      } else {              // element (row, k .. k+3)
+        const int row = m0 + (idx >> 2);
+        const int64_t k = k0 + (idx & 3) * 4;
+        if (row < g.M)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (k + q < kend) v |= (uint32_t)g.bits[(int64_t)row * g.lda + k + q] << (8 * q);
+      }
+      rm[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      float v = 0.f;
+      if (idx < BK * BN) {
+        const int64_t k = k0 + idx / BN;
+        const int cc = idx % BN, hl = cc / (32 * NTH), c = cc % (32 * NTH), h = hb0 + hl;
+        if (k < kend && h < g.H && c < cols_h)
+          v = c < g.Fp ? g.B1[k * g.ldb1 + (int64_t)h * g.Fp + c] : g.B2[k * g.ldb2 + (int64_t)h * g.Fp + (c - g.Fp)];
+      }
+      rb[i] = v;
+    }
+  };
+  auto sstore = [&](int buf) {
+    float* as = As + buf * BK * LDAS;
+    unsigned char* ms = Ms + buf * BK * LDAS;
+    if constexpr (TA) store_kstrided<BM, NVA, LDAS>(as, ra);
+    else store_kcontig<BM, NVA, LDAS>(as, ra);
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      if constexpr (TA) {
+        unsigned char* d = ms + (idx / (BM / 4)) * LDAS + (idx % (BM / 4)) * 4;
+        d[0] = (unsigned char)rm[i]; d[1] = (unsigned char)(rm[i] >> 8); d[2] = (unsigned char)(rm[i] >> 16); d[3] = (unsigned char)(rm[i] >> 24);
+      } else {
+        const int row = idx >> 2, kq = (idx & 3) * 4;
+        ms[(kq + 0) * LDAS + row] = (unsigned char)rm[i]; ms[(kq + 1) * LDAS + row] = (unsigned char)(rm[i] >> 8);
+        ms[(kq + 2) * LDAS + row] = (unsigned char)(rm[i] >> 16); ms[(kq + 3) * LDAS + row] = (unsigned char)(rm[i] >> 24);
+      }
+    }
+    float* bs = Bs + buf * BK * LDBS;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      if (idx < BK * BN) bs[(idx / BN) * LDBS + idx % BN] = rb[i];
+    }
+  };
+
+  const int64_t nkt = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
+  if (nkt > 0) { gload(kbeg); sstore(0); }
+  __syncthreads();
+  const int fr = lane & 31, fk = lane >> 5;
+  for (int64_t kt = 0; kt < nkt; ++kt) {
+    const int buf = (int)(kt & 1);
+    if (kt + 1 < nkt) gload(kbeg + (kt + 1) * BK);
+    const float* as = As + buf * BK * LDAS + fk * LDAS + 32 * w + fr;
+    const unsigned char* ms = Ms + buf * BK * LDAS + fk * LDAS + 32 * w + fr;
+    const float* bs = Bs + buf * BK * LDBS + fk * LDBS + fr;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float xs = as[kk * LDAS];
+      const uint32_t mb = (uint32_t)ms[kk * LDAS] >> hb0;
+#pragma unroll
+      for (int hl = 0; hl < HB; ++hl) {
+        const float a = ((mb >> hl) & 1u) ? xs : 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NTH; ++nt)
+          acc[hl * NTH + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bs[kk * LDBS + 32 * (hl * NTH + nt)], acc[hl * NTH + nt], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nkt) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int64_t zoff = (int64_t)blockIdx.z * g.c_split_stride;
+#pragma unroll
+  for (int hl = 0; hl < HB; ++hl) {
+    const int h = hb0 + hl;
+    if (h >= g.H) continue;
+#pragma unroll
+    for (int nt = 0; nt < NTH; ++nt) {
+      const int c = 32 * nt + fr;
+      if (c >= cols_h) continue;
+      float* base = c < g.Fp ? g.C1 + zoff + (int64_t)h * g.Fp + c : g.C2 + zoff + (int64_t)h * g.Fp + (c - g.Fp);
+      const int64_t ld = c < g.Fp ? g.ldc1 : g.ldc2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * fk;
+        if (row < g.M) base[(int64_t)row * ld] = acc[hl * NTH + nt][r] * g.scale;
+      }
+    }
+  }
+}
+
+template <bool TA>
+static int launch_headmask(const HeadMaskArgs& g, int splits, hipStream_t st) {
+  const int cols_h = g.B2 ? 2 * g.Fp : g.Fp;
+  const int nth = cols_h <= 32 ? 1 : cols_h <= 64 ? 2 : cols_h <= 128 ? 4 : 8;
+  const int hb = 8 / nth;
+  if (cols_h > 256 || g.H > 8) return 0;
+  dim3 grid((unsigned)cdiv(g.M, BM), (unsigned)cdiv(g.H, hb), (unsigned)splits);
+  const size_t lds = (size_t)(2 * BK * (BM + PAD) + 2 * BK * (32 * 8 + PAD)) * sizeof(float) + 2 * BK * (BM + PAD);
+  switch (nth) {
+    case 1: hipLaunchKernelGGL((gemm_headmask_kernel<TA, 8, 1>), grid, dim3(256), lds, st, g); break;
+    case 2: hipLaunchKernelGGL((gemm_headmask_kernel<TA, 4, 2>), grid, dim3(256), lds, st, g); break;
+    case 4: hipLaunchKernelGGL((gemm_headmask_kernel<TA, 2, 4>), grid, dim3(256), lds, st, g); break;
+    default: hipLaunchKernelGGL((gemm_headmask_kernel<TA, 1, 8>), grid, dim3(256), lds, st, g); break;
+  }
+  return 1;
+}
+
 template <bool TA, bool TB>
 static int launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
   const int nt_needed = (int)cdiv(g.N, 32);
@@ -420,5 +603,72 @@ extern "C" int pygat_wgrad(int n, int Fin, int H, int Fo, const float* X, int64_
   hipLaunchKernelGGL(unpack_wgrad_rank1_kernel, dim3((unsigned)cdiv((int64_t)H * Fin * Fo, 256)), dim3(256), 0, st, H, Fin,
                      Fo, Fp, (const float*)dWc, (int64_t)ldc, ds ? 1 : 0, a_pad, dW);
   PYGAT_CHECK_LAUNCH("wgrad(unpack)");
+  return PYGAT_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Projection / weight gradient under per-head input dropout, all heads in one launch, X read once (see
+// gemm_headmask_kernel).  bits [n x Fin] bytes: bit h = head h keeps x[i,k] (pygat_dropout_bits); p = drop rate.
+// Supported: H <= 8, (skip ? 2 : 1) * Fp <= 256 -- the callers fall back to the wide-operand path otherwise.
+extern "C" int pygat_headmask_supported(int H, int Fo, int skip) {
+  const int Fp = padded_width(Fo);
+  return (H >= 1 && H <= 8 && Fp > 0 && Fp * (skip ? 2 : 1) <= 256) ? 1 : 0;
+}
+
+/* [Wh | Sk] = (1/(1-p)) (X .* m_h) [W_h | Wskip_h] per head; Wcat as written by pygat_pack_params. */
+extern "C" int pygat_project_dropout(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const unsigned char* bits,
+                                     float p, const float* Wcat, int64_t ldw, float* Wh, float* Sk, void* stream) {
+  const int Fp = padded_width(Fo);
+  PYGAT_REQUIRE(n > 0 && Fin > 0 && X && bits && Wcat && Wh && ldx == Fin, "project_dropout: bad arguments (X must be dense: ldx == Fin)");
+  PYGAT_REQUIRE(pygat_headmask_supported(H, Fo, Sk != nullptr), "project_dropout: unsupported H=%d F'=%d", H, Fo);
+  PYGAT_REQUIRE(p >= 0.f && p <= 1.f, "project_dropout: p=%g outside [0,1]", (double)p);
+  const int R = H * Fp;
+  HeadMaskArgs g;
+  g.M = n; g.K = Fin; g.A = X; g.lda = ldx; g.bits = bits;
+  g.B1 = Wcat; g.ldb1 = ldw; g.B2 = Sk ? Wcat + R : nullptr; g.ldb2 = ldw;
+  g.C1 = Wh; g.ldc1 = R; g.C2 = Sk; g.ldc2 = R; g.c_split_stride = 0;
+  g.H = H; g.Fp = Fp; g.scale = p < 1.f ? 1.f / (1.f - p) : 0.f; g.k_per_split = Fin;
+  launch_headmask<false>(g, 1, (hipStream_t)stream);
+  PYGAT_CHECK_LAUNCH("project_dropout");
+  return PYGAT_OK;
+}
+
+extern "C" size_t pygat_wgrad_dropout_workspace_bytes(int Fin, int H, int Fo, int skip, int split_k) {
+  const int Fp = padded_width(Fo);
+  if (Fin <= 0 || H <= 0 || Fp <= 0) return 0;
+  if (split_k < 1) split_k = 1;
+  return (size_t)split_k * (size_t)Fin * (size_t)(H * Fp * (skip ? 2 : 1)) * sizeof(float);
+}
+
+/* dWc [Fin x R (+R)] = (1/(1-p)) (X .* m_h)^T [dWh_h | Gp_h] per head (columns h*Fp.. of each half); Gp = NULL: no
+ * skip half.  split_k K slabs over the nodes, partial sums in ws, summed in slab order (deterministic). */
+extern "C" int pygat_wgrad_dropout(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const unsigned char* bits,
+                                   float p, const float* dWh, const float* Gp, int64_t ldgp, float* dWc, int split_k,
+                                   void* ws, void* stream) {
+  const int Fp = padded_width(Fo);
+  PYGAT_REQUIRE(n > 0 && Fin > 0 && X && bits && dWh && dWc && ldx == Fin, "wgrad_dropout: bad arguments");
+  PYGAT_REQUIRE(pygat_headmask_supported(H, Fo, Gp != nullptr), "wgrad_dropout: unsupported H=%d F'=%d", H, Fo);
+  if (split_k < 1) split_k = 1;
+  PYGAT_REQUIRE(split_k == 1 || ws, "wgrad_dropout: split_k > 1 needs a workspace");
+  const int R = H * Fp, ntot = R * (Gp ? 2 : 1);
+  hipStream_t st = (hipStream_t)stream;
+  int64_t kps = cdiv(cdiv(n, split_k), BK) * BK;
+  const int splits = (int)cdiv(n, kps);
+  float* out = splits > 1 ? (float*)ws : dWc;
+  HeadMaskArgs g;
+  g.M = Fin; g.K = n; g.A = X; g.lda = ldx; g.bits = bits;
+  g.B1 = dWh; g.ldb1 = R; g.B2 = Gp; g.ldb2 = ldgp;
+  g.C1 = out; g.ldc1 = ntot; g.C2 = out + R; g.ldc2 = ntot; g.c_split_stride = (int64_t)Fin * ntot;
+  g.H = H; g.Fp = Fp; g.scale = p < 1.f ? 1.f / (1.f - p) : 0.f; g.k_per_split = kps;
+  launch_headmask<true>(g, splits, st);
+  PYGAT_CHECK_LAUNCH("wgrad_dropout");
+  if (splits > 1) {
+    pygat_out_segments seg;
+    seg.nseg = 1; seg.col_start[0] = 0; seg.col_start[1] = ntot; seg.ptr[0] = dWc; seg.ld[0] = ntot;
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)cdiv((int64_t)Fin * ntot, 64)), dim3(512), 0, st, Fin, ntot,
+                       splits, (const float*)ws, seg, 0);
+    PYGAT_CHECK_LAUNCH("wgrad_dropout(reduce)");
+  }
   return PYGAT_OK;
 }

@@ -67,6 +67,41 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(int64_t count, DropRn
   }
 }
 
+// Input-dropout decisions of all heads as ONE byte per input element: bit h of bits[i, k] = "head h keeps x[i,k]"
+// (word (k & 3) of Philox(counter = (k >> 2, i, stream_id, h), key = seed) < keep * 2^32).  Consumed by the
+// head-masked GEMMs (k1_gemm.hip) and by dropout_head_sum_bits_kernel: 1 byte instead of 4H bytes per element.
+__global__ __launch_bounds__(256) void dropout_bits_kernel(int n, int Fin, int H, DropRng g, unsigned char* __restrict__ bits) {
+  const int q4 = (Fin + 3) / 4;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)n * q4) return;
+  const int i = (int)(idx / q4), c4 = (int)(idx % q4);
+  const uint64_t seed = *g.seed;
+  uint32_t b[4] = {0, 0, 0, 0};
+  for (int h = 0; h < H; ++h) {
+    const uint4 w = draw4(g, seed, (uint32_t)i, (uint32_t)h, (uint32_t)c4);
+    b[0] |= (w.x < g.thresh ? 1u : 0u) << h; b[1] |= (w.y < g.thresh ? 1u : 0u) << h;
+    b[2] |= (w.z < g.thresh ? 1u : 0u) << h; b[3] |= (w.w < g.thresh ? 1u : 0u) << h;
+  }
+  for (int q = 0; q < 4 && 4 * c4 + q < Fin; ++q) bits[(int64_t)i * Fin + 4 * c4 + q] = (unsigned char)b[q];
+}
+
+// dx[i,k] (+)= scale * sum_h bit_h[i,k] * dxe[i, h*Fin + k]  -- back through the per-head input dropout (bits form)
+__global__ __launch_bounds__(256) void dropout_head_sum_bits_kernel(int n, int Fin, int H, const float* __restrict__ dxe,
+                                                                    int64_t lde, const unsigned char* __restrict__ bits,
+                                                                    float scale, float* __restrict__ dx, int64_t ldx,
+                                                                    int accumulate) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)n * Fin) return;
+  const int i = (int)(idx / Fin), k = (int)(idx - (int64_t)i * Fin);
+  const uint32_t b = bits[idx];
+  float acc = 0.f;
+  for (int h = 0; h < H; ++h)
+    if ((b >> h) & 1u) acc += dxe[(int64_t)i * lde + (int64_t)h * Fin + k];
+  acc *= scale;
+  float* o = dx + (int64_t)i * ldx + k;
+  *o = accumulate ? *o + acc : acc;
+}
+
 // A'[i, h*Fin + k] = x[i,k] * m_h[i,k]; one work-group per (row, 1024-column chunk), thread = 4 columns
 __global__ __launch_bounds__(256) void dropout_expand_kernel(int n, int Fin, int H, int nchunks,
                                                              const float* __restrict__ x, int64_t ldx,
@@ -228,5 +263,28 @@ extern "C" int pygat_unpack_blockdiag(int H, int Fin, int Fo, const float* dBp, 
   hipLaunchKernelGGL(unpack_blockdiag_kernel, dim3((unsigned)cdiv((int64_t)H * Fin * Fo, 256)), dim3(256), 0,
                      (hipStream_t)stream, H, Fin, Fo, Fp, dBp, ldb, col_offset, dW);
   PYGAT_CHECK_LAUNCH("unpack_blockdiag");
+  return PYGAT_OK;
+}
+
+
+/* bits [n x Fin] bytes, bit h = head h keeps x[i,k] (H <= 8); drawn from (seed, stream_id) like the other masks. */
+extern "C" int pygat_dropout_bits(int n, int Fin, int H, float p, const void* seed, int stream_id, unsigned char* bits,
+                                  void* stream) {
+  DropRng g;
+  PYGAT_REQUIRE(n > 0 && Fin > 0 && H >= 1 && H <= 8 && seed && bits, "dropout_bits: bad arguments (H <= 8)");
+  PYGAT_REQUIRE(make_rng(p, seed, (uint32_t)stream_id, &g), "dropout_bits: p=%g outside [0,1]", (double)p);
+  const int64_t tot = (int64_t)n * ((Fin + 3) / 4);
+  hipLaunchKernelGGL(dropout_bits_kernel, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, n, Fin, H, g, bits);
+  PYGAT_CHECK_LAUNCH("dropout_bits");
+  return PYGAT_OK;
+}
+
+extern "C" int pygat_dropout_head_sum_bits(int n, int Fin, int H, const float* dxe, int64_t lde, const unsigned char* bits,
+                                           float p, float* dx, int64_t ldx, int accumulate, void* stream) {
+  PYGAT_REQUIRE(n > 0 && Fin > 0 && H >= 1 && H <= 8 && dxe && bits && dx && p >= 0.f && p <= 1.f, "dropout_head_sum_bits: bad arguments");
+  const float scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
+  hipLaunchKernelGGL(dropout_head_sum_bits_kernel, dim3((unsigned)cdiv((int64_t)n * Fin, 256)), dim3(256), 0,
+                     (hipStream_t)stream, n, Fin, H, dxe, lde, bits, scale, dx, ldx, accumulate);
+  PYGAT_CHECK_LAUNCH("dropout_head_sum_bits");
   return PYGAT_OK;
 }

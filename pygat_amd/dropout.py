@@ -10,10 +10,15 @@ heads one after another (models.py:32,34):
                                          (sparse layer: numerators dropped AFTER the row sum)
 
 A per-head input mask means the fused all-heads projection is no longer one GEMM on x.
-Here the masked input is written once as one wide operand A' [N, H*Fin] (A'[i, h*Fin+k] =
-x[i,k] m_h[i,k]) and multiplied with the block-diagonal stack of the head weights: ONE MFMA
-GEMM with K = H*Fin for all heads (csrc/k7_dropout.hip; the first version ran one GEMM per
-head and spent a third of a Cora epoch there).  s,t are re-derived from the dropped Wh
+Round 2 (default where supported: H <= 8, row of one head <= 256 floats): the decisions of all
+heads for x[i,k] are ONE byte (bit h = head h keeps it, csrc/k7_dropout.hip dropout_bits_kernel),
+and the projection and its weight gradient run for all heads in one launch with x read once --
+the A tile sits in LDS with its mask bytes and the heads are an inner loop over the MFMA fragments
+(csrc/k1_gemm.hip gemm_headmask_kernel).  Memory N*Fin bytes instead of N*H*Fin*4 (Citeseer:
+12 MB instead of 394 MB), no products with zero blocks.  Round 1's form remains as the fallback
+(PYGAT_DROPOUT_WIDE=1 forces it): the masked input written once as one wide operand A' [N, H*Fin]
+(A'[i, h*Fin+k] = x[i,k] m_h[i,k]) multiplied with the block-diagonal stack of the head weights,
+ONE MFMA GEMM with K = H*Fin for all heads.  s,t are re-derived from the dropped Wh
 (pygat_attn_scores) and the attention mask goes to K2/K3b/K4.  In training the masks are
 drawn in-kernel (Philox-4x32-10) from one int64 seed taken from torch's generator; the
 reference's own RNG stream cannot be reproduced bit-for-bit by any other implementation, so
@@ -26,6 +31,8 @@ from typing import Optional, Sequence
 
 import torch
 
+import os
+
 from . import _lib, ops
 from ._lib import lib, check, padded_width
 from .graph import CSRGraph, slot_edges_for
@@ -33,6 +40,14 @@ from .ops import _Level, _ptr, _span, _stream, gemm
 
 
 STREAM_X, STREAM_WH, STREAM_ATT = 1, 2, 3     # Philox stream ids of the three masks drawn from one seed
+FORCE_WIDE = os.environ.get("PYGAT_DROPOUT_WIDE", "0") == "1"   # round 1's wide-operand projection everywhere
+
+
+def _pack_bits(mask_x: torch.Tensor) -> torch.Tensor:
+    """Explicit per-head input masks [H,N,Fin] (0 or 1/(1-p)) -> one byte per input element, bit h = head h keeps."""
+    H = mask_x.shape[0]
+    w = (1 << torch.arange(H, device=mask_x.device, dtype=torch.int32)).view(H, 1, 1)
+    return ((mask_x != 0).to(torch.int32) * w).sum(0).to(torch.uint8).contiguous()
 
 
 def draw_masks(p: float, H: int, N: int, Fin: int, Fo: int, E: int, device, generator=None):
@@ -83,22 +98,34 @@ class GATLevelDropoutFn(torch.autograd.Function):
                 matt = torch.empty(E, H, dtype=f32, device=dev)
                 check(lib.pygat_dropout_mask(L.N * R, p, seed.data_ptr(), STREAM_WH, mwh.data_ptr(), st), "dropout_mask")
                 check(lib.pygat_dropout_mask(E * H, p, seed.data_ptr(), STREAM_ATT, matt.data_ptr(), st), "dropout_mask")
-            Wcat = torch.empty(Fin, L.ldw, dtype=f32, device=dev)     # only a_pad is used from this packing
+            Wcat = torch.empty(Fin, L.ldw, dtype=f32, device=dev)
             a_pad = torch.empty(H, 2, L.Fp, dtype=f32, device=dev)
             check(lib.pygat_pack_params(H, Fin, Fo, W.data_ptr(), a.data_ptr(), _ptr(Wskip), Wcat.data_ptr(), L.ldw,
                                         a_pad.data_ptr(), st), "pack_params")
-            del Wcat
-            # per-head masked input as ONE operand A' [N, H*Fin] against the block-diagonal weights B' (layers.py:34,132)
-            Bp = torch.empty(HF, ncb, dtype=f32, device=dev)
-            check(lib.pygat_pack_blockdiag(H, Fin, Fo, W.data_ptr(), _ptr(Wskip), Bp.data_ptr(), ncb, st), "pack_blockdiag")
-            Ae = torch.empty(L.N, HF, dtype=f32, device=dev)
-            check(lib.pygat_dropout_expand(L.N, Fin, H, x.data_ptr(), Fin, _ptr(mask_x) if explicit else None, p,
-                                           None if explicit else seed.data_ptr(), STREAM_X, Ae.data_ptr(), HF, st),
-                  "dropout_expand")
             Wh = torch.empty(L.N, R, dtype=f32, device=dev)
             Sk = torch.empty(L.N, R, dtype=f32, device=dev) if skip else None   # mm(h, skip) uses the dropped h (layers.py:48,166)
-            with _span("k1_project"):
-                gemm(False, False, L.N, ncb, HF, Ae, HF, Bp, ncb, [(R, Wh, R)] + ([(R, Sk, R)] if skip else []))
+            use_bits = (not FORCE_WIDE) and bool(lib.pygat_headmask_supported(H, Fo, int(skip))) and L.hg == H
+            Ae = Bp = bits = None
+            if use_bits:
+                # per-head input masks as one byte per element; all heads in one launch, x read once (layers.py:34,132)
+                if explicit:
+                    bits = _pack_bits(mask_x)
+                else:
+                    bits = torch.empty(L.N, Fin, dtype=torch.uint8, device=dev)
+                    check(lib.pygat_dropout_bits(L.N, Fin, H, p, seed.data_ptr(), STREAM_X, bits.data_ptr(), st), "dropout_bits")
+                with _span("k1_project"):
+                    check(lib.pygat_project_dropout(L.N, Fin, H, Fo, x.data_ptr(), Fin, bits.data_ptr(), p, Wcat.data_ptr(),
+                                                    L.ldw, Wh.data_ptr(), _ptr(Sk), st), "project_dropout")
+            else:
+                # per-head masked input as ONE operand A' [N, H*Fin] against the block-diagonal weights B'
+                Bp = torch.empty(HF, ncb, dtype=f32, device=dev)
+                check(lib.pygat_pack_blockdiag(H, Fin, Fo, W.data_ptr(), _ptr(Wskip), Bp.data_ptr(), ncb, st), "pack_blockdiag")
+                Ae = torch.empty(L.N, HF, dtype=f32, device=dev)
+                check(lib.pygat_dropout_expand(L.N, Fin, H, x.data_ptr(), Fin, _ptr(mask_x) if explicit else None, p,
+                                               None if explicit else seed.data_ptr(), STREAM_X, Ae.data_ptr(), HF, st),
+                      "dropout_expand")
+                with _span("k1_project"):
+                    gemm(False, False, L.N, ncb, HF, Ae, HF, Bp, ncb, [(R, Wh, R)] + ([(R, Sk, R)] if skip else []))
             Wh.mul_(mwh)                           # layers.py:37,136
             s = torch.empty(L.N, H, dtype=f32, device=dev); t = torch.empty(L.N, H, dtype=f32, device=dev)
             check(lib.pygat_attn_scores(L.N, H, Fo, Wh.data_ptr(), a_pad.data_ptr(), s.data_ptr(), t.data_ptr(), st),
@@ -118,16 +145,17 @@ class GATLevelDropoutFn(torch.autograd.Function):
                                             _ptr(aneg), _ptr(qneg), part.data_ptr(), st), "gat_forward")
             if not concat:
                 check(lib.pygat_head_mean(L.N, H, Fo, hattn.data_ptr(), _ptr(Sk), out.data_ptr(), st), "head_mean")
-        ctx.save_for_backward(Ae, Bp, a_pad, Wh, s, Sk, out if concat else hattn, m, Z, mask_x if explicit else seed,
-                              mwh, matt, aneg, qneg)
+        ctx.save_for_backward(x if use_bits else Ae, bits if use_bits else Bp, a_pad, Wh, s, Sk, out if concat else hattn, m, Z,
+                              mask_x if explicit else seed, mwh, matt, aneg, qneg, Wcat if use_bits else None)
         ctx.graph, ctx.L, ctx.alpha, ctx.concat, ctx.flags, ctx.p, ctx.explicit = \
             graph, L, float(alpha), concat, flags, p, explicit
+        ctx.use_bits = use_bits
         ctx.flavour = flavour
         return out
 
     @staticmethod
     def backward(ctx, G):
-        Ae, Bp, a_pad, Wh, s, Sk, y, m, Z, mx_or_seed, mwh, matt, aneg, qneg = ctx.saved_tensors
+        Ae, Bp, a_pad, Wh, s, Sk, y, m, Z, mx_or_seed, mwh, matt, aneg, qneg, Wcat = ctx.saved_tensors
         graph, L, H, Fo, p = ctx.graph, ctx.L, ctx.L.H, ctx.L.Fo, ctx.p
         dev, f32 = Ae.device, torch.float32
         G = G.contiguous().float()
@@ -173,6 +201,10 @@ class GATLevelDropoutFn(torch.autograd.Function):
                                    None if two_gather else a_pad.data_ptr(), None if two_gather else dWh.data_ptr(), 0, 0, st),
                   "a_grad")
             dWh.mul_(mwh)                          # back through the Wh dropout
+            if ctx.use_bits:     # Ae is x and Bp the mask bytes on this path
+                dx, dW, dWs = _backward_bits(ctx, Ae, Bp, Wcat, dWh, GR, RW, st)
+                cast = lambda g_, k: g_ if g_ is None or g_.dtype == ctx.in_dtypes[k] else g_.to(ctx.in_dtypes[k])  # noqa: E731
+                return cast(dx, 0), cast(dW, 1), cast(da, 2), cast(dWs, 3), None, None, None, None, None, None, None, None
             # dW_h = (x o m_h)^T dWh_h: the diagonal blocks of A'^T dWh
             dBp = torch.empty(HF, R, dtype=f32, device=dev)
             with _span("k5_wgrad"):
@@ -201,6 +233,44 @@ class GATLevelDropoutFn(torch.autograd.Function):
                                                  dx.data_ptr(), Fin, 0, st), "dropout_head_sum")
         cast = lambda g_, k: g_ if g_ is None or g_.dtype == ctx.in_dtypes[k] else g_.to(ctx.in_dtypes[k])  # noqa: E731
         return cast(dx, 0), cast(dW, 1), cast(da, 2), cast(dWs, 3), None, None, None, None, None, None, None, None
+
+
+def _backward_bits(ctx, x, bits, Wcat, dWh, GR, RW, st):
+    """dW / dWskip / dX of the projection under per-head input dropout, bits form (forward: pygat_project_dropout)."""
+    L, H, Fo, p = ctx.L, ctx.L.H, ctx.L.Fo, ctx.p
+    dev, f32 = x.device, torch.float32
+    Fin, R = L.Fin, L.R
+    ntot = R * (2 if L.skip else 1)
+    # dW_h = (x o m_h)^T dWh_h, dWskip_h = (x o m_h)^T Gp_h: one launch for all heads, x read once; K slabs over the nodes
+    tiles = -(-Fin // 128) * -(-H // max(1, 8 // max(1, (L.Fp * (2 if L.skip else 1) + 31) // 32)))
+    split_k = max(1, min(256 // max(tiles, 1), L.N // 256))
+    ws = torch.empty(lib.pygat_wgrad_dropout_workspace_bytes(Fin, H, Fo, int(L.skip), split_k) // 4, dtype=f32, device=dev)
+    dWc = torch.empty(Fin, ntot, dtype=f32, device=dev)
+    with _span("k5_wgrad"):
+        check(lib.pygat_wgrad_dropout(L.N, Fin, H, Fo, x.data_ptr(), Fin, bits.data_ptr(), p, dWh.data_ptr(),
+                                      GR.data_ptr() if L.skip else None, RW, dWc.data_ptr(), split_k, ws.data_ptr(), st),
+              "wgrad_dropout")
+    dW = torch.empty(H, Fin, Fo, dtype=f32, device=dev)
+    check(lib.pygat_unpack_wgrad(H, Fin, Fo, dWc.data_ptr(), ntot, 0, dW.data_ptr(), st), "unpack_wgrad")
+    dWs = None
+    if L.skip:
+        dWs = torch.empty(H, Fin, Fo, dtype=f32, device=dev)
+        check(lib.pygat_unpack_wgrad(H, Fin, Fo, dWc.data_ptr(), ntot, R, dWs.data_ptr(), st), "unpack_wgrad")
+    dx = None
+    if ctx.needs_input_grad[0]:
+        # dxe[i, h*Fin + k] = dWh_h[i,:] . W_h[k,:] (+ Gp_h . Wskip_h), head by head, then folded under the mask bits
+        HF = H * Fin
+        dxe = torch.empty(L.N, HF, dtype=f32, device=dev)
+        for h in range(H):
+            c0 = h * L.Fp
+            gemm(False, True, L.N, Fin, L.Fp, dWh[:, c0:], R, Wcat[:, c0:], L.ldw, [(Fin, dxe[:, h * Fin:], HF)], split_k=1)
+            if L.skip:
+                gemm(False, True, L.N, Fin, L.Fp, GR[:, c0:], RW, Wcat[:, R + c0:], L.ldw, [(Fin, dxe[:, h * Fin:], HF)],
+                     accumulate=True, split_k=1)
+        dx = torch.empty(L.N, Fin, dtype=f32, device=dev)
+        check(lib.pygat_dropout_head_sum_bits(L.N, Fin, H, dxe.data_ptr(), HF, bits.data_ptr(), p, dx.data_ptr(), Fin, 0, st),
+              "dropout_head_sum_bits")
+    return dx, dW, dWs
 
 
 def gat_level_dropout(x, graph: CSRGraph, Ws: Sequence[torch.Tensor], As: Sequence[torch.Tensor],

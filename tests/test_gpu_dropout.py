@@ -15,9 +15,13 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("H,Fin,Fo,skip,concat", [(3, 10, 8, False, True), (2, 7, 5, True, False), (8, 20, 8, True, True),
                                                   (3, 9, 128, True, True), (5, 6, 100, True, False), (6, 5, 128, True, True)])   # last two: head windows
-@pytest.mark.parametrize("two_gather", [None, False, True])
+@pytest.mark.parametrize("two_gather", [None, False, True, "wide"])
 def test_dropout_explicit_masks(pg, monkeypatch, two_gather, H, Fin, Fo, skip, concat):  # noqa: F811
+    from pygat_amd import dropout as D
     from pygat_amd.dropout import gat_level_dropout
+    if two_gather == "wide":       # round 1's wide-operand projection instead of the mask-byte one (default backward)
+        monkeypatch.setattr(D, "FORCE_WIDE", True)
+        two_gather = None
     monkeypatch.setattr(pg.ops, "TWO_GATHER_BACKWARD", two_gather)   # all backward flavours carry the attention mask (None: the default, row-local one)
     monkeypatch.setenv("PYGAT_BWD_WINDOW_BYTES", "0")   # rows > 512 floats: backward in head windows
     N, p = 70, 0.6
@@ -161,3 +165,80 @@ def test_dropout_p_one_and_float64_inputs(pg):  # noqa: F811
     assert x64.grad is not None and x64.grad.dtype == torch.float64 and torch.isfinite(x64.grad).all()
     yr = layer(x64.detach().float(), g)
     assert torch.equal(y.detach(), yr.detach())
+
+
+@pytest.mark.parametrize("N,Fin,H,Fo,skip", [(3000, 1433, 8, 8, False), (700, 50, 4, 16, True), (1300, 77, 3, 64, True),
+                                            (900, 33, 1, 128, True), (5000, 64, 8, 3, False)])
+def test_headmask_projection_and_weight_gradient(pg, N, Fin, H, Fo, skip):  # noqa: F811
+    """The mask-byte projection (pygat_project_dropout) and its weight gradient (pygat_wgrad_dropout, K slabs over the
+    nodes) through the C ABI against fp64 torch on the same decisions; and the statistics of pygat_dropout_bits
+    (keep rate, independent heads, one seed -> one mask, bit h of the byte = head h)."""
+    from pygat_amd._lib import lib, check
+    dev = torch.device("cuda", 0)
+    p, keep = 0.6, 0.4
+    Fp = pg.padded_width(Fo); R = H * Fp
+    assert lib.pygat_headmask_supported(H, Fo, int(skip)) == 1
+    seed = torch.tensor([987654321], dtype=torch.int64, device=dev)
+    bits = torch.empty(N, Fin, dtype=torch.uint8, device=dev)
+    check(lib.pygat_dropout_bits(N, Fin, H, p, seed.data_ptr(), 1, bits.data_ptr(), None))
+    bits2 = torch.empty_like(bits)
+    check(lib.pygat_dropout_bits(N, Fin, H, p, seed.data_ptr(), 1, bits2.data_ptr(), None))
+    assert torch.equal(bits, bits2)
+    M = torch.stack([((bits >> h) & 1).bool() for h in range(H)])                 # [H,N,Fin]
+    assert int(bits.max()) < (1 << H)
+    n_el = N * Fin
+    for h in range(H):
+        assert abs(float(M[h].float().mean()) - keep) < 5 * (keep * (1 - keep) / n_el) ** 0.5
+    if H > 1:
+        agree = float((M[0] == M[1]).float().mean())
+        assert abs(agree - (keep * keep + (1 - keep) ** 2)) < 0.02
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(N, Fin, generator=gen)
+    W = torch.randn(H, Fin, Fo, generator=gen) * 0.2
+    a = torch.randn(H, 2 * Fo, generator=gen) * 0.2
+    Ws = torch.randn(H, Fin, Fo, generator=gen) * 0.2 if skip else None
+    xd, Wd, ad = x.to(dev), W.to(dev), a.to(dev)
+    Wsd = Ws.to(dev) if skip else None
+    ldw = -(-(R * (2 if skip else 1) + 2 * H) // 4) * 4
+    Wcat = torch.empty(Fin, ldw, device=dev); a_pad = torch.empty(H, 2, Fp, device=dev)
+    check(lib.pygat_pack_params(H, Fin, Fo, Wd.data_ptr(), ad.data_ptr(), Wsd.data_ptr() if skip else None, Wcat.data_ptr(), ldw,
+                                a_pad.data_ptr(), None))
+    Wh = torch.zeros(N, R, device=dev); Sk = torch.zeros(N, R, device=dev) if skip else None
+    check(lib.pygat_project_dropout(N, Fin, H, Fo, xd.data_ptr(), Fin, bits.data_ptr(), p, Wcat.data_ptr(), ldw, Wh.data_ptr(),
+                                    Sk.data_ptr() if skip else None, None))
+    Mc = M.cpu().double() / keep
+    for h in range(H):
+        xm = x.double() * Mc[h]
+        ref = xm @ W[h].double()
+        got = Wh.view(N, H, Fp)[:, h, :Fo].double().cpu()
+        assert float((got - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), h
+        if Fp > Fo:
+            assert float(Wh.view(N, H, Fp)[:, h, Fo:].abs().max()) == 0.0
+        if skip:
+            refs = xm @ Ws[h].double()
+            assert float((Sk.view(N, H, Fp)[:, h, :Fo].double().cpu() - refs).abs().max()) <= 1e-5 * max(1.0, float(refs.abs().max()))
+    # weight gradient: dWc [Fin, R (+R)] = (x o m_h)^T [dWh_h | Gp_h]
+    dWh = torch.randn(N, R, generator=gen).to(dev)
+    RW = R + 4 * H
+    GR = torch.randn(N, RW, generator=gen).to(dev) if skip else None
+    ntot = R * (2 if skip else 1)
+    for split_k in (1, 7):
+        ws = torch.empty(max(1, lib.pygat_wgrad_dropout_workspace_bytes(Fin, H, Fo, int(skip), split_k) // 4), device=dev)
+        dWc = torch.empty(Fin, ntot, device=dev)
+        check(lib.pygat_wgrad_dropout(N, Fin, H, Fo, xd.data_ptr(), Fin, bits.data_ptr(), p, dWh.data_ptr(),
+                                      GR.data_ptr() if skip else None, RW, dWc.data_ptr(), split_k, ws.data_ptr(), None))
+        for h in range(H):
+            xm = x.double() * Mc[h]
+            ref = xm.t() @ dWh.view(N, H, Fp)[:, h].double().cpu()
+            got = dWc[:, h * Fp:(h + 1) * Fp].double().cpu()
+            assert float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), (split_k, h)
+            if skip:
+                refs = xm.t() @ GR[:, h * Fp:(h + 1) * Fp].double().cpu()
+                gots = dWc[:, R + h * Fp:R + (h + 1) * Fp].double().cpu()
+                assert float((gots - refs).abs().max()) <= 2e-5 * max(1.0, float(refs.abs().max())), (split_k, h)
+    # head sum under the same bytes
+    dxe = torch.randn(N, H * Fin, generator=gen).to(dev)
+    dx = torch.empty(N, Fin, device=dev)
+    check(lib.pygat_dropout_head_sum_bits(N, Fin, H, dxe.data_ptr(), H * Fin, bits.data_ptr(), p, dx.data_ptr(), Fin, 0, None))
+    ref = (Mc.permute(1, 0, 2) * dxe.view(N, H, Fin).double().cpu()).sum(1)
+    assert float((dx.double().cpu() - ref).abs().max()) < 1e-4

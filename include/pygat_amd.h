@@ -319,15 +319,17 @@ int pygat_unpack_blockdiag(int H, int Fin, int Fo, const float* dBp, int64_t ldb
  *   pygat_dropout_bits        bits[i,k] bit h = head h keeps x[i,k]   (Philox counter (k >> 2, i, stream_id, h))
  * and the projection and its weight gradient run for ALL heads in one launch with X read once -- the A tile is staged
  * in LDS with its mask bytes and the heads are an inner loop over the MFMA fragments (a_h = bit_h ? x : 0):
- *   pygat_project_dropout     [Wh | Sk] = 1/(1-p) (X .* m_h) [W_h | Wskip_h]           Wcat from pygat_pack_params
+ *   pygat_project_dropout     [Wh | Sk] = 1/(1-p) (X .* m_h) [W_h | Wskip_h]           Wcat from pygat_pack_params;
+ *                             split_k K slabs over Fin for graphs with few 128-row tiles
  *   pygat_wgrad_dropout       dWc [Fin x R (+R)] = 1/(1-p) (X .* m_h)^T [dWh_h | Gp_h]  (then pygat_unpack_wgrad)
  *   pygat_dropout_head_sum_bits  dx[i,k] (+)= 1/(1-p) sum_h bit_h[i,k] dxe[i, h*Fin + k]
  * Memory: N*Fin bytes instead of N*H*Fin*4 (Citeseer: 12 MB instead of 394 MB); no products with zero blocks.
  * X must be dense (ldx == Fin).  Explicit masks (tests) are packed into the same bytes by the caller. */
 int pygat_headmask_supported(int H, int Fo, int skip);
 int pygat_dropout_bits(int n, int Fin, int H, float p, const void* seed, int stream_id, unsigned char* bits, void* stream);
+size_t pygat_project_dropout_workspace_bytes(int n, int H, int Fo, int skip, int split_k);
 int pygat_project_dropout(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const unsigned char* bits, float p,
-                          const float* Wcat, int64_t ldw, float* Wh, float* Sk, void* stream);
+                          const float* Wcat, int64_t ldw, float* Wh, float* Sk, int split_k, void* ws, void* stream);
 size_t pygat_wgrad_dropout_workspace_bytes(int Fin, int H, int Fo, int skip, int split_k);
 int pygat_wgrad_dropout(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const unsigned char* bits, float p,
                         const float* dWh, const float* Gp, int64_t ldgp, float* dWc, int split_k, void* ws, void* stream);

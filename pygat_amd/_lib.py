@@ -29,7 +29,8 @@ SYMBOLS = [
     "pygat_gatv2_forward", "pygat_gatv2_backward_prepare", "pygat_gatv2_workspace_bytes", "pygat_gatv2_backward",
     "pygat_dropout_mask", "pygat_dropout_expand", "pygat_dropout_head_sum", "pygat_pack_blockdiag",
     "pygat_unpack_blockdiag",
-    "pygat_headmask_supported", "pygat_dropout_bits", "pygat_project_dropout", "pygat_wgrad_dropout_workspace_bytes",
+    "pygat_headmask_supported", "pygat_dropout_bits", "pygat_project_dropout_workspace_bytes", "pygat_project_dropout",
+    "pygat_wgrad_dropout_workspace_bytes",
     "pygat_wgrad_dropout", "pygat_dropout_head_sum_bits",
 ]
 
@@ -103,7 +104,9 @@ def _load():
     lib.pygat_unpack_blockdiag.argtypes = [i, i, i, p, i64, i, p, p]
     lib.pygat_headmask_supported.argtypes = [i, i, i]
     lib.pygat_dropout_bits.argtypes = [i, i, i, f, p, i, p, p]
-    lib.pygat_project_dropout.argtypes = [i, i, i, i, p, i64, p, f, p, i64, p, p, p]
+    lib.pygat_project_dropout_workspace_bytes.argtypes = [i, i, i, i, i]
+    lib.pygat_project_dropout_workspace_bytes.restype = sz
+    lib.pygat_project_dropout.argtypes = [i, i, i, i, p, i64, p, f, p, i64, p, p, i, p, p]
     lib.pygat_wgrad_dropout_workspace_bytes.argtypes = [i, i, i, i, i]
     lib.pygat_wgrad_dropout_workspace_bytes.restype = sz
     lib.pygat_wgrad_dropout.argtypes = [i, i, i, i, p, i64, p, f, p, p, i64, p, i, p, p]

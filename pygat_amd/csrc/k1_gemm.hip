@@ -616,21 +616,47 @@ extern "C" int pygat_headmask_supported(int H, int Fo, int skip) {
   return (H >= 1 && H <= 8 && Fp > 0 && Fp * (skip ? 2 : 1) <= 256) ? 1 : 0;
 }
 
-/* [Wh | Sk] = (1/(1-p)) (X .* m_h) [W_h | Wskip_h] per head; Wcat as written by pygat_pack_params. */
+/* [Wh | Sk] = (1/(1-p)) (X .* m_h) [W_h | Wskip_h] per head; Wcat as written by pygat_pack_params.
+ * split_k > 1: K slabs over Fin (a small graph has few 128-row tiles: Cora 22), partial sums in ws
+ * (>= pygat_project_dropout_workspace_bytes), summed in slab order. */
+extern "C" size_t pygat_project_dropout_workspace_bytes(int n, int H, int Fo, int skip, int split_k) {
+  const int Fp = padded_width(Fo);
+  if (n <= 0 || H <= 0 || Fp <= 0 || split_k <= 1) return 0;
+  return (size_t)split_k * (size_t)n * (size_t)(H * Fp * (skip ? 2 : 1)) * sizeof(float);
+}
+
 extern "C" int pygat_project_dropout(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const unsigned char* bits,
-                                     float p, const float* Wcat, int64_t ldw, float* Wh, float* Sk, void* stream) {
+                                     float p, const float* Wcat, int64_t ldw, float* Wh, float* Sk, int split_k, void* ws,
+                                     void* stream) {
   const int Fp = padded_width(Fo);
   PYGAT_REQUIRE(n > 0 && Fin > 0 && X && bits && Wcat && Wh && ldx == Fin, "project_dropout: bad arguments (X must be dense: ldx == Fin)");
   PYGAT_REQUIRE(pygat_headmask_supported(H, Fo, Sk != nullptr), "project_dropout: unsupported H=%d F'=%d", H, Fo);
   PYGAT_REQUIRE(p >= 0.f && p <= 1.f, "project_dropout: p=%g outside [0,1]", (double)p);
-  const int R = H * Fp;
+  if (split_k < 1) split_k = 1;
+  PYGAT_REQUIRE(split_k == 1 || ws, "project_dropout: split_k > 1 needs a workspace");
+  const int R = H * Fp, ntot = R * (Sk ? 2 : 1);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t kps = cdiv(cdiv(Fin, split_k), BK) * BK;
+  const int splits = (int)cdiv(Fin, kps);
   HeadMaskArgs g;
   g.M = n; g.K = Fin; g.A = X; g.lda = ldx; g.bits = bits;
   g.B1 = Wcat; g.ldb1 = ldw; g.B2 = Sk ? Wcat + R : nullptr; g.ldb2 = ldw;
-  g.C1 = Wh; g.ldc1 = R; g.C2 = Sk; g.ldc2 = R; g.c_split_stride = 0;
-  g.H = H; g.Fp = Fp; g.scale = p < 1.f ? 1.f / (1.f - p) : 0.f; g.k_per_split = Fin;
-  launch_headmask<false>(g, 1, (hipStream_t)stream);
+  if (splits > 1) {
+    g.C1 = (float*)ws; g.ldc1 = ntot; g.C2 = (float*)ws + R; g.ldc2 = ntot; g.c_split_stride = (int64_t)n * ntot;
+  } else {
+    g.C1 = Wh; g.ldc1 = R; g.C2 = Sk; g.ldc2 = R; g.c_split_stride = 0;
+  }
+  g.H = H; g.Fp = Fp; g.scale = p < 1.f ? 1.f / (1.f - p) : 0.f; g.k_per_split = kps;
+  launch_headmask<false>(g, splits, st);
   PYGAT_CHECK_LAUNCH("project_dropout");
+  if (splits > 1) {
+    pygat_out_segments seg;
+    seg.nseg = Sk ? 2 : 1; seg.col_start[0] = 0; seg.ptr[0] = Wh; seg.ld[0] = R; seg.col_start[1] = R;
+    if (Sk) { seg.ptr[1] = Sk; seg.ld[1] = R; seg.col_start[2] = 2 * R; }
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)cdiv((int64_t)n * ntot, 64)), dim3(512), 0, st, n, ntot,
+                       splits, (const float*)ws, seg, 0);
+    PYGAT_CHECK_LAUNCH("project_dropout(reduce)");
+  }
   return PYGAT_OK;
 }
 

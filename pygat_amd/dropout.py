@@ -43,6 +43,13 @@ STREAM_X, STREAM_WH, STREAM_ATT = 1, 2, 3     # Philox stream ids of the three m
 FORCE_WIDE = os.environ.get("PYGAT_DROPOUT_WIDE", "0") == "1"   # round 1's wide-operand projection everywhere
 
 
+def _headmask_splits(tiles_m: int, H: int, Fp: int, skip: bool, K: int) -> int:
+    """K slabs of a head-masked GEMM: enough work-groups (tiles x head groups x slabs) for the 256 CUs, slabs of >= 64."""
+    nth = max(1, (Fp * (2 if skip else 1) + 31) // 32)
+    groups = -(-H // max(1, 8 // nth))
+    return max(1, min(-(-384 // (tiles_m * groups)), K // 64))
+
+
 def _pack_bits(mask_x: torch.Tensor) -> torch.Tensor:
     """Explicit per-head input masks [H,N,Fin] (0 or 1/(1-p)) -> one byte per input element, bit h = head h keeps."""
     H = mask_x.shape[0]
@@ -113,9 +120,12 @@ class GATLevelDropoutFn(torch.autograd.Function):
                 else:
                     bits = torch.empty(L.N, Fin, dtype=torch.uint8, device=dev)
                     check(lib.pygat_dropout_bits(L.N, Fin, H, p, seed.data_ptr(), STREAM_X, bits.data_ptr(), st), "dropout_bits")
+                split_k = _headmask_splits(-(-L.N // 128), H, L.Fp, skip, Fin)
+                wsp = torch.empty(lib.pygat_project_dropout_workspace_bytes(L.N, H, Fo, int(skip), split_k) // 4 + 1, dtype=f32,
+                                  device=dev)
                 with _span("k1_project"):
                     check(lib.pygat_project_dropout(L.N, Fin, H, Fo, x.data_ptr(), Fin, bits.data_ptr(), p, Wcat.data_ptr(),
-                                                    L.ldw, Wh.data_ptr(), _ptr(Sk), st), "project_dropout")
+                                                    L.ldw, Wh.data_ptr(), _ptr(Sk), split_k, wsp.data_ptr(), st), "project_dropout")
             else:
                 # per-head masked input as ONE operand A' [N, H*Fin] against the block-diagonal weights B'
                 Bp = torch.empty(HF, ncb, dtype=f32, device=dev)
@@ -242,8 +252,7 @@ def _backward_bits(ctx, x, bits, Wcat, dWh, GR, RW, st):
     Fin, R = L.Fin, L.R
     ntot = R * (2 if L.skip else 1)
     # dW_h = (x o m_h)^T dWh_h, dWskip_h = (x o m_h)^T Gp_h: one launch for all heads, x read once; K slabs over the nodes
-    tiles = -(-Fin // 128) * -(-H // max(1, 8 // max(1, (L.Fp * (2 if L.skip else 1) + 31) // 32)))
-    split_k = max(1, min(256 // max(tiles, 1), L.N // 256))
+    split_k = _headmask_splits(-(-Fin // 128), H, L.Fp, L.skip, L.N)
     ws = torch.empty(lib.pygat_wgrad_dropout_workspace_bytes(Fin, H, Fo, int(L.skip), split_k) // 4, dtype=f32, device=dev)
     dWc = torch.empty(Fin, ntot, dtype=f32, device=dev)
     with _span("k5_wgrad"):

@@ -151,7 +151,7 @@ class FusedEpoch:
 
     def _eager_epoch(self):
         self.model.train()
-        self.opt.zero_grad(set_to_none=False)
+        self.opt.zero_grad(set_to_none=True)     # no fill kernels; the first gradient of a step is adopted, not added
         loss = self.loss_fn(self.model(self.x, self.graph))
         loss.backward()
         self.opt.step()

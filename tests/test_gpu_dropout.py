@@ -203,15 +203,17 @@ def test_headmask_projection_and_weight_gradient(pg, N, Fin, H, Fo, skip):  # no
     Wcat = torch.empty(Fin, ldw, device=dev); a_pad = torch.empty(H, 2, Fp, device=dev)
     check(lib.pygat_pack_params(H, Fin, Fo, Wd.data_ptr(), ad.data_ptr(), Wsd.data_ptr() if skip else None, Wcat.data_ptr(), ldw,
                                 a_pad.data_ptr(), None))
-    Wh = torch.zeros(N, R, device=dev); Sk = torch.zeros(N, R, device=dev) if skip else None
-    check(lib.pygat_project_dropout(N, Fin, H, Fo, xd.data_ptr(), Fin, bits.data_ptr(), p, Wcat.data_ptr(), ldw, Wh.data_ptr(),
-                                    Sk.data_ptr() if skip else None, None))
     Mc = M.cpu().double() / keep
-    for h in range(H):
+    for fsplit in (1, 5):
+      Wh = torch.zeros(N, R, device=dev); Sk = torch.zeros(N, R, device=dev) if skip else None
+      wsp = torch.empty(lib.pygat_project_dropout_workspace_bytes(N, H, Fo, int(skip), fsplit) // 4 + 1, device=dev)
+      check(lib.pygat_project_dropout(N, Fin, H, Fo, xd.data_ptr(), Fin, bits.data_ptr(), p, Wcat.data_ptr(), ldw, Wh.data_ptr(),
+                                      Sk.data_ptr() if skip else None, fsplit, wsp.data_ptr(), None))
+      for h in range(H):
         xm = x.double() * Mc[h]
         ref = xm @ W[h].double()
         got = Wh.view(N, H, Fp)[:, h, :Fo].double().cpu()
-        assert float((got - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), h
+        assert float((got - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), (fsplit, h)
         if Fp > Fo:
             assert float(Wh.view(N, H, Fp)[:, h, Fo:].abs().max()) == 0.0
         if skip:

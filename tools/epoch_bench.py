@@ -84,7 +84,7 @@ def main():
 
     def epoch():
         model.train()
-        opt.zero_grad(set_to_none=False)
+        opt.zero_grad(set_to_none=True)
         loss = loss_fn(model(xd, graph))
         loss.backward()
         opt.step()

@@ -270,12 +270,17 @@ struct HeadMaskArgs {
   int64_t k_per_split;
 };
 
+// 16-byte / 4-byte loads that are only 4-byte / 1-byte aligned (rows of Fin = 1433 floats, mask bytes): gfx950 takes
+// them as one global_load_dwordx4 / global_load_dword (unaligned access mode of the amdhsa target)
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32_u __attribute__((aligned(1)));
+
 template <bool TA, int HB, int NTH>
-__global__ __launch_bounds__(256) void gemm_headmask_kernel(HeadMaskArgs g) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_headmask_kernel(HeadMaskArgs g) {
   constexpr int NTOT = HB * NTH, BN = 32 * NTOT;
   constexpr int LDAS = BM + PAD, LDBS = BN + PAD;
   constexpr int NVA = 2;
-  constexpr int NB = (BK * BN + 255) / 256;   // B elements per thread and k-tile
+  constexpr int NU = (BK * HB * 8 * NTH + 255) / 256;   // float4 units of B per thread and k-tile (<= 32*NTH columns per head)
   extern __shared__ __attribute__((aligned(16))) float hm_sm[];
   float* As = hm_sm;                                   // [2][BK * LDAS]
   float* Bs = As + 2 * BK * LDAS;                      // [2][BK * LDBS]
@@ -285,6 +290,8 @@ __global__ __launch_bounds__(256) void gemm_headmask_kernel(HeadMaskArgs g) {
   const int64_t kend = (kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int cols_h = g.B2 ? 2 * g.Fp : g.Fp;
+  const int q_h = cols_h >> 2;                         // float4 units per head and k row (Fp % 4 == 0)
+  const int units = BK * HB * q_h;
 
   f32x16 acc[NTOT];
 #pragma unroll
@@ -294,40 +301,47 @@ __global__ __launch_bounds__(256) void gemm_headmask_kernel(HeadMaskArgs g) {
 
   float4 ra[NVA];
   uint32_t rm[NVA];   // 4 mask bytes matching ra
-  float rb[NB];
+  float4 rb[NU];
   auto gload = [&](int64_t k0) {
-    if constexpr (TA) load_kstrided<BM, NVA>(g.A, g.lda, 0, m0, g.M, k0, kend, ra);
-    else load_kcontig<BM, NVA>(g.A, g.lda, 0, m0, g.M, k0, kend, ra);
 #pragma unroll
     for (int i = 0; i < NVA; ++i) {
       const int idx = threadIdx.x + 256 * i;
-      uint32_t v = 0;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      uint32_t mv = 0;
+      int64_t off;     // element offset of the 4 values (same for x and its mask bytes)
+      int nval;        // how many of them exist
       if constexpr (TA) {   // element (k, m .. m+3)
         const int64_t k = k0 + idx / (BM / 4);
         const int c = m0 + (idx % (BM / 4)) * 4;
-        if (k < kend)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (c + q < g.M) v |= (uint32_t)g.bits[k * g.lda + c + q] << (8 * q);
+        off = k * g.lda + c;
+        nval = (k < kend) ? (g.M - c) : 0;
       } else {              // element (row, k .. k+3)
         const int row = m0 + (idx >> 2);
         const int64_t k = k0 + (idx & 3) * 4;
-        if (row < g.M)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (k + q < kend) v |= (uint32_t)g.bits[(int64_t)row * g.lda + k + q] << (8 * q);
+        off = (int64_t)row * g.lda + k;
+        nval = (row < g.M) ? (int)(kend - k) : 0;
       }
-      rm[i] = v;
+      if (nval >= 4) {
+        const f32x4_u t = *reinterpret_cast<const f32x4_u*>(g.A + off);
+        v = make_float4(t.x, t.y, t.z, t.w);
+        mv = *reinterpret_cast<const u32_u*>(g.bits + off);
+      } else if (nval > 0) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < nval; ++q) { t[q] = g.A[off + q]; mv |= (uint32_t)g.bits[off + q] << (8 * q); }
+        v = make_float4(t[0], t[1], t[2], t[3]);
+      }
+      ra[i] = v; rm[i] = mv;
     }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int idx = threadIdx.x + 256 * i;
-      float v = 0.f;
-      if (idx < BK * BN) {
-        const int64_t k = k0 + idx / BN;
-        const int cc = idx % BN, hl = cc / (32 * NTH), c = cc % (32 * NTH), h = hb0 + hl;
-        if (k < kend && h < g.H && c < cols_h)
-          v = c < g.Fp ? g.B1[k * g.ldb1 + (int64_t)h * g.Fp + c] : g.B2[k * g.ldb2 + (int64_t)h * g.Fp + (c - g.Fp)];
+    for (int i = 0; i < NU; ++i) {
+      const int u = threadIdx.x + 256 * i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (u < units) {
+        const int kk = u / (HB * q_h), r2 = u - kk * (HB * q_h), hl = r2 / q_h, c = (r2 - hl * q_h) * 4;
+        const int64_t k = k0 + kk;
+        const int h = hb0 + hl;
+        if (k < kend && h < g.H)
+          v = c < g.Fp ? ld4(g.B1 + k * g.ldb1 + (int64_t)h * g.Fp + c) : ld4(g.B2 + k * g.ldb2 + (int64_t)h * g.Fp + (c - g.Fp));
       }
       rb[i] = v;
     }
@@ -341,8 +355,7 @@ __global__ __launch_bounds__(256) void gemm_headmask_kernel(HeadMaskArgs g) {
     for (int i = 0; i < NVA; ++i) {
       const int idx = threadIdx.x + 256 * i;
       if constexpr (TA) {
-        unsigned char* d = ms + (idx / (BM / 4)) * LDAS + (idx % (BM / 4)) * 4;
-        d[0] = (unsigned char)rm[i]; d[1] = (unsigned char)(rm[i] >> 8); d[2] = (unsigned char)(rm[i] >> 16); d[3] = (unsigned char)(rm[i] >> 24);
+        *reinterpret_cast<uint32_t*>(ms + (idx / (BM / 4)) * LDAS + (idx % (BM / 4)) * 4) = rm[i];   // LDAS % 4 == 0
       } else {
         const int row = idx >> 2, kq = (idx & 3) * 4;
         ms[(kq + 0) * LDAS + row] = (unsigned char)rm[i]; ms[(kq + 1) * LDAS + row] = (unsigned char)(rm[i] >> 8);
@@ -351,9 +364,12 @@ __global__ __launch_bounds__(256) void gemm_headmask_kernel(HeadMaskArgs g) {
     }
     float* bs = Bs + buf * BK * LDBS;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int idx = threadIdx.x + 256 * i;
-      if (idx < BK * BN) bs[(idx / BN) * LDBS + idx % BN] = rb[i];
+    for (int i = 0; i < NU; ++i) {
+      const int u = threadIdx.x + 256 * i;
+      if (u < units) {
+        const int kk = u / (HB * q_h), r2 = u - kk * (HB * q_h), hl = r2 / q_h, c = (r2 - hl * q_h) * 4;
+        st4(bs + kk * LDBS + hl * 32 * NTH + c, rb[i]);   // columns >= cols_h of a head stay unwritten: never stored
+      }
     }
   };
 

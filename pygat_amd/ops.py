@@ -114,6 +114,7 @@ def _side_stream(dev) -> "torch.cuda.Stream":
     return _side[key]
 
 
+_K1_SLAB = int(os.environ.get("PYGAT_K1_SPLIT_MIN_K", "128"))   # measured: Cora epoch 0.614 / 0.596 / 0.595 ms at 256 / 128 / 64
 OVERLAP_BACKWARD = os.environ.get("PYGAT_OVERLAP_BACKWARD", "0") == "1"   # measured: the fork/join costs more than it hides
 
 
@@ -230,7 +231,8 @@ class GATLevelFn(torch.autograd.Function):
             s = torch.empty(L.N, H, dtype=f32, device=dev)
             ncols = L.R * (2 if skip else 1) + H
             tiles = -(-L.N // 128) * -(-ncols // 128)
-            split_k = max(1, min(256 // tiles, Fin // 256)) if tiles < 256 else 1
+            # few row tiles (Cora: 22): K slabs of >= 128 until ~1.5 work-groups per CU (PYGAT_K1_SPLIT_MIN_K: slab floor)
+            split_k = max(1, min(-(-384 // tiles), Fin // _K1_SLAB)) if tiles < 256 else 1
             ws = torch.empty(lib.pygat_gemm_workspace_bytes(L.N, ncols, split_k) // 4, dtype=f32, device=dev) \
                 if split_k > 1 else None
             with _span("k1_project"):

@@ -74,7 +74,8 @@ def test_argument_validation_returns_einval(lib):
 
 QUERIES = {"pygat_abi_version", "pygat_last_error", "pygat_padded_width", "pygat_device_count", "pygat_device_name",
            "pygat_scan_workspace_bytes", "pygat_gemm_workspace_bytes", "pygat_partials_bytes", "pygat_head_group",
-           "pygat_agrad_workspace_bytes", "pygat_gatv2_workspace_bytes", "pygat_wgrad_workspace_bytes"}
+           "pygat_agrad_workspace_bytes", "pygat_gatv2_workspace_bytes", "pygat_wgrad_workspace_bytes",
+           "pygat_headmask_supported", "pygat_project_dropout_workspace_bytes", "pygat_wgrad_dropout_workspace_bytes"}
 
 
 def test_every_launcher_rejects_null_arguments(lib):

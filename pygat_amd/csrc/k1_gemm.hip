@@ -456,7 +456,8 @@ static int launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
 }
 
 int try_gemm_smallk(int transB, int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
-                    const pygat_out_segments* out, int accumulate, hipStream_t st);
+                    const pygat_out_segments* out, int accumulate, hipStream_t st, const float* svec = nullptr,
+                    int64_t sv_ld = 0, int sv_n = 0, float* s_out = nullptr, int64_t s_ld = 0);
 int try_gemm_tn_stream(int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                        int max_splits, float* ws, hipStream_t st, int N1, const float* B2, int64_t ldb2);
 
@@ -525,8 +526,10 @@ extern "C" int pygat_gemm_f32(int transA, int transB, int M, int N, int64_t K, c
 
 // Projection of one level in one GEMM: [Wh | Sk | s] = X * Wcat[:, :R (+R) + H] -- the H columns behind the
 // heads are W_h a_src_h (written by pygat_pack_params), so s_i = Wh_i . a_src (layers.py:60) falls out of
-// the same MFMA pass.  (Computing s in the GEMM epilogue from the accumulators instead was tried: the
-// 64 cross-lane reductions per wave tile cost more than the fifth 32-column MFMA block they save.)
+// the same pass.  On the small-K fast path with H <= 8 the s columns do not get MFMA tiles of their own (8 columns
+// would occupy a fifth 32-column tile, 20 % of the kernel): the lane that streams row i accumulates them on the VALU
+// in the shadow of the MFMAs (gemm_smallk_kernel, SV).  (Computing s in the GEMM epilogue from the accumulators
+// instead was tried in round 1: the 64 cross-lane reductions per wave tile cost more than the tile they save.)
 extern "C" int pygat_project(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const float* Wcat, int64_t ldw,
                              float* Wh, float* Sk, float* s, int split_k, void* ws, void* stream) {
   const int Fp = padded_width(Fo);
@@ -537,6 +540,13 @@ extern "C" int pygat_project(int n, int Fin, int H, int Fo, const float* X, int6
   int k = 0;
   seg.col_start[0] = 0; seg.ptr[k] = Wh; seg.ld[k] = R; ++k;
   if (Sk) { seg.col_start[k] = R; seg.ptr[k] = Sk; seg.ld[k] = R; ++k; }
+  static const bool sv_off = getenv("PYGAT_K1_NO_SV") != nullptr;   // development knob: s as GEMM columns everywhere
+  if (H <= 8 && split_k <= 1 && !sv_off) {   // s on the VALU of the small-K kernel, no MFMA tile for it
+    seg.col_start[k] = nw; seg.nseg = k;
+    const int r = try_gemm_smallk(0, n, nw, Fin, X, ldx, Wcat, ldw, &seg, 0, (hipStream_t)stream, Wcat + nw, ldw, H, s, H);
+    if (r < 0) return r;
+    if (r == 1) return PYGAT_OK;
+  }
   seg.col_start[k] = nw; seg.ptr[k] = s; seg.ld[k] = H; ++k;
   seg.col_start[k] = ncols;
   seg.nseg = k;

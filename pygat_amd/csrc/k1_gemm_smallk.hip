@@ -29,9 +29,19 @@ struct SmallKArgs {
   pygat_out_segments out;
   int accumulate;
   int tiles_m;  // 256-row tiles
+  // SV: s[i, h] = sum_k A[i,k] svec[k, h] for up to 8 extra "columns" WITHOUT MFMA tiles for them.  The lane that
+  // streams row i has its k values in registers anyway: each half-wave takes 4 of the columns, 4 FMAs per loaded
+  // float against an LDS broadcast of svec -- VALU work that issues in the shadow of the MFMAs, no cross-lane
+  // reduction (the projection's s_i = x_i . (W_h a_src), layers.py:60: a fifth 32-column tile for 8 columns costs
+  // 20 % of the kernel; reducing the accumulators across lanes in the epilogue cost more than that tile).
+  const float* svec;   // [K x sv_ld], columns 0 .. sv_n-1 used (sv_n <= 8)
+  int64_t sv_ld;
+  int sv_n;
+  float* s_out;        // [M x s_ld]
+  int64_t s_ld;
 };
 
-template <bool TB, int NT, int NBUF>
+template <bool TB, int NT, int NBUF, bool SV>
 __global__ __launch_bounds__(512) void gemm_smallk_kernel(SmallKArgs g) {
   constexpr int BN = 32 * NT;
   // chunks of the A row stream in flight per wave: a chunk's MFMAs take 16 * NT * 64 cycles, which for one or two
@@ -53,6 +63,13 @@ __global__ __launch_bounds__(512) void gemm_smallk_kernel(SmallKArgs g) {
     for (int idx = threadIdx.x; idx < g.K * BN; idx += 512) {
       const int n = idx / g.K, k = idx % g.K;
       Bs[k * LDB + n] = (n0 + n < g.N) ? g.B[(int64_t)(n0 + n) * g.ldb + k] : 0.f;
+    }
+  }
+  float* Us = Bs + g.K * LDB;   // [K][8]: svec, zero padded
+  if constexpr (SV) {
+    for (int idx = threadIdx.x; idx < g.K * 8; idx += 512) {
+      const int k = idx >> 3, h = idx & 7;
+      Us[idx] = (h < g.sv_n) ? g.svec[(int64_t)k * g.sv_ld + h] : 0.f;
     }
   }
   __syncthreads();
@@ -106,11 +123,25 @@ __global__ __launch_bounds__(512) void gemm_smallk_kernel(SmallKArgs g) {
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, BC1[nt], acc[nt], 0, 0, 0);        \
     __builtin_amdgcn_sched_barrier(0);                                                        \
   }
+#define PYGAT_SACC(V, C)                                                                      \
+  {                                                                                           \
+    const float4 u0 = ld4(us + (4 * (C) + 0) * 8), u1 = ld4(us + (4 * (C) + 1) * 8);          \
+    const float4 u2 = ld4(us + (4 * (C) + 2) * 8), u3 = ld4(us + (4 * (C) + 3) * 8);          \
+    sacc.x = fmaf((V).w, u3.x, fmaf((V).z, u2.x, fmaf((V).y, u1.x, fmaf((V).x, u0.x, sacc.x)))); \
+    sacc.y = fmaf((V).w, u3.y, fmaf((V).z, u2.y, fmaf((V).y, u1.y, fmaf((V).x, u0.y, sacc.y)))); \
+    sacc.z = fmaf((V).w, u3.z, fmaf((V).z, u2.z, fmaf((V).y, u1.z, fmaf((V).x, u0.z, sacc.z)))); \
+    sacc.w = fmaf((V).w, u3.w, fmaf((V).z, u2.w, fmaf((V).y, u1.w, fmaf((V).x, u0.w, sacc.w)))); \
+  }
 #define PYGAT_STEP(R, CIDX)                                                                   \
   {                                                                                           \
     const int c__ = (CIDX);                                                                   \
     const int t__ = c__ / nchunks, kc__ = c__ - t__ * nchunks;                                \
     const float* bs = Bs + (kc__ * 32 + fh) * LDB + fr;                                       \
+    if constexpr (SV) if (sv_on) {                                                            \
+      const float* us = Us + kc__ * 32 * 8 + 4 * fh;                                          \
+      PYGAT_SACC(R##0, 0) PYGAT_SACC(R##1, 1) PYGAT_SACC(R##2, 2) PYGAT_SACC(R##3, 3)         \
+      PYGAT_SACC(R##4, 4) PYGAT_SACC(R##5, 5) PYGAT_SACC(R##6, 6) PYGAT_SACC(R##7, 7)         \
+    }                                                                                         \
     float bx0[NT], bx1[NT], by0[NT], by1[NT];                                                 \
     PYGAT_BREAD(bx0, bx1, 0)                                                                  \
     PYGAT_MMA4(R##0, 0, bx0, bx1, by0, by1) PYGAT_MMA4(R##1, 1, by0, by1, bx0, bx1)           \
@@ -124,9 +155,21 @@ __global__ __launch_bounds__(512) void gemm_smallk_kernel(SmallKArgs g) {
   // The common case (no accumulate, tile fully inside M) is a straight run of 16 stores per column
   // block: per-element branches make hipcc wait vmcnt(0) around every store, which also drains the
   // prefetched A chunk.
+  float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);   // SV: columns 4*fh .. 4*fh+3 of row (tile row0 + fr)
+  const bool sv_on = SV && blockIdx.y == 0;        // one column tile of work-groups takes the extra columns
   auto store_tile = [&](int t) {
     const int64_t row0 = ((int64_t)blockIdx.x + (int64_t)t * gridDim.x) * 256 + 32 * w;
     const bool full = row0 + 32 <= g.M;  // wave-uniform
+    if constexpr (SV) {
+      if (sv_on && row0 + fr < g.M) {
+        float* so = g.s_out + (row0 + fr) * g.s_ld + 4 * fh;
+        if (4 * fh + 0 < g.sv_n) so[0] = sacc.x;
+        if (4 * fh + 1 < g.sv_n) so[1] = sacc.y;
+        if (4 * fh + 2 < g.sv_n) so[2] = sacc.z;
+        if (4 * fh + 3 < g.sv_n) so[3] = sacc.w;
+      }
+      sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int col = n0 + 32 * nt + fr;
@@ -196,12 +239,13 @@ __global__ __launch_bounds__(512) void gemm_smallk_kernel(SmallKArgs g) {
     }
   }
 #undef PYGAT_LOAD8
+#undef PYGAT_SACC
 #undef PYGAT_BREAD
 #undef PYGAT_MMA4
 #undef PYGAT_STEP
 }
 
-template <bool TB>
+template <bool TB, bool SV>
 static hipError_t launch_smallk(const SmallKArgs& g, int NT, dim3 grid, size_t lds, hipStream_t st) {
   int dev = -1;
   (void)hipGetDevice(&dev);
@@ -210,11 +254,11 @@ static hipError_t launch_smallk(const SmallKArgs& g, int NT, dim3 grid, size_t l
   {                                                                                                       \
     static bool attr_set[64] = {};   /* per device: the attribute belongs to the device's code object */ \
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {                                                         \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_smallk_kernel<TB, n, nb>),            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_smallk_kernel<TB, n, nb, SV>),        \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
       if (dev >= 0 && dev < 64) attr_set[dev] = true;                                                     \
     }                                                                                                     \
-    hipLaunchKernelGGL((gemm_smallk_kernel<TB, n, nb>), grid, dim3(512), lds, st, g);                     \
+    hipLaunchKernelGGL((gemm_smallk_kernel<TB, n, nb, SV>), grid, dim3(512), lds, st, g);                 \
   }
 #define PYGAT_SMALLK_CASE(n)                                                                              \
   case n:                                                                                                 \
@@ -234,23 +278,27 @@ static hipError_t launch_smallk(const SmallKArgs& g, int NT, dim3 grid, size_t l
 
 // returns 1 if the fast path took the call, 0 if the shape does not qualify, <0 on launch error
 int try_gemm_smallk(int transB, int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
-                    const pygat_out_segments* out, int accumulate, hipStream_t st) {
+                    const pygat_out_segments* out, int accumulate, hipStream_t st, const float* svec, int64_t sv_ld,
+                    int sv_n, float* s_out, int64_t s_ld) {
   if (K < 32 || K > 256 || (K % 32) != 0 || M < 8192) return 0;
   if (!aligned16(A) || (lda % 4) != 0) return 0;
+  if (svec && (sv_n < 1 || sv_n > 8 || !s_out || transB)) return 0;
   const int nt_needed = (int)cdiv(N, 32);
   // up to 160 columns in one tile; wider outputs in balanced 128-column tiles
   const int NT = nt_needed <= 5 ? nt_needed : 4;
-  const size_t lds = (size_t)K * (32 * NT + 4) * sizeof(float);
+  const size_t lds = (size_t)K * (32 * NT + 4) * sizeof(float) + (svec ? (size_t)K * 8 * sizeof(float) : 0);
   if (lds > 150 * 1024) return 0;
   SmallKArgs g;
   g.M = M; g.N = N; g.K = (int)K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.out = *out; g.accumulate = accumulate;
+  g.svec = svec; g.sv_ld = sv_ld; g.sv_n = sv_n; g.s_out = s_out; g.s_ld = s_ld;
   g.tiles_m = (int)cdiv(M, 256);
   const int tiles_n = (int)cdiv(N, 32 * NT);
   int gx = 256 / tiles_n;
   if (gx < 1) gx = 1;
   if (gx > g.tiles_m) gx = g.tiles_m;
   dim3 grid((unsigned)gx, (unsigned)tiles_n, 1);
-  hipError_t e = transB ? launch_smallk<true>(g, NT, grid, lds, st) : launch_smallk<false>(g, NT, grid, lds, st);
+  hipError_t e = transB ? launch_smallk<true, false>(g, NT, grid, lds, st)
+                        : (svec ? launch_smallk<false, true>(g, NT, grid, lds, st) : launch_smallk<false, false>(g, NT, grid, lds, st));
   if (e != hipSuccess) {
     set_error("gemm_smallk: %s", hipGetErrorString(e));
     return PYGAT_EHIP;

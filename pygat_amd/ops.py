@@ -57,7 +57,7 @@ TIMER: Optional[KernelTimer] = None
 _env = os.environ.get("PYGAT_TWO_GATHER_BACKWARD")
 TWO_GATHER_BACKWARD: Optional[bool] = None if _env is None else (_env == "1")
 
-# Default since round 2: "rowlocal".  The training forward (K2) also accumulates the share of every row sum that
+# Default since round 2 for rows of up to 256 floats (above: "rowsum"): "rowlocal".  The training forward (K2) also accumulates the share of every row sum that
 # went through the alpha branch of the LeakyReLU (aneg, qneg); since sum_j de_ij = 0 the row sums of dz follow
 # row-locally in K3a, ds_i = -(1 - alpha)(Gp_i . aneg_i - D_i qneg_i), so the backward needs neither the second
 # gather (K3b) nor per-edge dz records and their row-sum pass (K3c): K3a -> K4 -> da -> dW.  Costs one more [N, R]
@@ -77,7 +77,10 @@ def backward_flavour(row_floats: int) -> str:
         return BACKWARD_FLAVOUR
     if TWO_GATHER_BACKWARD is not None:
         return "two-gather" if TWO_GATHER_BACKWARD else "rowsum"
-    return "rowlocal"
+    # measured, config-5 graph, 8 heads x F': step with rowlocal / rowsum at 128 floats per row 3.69 / 3.81 ms, at 256
+    # 6.90 / 7.23, at 512 14.76 / 14.43, at 1024 29.4 / 28.3: from two 16-byte chunks per lane on the extra accumulators
+    # of the training forward cost more than the row-sum pass they replace
+    return "rowlocal" if row_floats <= 256 else "rowsum"
 
 
 class _span:

@@ -153,7 +153,7 @@ def test_host_policies(lib, monkeypatch):
     monkeypatch.setattr(ops, "TWO_GATHER_BACKWARD", True)
     assert ops.backward_flavour(128) == "two-gather"
     monkeypatch.setattr(ops, "TWO_GATHER_BACKWARD", None)
-    assert ops.backward_flavour(16) == ops.backward_flavour(1024) == "rowlocal"
+    assert ops.backward_flavour(16) == ops.backward_flavour(256) == "rowlocal" and ops.backward_flavour(512) == "rowsum"
     monkeypatch.setattr(ops, "BACKWARD_FLAVOUR", "rowsum")
     assert ops.backward_flavour(128) == "rowsum"
     # streamed-K weight gradient: slabs x column tiles = 256 (one work-group per CU)

@@ -16,6 +16,7 @@
 
 namespace pygat {
 
+constexpr int FIX_LIST_WAVES = 16;  // waves per work-group of the list-driven fix-up kernels
 constexpr int FIX_WIDE = 32;   // cut rows with more pieces are merged by a whole work-group
 constexpr int FIX_SCREEN = 8;  // slots screened per wave by the fix-up kernels (owned rows are merged serially)
 constexpr float NEG_BIG = -1.0e30f;  // running-max seed: exp(NEG_BIG - x) == 0, exp(NEG_BIG - NEG_BIG) == 1

@@ -299,9 +299,9 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
 }
 
 // Merge of one cut row: its pieces tail(k), head(k+1), ..., head(k + npieces - 1) are dealt round-robin to
-// nw waves x EPW lane groups (PF pieces in flight each -- the chain of a 26k-edge row has 400+ pieces), combined
+// nw (1, or the NW waves of the work-group) waves x EPW lane groups (PF pieces in flight each -- the chain of a 26k-edge row has 400+ pieces), combined
 // inside a wave with shuffles and across waves through LDS, always in the same order (reproducible).
-template <int LPR, int VEC, bool AUX>
+template <int LPR, int VEC, bool AUX, int NW>
 __device__ __forceinline__ void fwd_merge_row(const FwdArgs& a, const LaneCols<VEC>& lc, float* fix_sm, int64_t k, int r,
                                               int npieces, bool wide, int w) {
   constexpr int EPW = 64 / LPR;
@@ -311,7 +311,7 @@ __device__ __forceinline__ void fwd_merge_row(const FwdArgs& a, const LaneCols<V
   RowState<VEC, AUX> st;
   st.reset();
   if (wide || w == 0) {
-    const int nw = wide ? 4 : 1;
+    const int nw = wide ? NW : 1;
     for (int q = (wide ? w : 0) * EPW * PF + slot; q < npieces; q += nw * EPW * PF) {
       PartRec<VEC, AUX> rec[PF];
 #pragma unroll
@@ -347,7 +347,7 @@ __device__ __forceinline__ void fwd_merge_row(const FwdArgs& a, const LaneCols<V
     __syncthreads();
     if (w == 0 && slot == 0) {
 #pragma unroll
-      for (int ww = 1; ww < 4; ++ww) {
+      for (int ww = 1; ww < NW; ++ww) {
         PartRec<VEC, AUX> rec;
         part_load<VEC, AUX>(a, lc, fix_sm + ww * PS, rec);
         part_merge<VEC, AUX>(st, rec);
@@ -388,22 +388,24 @@ __global__ __launch_bounds__(256) void gat_fwd_fixup_kernel(FwdArgs a) {
     const int64_t k_e = slot_of(a.g, row_end - 1);
     const int npieces = (int)(k_e - k) + 1;
     const bool wide = npieces > EPW * PF;  // more pieces than one wave takes in a single round
-    fwd_merge_row<LPR, VEC, AUX>(a, lc, fix_sm, k, r, npieces, wide, w);
+    fwd_merge_row<LPR, VEC, AUX, 4>(a, lc, fix_sm, k, r, npieces, wide, w);
   }
 }
 
 // list-driven variant: entry q of g.cut = (owner slot k, row, pieces); the first n_cut_wide entries (long
-// chains) get a whole work-group each, the others one wave each.
+// chains) get a whole work-group of FIX_LIST_WAVES waves each (the 26 779-edge hub of config 5 is a chain of 420
+// pieces and the critical path of this launch: 16 waves take it in 4 rounds instead of 13), the others one wave each.
 template <int LPR, int VEC, bool AUX>
-__global__ __launch_bounds__(256) void gat_fwd_fixup_list_kernel(FwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float fix_sm[];  // [4][PS]
+__global__ __launch_bounds__(64 * FIX_LIST_WAVES) void gat_fwd_fixup_list_kernel(FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float fix_sm[];  // [FIX_LIST_WAVES][PS]
   const int w = threadIdx.x >> 6;
   const bool wide = (int)blockIdx.x < a.g.n_cut_wide;
-  const int q0 = wide ? (int)blockIdx.x : a.g.n_cut_wide + ((int)blockIdx.x - a.g.n_cut_wide) * 4 + w;
+  const int q0 = wide ? (int)blockIdx.x : a.g.n_cut_wide + ((int)blockIdx.x - a.g.n_cut_wide) * FIX_LIST_WAVES + w;
   if (q0 >= a.g.n_cut) return;   // never in a wide block: the __syncthreads of the merge are reached by all 4 waves
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
   // a lone wave plays wave 0 of the merge
-  fwd_merge_row<LPR, VEC, AUX>(a, lc, fix_sm, a.g.cut[3 * q0], a.g.cut[3 * q0 + 1], a.g.cut[3 * q0 + 2], wide, wide ? w : 0);
+  fwd_merge_row<LPR, VEC, AUX, FIX_LIST_WAVES>(a, lc, fix_sm, a.g.cut[3 * q0], a.g.cut[3 * q0 + 1], a.g.cut[3 * q0 + 2], wide,
+                                               wide ? w : 0);
 }
 
 
@@ -508,15 +510,17 @@ static int launch_forward(const pygat_graph* g, int H, int Fo, float alpha, int 
     else PYGAT_FWD(false, false, false);
 #undef PYGAT_FWD
     PYGAT_CHECK_LAUNCH("gat_forward");
-    const size_t fix_lds = 4 * (size_t)(aux ? part_stride<true>(a.rs) : part_stride<false>(a.rs)) * sizeof(float);
     const bool listed = a.g.cut != nullptr;   // the caller listed the cut rows: go straight to them
-    const unsigned fb = listed ? (unsigned)(a.g.n_cut_wide + cdiv(a.g.n_cut - a.g.n_cut_wide, 4)) : (unsigned)cdiv(nslots, FIX_SCREEN);
+    const int fix_waves = listed ? FIX_LIST_WAVES : 4;
+    const size_t fix_lds = fix_waves * (size_t)(aux ? part_stride<true>(a.rs) : part_stride<false>(a.rs)) * sizeof(float);
+    const unsigned fb = listed ? (unsigned)(a.g.n_cut_wide + cdiv(a.g.n_cut - a.g.n_cut_wide, FIX_LIST_WAVES))
+                               : (unsigned)cdiv(nslots, FIX_SCREEN);
     if (listed && a.g.n_cut == 0) continue;
 #define PYGAT_FIX(AUXV)                                                                                               \
     do {                                                                                                              \
       if (listed) {                                                                                                   \
         PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_fwd_fixup_list_kernel<LPR, VEC, AUXV>), dim3(fb),     \
-                                                          dim3(256), fix_lds, st, a));                                \
+                                                          dim3(64 * FIX_LIST_WAVES), fix_lds, st, a));                \
       } else {                                                                                                        \
         PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_fwd_fixup_kernel<LPR, VEC, AUXV>), dim3(fb), dim3(256), \
                                                           fix_lds, st, a));                                           \

@@ -276,13 +276,13 @@ __global__ __launch_bounds__(256) void gat_bwd_col_fixup_kernel(ColArgs a) {
 // list-driven variant: entry q of g.cut = (owner slot k, row, pieces); the first n_cut_wide entries (long
 // chains) get a whole work-group each, the others one wave each.
 template <int LPR, int VEC>
-__global__ __launch_bounds__(256) void gat_bwd_col_fixup_list_kernel(ColArgs a) {
+__global__ __launch_bounds__(64 * FIX_LIST_WAVES) void gat_bwd_col_fixup_list_kernel(ColArgs a) {
   constexpr int EPW = 64 / LPR;
   constexpr int PF = (VEC == 1) ? 4 : 2;
-  extern __shared__ __attribute__((aligned(16))) float fix_sm[];  // [4][R + 2H]
+  extern __shared__ __attribute__((aligned(16))) float fix_sm[];  // [FIX_LIST_WAVES][R + 2H]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const bool wide = (int)blockIdx.x < a.g.n_cut_wide;
-  const int q0 = wide ? (int)blockIdx.x : a.g.n_cut_wide + ((int)blockIdx.x - a.g.n_cut_wide) * 4 + w;
+  const int q0 = wide ? (int)blockIdx.x : a.g.n_cut_wide + ((int)blockIdx.x - a.g.n_cut_wide) * FIX_LIST_WAVES + w;
   if (q0 >= a.g.n_cut) return;
   const int64_t k = a.g.cut[3 * q0];
   const int r = a.g.cut[3 * q0 + 1];
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void gat_bwd_col_fixup_list_kernel(ColArgs a) 
 #pragma unroll
   for (int v = 0; v < VEC; ++v) { acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); dt[v] = 0.f; }
   {
-    const int nw = wide ? 4 : 1;
+    const int nw = wide ? FIX_LIST_WAVES : 1;
     for (int q = (wide ? w : 0) * EPW * PF + slot; q < npieces; q += nw * EPW * PF) {
       float4 xp[PF][VEC];
       float tp[PF][VEC];
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void gat_bwd_col_fixup_list_kernel(ColArgs a) 
     __syncthreads();
     if (wsel == 0 && slot == 0) {
 #pragma unroll
-      for (int ww = 1; ww < 4; ++ww) {
+      for (int ww = 1; ww < FIX_LIST_WAVES; ++ww) {
         const float* p = fix_sm + ww * PS;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
@@ -399,12 +399,12 @@ extern "C" int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm
                            hipLaunchKernelGGL((gat_bwd_col_kernel<LPR, VEC, false>), dim3(blocks), dim3(256), 0, st, a));
     }
     PYGAT_CHECK_LAUNCH("gat_backward_col");
-    const size_t fix_lds = 4 * (size_t)(a.rs.R + 2 * a.rs.H) * sizeof(float);
+    const size_t fix_lds = (a.g.cut ? FIX_LIST_WAVES : 4) * (size_t)(a.rs.R + 2 * a.rs.H) * sizeof(float);
     if (a.g.cut) {
       if (a.g.n_cut > 0) {
-        const unsigned fb = (unsigned)(a.g.n_cut_wide + cdiv(a.g.n_cut - a.g.n_cut_wide, 4));
-        PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_bwd_col_fixup_list_kernel<LPR, VEC>), dim3(fb), dim3(256),
-                                                          fix_lds, st, a));
+        const unsigned fb = (unsigned)(a.g.n_cut_wide + cdiv(a.g.n_cut - a.g.n_cut_wide, FIX_LIST_WAVES));
+        PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_bwd_col_fixup_list_kernel<LPR, VEC>), dim3(fb),
+                                                          dim3(64 * FIX_LIST_WAVES), fix_lds, st, a));
       }
     } else {
       PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_bwd_col_fixup_kernel<LPR, VEC>),

@@ -36,16 +36,17 @@ struct GemmArgs {
 };
 
 // operand stored [rows x K] (K contiguous): tile ROWS x 16, staged transposed into S[k][row]
-template <int ROWS, int NV>
+template <int ROWS, int NV, int BKT = BK>
 __device__ __forceinline__ void load_kcontig(const float* __restrict__ P, int64_t ld, int vec, int row0,
                                              int nrows, int64_t k0, int64_t kend, float4 (&r)[NV]) {
+  constexpr int QK = BKT / 4;   // float4 units per row of the tile
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     int idx = threadIdx.x + 256 * i;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (idx < ROWS * 4) {
-      int row = row0 + (idx >> 2);
-      int64_t k = k0 + (idx & 3) * 4;
+    if (idx < ROWS * QK) {
+      int row = row0 + (idx / QK);
+      int64_t k = k0 + (idx % QK) * 4;
       if (row < nrows && k < kend) {
         const float* p = P + (int64_t)row * ld + k;
         if (vec && k + 3 < kend) {
@@ -61,13 +62,14 @@ __device__ __forceinline__ void load_kcontig(const float* __restrict__ P, int64_
     r[i] = v;
   }
 }
-template <int ROWS, int NV, int LDS_LD>
+template <int ROWS, int NV, int LDS_LD, int BKT = BK>
 __device__ __forceinline__ void store_kcontig(float* S, const float4 (&r)[NV]) {
+  constexpr int QK = BKT / 4;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     int idx = threadIdx.x + 256 * i;
-    if (idx < ROWS * 4) {
-      int row = idx >> 2, kq = (idx & 3) * 4;
+    if (idx < ROWS * QK) {
+      int row = idx / QK, kq = (idx % QK) * 4;
       S[(kq + 0) * LDS_LD + row] = r[i].x;
       S[(kq + 1) * LDS_LD + row] = r[i].y;
       S[(kq + 2) * LDS_LD + row] = r[i].z;
@@ -77,7 +79,7 @@ __device__ __forceinline__ void store_kcontig(float* S, const float4 (&r)[NV]) {
 }
 
 // operand stored [K x cols] (K strided): tile 16 x COLS, staged as is into S[k][col]
-template <int COLS, int NV>
+template <int COLS, int NV, int BKT = BK>
 __device__ __forceinline__ void load_kstrided(const float* __restrict__ P, int64_t ld, int vec, int col0,
                                               int ncols, int64_t k0, int64_t kend, float4 (&r)[NV]) {
   constexpr int Q = COLS / 4;
@@ -85,7 +87,7 @@ __device__ __forceinline__ void load_kstrided(const float* __restrict__ P, int64
   for (int i = 0; i < NV; ++i) {
     int idx = threadIdx.x + 256 * i;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (idx < BK * Q) {
+    if (idx < BKT * Q) {
       int64_t k = k0 + idx / Q;
       int c = col0 + (idx % Q) * 4;
       if (k < kend && c < ncols) {
@@ -103,24 +105,27 @@ __device__ __forceinline__ void load_kstrided(const float* __restrict__ P, int64
     r[i] = v;
   }
 }
-template <int COLS, int NV, int LDS_LD>
+template <int COLS, int NV, int LDS_LD, int BKT = BK>
 __device__ __forceinline__ void store_kstrided(float* S, const float4 (&r)[NV]) {
   constexpr int Q = COLS / 4;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     int idx = threadIdx.x + 256 * i;
-    if (idx < BK * Q) st4(S + (idx / Q) * LDS_LD + (idx % Q) * 4, r[i]);
+    if (idx < BKT * Q) st4(S + (idx / Q) * LDS_LD + (idx % Q) * 4, r[i]);
   }
 }
 
-template <bool TA, bool TB, int NT>
+// BKT = depth of a k-tile: 16, or 32 for long K (half the barriers and LDS hand-offs per MFMA; twice the LDS)
+template <bool TA, bool TB, int NT, int BKT>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+  constexpr int BK = BKT;            // shadows the namespace-wide default inside this kernel
   constexpr int BN = 32 * NT;
   constexpr int LDAS = BM + PAD, LDBS = BN + PAD;
-  constexpr int NVA = 2;             // 128*16/4/256
-  constexpr int NVB = (NT + 1) / 2;  // BN*16/4/256 rounded up
-  __shared__ __attribute__((aligned(16))) float As[2][BK * LDAS];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDBS];
+  constexpr int NVA = BM * BK / 4 / 256;
+  constexpr int NVB = (BN * BK / 4 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float gm_sm[];   // As[2][BK * LDAS] | Bs[2][BK * LDBS]
+  float (*As)[BK * LDAS] = reinterpret_cast<float (*)[BK * LDAS]>(gm_sm);
+  float (*Bs)[BK * LDBS] = reinterpret_cast<float (*)[BK * LDBS]>(gm_sm + 2 * BK * LDAS);
 
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
@@ -135,16 +140,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 
   float4 ra[NVA], rb[NVB];
   auto gload = [&](int64_t k0) {
-    if constexpr (TA) load_kstrided<BM, NVA>(g.A, g.lda, g.a_vec, m0, g.M, k0, kend, ra);
-    else load_kcontig<BM, NVA>(g.A, g.lda, g.a_vec, m0, g.M, k0, kend, ra);
-    if constexpr (TB) load_kcontig<BN, NVB>(g.B, g.ldb, g.b_vec, n0, g.N, k0, kend, rb);
-    else load_kstrided<BN, NVB>(g.B, g.ldb, g.b_vec, n0, g.N, k0, kend, rb);
+    if constexpr (TA) load_kstrided<BM, NVA, BK>(g.A, g.lda, g.a_vec, m0, g.M, k0, kend, ra);
+    else load_kcontig<BM, NVA, BK>(g.A, g.lda, g.a_vec, m0, g.M, k0, kend, ra);
+    if constexpr (TB) load_kcontig<BN, NVB, BK>(g.B, g.ldb, g.b_vec, n0, g.N, k0, kend, rb);
+    else load_kstrided<BN, NVB, BK>(g.B, g.ldb, g.b_vec, n0, g.N, k0, kend, rb);
   };
   auto sstore = [&](int buf) {
-    if constexpr (TA) store_kstrided<BM, NVA, LDAS>(As[buf], ra);
-    else store_kcontig<BM, NVA, LDAS>(As[buf], ra);
-    if constexpr (TB) store_kcontig<BN, NVB, LDBS>(Bs[buf], rb);
-    else store_kstrided<BN, NVB, LDBS>(Bs[buf], rb);
+    if constexpr (TA) store_kstrided<BM, NVA, LDAS, BK>(As[buf], ra);
+    else store_kcontig<BM, NVA, LDAS, BK>(As[buf], ra);
+    if constexpr (TB) store_kcontig<BN, NVB, LDBS, BK>(Bs[buf], rb);
+    else store_kstrided<BN, NVB, LDBS, BK>(Bs[buf], rb);
   };
 
   const int64_t nkt = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
@@ -443,14 +448,32 @@ static int launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
   int NT = nt_needed <= 1 ? 1 : nt_needed <= 2 ? 2 : nt_needed <= 3 ? 3 : nt_needed <= 4 ? 4
          : nt_needed <= 5 ? 5 : nt_needed <= 6 ? 6 : nt_needed <= 8 ? 8 : 4;
   dim3 grid((unsigned)cdiv(g.M, BM), (unsigned)cdiv(g.N, 32 * NT), (unsigned)splits);
+  // 32-deep k-tiles for the 128-column tile when every K slab is long (the PPI-sized projections, K = 1024)
+  static const int bk_env = [] { const char* e = getenv("PYGAT_GEMM_BK"); return e ? atoi(e) : 0; }();
+  const bool deep = NT == 4 && (bk_env ? bk_env == 32 : g.k_per_split >= 256);
+  auto lds = [](int nt, int bk) { return (size_t)2 * bk * ((BM + PAD) + (32 * nt + PAD)) * sizeof(float); };
   switch (NT) {
-    case 1: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 1>), grid, dim3(256), 0, st, g); break;
-    case 2: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 2>), grid, dim3(256), 0, st, g); break;
-    case 3: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 3>), grid, dim3(256), 0, st, g); break;
-    case 4: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 4>), grid, dim3(256), 0, st, g); break;
-    case 5: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 5>), grid, dim3(256), 0, st, g); break;
-    case 6: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 6>), grid, dim3(256), 0, st, g); break;
-    default: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 8>), grid, dim3(256), 0, st, g); break;
+    case 1: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 1, 16>), grid, dim3(256), lds(1, 16), st, g); break;
+    case 2: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 2, 16>), grid, dim3(256), lds(2, 16), st, g); break;
+    case 3: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 3, 16>), grid, dim3(256), lds(3, 16), st, g); break;
+    case 4:
+      if (deep) {
+        int dev = -1;
+        (void)hipGetDevice(&dev);
+        static bool attr_set[64] = {};   // 66 KB of LDS: above the 64 KB a kernel gets without asking
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<TA, TB, 4, 32>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+          if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
+        hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 4, 32>), grid, dim3(256), lds(4, 32), st, g);
+      } else {
+        hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 4, 16>), grid, dim3(256), lds(4, 16), st, g);
+      }
+      break;
+    case 5: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 5, 16>), grid, dim3(256), lds(5, 16), st, g); break;
+    case 6: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 6, 16>), grid, dim3(256), lds(6, 16), st, g); break;
+    default: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 8, 16>), grid, dim3(256), lds(8, 16), st, g); break;
   }
   return 0;
 }

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Times pygat_gemm_f32 on a few shapes of the reference's configurations (development tool).
+
+    python tools/gemm_bench.py            # PPI level 2/3 projections, weight and input gradients; Cora eval projection
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import pygat_amd as pg  # noqa: E402
+
+SHAPES = [  # (name, transA, transB, M, N, K)
+    ("ppi L2 project   X[3144,1024] Wcat[1024,2056]", False, False, 3144, 2056, 1024),
+    ("ppi L2 dW        X^T[1024,3144] dWh[3144,1024]", True, False, 1024, 1024, 3144),
+    ("ppi L2 dX        dWh[3144,1024] Wcat^T[1024,1024]", False, True, 3144, 1024, 1024),
+    ("ppi L1 project   X[3144,50] Wcat[50,2056]", False, False, 3144, 2056, 50),
+    ("cora eval project X[2708,1433] Wcat[1433,72]", False, False, 2708, 72, 1433),
+    ("pubmed project   X[19717,500] Wcat[500,72]", False, False, 19717, 72, 500),
+]
+for name, tA, tB, M, N, K in SHAPES:
+    A = torch.randn((K, M) if tA else (M, K), device="cuda")
+    B = torch.randn((N, K) if tB else (K, N), device="cuda")
+    C = torch.empty(M, N, device="cuda")
+    lda, ldb = A.shape[1], B.shape[1]
+    ts = []
+    for _ in range(12):
+        a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+        a.record(); pg.gemm(tA, tB, M, N, K, A, lda, B, ldb, [(N, C, N)]); b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ms = float(np.median(ts[3:]))
+    ref = (A.t() if tA else A).double() @ (B.t() if tB else B).double()
+    err = float((C.double() - ref).abs().max() / ref.abs().max())
+    print(f"{name:52s} {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:7.1f} TF  rel err {err:.1e}", flush=True)

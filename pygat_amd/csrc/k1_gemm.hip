@@ -12,6 +12,7 @@
 // and all NT column blocks.  LDS images are k-major (As[k][m], Bs[k][n]) so a
 // fragment read is 32 consecutive floats per half-wave: conflict-free ds_read_b32.
 #include "common.h"
+#include <type_traits>
 
 namespace pygat {
 
@@ -115,6 +116,45 @@ __device__ __forceinline__ void store_kstrided(float* S, const float4 (&r)[NV]) 
   }
 }
 
+
+// Branch-free variants (16-byte aligned rows; K slab, and the extent along which a float4 runs, multiples of 4): every
+// load is unconditional -- rows / columns past the operand are CLAMPED to the last valid ones (their products only
+// reach rows / columns of C that are never stored) and k positions past the slab are multiplied by 0.  In the guarded
+// loaders above each value is `in range ? load : 0`; hipcc turns that select into a branch around the load and waits
+// vmcnt(0) for it BEFORE the MFMA phase of the current k-tile -- the prefetch of the next tile then overlaps nothing.
+template <int ROWS, int NV, int BKT>
+__device__ __forceinline__ void load_kcontig_fast(const float* __restrict__ P, int64_t ld, int row0, int nrows, int64_t k0,
+                                                  int64_t kend, float4 (&r)[NV]) {
+  constexpr int QK = BKT / 4;
+  static_assert(ROWS * QK == NV * 256, "exact cover");
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = threadIdx.x + 256 * i;
+    int row = row0 + idx / QK;
+    row = row < nrows ? row : nrows - 1;
+    const int64_t k = k0 + (idx % QK) * 4;
+    const float keep = k < kend ? 1.f : 0.f;
+    const float4 v = ld4(P + (int64_t)row * ld + (k < kend ? k : kend - 4));
+    r[i] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
+  }
+}
+template <int COLS, int NV, int BKT>
+__device__ __forceinline__ void load_kstrided_fast(const float* __restrict__ P, int64_t ld, int col0, int ncols, int64_t k0,
+                                                   int64_t kend, float4 (&r)[NV]) {
+  constexpr int Q = COLS / 4;
+  static_assert(BKT * Q == NV * 256, "exact cover");
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = threadIdx.x + 256 * i;
+    const int64_t k = k0 + idx / Q;
+    const float keep = k < kend ? 1.f : 0.f;
+    int c = col0 + (idx % Q) * 4;
+    c = c < ncols ? c : ncols - 4;
+    const float4 v = ld4(P + (k < kend ? k : kend - 1) * ld + c);
+    r[i] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
+  }
+}
+
 // BKT = depth of a k-tile: 16, or 32 for long K (half the barriers and LDS hand-offs per MFMA; twice the LDS)
 template <bool TA, bool TB, int NT, int BKT>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
@@ -138,44 +178,111 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  float4 ra[NVA], rb[NVB];
-  auto gload = [&](int64_t k0) {
-    if constexpr (TA) load_kstrided<BM, NVA, BK>(g.A, g.lda, g.a_vec, m0, g.M, k0, kend, ra);
-    else load_kcontig<BM, NVA, BK>(g.A, g.lda, g.a_vec, m0, g.M, k0, kend, ra);
-    if constexpr (TB) load_kcontig<BN, NVB, BK>(g.B, g.ldb, g.b_vec, n0, g.N, k0, kend, rb);
-    else load_kstrided<BN, NVB, BK>(g.B, g.ldb, g.b_vec, n0, g.N, k0, kend, rb);
-  };
-  auto sstore = [&](int buf) {
-    if constexpr (TA) store_kstrided<BM, NVA, LDAS, BK>(As[buf], ra);
-    else store_kcontig<BM, NVA, LDAS, BK>(As[buf], ra);
-    if constexpr (TB) store_kcontig<BN, NVB, LDBS, BK>(Bs[buf], rb);
-    else store_kstrided<BN, NVB, LDBS, BK>(Bs[buf], rb);
-  };
-
-  const int64_t nkt = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
-  if (nkt > 0) {
-    gload(kbeg);
-    sstore(0);
-  }
-  __syncthreads();
+  constexpr bool EXACT = (BN * BK / 4) % 256 == 0;      // the B tile is a whole number of float4 per thread
+  // branch-free staging loads (see load_*_fast): uniform in the launch
+  const bool interior = EXACT && g.a_vec && g.b_vec && kend > kbeg && (kbeg & 3) == 0 && (kend & 3) == 0 && kend - kbeg >= 4 &&
+                        (!TA || ((g.M & 3) == 0 && g.M >= 4)) && (TB || ((g.N & 3) == 0 && g.N >= 4));
   const int fr = lane & 31, fk = lane >> 5;
-  for (int64_t kt = 0; kt < nkt; ++kt) {
-    const int buf = (int)(kt & 1);
-    if (kt + 1 < nkt) gload(kbeg + (kt + 1) * BK);
-    const float* as = As[buf] + fk * LDAS + 32 * w + fr;
-    const float* bs = Bs[buf] + fk * LDBS + fr;
+  const int64_t nkt = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
+  // the whole k loop exists twice (FAST / guarded): one loop with a branch per load would merge the two loaders'
+  // registers at every join and wait for the loads there
+  auto kloop = [&](auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    float4 ra[NVA], rb[NVB];
+    auto gload = [&](int64_t k0) {
+      if constexpr (FAST && EXACT) {
+        if constexpr (TA) load_kstrided_fast<BM, NVA, BK>(g.A, g.lda, m0, g.M, k0, kend, ra);
+        else load_kcontig_fast<BM, NVA, BK>(g.A, g.lda, m0, g.M, k0, kend, ra);
+        if constexpr (TB) load_kcontig_fast<BN, NVB, BK>(g.B, g.ldb, n0, g.N, k0, kend, rb);
+        else load_kstrided_fast<BN, NVB, BK>(g.B, g.ldb, n0, g.N, k0, kend, rb);
+      } else {
+        if constexpr (TA) load_kstrided<BM, NVA, BK>(g.A, g.lda, g.a_vec, m0, g.M, k0, kend, ra);
+        else load_kcontig<BM, NVA, BK>(g.A, g.lda, g.a_vec, m0, g.M, k0, kend, ra);
+        if constexpr (TB) load_kcontig<BN, NVB, BK>(g.B, g.ldb, g.b_vec, n0, g.N, k0, kend, rb);
+        else load_kstrided<BN, NVB, BK>(g.B, g.ldb, g.b_vec, n0, g.N, k0, kend, rb);
+      }
+    };
+    auto sstore = [&](int buf) {
+      if constexpr (TA) store_kstrided<BM, NVA, LDAS, BK>(As[buf], ra);
+      else store_kcontig<BM, NVA, LDAS, BK>(As[buf], ra);
+      if constexpr (TB) store_kcontig<BN, NVB, LDBS, BK>(Bs[buf], rb);
+      else store_kstrided<BN, NVB, LDBS, BK>(Bs[buf], rb);
+    };
+    auto mma_tile = [&](int buf) {
+      const float* as = As[buf] + fk * LDAS + 32 * w + fr;
+      const float* bs = Bs[buf] + fk * LDBS + fr;
+      // all fragments of a group of k-pairs are read from LDS BEFORE its MFMAs are issued: left alone, hipcc sinks
+      // every ds_read to its first use through one register pair (ds_read -> lgkmcnt(0) -> 2 MFMAs -> ds_read ...),
+      // which exposes an LDS latency per MFMA pair
+      constexpr int KG = 8;   // k-pairs per group
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float a = as[kk * LDAS];
+      for (int k8 = 0; k8 < BK; k8 += 2 * KG) {
+        float av[KG], bv[KG][NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        float b = bs[kk * LDBS + 32 * nt];
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[nt], 0, 0, 0);
+        for (int q = 0; q < KG; ++q) {
+          av[q] = as[(k8 + 2 * q) * LDAS];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bv[q][nt] = bs[(k8 + 2 * q) * LDBS + 32 * nt];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < KG; ++q)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q][nt], acc[nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if constexpr (FAST && EXACT) {
+      // two register sets, two k-tiles of loads in flight: one tile of MFMAs (0.85 us at 4 column tiles) does not cover
+      // an HBM / L2 round trip under load, and the grid of a PPI-sized projection leaves 1-2 work-groups per CU
+      float4 ra2[NVA], rb2[NVB];
+      auto gload2 = [&](int64_t k0) {
+        if constexpr (TA) load_kstrided_fast<BM, NVA, BK>(g.A, g.lda, m0, g.M, k0, kend, ra2);
+        else load_kcontig_fast<BM, NVA, BK>(g.A, g.lda, m0, g.M, k0, kend, ra2);
+        if constexpr (TB) load_kcontig_fast<BN, NVB, BK>(g.B, g.ldb, n0, g.N, k0, kend, rb2);
+        else load_kstrided_fast<BN, NVB, BK>(g.B, g.ldb, n0, g.N, k0, kend, rb2);
+      };
+      auto sstore2 = [&](int buf) {
+        if constexpr (TA) store_kstrided<BM, NVA, LDAS, BK>(As[buf], ra2);
+        else store_kcontig<BM, NVA, LDAS, BK>(As[buf], ra2);
+        if constexpr (TB) store_kcontig<BN, NVB, LDBS, BK>(Bs[buf], rb2);
+        else store_kstrided<BN, NVB, LDBS, BK>(Bs[buf], rb2);
+      };
+      // tile t is loaded into set (t & 1) and staged into LDS buffer (t & 1); loads past the last tile are clamped
+      auto kof = [&](int64_t t) { return kbeg + (t < nkt ? t : nkt - 1) * BK; };
+      gload(kof(0));
+      gload2(kof(1));
+      sstore(0);
+      __syncthreads();
+      for (int64_t kt = 0; kt < nkt; kt += 2) {
+        gload(kof(kt + 2));            // set 0 is free: its tile kt is in LDS buffer 0
+        mma_tile(0);
+        if (kt + 1 < nkt) sstore2(1);  // tile kt+1, loaded one iteration ago
+        __syncthreads();
+        if (kt + 1 < nkt) {
+          gload2(kof(kt + 3));
+          mma_tile(1);
+          if (kt + 2 < nkt) sstore(0);
+          __syncthreads();
+        }
+      }
+    } else {
+      if (nkt > 0) {
+        gload(kbeg);
+        sstore(0);
+      }
+      __syncthreads();
+      for (int64_t kt = 0; kt < nkt; ++kt) {
+        const int buf = (int)(kt & 1);
+        if (kt + 1 < nkt) gload(kbeg + (kt + 1) * BK);
+        mma_tile(buf);
+        if (kt + 1 < nkt) sstore(buf ^ 1);
+        __syncthreads();
       }
     }
-    if (kt + 1 < nkt) sstore(buf ^ 1);
-    __syncthreads();
-  }
+  };
+  if (interior) kloop(std::true_type{});
+  else kloop(std::false_type{});
 
   // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -448,9 +555,11 @@ static int launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
   int NT = nt_needed <= 1 ? 1 : nt_needed <= 2 ? 2 : nt_needed <= 3 ? 3 : nt_needed <= 4 ? 4
          : nt_needed <= 5 ? 5 : nt_needed <= 6 ? 6 : nt_needed <= 8 ? 8 : 4;
   dim3 grid((unsigned)cdiv(g.M, BM), (unsigned)cdiv(g.N, 32 * NT), (unsigned)splits);
-  // 32-deep k-tiles for the 128-column tile when every K slab is long (the PPI-sized projections, K = 1024)
+  // 32-deep k-tiles for the 128-column tile: PYGAT_GEMM_BK=32 (development knob; measured on the PPI level-2
+  // projection 3144 x 2056 x 1024: 189 us with 16-deep tiles, 219 us with 32-deep ones -- 66 KB of LDS leave two
+  // work-groups per CU where 34 KB leave three)
   static const int bk_env = [] { const char* e = getenv("PYGAT_GEMM_BK"); return e ? atoi(e) : 0; }();
-  const bool deep = NT == 4 && (bk_env ? bk_env == 32 : g.k_per_split >= 256);
+  const bool deep = NT == 4 && bk_env == 32;
   auto lds = [](int nt, int bk) { return (size_t)2 * bk * ((BM + PAD) + (32 * nt + PAD)) * sizeof(float); };
   switch (NT) {
     case 1: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 1, 16>), grid, dim3(256), lds(1, 16), st, g); break;

@@ -148,7 +148,11 @@ def _split_k(M: int, N: int, K: int, streamed_k: bool = False) -> int:
     bn = 32 * (nt if nt <= 8 else 4)
     tiles = -(-M // 128) * -(-N // bn)
     by_traffic = int(0.125 * K * (M + N) / (M * N))
-    return max(1, min(256, 1024 // tiles, K // 256, max(by_traffic, 256 // tiles))) if tiles < 1024 else 1
+    # weight-gradient shapes of the general kernel (K = nodes, few output tiles) want ~2 work-groups per CU: the PPI
+    # level-2 dW (1024 x 1024 x 3144) takes 160 us with 4 slabs, 127 us with 8 (tools/diag/gemm_split_sweep.py);
+    # projections and input gradients (many tiles) lose with any split: their partial sums are as big as the output
+    want = (512 if streamed_k else 256) // tiles
+    return max(1, min(256, 1024 // tiles, K // 256, max(by_traffic, want))) if tiles < 1024 else 1
 
 
 def gemm(transA: bool, transB: bool, M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor,

@@ -27,7 +27,7 @@ One JSON line on rank 0: value = E / step time (max over ranks, K steps between 
                 steps carry no event records; SURVEY.md 8(d) algorithmic bytes / flops);
   kernels       the same figures for every kernel of the step;
   cpu_baseline  oracle/gat_oracle.c (CPU port of the same level) on this host's cores, N=1 only;
-  epoch_ms      Cora / Pubmed epochs (train.py:151-179) replayed from one HIP graph, N=1 only.
+  epoch_ms      Cora / Pubmed / PPI-shaped epochs (train.py:151-179, train_ppi.py) replayed from one HIP graph, N=1 only.
 """
 import argparse
 import json
@@ -105,10 +105,26 @@ def cpu_baseline(args, rowptr, col, X, W, a, G):
 # ---------------------------------------------------------------------------------------------------------
 # second half of BASELINE.json's metric: epoch time on the reference's small configurations
 # ---------------------------------------------------------------------------------------------------------
-EPOCH_CFG = {  # train.py:47-87
+EPOCH_CFG = {  # train.py:47-87, train_ppi.py:43-57
     "cora": dict(nheads=[8, 1], nfeats=[1433, 8, 7], dropout=0.6, lr=5e-3, wd=5e-4, ntrain=140),
     "pubmed": dict(nheads=[8, 8], nfeats=[500, 8, 3], dropout=0.6, lr=1e-2, wd=1e-3, ntrain=60),
+    "ppi": dict(nheads=[4, 4, 6], nfeats=[50, 256, 256, 121], dropout=0.0, lr=5e-3, wd=0.0),
 }
+
+
+def ppi_batch(pg, dev):
+    """A PPI-shaped batch (BASELINE.json config 4): two graphs with the node counts of the first two training graphs
+    (tests/golden/ppi_graph_sizes.npz; the reference's edge lists are missing blobs), seeded random symmetric edges of
+    mean degree 28 plus self loops each, batched block-diagonally (load_data_ppi.py:71-88)."""
+    sizes = np.load(os.path.join(ROOT, "tests", "golden", "ppi_graph_sizes.npz"), allow_pickle=False)["train"][:2]
+    gen = torch.Generator().manual_seed(100)
+    graphs = []
+    for n in (int(v) for v in sizes):
+        m = n * 14
+        r = torch.randint(0, n, (m,), generator=gen)
+        c = torch.randint(0, n, (m,), generator=gen)
+        graphs.append(pg.CSRGraph.from_edge_index(r.to(dev), c.to(dev), n, symmetrize=True, self_loops=True))
+    return pg.CSRGraph.block_diag(graphs)
 
 
 def epoch_ms(pg, dev, name, epochs=200):
@@ -117,19 +133,27 @@ def epoch_ms(pg, dev, name, epochs=200):
     missing), replayed from ONE HIP graph (pygat_amd.FusedEpoch)."""
     import torch.nn.functional as F
     c = EPOCH_CFG[name]
-    z = np.load(os.path.join(ROOT, "tests", "golden", f"{name}_csr.npz"), allow_pickle=False)
-    rowptr, col = z["rowptr"], z["col"]
-    N = len(rowptr) - 1
     g = torch.Generator().manual_seed(72)
-    x = (torch.rand(N, c["nfeats"][0], generator=g) < 0.013).float()
-    x = (x / x.sum(1, keepdim=True).clamp(min=1)).to(dev)          # utils.normalize_features
-    y = torch.randint(0, c["nfeats"][-1], (N,), generator=g).to(dev)
-    it = torch.arange(c["ntrain"], device=dev)
-    graph = pg.CSRGraph(torch.as_tensor(rowptr, device=dev), torch.as_tensor(col, device=dev))
+    if name == "ppi":
+        graph = ppi_batch(pg, dev)
+        N, E = graph.n, graph.nnz
+        x = torch.randn(N, c["nfeats"][0], generator=g).to(dev)
+        y = (torch.rand(N, c["nfeats"][-1], generator=g) < 0.3).float().to(dev)
+        loss_fn = lambda out: F.binary_cross_entropy_with_logits(out, y)                   # noqa: E731  train_ppi.py:104
+    else:
+        z = np.load(os.path.join(ROOT, "tests", "golden", f"{name}_csr.npz"), allow_pickle=False)
+        rowptr, col = z["rowptr"], z["col"]
+        N, E = len(rowptr) - 1, int(len(col))
+        x = (torch.rand(N, c["nfeats"][0], generator=g) < 0.013).float()
+        x = (x / x.sum(1, keepdim=True).clamp(min=1)).to(dev)          # utils.normalize_features
+        y = torch.randint(0, c["nfeats"][-1], (N,), generator=g).to(dev)
+        it = torch.arange(c["ntrain"], device=dev)
+        graph = pg.CSRGraph(torch.as_tensor(rowptr, device=dev), torch.as_tensor(col, device=dev))
+        loss_fn = lambda out: F.nll_loss(F.log_softmax(F.elu(out), dim=1)[it], y[it])      # noqa: E731  train.py:151-152,159
     torch.manual_seed(72)
-    model = pg.GAT(c["nfeats"], c["nheads"], 2, c["dropout"], 0.2, pg.SpGraphAttentionLayer).to(dev)
+    model = pg.GAT(c["nfeats"], c["nheads"], len(c["nheads"]), c["dropout"], 0.2, pg.SpGraphAttentionLayer,
+                   skip_connection=(name == "ppi")).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=c["lr"], weight_decay=c["wd"], capturable=True)
-    loss_fn = lambda out: F.nll_loss(F.log_softmax(F.elu(out), dim=1)[it], y[it])      # noqa: E731  train.py:151-152,159
     ep = pg.FusedEpoch(model, opt, x, graph, loss_fn)
     for _ in range(10):
         ep.run()
@@ -138,10 +162,12 @@ def epoch_ms(pg, dev, name, epochs=200):
     for _ in range(epochs):
         ep.run()
     torch.cuda.synchronize()
-    return {"ms": (time.perf_counter() - t0) / epochs * 1e3, "nodes": N, "edges": int(len(col)),
-            "config": f"{c['nfeats'][0]} -> {c['nheads'][0]} x {c['nfeats'][1]} -> {c['nheads'][1]} x {c['nfeats'][2]}, "
-                      f"dropout {c['dropout']}, Adam, train step + eval forward, one HIP-graph replay per epoch",
-            "data": "real topology, synthetic features/labels"}
+    shape = f"{c['nfeats'][0]} -> " + " -> ".join(f"{h} x {f}" for h, f in zip(c["nheads"], c["nfeats"][1:]))
+    return {"ms": (time.perf_counter() - t0) / epochs * 1e3, "nodes": N, "edges": E,
+            "config": f"{shape}{', skip connections' if name == 'ppi' else ''}, dropout {c['dropout']}, Adam, train step + "
+                      f"eval forward, one HIP-graph replay per epoch",
+            "data": ("two synthetic graphs with real PPI node counts, block-diagonal batch, synthetic features/labels"
+                     if name == "ppi" else "real topology, synthetic features/labels")}
 
 
 def main():
@@ -396,9 +422,9 @@ def main():
                                         "cpu": cpu_model(), "sample": f"failed: {ex!r}"}
         if world == 1 and model_world == 1 and not args.no_epoch:
             line["epoch_ms"] = {}
-            for name in ("cora", "pubmed"):
+            for name in ("cora", "pubmed", "ppi"):
                 try:
-                    line["epoch_ms"][name] = epoch_ms(pg, dev, name)
+                    line["epoch_ms"][name] = epoch_ms(pg, dev, name, epochs=100 if name == "ppi" else 200)
                 except Exception as ex:
                     line["epoch_ms"][name] = {"ms": None, "error": repr(ex)}
         print(json.dumps(line), file=real_stdout, flush=True)

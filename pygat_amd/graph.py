@@ -17,6 +17,7 @@ accepted and transposed with a device sort.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 from typing import Optional, Tuple
 
@@ -33,6 +34,9 @@ def auto_slot_edges(nnz: int) -> int:
     rounds of 4 edges), so a small graph wants short slots -- enough of them (>= 8192) to occupy the
     256 CUs -- while a large one wants 64-edge slots (fewer cut rows, less fix-up work).  Measured K2 on
     MI355X, 8 heads x 8: Cora (13 264 edges) 48 us at 64 -> 12.7 us at 4; Pubmed (108 365) 56 -> 20 us at 8."""
+    forced = os.environ.get("PYGAT_SLOT_EDGES")     # development knob
+    if forced:
+        return int(forced)
     ts = DEFAULT_SLOT_EDGES
     while ts > 4 and nnz // ts < 8192:
         ts //= 2

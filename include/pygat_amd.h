@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PYGAT_ABI_VERSION 9
+#define PYGAT_ABI_VERSION 10
 
 enum {
   PYGAT_OK = 0,
@@ -56,6 +56,18 @@ int pygat_padded_width(int f_out);
 /* number of HIP devices visible / name of the current one (host buffers). */
 int pygat_device_count(void);
 int pygat_device_name(char* host_buf, int len);
+
+/* How the two streamed fp32 GEMMs of a level (the projection `mm(h, W)`, layers.py:35,134, and its weight gradient)
+ * form their products.  Operands, accumulators and results are fp32 in both modes.
+ *   PYGAT_GEMM_SPLIT_BF16 (default): each operand is cut EXACTLY into three bf16 pieces (8 + 8 + 8 significant
+ *     bits) and all nine piece products are summed into fp32 accumulators by v_mfma_f32_32x32x16_bf16 -- no operand
+ *     bit is dropped, the fp32 additions happen in another order than below; 288 instead of 512 MFMA cycles per
+ *     32 x 32 x 16 block.  Shapes the split kernels do not take use the fp32 kernels.
+ *   PYGAT_GEMM_FP32_MFMA: v_mfma_f32_32x32x2_f32 throughout (also: PYGAT_GEMM_F32=1 in the environment).
+ * Process-wide; takes effect for launches made after the call. */
+enum { PYGAT_GEMM_SPLIT_BF16 = 0, PYGAT_GEMM_FP32_MFMA = 1 };
+int pygat_set_gemm_mode(int mode);
+int pygat_get_gemm_mode(void);
 
 /* ------------------------------------------------------------------ K0: graph
  * Replaces `adj.nonzero().t()` (layers.py:129), run ONCE per graph instead of
@@ -113,8 +125,10 @@ int pygat_pack_params(int H, int Fin, int Fo, const float* W, const float* a,
                       void* stream);
 /* Projection of one level in one GEMM: [Wh | Sk | s] = X * Wcat[:, :R (+R) + H]; the H columns behind the
  * heads are W_h a_src_h (pygat_pack_params), so s_i = Wh_i . a_src (layers.py:60) comes out of the same pass.
+ * a_pad (pygat_pack_params; may be NULL): lets the kernel form s from the Wh accumulators themselves -- the
+ * reference's own order, Wh_i . a_src -- where a head is 8 or 16 columns wide and Fin is 64 or 128.
  * Sk may be NULL (no skip).  split_k / ws as pygat_gemm_f32. */
-int pygat_project(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const float* Wcat, int64_t ldw,
+int pygat_project(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const float* Wcat, int64_t ldw, const float* a_pad,
                   float* Wh, float* Sk, float* s, int split_k, void* ws, void* stream);
 /* s[n x H], t[n x H] (t may be NULL) from an (already masked) Wh table: s_ih = Wh_ih . a_src_h, t_ih = Wh_ih . a_dst_h
  * (layers.py:60-61 after the Wh dropout of layers.py:37,136).  a_pad as written by pygat_pack_params. */

@@ -12,14 +12,14 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpygat_amd.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 F_ELU = 1
 F_SKIP = 2
 
 # every entry point declared in include/pygat_amd.h
 SYMBOLS = [
     "pygat_abi_version", "pygat_last_error", "pygat_padded_width", "pygat_device_count",
-    "pygat_device_name", "pygat_dense_row_counts", "pygat_scan_workspace_bytes",
+    "pygat_device_name", "pygat_set_gemm_mode", "pygat_get_gemm_mode", "pygat_dense_row_counts", "pygat_scan_workspace_bytes",
     "pygat_exclusive_scan_i32", "pygat_dense_fill_cols", "pygat_csr_symmetric_perm",
     "pygat_gemm_workspace_bytes", "pygat_gemm_f32", "pygat_pack_params", "pygat_project", "pygat_attn_scores",
     "pygat_unpack_wgrad",
@@ -60,6 +60,8 @@ def _load():
     lib.pygat_last_error.restype = C.c_char_p
     lib.pygat_padded_width.argtypes = [i]
     lib.pygat_device_name.argtypes = [C.c_char_p, i]
+    lib.pygat_set_gemm_mode.argtypes = [i]
+    lib.pygat_get_gemm_mode.argtypes = []
     lib.pygat_dense_row_counts.argtypes = [p, i, i64, i, p, p]
     lib.pygat_scan_workspace_bytes.argtypes = [i64]
     lib.pygat_scan_workspace_bytes.restype = sz
@@ -72,7 +74,7 @@ def _load():
     lib.pygat_pack_params.argtypes = [i, i, i, p, p, p, p, i64, p, p]
     lib.pygat_unpack_wgrad.argtypes = [i, i, i, p, i64, i, p, p]
     lib.pygat_attn_scores.argtypes = [i, i, i, p, p, p, p, p]
-    lib.pygat_project.argtypes = [i, i, i, i, p, i64, p, i64, p, p, p, i, p, p]
+    lib.pygat_project.argtypes = [i, i, i, i, p, i64, p, i64, p, p, p, p, i, p, p]
     lib.pygat_edge_pairs.argtypes = [i, p, p, p, p]
     lib.pygat_slot_bounds.argtypes = [i, i64, p, p, i, p, p]
     lib.pygat_partials_bytes.argtypes = [i64, i, i, i]

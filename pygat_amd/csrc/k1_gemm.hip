@@ -592,6 +592,8 @@ int try_gemm_smallk(int transB, int M, int N, int64_t K, const float* A, int64_t
                     int64_t sv_ld = 0, int sv_n = 0, float* s_out = nullptr, int64_t s_ld = 0);
 int try_gemm_tn_stream(int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                        int max_splits, float* ws, hipStream_t st, int N1, const float* B2, int64_t ldb2);
+int try_project_x3(int n, int Fin, int H, int Fp, const float* X, int64_t ldx, const float* Wcat, int64_t ldw, float* Wh,
+                   float* s, const float* a_pad, hipStream_t st);
 
 }  // namespace pygat
 
@@ -660,16 +662,27 @@ extern "C" int pygat_gemm_f32(int transA, int transB, int M, int N, int64_t K, c
 // heads are W_h a_src_h (written by pygat_pack_params), so s_i = Wh_i . a_src (layers.py:60) falls out of
 // the same pass.  On the small-K fast path with H <= 8 the s columns do not get MFMA tiles of their own (8 columns
 // would occupy a fifth 32-column tile, 20 % of the kernel): the lane that streams row i accumulates them on the VALU
-// in the shadow of the MFMAs (gemm_smallk_kernel, SV).  (Computing s in the GEMM epilogue from the accumulators
-// instead was tried in round 1: the 64 cross-lane reductions per wave tile cost more than the tile they save.)
+// in the shadow of the MFMAs (gemm_smallk_kernel, SV).  With a_pad given, heads of 8 / 16 columns and Fin = 64 / 128
+// (split-bf16 mode) s comes from the accumulators in the epilogue instead, Wh_i . a_src as the reference forms it:
+// a head is 8 / 16 LANES of one MFMA tile, its sum four DPP adds per row register (round 1 tried this with
+// ds_bpermute reductions over whole tiles, which cost more than the fifth tile they saved).
 extern "C" int pygat_project(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const float* Wcat, int64_t ldw,
-                             float* Wh, float* Sk, float* s, int split_k, void* ws, void* stream) {
+                             const float* a_pad, float* Wh, float* Sk, float* s, int split_k, void* ws, void* stream) {
   const int Fp = padded_width(Fo);
   PYGAT_REQUIRE(n > 0 && Fin > 0 && H > 0 && Fp > 0 && X && Wcat && Wh && s, "project: bad arguments");
   const int R = H * Fp, nw = R * (Sk ? 2 : 1), ncols = nw + H;
   PYGAT_REQUIRE(ldw >= nw + 2 * H && ldx >= Fin, "project: leading dimension too small");
   pygat_out_segments seg;
   int k = 0;
+  if (a_pad && split_k <= 1) {   // heads of 8 / 16 columns, Fin 64 / 128: s = Wh . a_src from the accumulators (k1_gemm_x3.hip)
+    const int r = try_project_x3(n, Fin, H, Fp, X, ldx, Wcat, ldw, Wh, s, a_pad, (hipStream_t)stream);
+    if (r < 0) return r;
+    if (r == 1) {
+      if (!Sk) return PYGAT_OK;
+      seg.nseg = 1; seg.col_start[0] = 0; seg.col_start[1] = R; seg.ptr[0] = Sk; seg.ld[0] = R;
+      return pygat_gemm_f32(0, 0, n, R, Fin, X, ldx, Wcat + R, ldw, &seg, 0, 1, nullptr, stream);
+    }
+  }
   seg.col_start[0] = 0; seg.ptr[k] = Wh; seg.ld[k] = R; ++k;
   if (Sk) { seg.col_start[k] = R; seg.ptr[k] = Sk; seg.ld[k] = R; ++k; }
   static const bool sv_off = getenv("PYGAT_K1_NO_SV") != nullptr;   // development knob: s as GEMM columns everywhere

@@ -14,32 +14,11 @@
 //   * 8 waves per work-group (2 per SIMD) share the LDS image; work-groups are persistent and
 //     walk the row tiles with the next chunk prefetched during the current chunk's MFMAs.
 #include "common.h"
+#include "gemm_fast.h"
 #include <stdlib.h>
 
 namespace pygat {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct SmallKArgs {
-  int M, N, K;
-  const float* A;
-  int64_t lda;
-  const float* B;
-  int64_t ldb;
-  pygat_out_segments out;
-  int accumulate;
-  int tiles_m;  // 256-row tiles
-  // SV: s[i, h] = sum_k A[i,k] svec[k, h] for up to 8 extra "columns" WITHOUT MFMA tiles for them.  The lane that
-  // streams row i has its k values in registers anyway: each half-wave takes 4 of the columns, 4 FMAs per loaded
-  // float against an LDS broadcast of svec -- VALU work that issues in the shadow of the MFMAs, no cross-lane
-  // reduction (the projection's s_i = x_i . (W_h a_src), layers.py:60: a fifth 32-column tile for 8 columns costs
-  // 20 % of the kernel; reducing the accumulators across lanes in the epilogue cost more than that tile).
-  const float* svec;   // [K x sv_ld], columns 0 .. sv_n-1 used (sv_n <= 8)
-  int64_t sv_ld;
-  int sv_n;
-  float* s_out;        // [M x s_ld]
-  int64_t s_ld;
-};
 
 template <bool TB, int NT, int NBUF, bool SV>
 __global__ __launch_bounds__(512) void gemm_smallk_kernel(SmallKArgs g) {
@@ -173,12 +152,9 @@ __global__ __launch_bounds__(512) void gemm_smallk_kernel(SmallKArgs g) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int col = n0 + 32 * nt + fr;
-      int sgm = 0;
-#pragma unroll
-      for (int q = 1; q < 4; ++q)
-        if (q < g.out.nseg && col >= g.out.col_start[q]) sgm = q;
-      const int64_t ld = g.out.ld[sgm];
-      float* base = g.out.ptr[sgm] + (col - g.out.col_start[sgm]) + (row0 + 4 * fh) * ld;
+      int64_t ld;
+      float* base = out_segment(g.out, col, ld);
+      base += (row0 + 4 * fh) * ld;
       if (col < g.N) {
         if (full && !g.accumulate) {
 #pragma unroll
@@ -292,11 +268,16 @@ int try_gemm_smallk(int transB, int M, int N, int64_t K, const float* A, int64_t
   g.M = M; g.N = N; g.K = (int)K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.out = *out; g.accumulate = accumulate;
   g.svec = svec; g.sv_ld = sv_ld; g.sv_n = sv_n; g.s_out = s_out; g.s_ld = s_ld;
   g.tiles_m = (int)cdiv(M, 256);
+  g.transB = transB; g.sr_a = nullptr; g.sr_fp = 0;
   const int tiles_n = (int)cdiv(N, 32 * NT);
   int gx = 256 / tiles_n;
   if (gx < 1) gx = 1;
   if (gx > g.tiles_m) gx = g.tiles_m;
   dim3 grid((unsigned)gx, (unsigned)tiles_n, 1);
+  if (gemm_split_mode()) {   // the same GEMM on the bf16 MFMA pipe from exactly split operands (k1_gemm_x3.hip)
+    const int r = try_gemm_smallk_x3(g, NT, grid, st);
+    if (r != 0) return r;
+  }
   hipError_t e = transB ? launch_smallk<true, false>(g, NT, grid, lds, st)
                         : (svec ? launch_smallk<false, true>(g, NT, grid, lds, st) : launch_smallk<false, false>(g, NT, grid, lds, st));
   if (e != hipSuccess) {
@@ -314,21 +295,6 @@ int try_gemm_smallk(int transB, int M, int N, int64_t K, const float* A, int64_t
 // is two coalesced 128-B segments of one wave-wide dword load: no LDS, no barrier.  Each wave owns a
 // 32 x (32*NT) block of C, the work-group a 128 x (32*NT) tile of one K slab; slabs go to the
 // split-K workspace and are summed in slab order by gemm_splitk_reduce_kernel.
-struct TnArgs {
-  int M, N;
-  int64_t K;
-  const float* A;
-  int64_t lda;
-  const float* B;
-  int64_t ldb;
-  int64_t k_per_split;
-  float* ws;  // [splits][M][N]
-  // optional second B operand: columns [N1, N) come from B2 (its own leading dimension); N1 % 32 == 0 so a
-  // 32-column tile never straddles the two.  N1 == N: none.  (dW = X^T [dWh | ds], pygat_wgrad)
-  int N1;
-  const float* B2;
-  int64_t ldb2;
-};
 
 template <int NT, int UK>
 __global__ __launch_bounds__(256) void gemm_tn_stream_kernel(TnArgs g) {
@@ -520,6 +486,13 @@ int try_gemm_tn_stream(int M, int N, int64_t K, const float* A, int64_t lda, con
   g.N1 = N1; g.B2 = B2; g.ldb2 = ldb2;
   // the wide-load variant re-fetches A four times (once per wave) and measured slower (3.5 GB of HBM
   // reads for a 1 GB problem); it stays selectable for experiments
+  if (gemm_split_mode()) {
+    const int64_t kps16 = cdiv(cdiv(K, max_splits), 48) * 48;
+    TnArgs gx = g;
+    gx.k_per_split = kps16;
+    const int r = try_gemm_tn_x3(gx, (int)cdiv(K, kps16), st);
+    if (r != 0) return r;
+  }
   const bool wide = !B2 && getenv("PYGAT_TN_WIDE") && aligned16(A) && aligned16(B) && (lda % 4) == 0 && (ldb % 4) == 0 && (M % 4) == 0 && (N % 4) == 0 &&
                     M >= 4 && N >= 4;
   if (wide) {

@@ -1,0 +1,671 @@
+// The two streamed fp32 GEMMs of a GAT level (projection Wh = h W, layers.py:35,134; weight gradient dW = X^T dWh, its
+// autograd) with their products moved from the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32: 64 flop/clk/SIMD) to the bf16
+// one (v_mfma_f32_32x32x16_bf16: 1024 flop/clk/SIMD) WITHOUT giving up fp32 operands:
+//
+//   every fp32 value is cut exactly into three bf16 pieces, x = hi + mid + lo -- hi the top 8 significant bits of x
+//   (truncation, so all pieces share x's sign), mid the top 8 of the remainder x - hi (a subtraction fp32 does
+//   exactly), lo what is left (<= 8 bits): 8 + 8 + 8 = the 24 significant bits of an fp32.  A product x * y is then
+//   the sum of the nine piece products, each of which an fp32 holds exactly (8 x 8 bits), and the MFMA adds them
+//   into the same fp32 accumulators the fp32 MFMA would use.  No bit of an operand is dropped; only the order of the
+//   fp32 additions differs from the fp32-MFMA kernels (tests/test_gpu_gemm_split.py prices both against fp64).
+//   Nine bf16 MFMAs of 32 cycles replace eight fp32 MFMAs of 64 per 32 x 32 x 16 block: 288 cycles instead of 512,
+//   which is what lets these two GEMMs (20 flop/B) run at the HBM rate instead of the fp32-MFMA rate.
+//   (Non-finite inputs: inf - inf in the split gives NaN where the fp32 kernels give +-inf.)
+//
+// The split costs ~5.5 VALU operations per element and is done where the element is already in registers.
+#include "gemm_fast.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace pygat {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct U4 { uint32_t v[4]; };
+struct Frag3 { U4 h, m, l; };   // 8 bf16 per piece: one A or B operand of v_mfma_f32_32x32x16_bf16
+
+// two fp32 -> their pieces, element 0 in the low half-word (v_perm_b32 picks bytes 2,3 of each source)
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+  const uint32_t u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+  h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+  const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+  const uint32_t v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+  m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+  const float q0 = r0 - __uint_as_float(v0 & 0xffff0000u), q1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+  l = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+}
+__device__ __forceinline__ Frag3 split8(float x0, float x1, float x2, float x3, float x4, float x5, float x6, float x7) {
+  Frag3 f;
+  split_pair(x0, x1, f.h.v[0], f.m.v[0], f.l.v[0]);
+  split_pair(x2, x3, f.h.v[1], f.m.v[1], f.l.v[1]);
+  split_pair(x4, x5, f.h.v[2], f.m.v[2], f.l.v[2]);
+  split_pair(x6, x7, f.h.v[3], f.m.v[3], f.l.v[3]);
+  return f;
+}
+__device__ __forceinline__ Frag3 split8v(const float4& a, const float4& b) { return split8(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w); }
+__device__ __forceinline__ void split_one(float x, uint16_t& h, uint16_t& m, uint16_t& l) {
+  const uint32_t u = __float_as_uint(x);
+  h = (uint16_t)(u >> 16);
+  const float r = x - __uint_as_float(u & 0xffff0000u);
+  const uint32_t v = __float_as_uint(r);
+  m = (uint16_t)(v >> 16);
+  const float q = r - __uint_as_float(v & 0xffff0000u);
+  l = (uint16_t)(__float_as_uint(q) >> 16);
+}
+
+template <class TA_, class TB_>
+__device__ __forceinline__ f32x16 mfma_bf16(const TA_& a, const TB_& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// pair j (0..3) of the eight floats (a, b) of one step
+__device__ __forceinline__ void pair_of(const float4& a, const float4& b, int j, float& x0, float& x1) {
+  if (j == 0) { x0 = a.x; x1 = a.y; } else if (j == 1) { x0 = a.z; x1 = a.w; } else if (j == 2) { x0 = b.x; x1 = b.y; } else { x0 = b.z; x1 = b.w; }
+}
+// all nine piece products of one 32 x 32 x 16 block, small terms first
+template <class TB_>
+__device__ __forceinline__ f32x16 mma9(const Frag3& a, const TB_& bh, const TB_& bm, const TB_& bl, f32x16 c) {
+  c = mfma_bf16(a.l, bl, c);
+  c = mfma_bf16(a.l, bm, c);
+  c = mfma_bf16(a.m, bl, c);
+  c = mfma_bf16(a.l, bh, c);
+  c = mfma_bf16(a.h, bl, c);
+  c = mfma_bf16(a.m, bm, c);
+  c = mfma_bf16(a.m, bh, c);
+  c = mfma_bf16(a.h, bm, c);
+  c = mfma_bf16(a.h, bh, c);
+  return c;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// C[M x N] = A[M x K] op(B), K <= 256, M huge: same structure as gemm_smallk_kernel (persistent 512-thread
+// work-groups, op(B) staged once into LDS, A streamed row-per-lane straight into registers, waves run free), with
+//   * op(B) held as three bf16 images [column][k] (k contiguous: a B fragment = 8 consecutive k of one column is one
+//     ds_read_b128; rows padded by 8 elements = 16 B, which spreads 16 consecutive columns over all banks);
+//   * lane (i = l&31, h = l>>5) loading k = 16 q + 8 h .. + 7 of row i per 16-deep step: the A fragment of the bf16
+//     MFMA, and no address is fetched by both half-waves any more;
+//   * the s columns (SV) on the VALU as before, each lane over its half of k, the halves added once per row tile.
+//   * SPC = 1 / 2 (K = 64 / 128: a row tile is exactly one turn of the four-chunk register ring, a chunk SPC steps of
+//     16 k): the tile loop is straight-line code with an unconditional epilogue and a peeled first tile.  vmcnt counts
+//     loads and stores together in issue order, and hipcc merges wait counts conservatively at every join: behind a
+//     CONDITIONAL epilogue (SPC = 0, any K % 32 == 0) the first chunk of the next tile -- loaded long before -- waits
+//     for the tile's 64 stores to be acknowledged, 22 % of the kernel.
+//   * SM = 0: no s columns; 1: SV; 8 / 16: SR, s from the accumulators for heads of 8 / 16 columns (SmallKArgs).
+template <bool TB, int NT, int SM, int SPC>
+__global__ __launch_bounds__(512) void gemm_smallk_x3_kernel(SmallKArgs g) {
+  constexpr bool SV = (SM == 1);
+  constexpr int SRF = (SM >= 4) ? SM : 0;
+  constexpr int BN = 32 * NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_x3[];
+  const int KP = g.K + 8;
+  uint16_t* Bimg = reinterpret_cast<uint16_t*>(smem_x3);          // [3][BN][KP]
+  const int IMG = BN * KP;
+  float* Us = reinterpret_cast<float*>(Bimg + 3 * IMG);            // [K][8]: svec, zero padded
+  const int n0 = blockIdx.y * BN;
+  for (int idx = threadIdx.x; idx < g.K * BN; idx += 512) {
+    int k, n;
+    float v;
+    if constexpr (!TB) {
+      k = idx / BN; n = idx % BN;
+      v = (n0 + n < g.N) ? g.B[(int64_t)k * g.ldb + n0 + n] : 0.f;
+    } else {
+      n = idx / g.K; k = idx % g.K;
+      v = (n0 + n < g.N) ? g.B[(int64_t)(n0 + n) * g.ldb + k] : 0.f;
+    }
+    uint16_t h, m, l;
+    split_one(v, h, m, l);
+    Bimg[n * KP + k] = h; Bimg[IMG + n * KP + k] = m; Bimg[2 * IMG + n * KP + k] = l;
+  }
+  if constexpr (SV) {
+    for (int idx = threadIdx.x; idx < g.K * 8; idx += 512) {
+      const int k = idx >> 3, h = idx & 7;
+      Us[idx] = (h < g.sv_n) ? g.svec[(int64_t)k * g.sv_ld + h] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int nchunks = g.K / 32;
+  if ((int)blockIdx.x >= g.tiles_m) return;
+  const int my_tiles = (g.tiles_m - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int total = my_tiles * nchunks;  // 32-deep chunks this wave streams, tile after tile
+
+  auto chunk_ptr = [&](int c) -> const float* {   // clamped: every load is unconditional
+    if (c > total - 1) c = total - 1;
+    const int t = c / nchunks, kc = c - t * nchunks;
+    int64_t row = ((int64_t)blockIdx.x + (int64_t)t * gridDim.x) * 256 + 32 * w + fr;
+    if (row > g.M - 1) row = g.M - 1;
+    return g.A + row * g.lda + kc * 32 + 8 * fh;
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float sacc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sacc[i] = 0.f;
+  const bool sv_on = SV && blockIdx.y == 0;
+  float avr[NT];   // SR: a_src of the lane's column in each column tile
+  if constexpr (SRF > 0) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = n0 + 32 * nt + fr;
+      avr[nt] = g.sr_a[(col / SRF) * 2 * SRF + (col % SRF)];
+    }
+  }
+
+  // FAST: the caller knows the wave's 32 rows lie inside M and accumulate is off -- no branch at all (a branch is a
+  // join, and behind a join hipcc waits for the stores: see SPC above)
+  auto store_tile = [&](int t, auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    const int64_t row0 = ((int64_t)blockIdx.x + (int64_t)t * gridDim.x) * 256 + 32 * w;
+    const bool full = FAST || row0 + 32 <= g.M;  // wave-uniform
+    if constexpr (SV) {
+      if (sv_on) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sacc[i] += __shfl_xor(sacc[i], 32);
+        if (fh == 0 && (FAST || row0 + fr < g.M)) {
+          float* so = g.s_out + (row0 + fr) * g.s_ld;
+          if (FAST && g.sv_n == 8) {   // (wave-uniform)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) so[i] = sacc[i];
+          } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+              if (i < g.sv_n) so[i] = sacc[i];
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sacc[i] = 0.f;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = n0 + 32 * nt + fr;
+      if constexpr (SRF > 0) {
+        // each of the 16 row registers summed over the head's SRF lanes; lane c of a head keeps rows c, c + SRF, ..
+        const int cl = fr & (SRF - 1);
+        float keep[16 / SRF];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float tot = group_sum<SRF>(acc[nt][r] * avr[nt]);
+          if ((r % SRF) == 0) keep[r / SRF] = tot;
+          else keep[r / SRF] = (cl == (r % SRF)) ? tot : keep[r / SRF];
+        }
+#pragma unroll
+        for (int j = 0; j < 16 / SRF; ++j) {
+          const int q = cl + SRF * j;
+          const int64_t row = row0 + (q & 3) + 8 * (q >> 2) + 4 * fh;
+          if (FAST || row < g.M) g.s_out[row * g.s_ld + col / SRF] = keep[j];
+        }
+      }
+      int64_t ld;
+      float* base = out_segment(g.out, col, ld);
+      // (opaque to the optimiser: the 16 row offsets of every column tile are loop invariants, and hoisted out of the
+      // straight-line tile loop they cost more registers than the kernel has)
+      asm volatile("" : "+v"(ld));
+      base += (row0 + 4 * fh) * ld;
+      if (FAST || col < g.N) {
+        if (FAST || (full && !g.accumulate)) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float* p = base + 8 * q * ld;
+            p[0] = acc[nt][4 * q]; p[ld] = acc[nt][4 * q + 1]; p[2 * ld] = acc[nt][4 * q + 2]; p[3 * ld] = acc[nt][4 * q + 3];
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2);
+            if (row0 + 4 * fh + rr < g.M) {
+              if (g.accumulate) base[rr * ld] += acc[nt][r]; else base[rr * ld] = acc[nt][r];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    }
+  };
+
+  // one chunk = k 32 kc .. + 31 of the wave's rows: R0,R1 = k 8 fh .. + 7 (step 0), R2,R3 = k 16 + 8 fh .. (step 1)
+#define PYGAT_X3_LOAD(R, P)                                                                   \
+  {                                                                                           \
+    const float* p__ = (P);                                                                   \
+    R##0 = ld4(p__); R##1 = ld4(p__ + 4); R##2 = ld4(p__ + 16); R##3 = ld4(p__ + 20);         \
+  }
+#define PYGAT_X3_SACC(X, KK)                                                                  \
+  {                                                                                           \
+    const float4 ua = ld4(us + (KK) * 8), ub = ld4(us + (KK) * 8 + 4);                        \
+    sacc[0] = fmaf((X), ua.x, sacc[0]); sacc[1] = fmaf((X), ua.y, sacc[1]);                   \
+    sacc[2] = fmaf((X), ua.z, sacc[2]); sacc[3] = fmaf((X), ua.w, sacc[3]);                   \
+    sacc[4] = fmaf((X), ub.x, sacc[4]); sacc[5] = fmaf((X), ub.y, sacc[5]);                   \
+    sacc[6] = fmaf((X), ub.z, sacc[6]); sacc[7] = fmaf((X), ub.w, sacc[7]);                   \
+  }
+#define PYGAT_X3_SACC8(V0, V1, KK)                                                            \
+  PYGAT_X3_SACC((V0).x, (KK) + 0) PYGAT_X3_SACC((V0).y, (KK) + 1) PYGAT_X3_SACC((V0).z, (KK) + 2) PYGAT_X3_SACC((V0).w, (KK) + 3) \
+  PYGAT_X3_SACC((V1).x, (KK) + 4) PYGAT_X3_SACC((V1).y, (KK) + 5) PYGAT_X3_SACC((V1).z, (KK) + 6) PYGAT_X3_SACC((V1).w, (KK) + 7)
+  // B fragments of the next (step, column tile) are read from LDS before the nine MFMAs of the current one issue;
+  // the sched_barriers keep hipcc from sinking the reads to their first use.
+#define PYGAT_X3_BREAD(DST, S, NTI)                                                           \
+  {                                                                                           \
+    const uint16_t* q__ = bb + (NTI) * 32 * KP + (S) * 16;                                    \
+    DST[0] = *reinterpret_cast<const uint4*>(q__);                                            \
+    DST[1] = *reinterpret_cast<const uint4*>(q__ + IMG);                                      \
+    DST[2] = *reinterpret_cast<const uint4*>(q__ + 2 * IMG);                                  \
+  }
+#define PYGAT_X3_BODY(R, KOFF, NSTEP)                                                         \
+  {                                                                                           \
+    const uint16_t* bb = Bimg + fr * KP + (KOFF) + 8 * fh;                                    \
+    if constexpr (SV) if (sv_on) {                                                            \
+      const float* us = Us + ((KOFF) + 8 * fh) * 8;                                           \
+      PYGAT_X3_SACC8(R##0, R##1, 0)                                                           \
+      if constexpr ((NSTEP) == 2) { PYGAT_X3_SACC8(R##2, R##3, 16) }                          \
+    }                                                                                         \
+    Frag3 af[2];                                                                              \
+    af[0] = split8v((R##0), (R##1));                                                          \
+    if constexpr ((NSTEP) == 2) af[1] = split8v((R##2), (R##3));                              \
+    uint4 bf[2][3];                                                                           \
+    PYGAT_X3_BREAD(bf[0], 0, 0)                                                               \
+    _Pragma("unroll") for (int i__ = 0; i__ < (NSTEP) * NT; ++i__) {                          \
+      const int s__ = i__ / NT, nt__ = i__ % NT;                                              \
+      if (i__ + 1 < (NSTEP) * NT) PYGAT_X3_BREAD(bf[(i__ + 1) & 1], (i__ + 1) / NT, (i__ + 1) % NT) \
+      __builtin_amdgcn_sched_barrier(0);                                                      \
+      acc[nt__] = mma9(af[s__], bf[i__ & 1][0], bf[i__ & 1][1], bf[i__ & 1][2], acc[nt__]);   \
+      __builtin_amdgcn_sched_barrier(0);                                                      \
+    }                                                                                         \
+  }
+#define PYGAT_X3_STEP(R, CIDX)                                                                \
+  {                                                                                           \
+    const int c__ = (CIDX);                                                                   \
+    const int t__ = c__ / nchunks, kc__ = c__ - t__ * nchunks;                                \
+    PYGAT_X3_BODY(R, kc__ * 32, 2)                                                            \
+    if (kc__ == nchunks - 1) store_tile(t__, std::false_type{});                                              \
+  }
+
+  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, rc0, rc1, rc2, rc3, rd0, rd1, rd2, rd3;
+  if constexpr (SPC == 0) {
+    // (the sched_barriers pin the ISSUE ORDER of the prologue: vmcnt counts in issue order, and hipcc, free to issue
+    // chunk 2 first, then has to wait for all three chunks at the top of every iteration instead of the oldest one)
+    PYGAT_X3_LOAD(ra, chunk_ptr(0))
+    __builtin_amdgcn_sched_barrier(0);
+    PYGAT_X3_LOAD(rb, chunk_ptr(1))
+    __builtin_amdgcn_sched_barrier(0);
+    PYGAT_X3_LOAD(rc, chunk_ptr(2))
+    __builtin_amdgcn_sched_barrier(0);
+    for (int c = 0; c < total; c += 4) {
+      PYGAT_X3_LOAD(rd, chunk_ptr(c + 3))
+      PYGAT_X3_STEP(ra, c)
+      PYGAT_X3_LOAD(ra, chunk_ptr(c + 4))
+      if (c + 1 < total) PYGAT_X3_STEP(rb, c + 1)
+      PYGAT_X3_LOAD(rb, chunk_ptr(c + 5))
+      if (c + 2 < total) PYGAT_X3_STEP(rc, c + 2)
+      PYGAT_X3_LOAD(rc, chunk_ptr(c + 6))
+      if (c + 3 < total) PYGAT_X3_STEP(rd, c + 3)
+    }
+  } else {
+    constexpr int CW = 16 * SPC;   // k per chunk; K == 4 * CW
+    auto tile_ptr = [&](int c) -> const float* {   // chunk c & 3 of the wave's tile c >> 2, clamped to its last tile
+      int t = c >> 2;
+      if (t > my_tiles - 1) t = my_tiles - 1;
+      int64_t row = ((int64_t)blockIdx.x + (int64_t)t * gridDim.x) * 256 + 32 * w + fr;
+      if (row > g.M - 1) row = g.M - 1;
+      return g.A + row * g.lda + (c & 3) * CW + 8 * fh;
+    };
+#define PYGAT_X3_LOADC(R, P)                                                                  \
+  {                                                                                           \
+    const float* p__ = (P);                                                                   \
+    R##0 = ld4(p__); R##1 = ld4(p__ + 4);                                                     \
+    if constexpr (SPC == 2) { R##2 = ld4(p__ + 16); R##3 = ld4(p__ + 20); }                   \
+  }
+    // One 16-deep step, software-pipelined: while the 9 NT MFMAs of the current step (operand AC) issue, the NEXT step's
+    // eight floats (SRC0, SRC1) are split into AN, a quarter per column tile, and the s columns take their FMAs of the
+    // current step's floats (CUR0, CUR1) -- in program order BETWEEN the MFMAs (sched_group_barrier): an MFMA holds
+    // the SIMD's issue port for 8 of its 32 cycles, and both waves of a SIMD run the same stream in step, so VALU work
+    // left in a block of its own leaves the MFMA pipe idle for its whole length.
+    constexpr int PPG = (4 + NT - 1) / NT;   // pairs of floats handled per column-tile group
+    constexpr int VPM = ((11 + (SV ? 16 : 0)) * PPG + 8) / 9;
+#define PYGAT_X3_PSTEP(SIDX, AC, AN, SRC0, SRC1, CUR0, CUR1, KOFF, KNEXT)                     \
+  _Pragma("unroll") for (int i__ = 0; i__ < NT; ++i__) {                                      \
+    constexpr int par__ = 0;                                                                  \
+    (void)par__;                                                                              \
+    const int cur__ = ((SIDX) * NT + i__) & 1;                                                \
+    {                                                                                         \
+      const int nk__ = (i__ + 1 < NT) ? (KOFF) : (KNEXT), nn__ = (i__ + 1 < NT) ? i__ + 1 : 0; \
+      const uint16_t* q__ = Bimg + fr * KP + nk__ + 8 * fh + nn__ * 32 * KP;                  \
+      bfP[cur__ ^ 1][0] = *reinterpret_cast<const uint4*>(q__);                               \
+      bfP[cur__ ^ 1][1] = *reinterpret_cast<const uint4*>(q__ + IMG);                         \
+      bfP[cur__ ^ 1][2] = *reinterpret_cast<const uint4*>(q__ + 2 * IMG);                     \
+    }                                                                                         \
+    _Pragma("unroll") for (int j__ = i__ * PPG; j__ < (i__ + 1) * PPG && j__ < 4; ++j__) {    \
+      float x0__, x1__;                                                                       \
+      pair_of((SRC0), (SRC1), j__, x0__, x1__);                                               \
+      split_pair(x0__, x1__, AN.h.v[j__], AN.m.v[j__], AN.l.v[j__]);                          \
+      if constexpr (SV) if (sv_on) {                                                          \
+        pair_of((CUR0), (CUR1), j__, x0__, x1__);                                             \
+        const float* us = Us + ((KOFF) + 8 * fh + 2 * j__) * 8;                               \
+        PYGAT_X3_SACC(x0__, 0) PYGAT_X3_SACC(x1__, 1)                                         \
+      }                                                                                       \
+    }                                                                                         \
+    acc[i__] = mma9(AC, bfP[cur__][0], bfP[cur__][1], bfP[cur__][2], acc[i__]);               \
+    _Pragma("unroll") for (int m__ = 0; m__ < 9; ++m__) {                                     \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                      \
+      __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);                                    \
+      if (m__ < (SV ? 7 : 3)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);              \
+    }                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+  }
+#define PYGAT_X3_TILE(T, FAST)                                                                \
+  {                                                                                           \
+    const int t4__ = 4 * (T);                                                                 \
+    PYGAT_X3_LOADC(rd, tile_ptr(t4__ + 3))                                                    \
+    if constexpr (SPC == 2) {                                                                 \
+      PYGAT_X3_PSTEP(0, afA, afB, ra2, ra3, ra0, ra1, 0, 16)                                  \
+      PYGAT_X3_PSTEP(1, afB, afA, rb0, rb1, ra2, ra3, 16, 32)                                 \
+      PYGAT_X3_LOADC(ra, tile_ptr(t4__ + 4))                                                  \
+      PYGAT_X3_PSTEP(2, afA, afB, rb2, rb3, rb0, rb1, 32, 48)                                 \
+      PYGAT_X3_PSTEP(3, afB, afA, rc0, rc1, rb2, rb3, 48, 64)                                 \
+      PYGAT_X3_LOADC(rb, tile_ptr(t4__ + 5))                                                  \
+      PYGAT_X3_PSTEP(4, afA, afB, rc2, rc3, rc0, rc1, 64, 80)                                 \
+      PYGAT_X3_PSTEP(5, afB, afA, rd0, rd1, rc2, rc3, 80, 96)                                 \
+      PYGAT_X3_LOADC(rc, tile_ptr(t4__ + 6))                                                  \
+      PYGAT_X3_PSTEP(6, afA, afB, rd2, rd3, rd0, rd1, 96, 112)                                \
+      PYGAT_X3_PSTEP(7, afB, afA, ra0, ra1, rd2, rd3, 112, 0)                                 \
+    } else {                                                                                  \
+      PYGAT_X3_PSTEP(0, afA, afB, rb0, rb1, ra0, ra1, 0, 16)                                  \
+      PYGAT_X3_LOADC(ra, tile_ptr(t4__ + 4))                                                  \
+      PYGAT_X3_PSTEP(1, afB, afA, rc0, rc1, rb0, rb1, 16, 32)                                 \
+      PYGAT_X3_LOADC(rb, tile_ptr(t4__ + 5))                                                  \
+      PYGAT_X3_PSTEP(2, afA, afB, rd0, rd1, rc0, rc1, 32, 48)                                 \
+      PYGAT_X3_LOADC(rc, tile_ptr(t4__ + 6))                                                  \
+      PYGAT_X3_PSTEP(3, afB, afA, ra0, ra1, rd0, rd1, 48, 0)                                  \
+    }                                                                                         \
+    store_tile(T, FAST);                                                                      \
+  }
+    PYGAT_X3_LOADC(ra, tile_ptr(0))
+    __builtin_amdgcn_sched_barrier(0);
+    PYGAT_X3_LOADC(rb, tile_ptr(1))
+    __builtin_amdgcn_sched_barrier(0);
+    PYGAT_X3_LOADC(rc, tile_ptr(2))
+    __builtin_amdgcn_sched_barrier(0);
+    Frag3 afA = split8v(ra0, ra1), afB;
+    uint4 bfP[2][3];
+    {
+      const uint16_t* q__ = Bimg + fr * KP + 8 * fh;
+      bfP[0][0] = *reinterpret_cast<const uint4*>(q__);
+      bfP[0][1] = *reinterpret_cast<const uint4*>(q__ + IMG);
+      bfP[0][2] = *reinterpret_cast<const uint4*>(q__ + 2 * IMG);
+    }
+    // only a wave's last tile can reach past M; accumulate calls use the any-K kernel (launch_smallk_x3)
+    const int64_t last_row0 = ((int64_t)blockIdx.x + (int64_t)(my_tiles - 1) * gridDim.x) * 256 + 32 * w;
+    // (N % 32 != 0: a column tile is cut by N, every tile takes the guarded epilogue)
+    const int n_fast = (g.N % 32) != 0 ? 0 : ((last_row0 + 32 <= g.M) ? my_tiles : my_tiles - 1);
+    if (n_fast > 0) {
+      PYGAT_X3_TILE(0, std::true_type{})
+      for (int t = 1; t < n_fast; ++t) PYGAT_X3_TILE(t, std::true_type{})
+    }
+    for (int t = n_fast; t < my_tiles; ++t) PYGAT_X3_TILE(t, std::false_type{})
+#undef PYGAT_X3_LOADC
+#undef PYGAT_X3_TILE
+#undef PYGAT_X3_PSTEP
+  }
+#undef PYGAT_X3_LOAD
+#undef PYGAT_X3_SACC
+#undef PYGAT_X3_SACC8
+#undef PYGAT_X3_BREAD
+#undef PYGAT_X3_STEP
+#undef PYGAT_X3_BODY
+}
+
+template <bool TB, int SM, int SPC>
+static hipError_t launch_smallk_x3(const SmallKArgs& g, int NT, dim3 grid, size_t lds, hipStream_t st) {
+  int dev = -1;
+  (void)hipGetDevice(&dev);
+#define PYGAT_X3_LAUNCH(n)                                                                                \
+  case n: {                                                                                               \
+    static bool attr_set[64] = {};   /* per device: the attribute belongs to the device's code object */ \
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_smallk_x3_kernel<TB, n, SM, SPC>),    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
+      if (dev >= 0 && dev < 64) attr_set[dev] = true;                                                     \
+    }                                                                                                     \
+    hipLaunchKernelGGL((gemm_smallk_x3_kernel<TB, n, SM, SPC>), grid, dim3(512), lds, st, g);             \
+  } break;
+  switch (NT) {
+    PYGAT_X3_LAUNCH(1)
+    PYGAT_X3_LAUNCH(2)
+    PYGAT_X3_LAUNCH(3)
+    PYGAT_X3_LAUNCH(4)
+    default:
+    PYGAT_X3_LAUNCH(5)
+  }
+#undef PYGAT_X3_LAUNCH
+  return hipGetLastError();
+}
+
+int try_gemm_smallk_x3(const SmallKArgs& g, int NT, dim3 grid, hipStream_t st) {
+  const size_t lds = (size_t)3 * (32 * NT) * (g.K + 8) * sizeof(uint16_t) + (g.svec ? (size_t)g.K * 8 * sizeof(float) : 0);
+  if (lds > 150 * 1024 || (g.svec && NT == 5)) return 0;   // (5 tiles + the s accumulators do not fit 256 registers)
+  static const bool generic = getenv("PYGAT_X3_GENERIC") != nullptr;   // development knob: the any-K loop for K = 64 / 128 too
+  // s on the VALU (svec) keeps the any-K loop: the pipelined one has no registers left for its accumulators
+  // (five column tiles: the pipelined K = 128 loop spills)
+  const int spc = (generic || g.accumulate || g.svec || (NT == 5 && g.K == 128)) ? 0 : (g.K == 128 ? 2 : (g.K == 64 ? 1 : 0));
+  hipError_t e;
+  if (g.sr_a) {
+    if (spc == 0 || g.transB || g.svec || (g.sr_fp != 8 && g.sr_fp != 16) || (g.N % (32 * NT)) != 0) return 0;
+    if (spc == 2) e = g.sr_fp == 16 ? launch_smallk_x3<false, 16, 2>(g, NT, grid, lds, st) : launch_smallk_x3<false, 8, 2>(g, NT, grid, lds, st);
+    else e = g.sr_fp == 16 ? launch_smallk_x3<false, 16, 1>(g, NT, grid, lds, st) : launch_smallk_x3<false, 8, 1>(g, NT, grid, lds, st);
+  } else if (g.svec) {
+    e = launch_smallk_x3<false, 1, 0>(g, NT, grid, lds, st);
+  } else if (g.transB) {
+    e = spc == 2 ? launch_smallk_x3<true, 0, 2>(g, NT, grid, lds, st)
+                 : (spc == 1 ? launch_smallk_x3<true, 0, 1>(g, NT, grid, lds, st) : launch_smallk_x3<true, 0, 0>(g, NT, grid, lds, st));
+  } else {
+    e = spc == 2 ? launch_smallk_x3<false, 0, 2>(g, NT, grid, lds, st)
+                 : (spc == 1 ? launch_smallk_x3<false, 0, 1>(g, NT, grid, lds, st) : launch_smallk_x3<false, 0, 0>(g, NT, grid, lds, st));
+  }
+  if (e != hipSuccess) {
+    set_error("gemm_smallk_x3: %s", hipGetErrorString(e));
+    return PYGAT_EHIP;
+  }
+  return 1;
+}
+
+int try_project_x3(int n, int Fin, int H, int Fp, const float* X, int64_t ldx, const float* Wcat, int64_t ldw, float* Wh,
+                   float* s, const float* a_pad, hipStream_t st) {
+  const int R = H * Fp;
+  if (!gemm_split_mode() || !a_pad || (Fp != 8 && Fp != 16) || (R % 32) != 0 || (Fin != 64 && Fin != 128) || n < 8192) return 0;
+  if (!aligned16(X) || (ldx % 4) != 0) return 0;
+  const int nt_r = R / 32;
+  if (nt_r > 4 && (nt_r % 4) != 0) return 0;   // (whole 128-column tiles only: narrower ones re-read X once per tile)
+  const int NT = nt_r <= 4 ? nt_r : 4;
+  SmallKArgs g;
+  g.M = n; g.N = R; g.K = Fin; g.A = X; g.lda = ldx; g.B = Wcat; g.ldb = ldw; g.accumulate = 0;
+  g.out.nseg = 1; g.out.col_start[0] = 0; g.out.col_start[1] = R; g.out.ptr[0] = Wh; g.out.ld[0] = R;
+  g.svec = nullptr; g.sv_ld = 0; g.sv_n = 0; g.s_out = s; g.s_ld = H;
+  g.tiles_m = (int)cdiv(n, 256); g.transB = 0; g.sr_a = a_pad; g.sr_fp = Fp;
+  const int tiles_n = R / (32 * NT);
+  int gx = 256 / tiles_n;
+  if (gx < 1) gx = 1;
+  if (gx > g.tiles_m) gx = g.tiles_m;
+  return try_gemm_smallk_x3(g, NT, dim3((unsigned)gx, (unsigned)tiles_n, 1), st);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// C[M x N] = A^T B with A [K x M], B [K x N], K huge (one row per node): dW = X^T dWh.  Both operands are k-strided,
+// the bf16 MFMA wants 8 consecutive k per lane: the work-group (4 waves, a 128 x 128 tile of C over one K slab) moves
+// 16 k rows of both operands per step through LDS --
+//   * thread (kp = tid & 7, c4 = tid >> 3) loads rows k0 + 2 kp, k0 + 2 kp + 1, columns 4 c4 .. + 3 of A and of B with
+//     16-byte loads (a wave covers 128 contiguous bytes of 16 rows), three steps ahead, into a register ring;
+//   * it splits the (k even, k odd) pair of every column ONCE for the whole work-group (the register-only version
+//     split every element in two waves and was bound by those VALU instructions) and writes the three packed pieces
+//     to images [column][16 k] with 40-byte rows: the dword writes of a half-wave (8 k pairs x 4 column groups) and
+//     the 8-byte fragment reads of a half-wave (32 columns) both touch every bank once.  (48-byte rows read with
+//     ds_read_b128 put two column groups of every write on the same banks: a third of the LDS cycles were conflicts);
+//   * a wave owns a 64 x 64 block of C: 4 fragments x 3 pieces x 2 ds_read_b64 feed 36 MFMAs;
+//   * two LDS stages, one barrier per step; the splits and LDS writes of step i + 1 sit between the MFMAs of step i.
+// Needs 16-byte aligned rows (lda, ldb, M, N multiples of 4).
+constexpr int TNX_RS = 10;                         // dwords per image row (8 of data + 2: see the kernel's comment)
+constexpr int TNX_IMG = 128 * TNX_RS;              // dwords per piece image
+constexpr int TNX_STAGE = 6 * TNX_IMG;             // A(h, m, l), B(h, m, l)
+__device__ __forceinline__ uint4 ld_frag(const uint32_t* p) {   // 8-byte aligned: two ds_read_b64
+  const uint2 a = *reinterpret_cast<const uint2*>(p), b = *reinterpret_cast<const uint2*>(p + 2);
+  return make_uint4(a.x, a.y, b.x, b.y);
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_x3_kernel(TnArgs g) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_tn[];   // [2 * TNX_STAGE]: 60 KB, two work-groups per CU
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.z * 128;
+  const int64_t kbeg = (int64_t)blockIdx.x * g.k_per_split;
+  const int64_t kend = (kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K;
+  const int nsteps = (int)((kend - kbeg + 15) / 16);
+  // loader role: columns past M / N read column 0 (their products only reach rows / columns of C never stored)
+  const int kp = tid & 7, c4 = tid >> 3;
+  const float* la = g.A + ((m0 + 4 * c4 + 3 < g.M) ? m0 + 4 * c4 : 0);
+  const float* lb = g.B + ((n0 + 4 * c4 + 3 < g.N) ? n0 + 4 * c4 : 0);
+  // rows past kend (the last step of the last slab) read row kend - 1, and A's copy is zeroed
+#define PYGAT_TNL_LOAD(R, STEP)                                                               \
+  {                                                                                           \
+    const int st__ = (STEP) < nsteps ? (STEP) : nsteps - 1;                                   \
+    const int64_t k__ = kbeg + 16 * (int64_t)st__ + 2 * kp;                                   \
+    const int64_t k0__ = k__ < kend ? k__ : kend - 1, k1__ = k__ + 1 < kend ? k__ + 1 : kend - 1; \
+    R##a0 = ld4(la + k0__ * g.lda); R##a1 = ld4(la + k1__ * g.lda);                           \
+    R##b0 = ld4(lb + k0__ * g.ldb); R##b1 = ld4(lb + k1__ * g.ldb);                           \
+    R##z0 = k__ < kend ? 1.f : 0.f; R##z1 = k__ + 1 < kend ? 1.f : 0.f;                       \
+  }
+  // split the pairs (row 2 kp, row 2 kp + 1) of the thread's four columns and store the pieces: dword kp of the
+  // column's row in each piece image
+#define PYGAT_TNL_PUT(IMGBASE, X0, X1, COL)                                                   \
+  {                                                                                           \
+    uint32_t h__, m__, l__;                                                                   \
+    split_pair((X0), (X1), h__, m__, l__);                                                    \
+    uint32_t* q__ = (IMGBASE) + (4 * c4 + (COL)) * TNX_RS + kp;                               \
+    q__[0] = h__; q__[TNX_IMG] = m__; q__[2 * TNX_IMG] = l__;                                 \
+  }
+#define PYGAT_TNL_PUTA(R, STAGE, C, CMP)                                                       \
+  PYGAT_TNL_PUT(lds_tn + (STAGE) * TNX_STAGE, R##a0.CMP * R##z0, R##a1.CMP * R##z1, C)
+#define PYGAT_TNL_PUTB(R, STAGE, C, CMP)                                                       \
+  PYGAT_TNL_PUT(lds_tn + (STAGE) * TNX_STAGE + 3 * TNX_IMG, R##b0.CMP, R##b1.CMP, C)
+#define PYGAT_TNL_SPLIT(R, STAGE)                                                             \
+  PYGAT_TNL_PUTA(R, STAGE, 0, x) PYGAT_TNL_PUTA(R, STAGE, 1, y) PYGAT_TNL_PUTA(R, STAGE, 2, z) PYGAT_TNL_PUTA(R, STAGE, 3, w) \
+  PYGAT_TNL_PUTB(R, STAGE, 0, x) PYGAT_TNL_PUTB(R, STAGE, 1, y) PYGAT_TNL_PUTB(R, STAGE, 2, z) PYGAT_TNL_PUTB(R, STAGE, 3, w)
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // consumer role: wave (w >> 1, w & 1) owns rows 64 (w >> 1) .., columns 64 (w & 1) .. of the tile
+  const uint32_t* fa = lds_tn + (64 * (w >> 1) + fr) * TNX_RS + 4 * fh;
+  const uint32_t* fb = lds_tn + 3 * TNX_IMG + (64 * (w & 1) + fr) * TNX_RS + 4 * fh;
+  // (the fragment reads come FIRST in program order: hipcc cannot tell the two stages apart and keeps LDS reads
+  // behind every earlier LDS write -- with the split in front, no MFMA could start before its last write)
+#define PYGAT_TNL_READ(STAGE)                                                                 \
+  uint4 fq[4][3];                                                                             \
+  {                                                                                           \
+    const uint32_t* a__ = fa + (STAGE) * TNX_STAGE;                                           \
+    const uint32_t* b__ = fb + (STAGE) * TNX_STAGE;                                           \
+    _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                           \
+      fq[0][p] = ld_frag(a__ + p * TNX_IMG);                                                  \
+      fq[1][p] = ld_frag(a__ + p * TNX_IMG + 32 * TNX_RS);                                    \
+      fq[2][p] = ld_frag(b__ + p * TNX_IMG);                                                  \
+      fq[3][p] = ld_frag(b__ + p * TNX_IMG + 32 * TNX_RS);                                    \
+    }                                                                                         \
+  }
+  // one 32 x 32 tile of the wave's block: its nine MFMAs with a quarter of the next step's split (22 VALU
+  // instructions, 6 LDS writes) between them -- small scheduling regions, the whole step in one is beyond what
+  // hipcc's group scheduler arranges
+#define PYGAT_TNL_QUARTER(TM, TN, PUT0, PUT1)                                                 \
+  {                                                                                           \
+    PUT0 PUT1                                                                                 \
+    Frag3 af__;                                                                               \
+    af__.h = __builtin_bit_cast(U4, fq[TM][0]); af__.m = __builtin_bit_cast(U4, fq[TM][1]);   \
+    af__.l = __builtin_bit_cast(U4, fq[TM][2]);                                               \
+    acc[TM][TN] = mma9(af__, fq[2 + TN][0], fq[2 + TN][1], fq[2 + TN][2], acc[TM][TN]);       \
+    _Pragma("unroll") for (int m__ = 0; m__ < 9; ++m__) {                                     \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                      \
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                      \
+      if (m__ < 6) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                         \
+    }                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+  }
+#define PYGAT_TNL_STEP(RSPLIT, RLOAD, I)                                                      \
+  {                                                                                           \
+    PYGAT_TNL_LOAD(RLOAD, (I) + 3)                                                            \
+    PYGAT_TNL_READ((I) & 1)                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    const int sn__ = ((I) + 1) & 1;   /* (past the last step: clamped data into the idle stage) */ \
+    PYGAT_TNL_QUARTER(0, 0, PYGAT_TNL_PUTA(RSPLIT, sn__, 0, x), PYGAT_TNL_PUTA(RSPLIT, sn__, 1, y)) \
+    PYGAT_TNL_QUARTER(0, 1, PYGAT_TNL_PUTA(RSPLIT, sn__, 2, z), PYGAT_TNL_PUTA(RSPLIT, sn__, 3, w)) \
+    PYGAT_TNL_QUARTER(1, 0, PYGAT_TNL_PUTB(RSPLIT, sn__, 0, x), PYGAT_TNL_PUTB(RSPLIT, sn__, 1, y)) \
+    PYGAT_TNL_QUARTER(1, 1, PYGAT_TNL_PUTB(RSPLIT, sn__, 2, z), PYGAT_TNL_PUTB(RSPLIT, sn__, 3, w)) \
+    __syncthreads();                                                                          \
+  }
+  float4 r0a0, r0a1, r0b0, r0b1, r1a0, r1a1, r1b0, r1b1, r2a0, r2a1, r2b0, r2b1;
+  float r0z0, r0z1, r1z0, r1z1, r2z0, r2z1;
+  PYGAT_TNL_LOAD(r0, 0)
+  __builtin_amdgcn_sched_barrier(0);   // (issue order = wait order, see gemm_smallk_x3_kernel)
+  PYGAT_TNL_LOAD(r1, 1)
+  __builtin_amdgcn_sched_barrier(0);
+  PYGAT_TNL_LOAD(r2, 2)
+  __builtin_amdgcn_sched_barrier(0);
+  PYGAT_TNL_SPLIT(r0, 0)
+  __syncthreads();
+  // step i: MFMAs on stage i & 1; ring slot (i + 1) % 3 is split into stage (i + 1) & 1; slot i % 3 (split during
+  // step i - 1) takes the loads of step i + 3
+  for (int i = 0; i < nsteps; i += 3) {
+    PYGAT_TNL_STEP(r1, r0, i)
+    if (i + 1 < nsteps) PYGAT_TNL_STEP(r2, r1, i + 1)
+    if (i + 2 < nsteps) PYGAT_TNL_STEP(r0, r2, i + 2)
+  }
+#undef PYGAT_TNL_LOAD
+#undef PYGAT_TNL_PUT
+#undef PYGAT_TNL_SPLIT
+#undef PYGAT_TNL_QUARTER
+#undef PYGAT_TNL_PUTA
+#undef PYGAT_TNL_PUTB
+#undef PYGAT_TNL_READ
+#undef PYGAT_TNL_STEP
+  float* base = g.ws + (int64_t)blockIdx.x * g.M * g.N;
+  const int wm0 = m0 + 64 * (w >> 1), wn0 = n0 + 64 * (w & 1);
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int col = wn0 + 32 * tn + fr;
+      if (col >= g.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm0 + 32 * tm + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (row < g.M) base[(int64_t)row * g.N + col] = acc[tm][tn][r];
+      }
+    }
+}
+
+int try_gemm_tn_x3(const TnArgs& g, int splits, hipStream_t st) {
+  if (g.B2 || g.M <= 64 || g.N <= 64 || (g.k_per_split % 16) != 0) return 0;
+  if (!aligned16(g.A) || !aligned16(g.B) || (g.lda % 4) != 0 || (g.ldb % 4) != 0 || (g.M % 4) != 0 || (g.N % 4) != 0) return 0;
+  dim3 grid((unsigned)splits, (unsigned)cdiv(g.M, 128), (unsigned)cdiv(g.N, 128));
+  constexpr size_t lds = 2 * TNX_STAGE * sizeof(uint32_t);
+  int dev = -1;
+  (void)hipGetDevice(&dev);
+  static bool attr_set[64] = {};   // per device: the attribute belongs to the device's code object
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL(gemm_tn_x3_kernel, grid, dim3(256), lds, st, g);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("gemm_tn_x3: %s", hipGetErrorString(e));
+    return PYGAT_EHIP;
+  }
+  return splits;
+}
+
+}  // namespace pygat

@@ -142,6 +142,11 @@ def _split_k(M: int, N: int, K: int, streamed_k: bool = False) -> int:
     exactly one work-group per CU is the optimum at every width -- slabs x column tiles = 256 (128 columns:
     256 slabs 0.37 ms; 512 columns: 64 slabs 1.41 ms against 2.68 ms with 256; 1024 columns: 32 slabs)."""
     nt = -(-N // 32)
+    if streamed_k and K >= 4096 and M * N <= 512 * 512 and get_gemm_mode() == "split-bf16" and M > 64 and N > 64 \
+            and M % 4 == 0 and N % 4 == 0:
+        # the split-bf16 kernel (128 x 128 tiles through 60 KB of LDS): two work-groups per CU
+        tiles = -(-M // 128) * -(-N // 128)
+        return max(1, min(512 // tiles, K // 256)) if tiles < 512 else 1
     if streamed_k and K >= 4096 and M * N <= 512 * 512:
         tiles = -(-M // 128) * -(-N // (32 * min(nt, 5 if nt == 5 else 4)))
         return max(1, min(256 // tiles, K // 256)) if tiles < 256 else 1
@@ -155,9 +160,23 @@ def _split_k(M: int, N: int, K: int, streamed_k: bool = False) -> int:
     return max(1, min(256, 1024 // tiles, K // 256, max(by_traffic, want))) if tiles < 1024 else 1
 
 
+GEMM_MODES = {"split-bf16": 0, "fp32-mfma": 1}
+
+
+def set_gemm_mode(mode: str) -> None:
+    """'split-bf16' (default): the streamed GEMMs cut every fp32 operand exactly into three bf16 pieces and sum all
+    nine piece products in fp32 on the bf16 MFMA pipe; 'fp32-mfma': fp32 MFMA throughout (include/pygat_amd.h)."""
+    check(lib.pygat_set_gemm_mode(GEMM_MODES[mode]), "set_gemm_mode")
+
+
+def get_gemm_mode() -> str:
+    m = lib.pygat_get_gemm_mode()
+    return next(k for k, v in GEMM_MODES.items() if v == m)
+
+
 def gemm(transA: bool, transB: bool, M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor,
          ldb: int, segments, accumulate: bool = False, split_k: Optional[int] = None) -> None:
-    """C = op(A) op(B) on the fp32 MFMA kernel; `segments` = [(ncols, tensor, ld), ...]."""
+    """C = op(A) op(B), fp32 in / fp32 accumulate (see set_gemm_mode); `segments` = [(ncols, tensor, ld), ...]."""
     if split_k is None:
         split_k = _split_k(M, N, K, streamed_k=transA and not transB)
     ws = None
@@ -243,7 +262,7 @@ class GATLevelFn(torch.autograd.Function):
             ws = torch.empty(lib.pygat_gemm_workspace_bytes(L.N, ncols, split_k) // 4, dtype=f32, device=dev) \
                 if split_k > 1 else None
             with _span("k1_project"):
-                check(lib.pygat_project(L.N, Fin, H, Fo, x.data_ptr(), Fin, Wcat.data_ptr(), L.ldw, Wh.data_ptr(),
+                check(lib.pygat_project(L.N, Fin, H, Fo, x.data_ptr(), Fin, Wcat.data_ptr(), L.ldw, a_pad.data_ptr(), Wh.data_ptr(),
                                         _ptr(Sk), s.data_ptr(), split_k, _ptr(ws), st), "project")
             # K2
             flags = (_lib.F_ELU if concat else 0) | (_lib.F_SKIP if skip else 0)

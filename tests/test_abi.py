@@ -75,7 +75,19 @@ def test_argument_validation_returns_einval(lib):
 QUERIES = {"pygat_abi_version", "pygat_last_error", "pygat_padded_width", "pygat_device_count", "pygat_device_name",
            "pygat_scan_workspace_bytes", "pygat_gemm_workspace_bytes", "pygat_partials_bytes", "pygat_head_group",
            "pygat_agrad_workspace_bytes", "pygat_gatv2_workspace_bytes", "pygat_wgrad_workspace_bytes",
-           "pygat_headmask_supported", "pygat_project_dropout_workspace_bytes", "pygat_wgrad_dropout_workspace_bytes"}
+           "pygat_headmask_supported", "pygat_project_dropout_workspace_bytes", "pygat_wgrad_dropout_workspace_bytes",
+           "pygat_set_gemm_mode", "pygat_get_gemm_mode"}
+
+
+def test_gemm_mode_switch(lib):
+    """Default: the exact three-way bf16 split; the fp32-MFMA kernels stay selectable; unknown modes are refused."""
+    L = lib.lib
+    start = L.pygat_get_gemm_mode()
+    assert start in (0, 1)
+    assert L.pygat_set_gemm_mode(1) == 0 and L.pygat_get_gemm_mode() == 1
+    assert L.pygat_set_gemm_mode(0) == 0 and L.pygat_get_gemm_mode() == 0
+    assert L.pygat_set_gemm_mode(7) == -1 and b"unknown mode" in L.pygat_last_error()
+    assert L.pygat_set_gemm_mode(start) == 0
 
 
 def test_every_launcher_rejects_null_arguments(lib):
@@ -157,9 +169,18 @@ def test_host_policies(lib, monkeypatch):
     monkeypatch.setattr(ops, "BACKWARD_FLAVOUR", "rowsum")
     assert ops.backward_flavour(128) == "rowsum"
     # streamed-K weight gradient: slabs x column tiles = 256 (one work-group per CU)
-    assert ops._split_k(128, 128, 1 << 20, streamed_k=True) == 256
-    assert ops._split_k(128, 136, 1 << 20, streamed_k=True) == 256      # [dWh | ds]: still one 5-tile column block
-    assert ops._split_k(128, 520, 1 << 20, streamed_k=True) == 51
+    mode = ops.get_gemm_mode()
+    try:
+        ops.set_gemm_mode("fp32-mfma")
+        assert ops._split_k(128, 128, 1 << 20, streamed_k=True) == 256
+        assert ops._split_k(128, 136, 1 << 20, streamed_k=True) == 256      # [dWh | ds]: still one 5-tile column block
+        assert ops._split_k(128, 520, 1 << 20, streamed_k=True) == 51
+        ops.set_gemm_mode("split-bf16")                                      # 128 x 128 tiles through LDS: two work-groups per CU
+        assert ops._split_k(128, 128, 1 << 20, streamed_k=True) == 512
+        assert ops._split_k(256, 256, 1 << 20, streamed_k=True) == 128
+        assert ops._split_k(128, 16, 1 << 20, streamed_k=True) == 256       # narrow outputs keep the fp32 kernel
+    finally:
+        ops.set_gemm_mode(mode)
     # general kernel: the dropout projection shapes get more than "one work-group per CU"
     assert ops._split_k(2708, 64, 11464) == 22 and ops._split_k(11464, 64, 2708, streamed_k=True) == 5
     assert ops._split_k(1 << 20, 128, 128) == 1

@@ -365,7 +365,7 @@ def test_project(pg, H, Fo, skip):
                                 ldw, a_pad.data_ptr(), None))
     Xd = X.to(dev); Wh = torch.full((n, R), float("nan"), device=dev); s = torch.full((n, H), float("nan"), device=dev)
     Sk = torch.full((n, R), float("nan"), device=dev) if skip else None
-    check(lib.pygat_project(n, Fin, H, Fo, Xd.data_ptr(), Fin, Wcat.data_ptr(), ldw, Wh.data_ptr(),
+    check(lib.pygat_project(n, Fin, H, Fo, Xd.data_ptr(), Fin, Wcat.data_ptr(), ldw, a_pad.data_ptr(), Wh.data_ptr(),
                             Sk.data_ptr() if skip else None, s.data_ptr(), 1, None, None))
     torch.cuda.synchronize()
     ref_wh = torch.einsum("nk,hkf->nhf", X.double(), W.double())

@@ -13,6 +13,11 @@ import torch  # noqa: E402
 import pygat_amd as pg  # noqa: E402
 
 SHAPES = [  # (name, transA, transB, M, N, K)
+    ("cfg5 project     X[1M,128] W[128,128]", False, False, 1 << 20, 128, 128),
+    ("cfg5 dW          X^T[128,1M] dWh[1M,128]", True, False, 128, 128, 1 << 20),
+    ("cfg5 dX          dWh[1M,128] W^T[128,128]", False, True, 1 << 20, 128, 128),
+    ("hidden project   X[1M,64] W[64,128]", False, False, 1 << 20, 128, 64),
+    ("rank project     X[1M,128] W[128,32]", False, False, 1 << 20, 32, 128),
     ("ppi L2 project   X[3144,1024] Wcat[1024,2056]", False, False, 3144, 2056, 1024),
     ("ppi L2 dW        X^T[1024,3144] dWh[3144,1024]", True, False, 1024, 1024, 3144),
     ("ppi L2 dX        dWh[3144,1024] Wcat^T[1024,1024]", False, True, 3144, 1024, 1024),
@@ -20,7 +25,9 @@ SHAPES = [  # (name, transA, transB, M, N, K)
     ("cora eval project X[2708,1433] Wcat[1433,72]", False, False, 2708, 72, 1433),
     ("pubmed project   X[19717,500] Wcat[500,72]", False, False, 19717, 72, 500),
 ]
-for name, tA, tB, M, N, K in SHAPES:
+only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else ""
+for mode, (name, tA, tB, M, N, K) in [(m, sh) for sh in SHAPES for m in ("fp32-mfma", "split-bf16") if only in sh[0]]:
+    pg.set_gemm_mode(mode)
     A = torch.randn((K, M) if tA else (M, K), device="cuda")
     B = torch.randn((N, K) if tB else (K, N), device="cuda")
     C = torch.empty(M, N, device="cuda")
@@ -34,4 +41,4 @@ for name, tA, tB, M, N, K in SHAPES:
     ms = float(np.median(ts[3:]))
     ref = (A.t() if tA else A).double() @ (B.t() if tB else B).double()
     err = float((C.double() - ref).abs().max() / ref.abs().max())
-    print(f"{name:52s} {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:7.1f} TF  rel err {err:.1e}", flush=True)
+    print(f"{mode:10s} {name:52s} {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:7.1f} TF  rel err {err:.1e}", flush=True)

@@ -336,10 +336,26 @@ __global__ __launch_bounds__(256) void gemm_tn_stream_kernel(TnArgs g) {
           acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(AX[u], BX[u][nt], acc[nt], 0, 0, 0);
   int64_t k0 = kbeg;
   const int64_t nfull = (kend - kbeg) / (2 * UK);  // full blocks of 16 k rows
+  // Two-level sum: an MFMA accumulator rounds every addition at the size of the running sum, so the error of a slab
+  // grows with the root of its length -- every TN_FLUSH_ROWS rows the running tile is added into a second set of
+  // registers and restarted (8192-row slabs of a 262144-node level sat at 3.5-4.2 x the error of the fp32 CPU port,
+  // tests/test_gpu_fullsize.py; the kernel runs one wave per SIMD, the registers are free).
+  constexpr int TN_FLUSH_ROWS = 1024;
+  f32x16 acc2[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[i][r] = 0.f;
   if (nfull > 0) {
     float a0[UK], b0[UK][NT], a1[UK], b1[UK][NT];
     PYGAT_TN_LOAD(a0, b0, k0)
     for (int64_t i = 0; i < nfull; i += 2) {
+      if (i > 0 && (i % (TN_FLUSH_ROWS / (2 * UK))) == 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { acc2[t][r] += acc[t][r]; acc[t][r] = 0.f; }
+      }
       // clamp the prefetch address to the last full block: loads stay unconditional
       const int64_t kn1 = kbeg + ((i + 1 < nfull) ? i + 1 : nfull - 1) * 2 * UK;
       PYGAT_TN_LOAD(a1, b1, kn1)
@@ -365,6 +381,10 @@ __global__ __launch_bounds__(256) void gemm_tn_stream_kernel(TnArgs g) {
     for (int nt = 0; nt < NT; ++nt)
       acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[nt][kk * ldt[nt]], acc[nt], 0, 0, 0);
   }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] += acc2[t][r];
   float* base = g.ws + (int64_t)blockIdx.x * g.M * g.N;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {

@@ -373,10 +373,24 @@ def main():
                 traffic = pmc["traffic_bytes"]
         except Exception:
             traffic = {}
+        # split-bf16 mode: the streamed GEMMs run 9 bf16 MFMAs per fp32 32x32x16 block (288 cycles instead of the fp32
+        # pipe's 512) and are priced against the HBM roof on their operand + result bytes; their fp32-equivalent flops
+        # stay in the record
+        split = pg.get_gemm_mode() == "split-bf16"
+        gemm_bytes = {"k1_project": 4.0 * N * (Fin + Rf + Hf), "k5_wgrad": 4.0 * N * (Fin + Rb), "k5_xgrad": 4.0 * N * (Fin + Rb)}
         kernels = []
         for name, t in kt.items():
             bound, work = model.get(name, ("hbm", None))
             if work is None:
+                continue
+            if bound == "mfma" and split:
+                ach = gemm_bytes[name] / (t * 1e-3) / 1e9
+                kernels.append({"kernel": name, "bound": "hbm", "avg_ms": t, "achieved": ach, "peak": HBM_PEAK_GBPS,
+                                "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "algorithmic_bytes": int(gemm_bytes[name]),
+                                "flops": work, "fp32_equivalent_tflops": work / (t * 1e-3) / 1e12,
+                                "products": "exact three-way bf16 split of both fp32 operands, 9 v_mfma_f32_32x32x16_bf16 per "
+                                            "32x32x16 block, fp32 accumulators",
+                                "traffic": traffic.get(name)})
                 continue
             if bound == "hbm":
                 ach = work / (t * 1e-3) / 1e9
@@ -407,6 +421,7 @@ def main():
                                        + (" (rank-0 work only, modelled)" if model_world != world else ""))
                        if model_world > 1 else "single GPU",
                        "heads_per_gpu": h_loc,
+                       "gemm_products": pg.get_gemm_mode(),
                        "launch": "HIP-graph replay (pygat_amd.GraphedLevel)" if (args.hip_graph and not replicate)
                        else "stream launches (pygat_amd.GATLevelFn)"},
             "roofline": roof,

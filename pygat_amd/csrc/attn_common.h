@@ -205,6 +205,20 @@ __device__ __forceinline__ LaneCols<VEC> lane_cols(const RowShape& rs) {
 }
 
 // sum / online-softmax merge across the EPW edge slots of a wave (lanes l and l^off, off >= LPR)
+// "does any lane of my LPR-lane group say yes": a ballot, usable in divergent code as long as whole groups diverge
+template <int LPR>
+__device__ __forceinline__ bool row_any(bool p) {
+  const unsigned long long b = __ballot(p);
+  if constexpr (LPR >= 64) {
+    return b != 0ull;
+  } else if constexpr (LPR == 32) {   // one select between the two halves of the (scalar) ballot
+    return (((threadIdx.x & 32) ? (uint32_t)(b >> 32) : (uint32_t)b)) != 0u;
+  } else {
+    const int sh = (threadIdx.x & 63) & ~(LPR - 1);
+    return ((b >> sh) & ((1ull << LPR) - 1ull)) != 0ull;
+  }
+}
+
 template <int LPR>
 __device__ __forceinline__ float slot_sum(float x) {
 #pragma unroll

@@ -113,10 +113,26 @@ __device__ __forceinline__ float elu1(float x) {
 }
 
 // normalise, epilogue (skip, ELU) and stores of a finished row i (all lanes of the group)
-template <int VEC, bool AUX>
+template <int LPR, int VEC, bool AUX>
 __device__ __forceinline__ void fwd_finish(const FwdArgs& a, const LaneCols<VEC>& lc, int i, const RowState<VEC, AUX>& st) {
   const int Fo = a.rs.Fo, Fp = a.rs.Fp;
   const int64_t ldr = a.rs.ldr, ldh = a.rs.ldh, ldo = a.rs.ldo;
+  // AUX: a (row, head) needs aneg / qneg only if its edges lie on BOTH branches of the LeakyReLU -- all on the
+  // identity branch: both are 0; all on the alpha branch: zn went through the very operations of z (bitwise equal)
+  // and ds_i = -(1 - slope) sum_neg de = -(1 - slope) sum_all de = 0.  Such heads get qneg = 0 (K3a reads that as
+  // "ds = 0, ignore aneg"), and a row none of whose heads is mixed does not write its aneg row at all: 56 % of the
+  // rows of the R-MAT workload (tools/diag/mixed_rows.py; 55 % of its nodes have nothing but their self loop).
+  bool mixed[VEC];
+  bool row_mixed = false;
+  if constexpr (AUX) {
+    bool any = false;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      mixed[v] = lc.valid[v] && st.zn[v] != 0.f && st.zn[v] != st.z[v];
+      any = any || mixed[v];
+    }
+    row_mixed = row_any<LPR>(any);
+  }
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
     if (!lc.valid[v]) continue;
@@ -125,7 +141,8 @@ __device__ __forceinline__ void fwd_finish(const FwdArgs& a, const LaneCols<VEC>
     float4 hat = make_float4(st.acc[v].x * rz, st.acc[v].y * rz, st.acc[v].z * rz, st.acc[v].w * rz);
     if (a.hattn) st4(a.hattn + (int64_t)i * ldr + co, hat);
     if constexpr (AUX)
-      st4(a.aneg + (int64_t)i * ldr + co, make_float4(st.accn[v].x * rz, st.accn[v].y * rz, st.accn[v].z * rz, st.accn[v].w * rz));
+      if (row_mixed)
+        st4(a.aneg + (int64_t)i * ldr + co, make_float4(st.accn[v].x * rz, st.accn[v].y * rz, st.accn[v].z * rz, st.accn[v].w * rz));
     if (a.out) {
       float4 pre = hat;
       if (a.flags & PYGAT_F_SKIP) {
@@ -147,7 +164,7 @@ __device__ __forceinline__ void fwd_finish(const FwdArgs& a, const LaneCols<VEC>
     if (a.m && ((co >> 2) & (a.rs.lph - 1)) == 0) {
       a.m[(int64_t)i * ldh + h] = st.m[v];
       a.Z[(int64_t)i * ldh + h] = st.z[v];
-      if constexpr (AUX) a.qneg[(int64_t)i * ldh + h] = st.zn[v] * rz;
+      if constexpr (AUX) a.qneg[(int64_t)i * ldh + h] = mixed[v] ? st.zn[v] * rz : 0.f;
     }
   }
 }
@@ -194,13 +211,13 @@ __device__ __forceinline__ void part_merge(RowState<VEC, AUX>& st, const PartRec
 }
 
 // row finished inside the slot -> final stores; row continuing in a neighbour slot -> partial record
-template <int VEC, bool AUX>
+template <int LPR, int VEC, bool AUX>
 __device__ __forceinline__ void fwd_flush(const FwdArgs& a, const LaneCols<VEC>& lc, int64_t k, int i,
                                           bool is_head, bool is_tail, const RowState<VEC, AUX>& st) {
   if (is_head || is_tail) {
     part_store<VEC, AUX>(a, lc, a.part + (2 * k + (is_head ? 0 : 1)) * part_stride<AUX>(a.rs), st);
   } else {
-    fwd_finish<VEC, AUX>(a, lc, i, st);
+    fwd_finish<LPR, VEC, AUX>(a, lc, i, st);
   }
 }
 
@@ -210,7 +227,7 @@ __device__ __forceinline__ void fwd_flush(const FwdArgs& a, const LaneCols<VEC>&
 // a 32-bit lane offset per load instead of a 64-bit multiply-add per address) and the mask registers vanish --
 // 9-10 VGPRs less, which is what keeps the training forward (AUX) at 5 waves per SIMD.
 template <int LPR, int VEC, bool V2, bool AUX, bool FAST>
-__global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((AUX && FAST && VEC == 1) ? 5 : 1))) void gat_fwd_kernel(FwdArgs a) {
   constexpr int EPW = 64 / LPR;
   constexpr int U = (VEC == 1) ? 4 : 2;
   const int lane = threadIdx.x & 63;
@@ -281,7 +298,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
     for (int u = 0; u < U; ++u) {
       if (e + u < e1) {
         if (p[u].x != cur) {
-          fwd_flush<VEC, AUX>(a, lc, k, cur, cur == r_first && head_partial, false, st);
+          fwd_flush<LPR, VEC, AUX>(a, lc, k, cur, cur == r_first && head_partial, false, st);
           cur = p[u].x;
           st.reset();
         }
@@ -295,7 +312,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(FwdArgs a) {
     }
   }
   const bool tail_partial = a.g.rowptr[cur + 1] > e1;
-  fwd_flush<VEC, AUX>(a, lc, k, cur, cur == r_first && head_partial, tail_partial, st);
+  fwd_flush<LPR, VEC, AUX>(a, lc, k, cur, cur == r_first && head_partial, tail_partial, st);
 }
 
 // Merge of one cut row: its pieces tail(k), head(k+1), ..., head(k + npieces - 1) are dealt round-robin to
@@ -355,7 +372,7 @@ __device__ __forceinline__ void fwd_merge_row(const FwdArgs& a, const LaneCols<V
     }
     __syncthreads();
   }
-  if (w == 0 && slot == 0) fwd_finish<VEC, AUX>(a, lc, r, st);
+  if (w == 0 && slot == 0) fwd_finish<LPR, VEC, AUX>(a, lc, r, st);
 }
 
 // Fix-up of the rows cut by a slot border.  A work-group screens FIX_SCREEN consecutive slots: slot k

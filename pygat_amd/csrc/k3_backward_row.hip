@@ -113,12 +113,15 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_kernel(PrepArgs a) {
       if (a.whi) st4(a.GR + i * RW + R + 4 * H + co, ld4(a.whi + i * a.ld_whi + co));
     }
     const float D = group_sum_rt(dot4(g4, hat), lph);
+    // (qneg == 0: no edge of the head, or every edge, on the alpha branch -- ds = 0, and K2 may not have written the
+    // row of aneg at all: its value is selected away, never multiplied in)
+    const float qn = (a.aneg && lc.valid[v]) ? a.qneg[i * ldh + h] : 0.f;
     float gn = 0.f;
-    if (a.aneg) gn = group_sum_rt(lc.valid[v] ? dot4(g4, ld4(a.aneg + i * ldr + co)) : 0.f, lph);
+    if (a.aneg) gn = group_sum_rt((lc.valid[v] && qn != 0.f) ? dot4(g4, ld4(a.aneg + i * ldr + co)) : 0.f, lph);
     if (lc.valid[v] && ((co >> 2) & (a.rs.lph - 1)) == 0) {
       const int64_t q = i * ldh + h;
       st4(a.GR + i * RW + gr_rt_off(a, h), make_float4(a.s[q], a.m[q], 1.0f / a.Z[q], D));
-      if (a.aneg) a.ds[q] = (a.slope - 1.f) * (gn - D * a.qneg[q]);
+      if (a.aneg) a.ds[q] = (qn != 0.f) ? (a.slope - 1.f) * (gn - D * qn) : 0.f;
     }
   }
 }
@@ -142,15 +145,27 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_fast_kernel(PrepArgs a) {
   const int64_t gp_off = gr_gp_off(a, co, h), rt_off = gr_rt_off(a, h);
   float4 g4[RB], y4[RB], k4[RB], n4[RB];
   float sv[RB], mv[RB], zv[RB], qv[RB];
+  // qneg goes first (vmcnt counts in issue order): a row whose heads all have qneg == 0 -- no edge, or every edge, on
+  // the alpha branch: K2 did not write its aneg row -- skips the 4R-byte read, and the rows that need it issue theirs
+  // while G and y are still in flight
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int64_t i = (i0 + r < a.n) ? i0 + r : a.n - 1;
+    qv[r] = (a.aneg && valid) ? a.qneg[i * ldh + h] : 0.f;
+  }
 #pragma unroll
   for (int r = 0; r < RB; ++r) {
     const int64_t i = (i0 + r < a.n) ? i0 + r : a.n - 1;
     g4[r] = ld4(a.G + i * ldo + co);
     y4[r] = ld4(a.y + i * ldo + co);
     k4[r] = (a.flags & PYGAT_F_SKIP) ? ld4(a.sk + i * ldr + co) : make_float4(0.f, 0.f, 0.f, 0.f);
-    n4[r] = a.aneg ? ld4(a.aneg + i * ldr + co) : make_float4(0.f, 0.f, 0.f, 0.f);
     sv[r] = a.s[i * ldh + h]; mv[r] = a.m[i * ldh + h]; zv[r] = a.Z[i * ldh + h];
-    qv[r] = a.aneg ? a.qneg[i * ldh + h] : 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int64_t i = (i0 + r < a.n) ? i0 + r : a.n - 1;
+    n4[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row_any<LPR>(qv[r] != 0.f)) n4[r] = ld4(a.aneg + i * ldr + co);
   }
 #pragma unroll
   for (int r = 0; r < RB; ++r) {
@@ -169,7 +184,7 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_fast_kernel(PrepArgs a) {
     float4 g = valid ? make_float4(gq[0], gq[1], gq[2], gq[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 hat = make_float4(pq[0] - k4[r].x, pq[1] - k4[r].y, pq[2] - k4[r].z, pq[3] - k4[r].w);
     const float D = group_sum_rt(dot4(g, hat), lph);
-    const float gn = a.aneg ? group_sum_rt(dot4(g, n4[r]), lph) : 0.f;
+    const float gn = a.aneg ? group_sum_rt(qv[r] != 0.f ? dot4(g, n4[r]) : 0.f, lph) : 0.f;
     if (i < a.n) {
       if (valid) {
         st4(a.GR + i * RW + gp_off, g);
@@ -177,7 +192,7 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_fast_kernel(PrepArgs a) {
       }
       if (lead) {
         st4(a.GR + i * RW + rt_off, make_float4(sv[r], mv[r], 1.0f / zv[r], D));
-        if (a.aneg) a.ds[i * ldh + h] = (a.slope - 1.f) * (gn - D * qv[r]);
+        if (a.aneg) a.ds[i * ldh + h] = (qv[r] != 0.f) ? (a.slope - 1.f) * (gn - D * qv[r]) : 0.f;
       }
     }
   }

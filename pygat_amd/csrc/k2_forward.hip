@@ -226,7 +226,9 @@ __device__ __forceinline__ void fwd_flush(const FwdArgs& a, const LaneCols<VEC>&
 // FAST = no attention mask and every gathered table below 4 GiB: element offsets are 32-bit (a scalar base plus
 // a 32-bit lane offset per load instead of a 64-bit multiply-add per address) and the mask registers vanish --
 // 9-10 VGPRs less, which is what keeps the training forward (AUX) at 5 waves per SIMD.
-template <int LPR, int VEC, bool V2, bool AUX, bool FAST>
+// LPH > 0: lanes per head known at compile time (0: read from the shape) -- the per-edge head sums are DPP chains whose
+// length otherwise costs a scalar branch per step, six per edge.
+template <int LPR, int VEC, bool V2, bool AUX, bool FAST, int LPH = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((AUX && FAST && VEC == 1) ? 5 : 1))) void gat_fwd_kernel(FwdArgs a) {
   constexpr int EPW = 64 / LPR;
   constexpr int U = (VEC == 1) ? 4 : 2;
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((AUX && FAS
   const int r_first = rc[e0].x;
   const bool head_partial = a.g.rowptr[r_first] < e0;
   int cur = r_first;
-  const int lph = a.rs.lph < 64 ? a.rs.lph : 64;
+  const int lph = LPH > 0 ? LPH : (a.rs.lph < 64 ? a.rs.lph : 64);
   float4 adst[VEC];  // this lane's slice of a_dst (zero on padded / invalid chunks)
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
@@ -522,6 +524,8 @@ static int launch_forward(const pygat_graph* g, int H, int Fo, float alpha, int 
     PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_fwd_kernel<LPR, VEC, V2V, AUXV, FASTV>), dim3(blocks),    \
                                                       dim3(256), 0, st, a))
     if (v2) PYGAT_FWD(true, false, false);
+    else if (aux && fast && lpr == 32 && vec == 1 && a.rs.lph == 4 && !getenv("PYGAT_K2_NO_LPH"))   // 8 heads x 16: the headline shape
+      hipLaunchKernelGGL((gat_fwd_kernel<32, 1, false, true, true, 4>), dim3(blocks), dim3(256), 0, st, a);
     else if (aux && fast) PYGAT_FWD(false, true, true);
     else if (aux) PYGAT_FWD(false, true, false);
     else PYGAT_FWD(false, false, false);

@@ -109,7 +109,8 @@ def test_small_integers_sum_exactly(pg):
 
 
 @pytest.mark.parametrize("n,Fin,H,Fo,with_a", [(30011, 128, 8, 16, True), (30011, 128, 8, 16, False), (70003, 64, 8, 8, True),
-                                                (70003, 64, 4, 16, True), (20000, 128, 6, 7, True), (20000, 96, 8, 16, True)])
+                                                (70003, 64, 4, 16, True), (20000, 128, 6, 7, True), (20000, 96, 8, 16, True),
+                                                (40001, 128, 8, 7, True), (40001, 64, 16, 13, True)])
 def test_projection_with_s_columns_both_modes(pg, n, Fin, H, Fo, with_a):
     """pygat_project (Wh, s in one launch) gives the same level in both modes: s on the VALU of the streaming lanes
     (no a_pad), or -- split mode, heads of 8 / 16 columns, Fin 64 / 128 -- from the Wh accumulators in the epilogue."""
@@ -140,3 +141,34 @@ def test_projection_with_s_columns_both_modes(pg, n, Fin, H, Fo, with_a):
     print("\n  projection (Wh, s) rel err:", res)
     assert res["fp32-mfma"][0] < 1e-5 and res["split-bf16"][0] <= 2 * res["fp32-mfma"][0] + 1e-7
     assert res["split-bf16"][1] <= 2 * res["fp32-mfma"][1] + 1e-7
+
+
+def test_projection_with_skip_both_modes(pg):
+    """[Wh | Sk | s] with a skip projection: in split mode Wh and s come from the accumulator kernel, Sk from a second
+    launch over the skip columns of Wcat."""
+    from pygat_amd._lib import lib, check
+    n, Fin, H, Fo = 25013, 128, 8, 16
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(n, Fin, device="cuda", generator=g)
+    W = torch.randn(H, Fin, Fo, device="cuda", generator=g) * 0.2
+    Ws = torch.randn(H, Fin, Fo, device="cuda", generator=g) * 0.2
+    a = torch.randn(H, 2 * Fo, device="cuda", generator=g)
+    Fp = pg.padded_width(Fo)
+    R = H * Fp
+    ldw = -(-(2 * R + 2 * H) // 4) * 4
+    Wcat = torch.empty(Fin, ldw, device="cuda"); a_pad = torch.empty(H, 2, Fp, device="cuda")
+    check(lib.pygat_pack_params(H, Fin, Fo, W.data_ptr(), a.data_ptr(), Ws.data_ptr(), Wcat.data_ptr(), ldw, a_pad.data_ptr(), None),
+          "pack")
+    Wh64 = torch.einsum("nk,hkf->nhf", x.double(), W.double())
+    Sk64 = torch.einsum("nk,hkf->nhf", x.double(), Ws.double())
+    s64 = torch.einsum("nhf,hf->nh", Wh64, a[:, :Fo].double())
+    for mode in ("fp32-mfma", "split-bf16"):
+        pg.set_gemm_mode(mode)
+        Wh = torch.full((n, R), float("nan"), device="cuda"); Sk = torch.full((n, R), float("nan"), device="cuda")
+        s = torch.full((n, H), float("nan"), device="cuda")
+        check(lib.pygat_project(n, Fin, H, Fo, x.data_ptr(), Fin, Wcat.data_ptr(), ldw, a_pad.data_ptr(), Wh.data_ptr(), Sk.data_ptr(),
+                                s.data_ptr(), 1, None, None), "project")
+        torch.cuda.synchronize()
+        for got, ref, what in ((Wh.view(n, H, Fp)[:, :, :Fo], Wh64, "Wh"), (Sk.view(n, H, Fp)[:, :, :Fo], Sk64, "Sk"), (s, s64, "s")):
+            err = float((got.double() - ref).abs().max() / ref.abs().max())
+            assert err < 2e-6, (mode, what, err)

@@ -86,7 +86,9 @@ __device__ __forceinline__ T pick(const T (&x)[U], int u) {
 // here, so that the row sums become a pure stream, was measured too: the random 32-byte stores cost K4
 // 0.48 ms and saved 0.10 ms there.)
 // The lanes of a head all hold dz for the U edges of a round: lane (u mod S) of the head stores edge u.
-template <int LPR, int VEC, bool WRITE_DZ>
+// LPH > 0: lanes per head known at compile time (0: read from the shape): the two head sums per edge are DPP chains
+// whose length otherwise costs a scalar branch per step.
+template <int LPR, int VEC, bool WRITE_DZ, int LPH = 0>
 __global__ __launch_bounds__(256) void gat_bwd_col_kernel(ColArgs a) {
   constexpr int EPW = 64 / LPR;
   constexpr int U = (VEC == 1) ? 4 : 2;
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void gat_bwd_col_kernel(ColArgs a) {
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
   const int R = a.rs.R;
   const int64_t RW = a.ldgr, ldr = a.rs.ldr, ldh = a.rs.ldh;
-  const int lph = a.rs.lph < 64 ? a.rs.lph : 64;
+  const int lph = LPH > 0 ? LPH : (a.rs.lph < 64 ? a.rs.lph : 64);
   const int2* __restrict__ rc = a.g.rc;
   float4 adst[VEC];
 #pragma unroll
@@ -394,6 +396,8 @@ extern "C" int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm
     if (dz_t) {
       PYGAT_DISPATCH_LANES(lpr, vec,
                            hipLaunchKernelGGL((gat_bwd_col_kernel<LPR, VEC, true>), dim3(blocks), dim3(256), 0, st, a));
+    } else if (lpr == 32 && vec == 1 && a.rs.lph == 4) {   // 8 heads x 16: the headline shape
+      hipLaunchKernelGGL((gat_bwd_col_kernel<32, 1, false, 4>), dim3(blocks), dim3(256), 0, st, a);
     } else {
       PYGAT_DISPATCH_LANES(lpr, vec,
                            hipLaunchKernelGGL((gat_bwd_col_kernel<LPR, VEC, false>), dim3(blocks), dim3(256), 0, st, a));

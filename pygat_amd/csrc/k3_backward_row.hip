@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_kernel(PrepArgs a) {
 
 // Fast variant for the common layout (concat mode, F' == Fp, one chunk per lane): RB rows per
 // lane group with all loads issued up front (the kernel is a pure stream: 2 reads + 1 write).
-template <int LPR>
+template <int LPR, int LPH = 0>   // LPH > 0: lanes per head known at compile time
 __global__ __launch_bounds__(256) void gat_bwd_prepare_fast_kernel(PrepArgs a) {
   constexpr int EPW = 64 / LPR;
   constexpr int RB = 4;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_fast_kernel(PrepArgs a) {
   const LaneCols<1> lc = lane_cols<LPR, 1>(a.rs);
   const int H = a.rs.H, R = a.rs.R;
   const int64_t RW = a.ldgr, ldr = a.rs.ldr, ldh = a.rs.ldh, ldo = a.rs.ldo;
-  const int lph = a.rs.lph < 64 ? a.rs.lph : 64;
+  const int lph = LPH > 0 ? LPH : (a.rs.lph < 64 ? a.rs.lph : 64);
   const int co = lc.cofs[0], h = lc.head[0];
   const bool valid = lc.valid[0];
   const bool lead = valid && (((co >> 2) & (a.rs.lph - 1)) == 0);
@@ -477,7 +477,10 @@ static int launch_prepare(int n, int H, int Fo, int flags, int mean_mode, const 
         case 4: hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<4>), dim3(fb), dim3(256), 0, st, a); break;
         case 8: hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<8>), dim3(fb), dim3(256), 0, st, a); break;
         case 16: hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<16>), dim3(fb), dim3(256), 0, st, a); break;
-        case 32: hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<32>), dim3(fb), dim3(256), 0, st, a); break;
+        case 32:
+          if (a.rs.lph == 4) hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<32, 4>), dim3(fb), dim3(256), 0, st, a);
+          else hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<32>), dim3(fb), dim3(256), 0, st, a);
+          break;
         default: hipLaunchKernelGGL((gat_bwd_prepare_fast_kernel<64>), dim3(fb), dim3(256), 0, st, a); break;
       }
     } else {

@@ -113,10 +113,12 @@ __device__ __forceinline__ float elu1(float x) {
 }
 
 // normalise, epilogue (skip, ELU) and stores of a finished row i (all lanes of the group)
-template <int LPR, int VEC, bool AUX>
+// CR > 0 (with LPH > 0, VEC == 1): the row tables are dense with CR floats per row, heads of 4 LPH columns, F' == Fp --
+// strides become constants (shifts instead of 32/64-bit multiplies, which run at a quarter of the VALU rate)
+template <int LPR, int VEC, bool AUX, int LPH = 0, int CR = 0>
 __device__ __forceinline__ void fwd_finish(const FwdArgs& a, const LaneCols<VEC>& lc, int i, const RowState<VEC, AUX>& st) {
-  const int Fo = a.rs.Fo, Fp = a.rs.Fp;
-  const int64_t ldr = a.rs.ldr, ldh = a.rs.ldh, ldo = a.rs.ldo;
+  const int Fo = CR ? 4 * LPH : a.rs.Fo, Fp = CR ? 4 * LPH : a.rs.Fp;
+  const int64_t ldr = CR ? CR : a.rs.ldr, ldh = CR ? CR / (4 * (LPH ? LPH : 1)) : a.rs.ldh, ldo = CR ? CR : a.rs.ldo;
   // AUX: a (row, head) needs aneg / qneg only if its edges lie on BOTH branches of the LeakyReLU -- all on the
   // identity branch: both are 0; all on the alpha branch: zn went through the very operations of z (bitwise equal)
   // and ds_i = -(1 - slope) sum_neg de = -(1 - slope) sum_all de = 0.  Such heads get qneg = 0 (K3a reads that as
@@ -211,13 +213,13 @@ __device__ __forceinline__ void part_merge(RowState<VEC, AUX>& st, const PartRec
 }
 
 // row finished inside the slot -> final stores; row continuing in a neighbour slot -> partial record
-template <int LPR, int VEC, bool AUX>
+template <int LPR, int VEC, bool AUX, int LPH = 0, int CR = 0>
 __device__ __forceinline__ void fwd_flush(const FwdArgs& a, const LaneCols<VEC>& lc, int64_t k, int i,
                                           bool is_head, bool is_tail, const RowState<VEC, AUX>& st) {
   if (is_head || is_tail) {
     part_store<VEC, AUX>(a, lc, a.part + (2 * k + (is_head ? 0 : 1)) * part_stride<AUX>(a.rs), st);
   } else {
-    fwd_finish<LPR, VEC, AUX>(a, lc, i, st);
+    fwd_finish<LPR, VEC, AUX, LPH, CR>(a, lc, i, st);
   }
 }
 
@@ -228,7 +230,7 @@ __device__ __forceinline__ void fwd_flush(const FwdArgs& a, const LaneCols<VEC>&
 // 9-10 VGPRs less, which is what keeps the training forward (AUX) at 5 waves per SIMD.
 // LPH > 0: lanes per head known at compile time (0: read from the shape) -- the per-edge head sums are DPP chains whose
 // length otherwise costs a scalar branch per step, six per edge.
-template <int LPR, int VEC, bool V2, bool AUX, bool FAST, int LPH = 0>
+template <int LPR, int VEC, bool V2, bool AUX, bool FAST, int LPH = 0, int CR = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((AUX && FAST && VEC == 1) ? 5 : 1))) void gat_fwd_kernel(FwdArgs a) {
   constexpr int EPW = 64 / LPR;
   constexpr int U = (VEC == 1) ? 4 : 2;
@@ -239,8 +241,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((AUX && FAS
   int64_t e0, e1;
   slot_range(a.g, k, &e0, &e1);
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
-  const int R = a.rs.R;
-  const int64_t ldh = a.rs.ldh;
+  const int R = CR ? CR : a.rs.R;
+  const int64_t ldh = CR ? CR / (4 * (LPH ? LPH : 1)) : a.rs.ldh;
   const int2* __restrict__ rc = a.g.rc;
 
   const int r_first = rc[e0].x;
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((AUX && FAS
                  : ld4(a.a_pad + (int64_t)lc.head[v] * 2 * a.rs.Fp + a.rs.Fp + (lc.cofs[v] & (a.rs.Fp - 1)));
     if (!lc.valid[v]) adst[v] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  const int64_t ldw = a.ldwh;
+  const int64_t ldw = CR ? CR : a.ldwh;
   RowState<VEC, AUX> st;
   st.reset();
 
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((AUX && FAS
     for (int u = 0; u < U; ++u) {
       if (e + u < e1) {
         if (p[u].x != cur) {
-          fwd_flush<LPR, VEC, AUX>(a, lc, k, cur, cur == r_first && head_partial, false, st);
+          fwd_flush<LPR, VEC, AUX, LPH, CR>(a, lc, k, cur, cur == r_first && head_partial, false, st);
           cur = p[u].x;
           st.reset();
         }
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((AUX && FAS
     }
   }
   const bool tail_partial = a.g.rowptr[cur + 1] > e1;
-  fwd_flush<LPR, VEC, AUX>(a, lc, k, cur, cur == r_first && head_partial, tail_partial, st);
+  fwd_flush<LPR, VEC, AUX, LPH, CR>(a, lc, k, cur, cur == r_first && head_partial, tail_partial, st);
 }
 
 // Merge of one cut row: its pieces tail(k), head(k+1), ..., head(k + npieces - 1) are dealt round-robin to
@@ -525,7 +527,10 @@ static int launch_forward(const pygat_graph* g, int H, int Fo, float alpha, int 
                                                       dim3(256), 0, st, a))
     if (v2) PYGAT_FWD(true, false, false);
     else if (aux && fast && lpr == 32 && vec == 1 && a.rs.lph == 4 && !getenv("PYGAT_K2_NO_LPH"))   // 8 heads x 16: the headline shape
-      hipLaunchKernelGGL((gat_fwd_kernel<32, 1, false, true, true, 4>), dim3(blocks), dim3(256), 0, st, a);
+      if (a.rs.R == 128 && a.rs.ldr == 128 && a.rs.ldh == 8 && a.rs.ldo == 128 && a.rs.Fo == 16 && a.ldwh == 128 && !(flags & PYGAT_F_SKIP))
+        hipLaunchKernelGGL((gat_fwd_kernel<32, 1, false, true, true, 4, 128>), dim3(blocks), dim3(256), 0, st, a);
+      else
+        hipLaunchKernelGGL((gat_fwd_kernel<32, 1, false, true, true, 4>), dim3(blocks), dim3(256), 0, st, a);
     else if (aux && fast) PYGAT_FWD(false, true, true);
     else if (aux) PYGAT_FWD(false, true, false);
     else PYGAT_FWD(false, false, false);

@@ -31,11 +31,12 @@ struct ColArgs {
   float* part;  // [2 * nslots][R + 2H]: acc[R], dt[H]
 };
 
-template <int VEC>
+// CR > 0 (with LPH > 0, VEC == 1): dense row tables of CR floats, heads of 4 LPH columns -- constant strides
+template <int VEC, int LPH = 0, int CR = 0>
 __device__ __forceinline__ void col_finish(const ColArgs& a, const LaneCols<VEC>& lc, int j,
                                            const float4 (&acc)[VEC], const float (&dt)[VEC]) {
-  const int Fp = a.rs.Fp;
-  const int64_t ldr = a.rs.ldr, ldh = a.rs.ldh;
+  const int Fp = CR ? 4 * LPH : a.rs.Fp;
+  const int64_t ldr = CR ? CR : a.rs.ldr, ldh = CR ? CR / (4 * (LPH ? LPH : 1)) : a.rs.ldh;
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
     if (!lc.valid[v]) continue;
@@ -53,7 +54,7 @@ __device__ __forceinline__ void col_finish(const ColArgs& a, const LaneCols<VEC>
   }
 }
 
-template <int VEC>
+template <int VEC, int LPH = 0, int CR = 0>
 __device__ __forceinline__ void col_flush(const ColArgs& a, const LaneCols<VEC>& lc, int64_t k, int j,
                                           bool is_head, bool is_tail, const float4 (&acc)[VEC],
                                           const float (&dt)[VEC]) {
@@ -66,7 +67,7 @@ __device__ __forceinline__ void col_flush(const ColArgs& a, const LaneCols<VEC>&
       if (((lc.cofs[v] >> 2) & (a.rs.lph - 1)) == 0) p[a.rs.R + lc.head[v]] = dt[v];
     }
   } else {
-    col_finish<VEC>(a, lc, j, acc, dt);
+    col_finish<VEC, LPH, CR>(a, lc, j, acc, dt);
   }
 }
 
@@ -88,7 +89,7 @@ __device__ __forceinline__ T pick(const T (&x)[U], int u) {
 // The lanes of a head all hold dz for the U edges of a round: lane (u mod S) of the head stores edge u.
 // LPH > 0: lanes per head known at compile time (0: read from the shape): the two head sums per edge are DPP chains
 // whose length otherwise costs a scalar branch per step.
-template <int LPR, int VEC, bool WRITE_DZ, int LPH = 0>
+template <int LPR, int VEC, bool WRITE_DZ, int LPH = 0, int CR = 0>
 __global__ __launch_bounds__(256) void gat_bwd_col_kernel(ColArgs a) {
   constexpr int EPW = 64 / LPR;
   constexpr int U = (VEC == 1) ? 4 : 2;
@@ -98,8 +99,9 @@ __global__ __launch_bounds__(256) void gat_bwd_col_kernel(ColArgs a) {
   int64_t e0, e1;
   slot_range(a.g, k, &e0, &e1);
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
-  const int R = a.rs.R;
-  const int64_t RW = a.ldgr, ldr = a.rs.ldr, ldh = a.rs.ldh;
+  const int R = CR ? CR : a.rs.R;
+  constexpr int HC = CR / (4 * (LPH ? LPH : 1));   // heads, when CR > 0
+  const int64_t RW = CR ? CR + 4 * HC : a.ldgr, ldr = CR ? CR : a.rs.ldr, ldh = CR ? HC : a.rs.ldh;
   const int lph = LPH > 0 ? LPH : (a.rs.lph < 64 ? a.rs.lph : 64);
   const int2* __restrict__ rc = a.g.rc;
   float4 adst[VEC];
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void gat_bwd_col_kernel(ColArgs a) {
     for (int u = 0; u < U; ++u) {
       if (e + u < e1) {
         if (p[u].x != cur) {
-          col_flush<VEC>(a, lc, k, cur, cur == r_first && head_partial, false, acc, dt);
+          col_flush<VEC, LPH, CR>(a, lc, k, cur, cur == r_first && head_partial, false, acc, dt);
           cur = p[u].x;
 #pragma unroll
           for (int v = 0; v < VEC; ++v) { acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); dt[v] = 0.f; }
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(256) void gat_bwd_col_kernel(ColArgs a) {
     }
   }
   const bool tail_partial = a.g.rowptr[cur + 1] > e1;
-  col_flush<VEC>(a, lc, k, cur, cur == r_first && head_partial, tail_partial, acc, dt);
+  col_flush<VEC, LPH, CR>(a, lc, k, cur, cur == r_first && head_partial, tail_partial, acc, dt);
 }
 
 // Fix-up of cut rows (same scheme as gat_fwd_fixup_kernel): a work-group screens FIX_SCREEN slots, the
@@ -397,7 +399,10 @@ extern "C" int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm
       PYGAT_DISPATCH_LANES(lpr, vec,
                            hipLaunchKernelGGL((gat_bwd_col_kernel<LPR, VEC, true>), dim3(blocks), dim3(256), 0, st, a));
     } else if (lpr == 32 && vec == 1 && a.rs.lph == 4) {   // 8 heads x 16: the headline shape
-      hipLaunchKernelGGL((gat_bwd_col_kernel<32, 1, false, 4>), dim3(blocks), dim3(256), 0, st, a);
+      if (a.rs.R == 128 && a.rs.ldr == 128 && a.rs.ldh == 8 && a.ldgr == 160 && a.rs.H == 8)
+        hipLaunchKernelGGL((gat_bwd_col_kernel<32, 1, false, 4, 128>), dim3(blocks), dim3(256), 0, st, a);
+      else
+        hipLaunchKernelGGL((gat_bwd_col_kernel<32, 1, false, 4>), dim3(blocks), dim3(256), 0, st, a);
     } else {
       PYGAT_DISPATCH_LANES(lpr, vec,
                            hipLaunchKernelGGL((gat_bwd_col_kernel<LPR, VEC, false>), dim3(blocks), dim3(256), 0, st, a));

@@ -128,10 +128,17 @@ __global__ __launch_bounds__(256) void gat_bwd_col_kernel(ColArgs a) {
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
+        if constexpr (CR > 0) {   // both tables below 4 GiB (checked at launch): 32-bit element offsets from a scalar base
+          const uint32_t go = (uint32_t)p[u].y * (uint32_t)RW;
+          gv[u][v] = ld4(a.GR + (go + (uint32_t)lc.cofs[v]));
+          rt[u][v] = ld4(a.GR + (go + (uint32_t)(R + 4 * lc.head[v])));
+          wv[u][v] = ld4(a.Wh + ((uint32_t)p[u].x * (uint32_t)ldr + (uint32_t)lc.cofs[v]));
+        } else {
         const float* gr = a.GR + (int64_t)p[u].y * RW;           // gathered: one contiguous row
         gv[u][v] = ld4(gr + lc.cofs[v]);
         rt[u][v] = ld4(gr + R + 4 * lc.head[v]);
         wv[u][v] = ld4(a.Wh + (int64_t)p[u].x * ldr + lc.cofs[v]);  // row-local (L1 after the first edge)
+        }
         mk[u][v] = 1.f;
         if (a.mask) mk[u][v] = a.mask[(int64_t)a.perm[(e + u < e1) ? e + u : e1 - 1] * ldh + lc.head[v]];
       }
@@ -399,7 +406,8 @@ extern "C" int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm
       PYGAT_DISPATCH_LANES(lpr, vec,
                            hipLaunchKernelGGL((gat_bwd_col_kernel<LPR, VEC, true>), dim3(blocks), dim3(256), 0, st, a));
     } else if (lpr == 32 && vec == 1 && a.rs.lph == 4) {   // 8 heads x 16: the headline shape
-      if (a.rs.R == 128 && a.rs.ldr == 128 && a.rs.ldh == 8 && a.ldgr == 160 && a.rs.H == 8)
+      if (a.rs.R == 128 && a.rs.ldr == 128 && a.rs.ldh == 8 && a.ldgr == 160 && a.rs.H == 8 && !att_mask &&
+          (int64_t)a.g.n * 160 * 4 < ((int64_t)1 << 32) && !getenv("PYGAT_K4_NO_CONST"))   // (development knob)
         hipLaunchKernelGGL((gat_bwd_col_kernel<32, 1, false, 4, 128>), dim3(blocks), dim3(256), 0, st, a);
       else
         hipLaunchKernelGGL((gat_bwd_col_kernel<32, 1, false, 4>), dim3(blocks), dim3(256), 0, st, a);

@@ -148,3 +148,28 @@ def test_wide_rows_at_scale_against_c_oracle():
     e, e32 = close_grad(out, r64["out"], r32["out"], "out")
     print(f"wide rows: out err {e:.2e} (fp32 oracle {e32:.2e}, max {np.abs(r64['out']).max():.3g})")
     print("wide rows: " + check_grads(W.grad, a.grad, r64, r32, X, rowptr, col, W, a, "wide rows"))
+
+
+@pytest.mark.parametrize("Fin,H,Fo", [(128, 8, 16), (64, 8, 8), (96, 4, 16), (128, 8, 7), (64, 2, 32), (32, 3, 16)])
+def test_midsize_levels_against_c_oracle(Fin, H, Fo):
+    """32768-node R-MAT graph, the size at which the streamed GEMM paths take over (n >= 8192): every projection flavour
+    of the split-bf16 mode -- s from the accumulators for heads of 16 and 8 columns (Fin 128 / 64), s on the VALU of the
+    any-K loop (Fin 96, 32; padded and 32-wide heads), the LDS weight-gradient kernel and the narrow ones -- as a whole
+    level against the C oracle, forward and gradients, same rule as the full-size cases."""
+    import pygat_amd as pg
+    from pygat_amd.rmat import rmat_csr
+    dev = torch.device("cuda", 0)
+    rowptr, col = rmat_csr(15, 200_000, seed=7, device=dev)
+    graph = pg.CSRGraph(rowptr, col)
+    g = torch.Generator(device=dev).manual_seed(Fin + 10 * H + Fo)
+    X = torch.randn(graph.n, Fin, generator=g, device=dev)
+    W = (torch.randn(H, Fin, Fo, generator=g, device=dev) * (1.414 * (2.0 / (Fin + Fo)) ** 0.5)).requires_grad_(True)
+    a = (torch.randn(H, 2 * Fo, generator=g, device=dev) * (1.414 * (2.0 / (1 + 2 * Fo)) ** 0.5)).requires_grad_(True)
+    G = torch.randn(graph.n, H * Fo, generator=g, device=dev)
+    out = pg.GATLevelFn.apply(X, W, a, None, graph, 0.2, True)
+    out.backward(G)
+    torch.cuda.synchronize()
+    r64, r32 = c_refs(X, rowptr, col, W, a, G)
+    e, e32 = close_grad(out, r64["out"], r32["out"], "out")
+    print(f"midsize[{Fin},{H},{Fo}]: out err {e:.2e} (fp32 oracle {e32:.2e}); "
+          + check_grads(W.grad, a.grad, r64, r32, X, rowptr, col, W, a, f"midsize[{Fin},{H},{Fo}]"))

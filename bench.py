@@ -309,6 +309,26 @@ def main():
     step_ms = sorted(a_.elapsed_time(b_) for a_, b_ in ev)
     ms_median = step_ms[len(step_ms) // 2]
 
+    # ---- the same K steps with the two streamed GEMMs on the fp32 MFMA pipe (pygat_set_gemm_mode): reported beside
+    # the headline so that the effect of the split-bf16 products is on record in every run.  Single GPU, stream launches.
+    alt = None
+    if world == 1 and pg.get_gemm_mode() == "split-bf16" and not (args.hip_graph and not replicate):
+        pg.set_gemm_mode("fp32-mfma")
+        try:
+            for _ in range(max(2, args.warmup)):
+                step()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            barrier()
+            alt = {"gemm_products": "fp32-mfma", "ms_per_step": (time.perf_counter() - t1) / args.steps * 1e3}
+        finally:
+            pg.set_gemm_mode("split-bf16")
+        for _ in range(2):   # (back in the headline mode for the instrumented pass)
+            step()
+        barrier()
+
     # ---- instrumented pass: the same steps launched eagerly with HIP events around every kernel ------
     timer = ops.KernelTimer()
     if replicate:
@@ -427,6 +447,7 @@ def main():
             "roofline": roof,
             "kernels": kernels,
             "kernels_ms_sum": float(sum(kt.values())),
+            "alt": alt,
         }
         if world == 1 and not args.no_cpu:
             try:

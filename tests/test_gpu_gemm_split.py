@@ -61,12 +61,14 @@ def test_split_mode_is_as_accurate_as_fp32_mfma(pg, tA, tB, M, N, K):
     assert err["split-bf16"] <= 2.0 * err["fp32-mfma"] + 1e-7
 
 
-@pytest.mark.parametrize("tA", [False, True])
-def test_split_mode_is_exact_where_fp32_is(pg, tA):
+@pytest.mark.parametrize("tA,big", [(False, False), (True, False), (False, True)])
+def test_split_mode_is_exact_where_fp32_is(pg, tA, big):
     """Operands with all 24 significant bits set at random against a signed power-of-two selection matrix: every
     product and every sum is exact in fp32, so the result must equal the float64 product BIT FOR BIT in both modes.
     A lost low piece (or a lost piece product) shows up as a wrong last bit."""
-    M, N, K = (128, 128, 65536) if tA else (16384, 128, 128)
+    # big: 1024 row tiles over 256 persistent work-groups -- the straight-line tile loop with its prefetch ring and more
+    # than 63 memory operations in flight per wave
+    M, N, K = (128, 128, 65536) if tA else ((262144 + 77, 128, 128) if big else (16384, 128, 128))
     g = torch.Generator(device="cuda").manual_seed(5)
     rows, cols = ((K, M) if tA else (M, K))
     mant = torch.randint(1 << 23, 1 << 24, (rows, cols), device="cuda", generator=g).float()   # 24-bit integers, exact

@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--epochs", type=int, default=50)
     ap.add_argument("--graph-capture", action="store_true")
     ap.add_argument("--fastmode", action="store_true")
+    ap.add_argument("--fused-adam", action="store_true", help="torch's single-kernel Adam (same update rule)")
     ap.add_argument("--cpu-epochs", type=int, default=2)
     args = ap.parse_args()
     c = CFG[args.dataset]
@@ -74,7 +75,8 @@ def main():
     torch.manual_seed(72)
     model = pg.GAT(c["nfeats"], c["nheads"], c["nlayers"], c["dropout"], c["alpha"], pg.SpGraphAttentionLayer,
                    skip_connection=c["skip"]).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=c["lr"], weight_decay=c["wd"], capturable=args.graph_capture)
+    opt = torch.optim.Adam(model.parameters(), lr=c["lr"], weight_decay=c["wd"], capturable=args.graph_capture,
+                           **({"fused": True} if args.fused_adam else {}))
     xd, yd, it = x.to(dev), y.to(dev), idx_train.to(dev)
 
     def loss_fn(out):

@@ -32,7 +32,6 @@ One JSON line on rank 0: value = E / step time (max over ranks, K steps between 
 import argparse
 import json
 import os
-import subprocess
 import sys
 import time
 
@@ -86,8 +85,7 @@ def cpu_model():
 
 def cpu_baseline(args, rowptr, col, X, W, a, G):
     """oracle/gat_oracle.c (kind "port") on the host cores: the same level, same inputs."""
-    subprocess.run(["make", "-B", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
-    from oracle import c_oracle
+    from oracle import c_oracle           # built for this host at start-up (main), before the GPU was initialised
     lib = c_oracle.load()
     tp = c_oracle.transpose_pattern(rowptr, col)
     times = []
@@ -182,6 +180,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and not args.no_cpu:
+        try:        # the cpu_baseline leg's library (-march=native) is rebuilt for this host NOW, before the GPU is touched
+            from oracle import c_oracle
+            c_oracle.build_for_host()
+        except Exception as ex:
+            print(f"bench: oracle build failed ({ex!r}); cpu_baseline will report the failure", file=sys.stderr)
     if world != args.gpus:
         if rank == 0:
             print(f"bench: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
@@ -265,12 +269,22 @@ def main():
     # torch.cat) are all-gathered on RCCL's own stream while chunk c+1 is computed; the rest of the exchange hides
     # behind this level's backward, which does not depend on it, and is joined at the end of the step.  The gathered
     # chunks stay rank-major [world, rows, w]: pygat_amd.dist copies them into their column slices as they land.
-    chunk_rows = [(r0, r1) for _, r0, r1 in graph.fwd.row_chunks(max(1, args.chunks))] if use_pg else []
-    gbufs = [torch.empty(world, r1 - r0, h_loc * Fo, device=dev) for r0, r1 in chunk_rows]
+    # The chunk borders are the level's own (GATLevelFn cuts with the slot length of ITS row width: 32-edge slots for a
+    # one-head 64-byte row, graph.slot_edges otherwise), so the receive buffers are sized from the (r0, r1) the callback
+    # gets: allocated on the first step, reused -- and checked -- on every later one.
+    nchunks = max(1, args.chunks) if use_pg else 0
+    gbufs = {}
     works = []
 
     def on_chunk(c, r0, r1, out):
-        works.append(dist.all_gather_into_tensor(gbufs[c].view(world * (r1 - r0), h_loc * Fo), out[r0:r1], async_op=True))
+        buf = gbufs.get(c)
+        if buf is None:
+            buf = gbufs[c] = torch.empty(world, r1 - r0, h_loc * Fo, device=dev)
+            chunk_rows[c] = (r0, r1)
+        assert chunk_rows[c] == (r0, r1), f"chunk {c}: rows {(r0, r1)} now, {chunk_rows[c]} before"
+        works.append(dist.all_gather_into_tensor(buf.view(world * (r1 - r0), h_loc * Fo), out[r0:r1], async_op=True))
+
+    chunk_rows = {}
 
     def step():
         if use_pg:
@@ -278,11 +292,11 @@ def main():
             W_loc.grad = a_loc.grad = None
             if args.dx:
                 Xb.grad = None
-            out = pg.GATLevelFn.apply(Xb, W_loc, a_loc, None, graph, 0.2, True, None, (len(chunk_rows), on_chunk))
+            out = pg.GATLevelFn.apply(Xb, W_loc, a_loc, None, graph, 0.2, True, None, (nchunks, on_chunk))
             out.backward(G_loc)
             for wk in works:
                 wk.wait()
-            return gbufs
+            return [gbufs[c] for c in sorted(gbufs)]
         out = level_fwd()
         level_bwd(out)
         return out
@@ -311,12 +325,12 @@ def main():
     step_ms = sorted(a_.elapsed_time(b_) for a_, b_ in ev)
     ms_median = step_ms[len(step_ms) // 2]
 
-    # ---- the same K steps with the two streamed GEMMs on the fp32 MFMA pipe (pygat_set_gemm_mode): reported beside
+    # ---- the same K steps with the two streamed GEMMs on the fp32 MFMA pipe (the gemm_mode argument of the C ABI): reported beside
     # the headline so that the effect of the split-bf16 products is on record in every run.  Single GPU, stream launches.
     alt = None
     if world == 1 and pg.get_gemm_mode() == "split-bf16" and not (args.hip_graph and not replicate):
-        pg.set_gemm_mode("fp32-mfma")
         try:
+            pg.set_gemm_mode("fp32-mfma")
             for _ in range(max(2, args.warmup)):
                 step()
             barrier()
@@ -326,7 +340,7 @@ def main():
             barrier()
             alt = {"gemm_products": "fp32-mfma", "ms_per_step": (time.perf_counter() - t1) / args.steps * 1e3}
         finally:
-            pg.set_gemm_mode("split-bf16")
+            pg.set_gemm_mode(None)
         for _ in range(2):   # (back in the headline mode for the instrumented pass)
             step()
         barrier()
@@ -387,12 +401,16 @@ def main():
             "k5_wgrad": ("mfma", 2.0 * N * Fin * (Rb + Hb)),
             "k5_xgrad": ("mfma", 2.0 * N * Fin * Rb),
         }
-        traffic = {}
+        traffic, traffic_source = {}, None
         try:   # HBM traffic from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of
                # this same command; FETCH_SIZE doubled as the gfx950 guide prescribes): main + fix-up launches
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
             if pmc.get("workload_edges") == E and pmc.get("heads_per_gpu") == h_loc:
                 traffic = pmc["traffic_bytes"]
+                # NOT measured in this run: counters need their own rocprofv3 --pmc passes; the line says where they are from
+                traffic_source = ("replayed from the committed profiles/pmc_latest.json = " + str(pmc.get("source", "?"))
+                                  + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, "
+                                    "FETCH_SIZE x 2 per the gfx950 guide); not measured in this run")
         except Exception:
             traffic = {}
         # split-bf16 mode: the streamed GEMMs run 9 bf16 MFMAs per fp32 32x32x16 block (288 cycles instead of the fp32
@@ -427,6 +445,7 @@ def main():
         dominant = max(kernels, key=lambda r: r["avg_ms"])
         roof = dict(dominant)
         roof["timing"] = "HIP events around each launch, instrumented eager pass of the same steps after the timed region"
+        roof["traffic_source"] = traffic_source
         line = {
             "metric": "GAT-layer fwd+bwd edges/sec", "value": E / (ms * 1e-3), "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -449,6 +468,7 @@ def main():
             "roofline": roof,
             "kernels": kernels,
             "kernels_ms_sum": float(sum(kt.values())),
+            "traffic_source": traffic_source,
             "alt": alt,
         }
         if world == 1 and not args.no_cpu:

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PYGAT_ABI_VERSION 10
+#define PYGAT_ABI_VERSION 11
 
 enum {
   PYGAT_OK = 0,
@@ -57,17 +57,22 @@ int pygat_padded_width(int f_out);
 int pygat_device_count(void);
 int pygat_device_name(char* host_buf, int len);
 
-/* How the two streamed fp32 GEMMs of a level (the projection `mm(h, W)`, layers.py:35,134, and its weight gradient)
- * form their products.  Operands, accumulators and results are fp32 in both modes.
- *   PYGAT_GEMM_SPLIT_BF16 (default): each operand is cut EXACTLY into three bf16 pieces (8 + 8 + 8 significant
- *     bits) and all nine piece products are summed into fp32 accumulators by v_mfma_f32_32x32x16_bf16 -- no operand
- *     bit is dropped, the fp32 additions happen in another order than below; 288 instead of 512 MFMA cycles per
- *     32 x 32 x 16 block.  Shapes the split kernels do not take use the fp32 kernels.
- *   PYGAT_GEMM_FP32_MFMA: v_mfma_f32_32x32x2_f32 throughout (also: PYGAT_GEMM_F32=1 in the environment).
- * Process-wide; takes effect for launches made after the call. */
-enum { PYGAT_GEMM_SPLIT_BF16 = 0, PYGAT_GEMM_FP32_MFMA = 1 };
-int pygat_set_gemm_mode(int mode);
-int pygat_get_gemm_mode(void);
+/* How the fp32 GEMMs of a level (the projection `mm(h, W)`, layers.py:35,134, its weight and input gradients) form
+ * their products.  Operands, accumulators and results are fp32 in both modes.
+ *   PYGAT_GEMM_SPLIT_BF16: each operand is cut EXACTLY into three bf16 pieces (8 + 8 + 8 significant bits) and all
+ *     nine piece products are summed into fp32 accumulators by v_mfma_f32_32x32x16_bf16 -- no operand bit is dropped,
+ *     the fp32 additions happen in another order than below; 288 instead of 512 MFMA cycles per 32 x 32 x 16 block.
+ *     Shapes the split kernels do not take use the fp32 kernels.  Caveats: the cut is exact for finite operands whose
+ *     mid and low pieces stay normal bf16 numbers (|x| >= 2^-110 or x == 0; smaller magnitudes lose their low bits,
+ *     i.e. are treated as fp32 denormal-range values); a NON-FINITE operand gives NaN where the fp32 kernels give
+ *     +-inf (inf - inf inside the cut).
+ *   PYGAT_GEMM_FP32_MFMA: v_mfma_f32_32x32x2_f32 throughout.
+ *   PYGAT_GEMM_DEFAULT: the process default -- split-bf16, or fp32 MFMA with PYGAT_GEMM_F32=1 in the environment
+ *     (read once when the library is loaded; pygat_default_gemm_mode() reports it).
+ * The mode is an ARGUMENT (`gemm_mode`) of every entry point that runs a GEMM: the library holds no mutable state
+ * besides the thread-local error string, so two threads / two models may use different modes at the same time. */
+enum { PYGAT_GEMM_DEFAULT = -1, PYGAT_GEMM_SPLIT_BF16 = 0, PYGAT_GEMM_FP32_MFMA = 1 };
+int pygat_default_gemm_mode(void);
 
 /* ------------------------------------------------------------------ K0: graph
  * Replaces `adj.nonzero().t()` (layers.py:129), run ONCE per graph instead of
@@ -94,14 +99,16 @@ int pygat_csr_symmetric_perm(int n, const int32_t* rowptr, const int32_t* col,
  * Replaces torch.mm(h, W) per head (layers.py:35,134), the skip torch.mm
  * (layers.py:48,166) and the two a-halves matmuls (layers.py:60-61):
  *   C[M x N] = op(A) * op(B) (+ C if accumulate), fp32 MFMA, row-major.
- * Output columns can be routed to up to 4 destination tables (seg_*): columns
- * [seg_col[s], seg_col[s+1]) of C go to seg_ptr[s] with row stride seg_ld[s].
+ * Output columns can be routed to up to PYGAT_MAX_SEGMENTS destination tables (seg_*): columns
+ * [seg_col[s], seg_col[s+1]) of C go to seg_ptr[s] with row stride seg_ld[s] (the projection's Wh | Sk | s
+ * tables; the per-rank column blocks of a head-parallel level's input gradient, pygat_amd/dist.py).
  */
+#define PYGAT_MAX_SEGMENTS 4
 typedef struct {
-  int nseg;                 /* 1..4 */
-  int32_t col_start[5];     /* col_start[0] = 0, col_start[nseg] = N */
-  float* ptr[4];
-  int64_t ld[4];
+  int nseg;                                       /* 1..PYGAT_MAX_SEGMENTS */
+  int32_t col_start[PYGAT_MAX_SEGMENTS + 1];      /* col_start[0] = 0, col_start[nseg] = N */
+  float* ptr[PYGAT_MAX_SEGMENTS];
+  int64_t ld[PYGAT_MAX_SEGMENTS];
 } pygat_out_segments;
 
 /* transA: A is stored [K x M]; transB: B is stored [N x K]. split_k >= 1: when >1 the
@@ -111,7 +118,7 @@ size_t pygat_gemm_workspace_bytes(int M, int N, int split_k);
 int pygat_gemm_f32(int transA, int transB, int M, int N, int64_t K,
                    const float* A, int64_t lda, const float* B, int64_t ldb,
                    const pygat_out_segments* out, int accumulate,
-                   int split_k, void* ws, void* stream);
+                   int split_k, void* ws, int gemm_mode, void* stream);
 
 /* Pack the per-head parameters of one level into the projection operand
  *   Wcat [Fin x ldw], columns: [0,R) W heads (padded to Fp), [R,2R) skip heads if
@@ -129,7 +136,7 @@ int pygat_pack_params(int H, int Fin, int Fo, const float* W, const float* a,
  * reference's own order, Wh_i . a_src -- where a head is 8 or 16 columns wide and Fin is 64 or 128.
  * Sk may be NULL (no skip).  split_k / ws as pygat_gemm_f32. */
 int pygat_project(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const float* Wcat, int64_t ldw, const float* a_pad,
-                  float* Wh, float* Sk, float* s, int split_k, void* ws, void* stream);
+                  float* Wh, float* Sk, float* s, int split_k, void* ws, int gemm_mode, void* stream);
 /* s[n x H], t[n x H] (t may be NULL) from an (already masked) Wh table: s_ih = Wh_ih . a_src_h, t_ih = Wh_ih . a_dst_h
  * (layers.py:60-61 after the Wh dropout of layers.py:37,136).  a_pad as written by pygat_pack_params. */
 int pygat_attn_scores(int n, int H, int Fo, const float* Wh, const float* a_pad,
@@ -278,7 +285,7 @@ int pygat_a_grad(int n, int H, int Fo, const float* Wh, const float* ds, const f
  * ws >= pygat_wgrad_workspace_bytes(Fin, H, F', split_k); split_k as in pygat_gemm_f32. */
 size_t pygat_wgrad_workspace_bytes(int Fin, int H, int Fo, int split_k);
 int pygat_wgrad(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const float* dWh, const float* ds,
-                const float* a_pad, float* dW, int split_k, void* ws, int h_first, int h_count, void* stream);
+                const float* a_pad, float* dW, int split_k, void* ws, int h_first, int h_count, int gemm_mode, void* stream);
 
 /* ------------------------------------------------ GATv2 (next row of the scope table)
  * The reference's SpGraphAttentionLayerV2 (layers.py:258-313): per head

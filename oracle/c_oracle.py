@@ -5,7 +5,27 @@ import os
 
 import numpy as np
 
-_SO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libgat_oracle.so")
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_DIR, "_build", "libgat_oracle.so")
+
+
+def build_for_host():
+    """gat_oracle.c is compiled -march=native, so the library built in the build container is rebuilt once on another
+    host (the GPU box).  Callers (tests/conftest.py at collection time, bench.py at start-up) run this BEFORE their
+    process initialises the GPU: no child process is ever started from one that holds the device."""
+    import subprocess
+    stamp = os.path.join(_DIR, "_build", ".host")
+    try:
+        host = next(ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name"))
+    except (OSError, StopIteration):
+        host = "unknown"
+    try:
+        same = open(stamp).read() == host and os.path.exists(_SO)
+    except OSError:
+        same = False
+    subprocess.run(["make", "-C", _DIR] + ([] if same else ["-B"]), check=True, capture_output=True)
+    if not same:
+        open(stamp, "w").write(host)
 
 
 def load():

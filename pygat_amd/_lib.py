@@ -12,14 +12,14 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpygat_amd.so")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 F_ELU = 1
 F_SKIP = 2
 
 # every entry point declared in include/pygat_amd.h
 SYMBOLS = [
     "pygat_abi_version", "pygat_last_error", "pygat_padded_width", "pygat_device_count",
-    "pygat_device_name", "pygat_set_gemm_mode", "pygat_get_gemm_mode", "pygat_dense_row_counts", "pygat_scan_workspace_bytes",
+    "pygat_device_name", "pygat_default_gemm_mode", "pygat_dense_row_counts", "pygat_scan_workspace_bytes",
     "pygat_exclusive_scan_i32", "pygat_dense_fill_cols", "pygat_csr_symmetric_perm",
     "pygat_gemm_workspace_bytes", "pygat_gemm_f32", "pygat_pack_params", "pygat_project", "pygat_attn_scores",
     "pygat_unpack_wgrad",
@@ -35,9 +35,12 @@ SYMBOLS = [
 ]
 
 
+MAX_SEGMENTS = 4    # PYGAT_MAX_SEGMENTS
+
+
 class OutSegments(C.Structure):
-    _fields_ = [("nseg", C.c_int), ("col_start", C.c_int32 * 5), ("ptr", C.c_void_p * 4),
-                ("ld", C.c_int64 * 4)]
+    _fields_ = [("nseg", C.c_int), ("col_start", C.c_int32 * (MAX_SEGMENTS + 1)), ("ptr", C.c_void_p * MAX_SEGMENTS),
+                ("ld", C.c_int64 * MAX_SEGMENTS)]
 
 
 class Graph(C.Structure):
@@ -60,8 +63,7 @@ def _load():
     lib.pygat_last_error.restype = C.c_char_p
     lib.pygat_padded_width.argtypes = [i]
     lib.pygat_device_name.argtypes = [C.c_char_p, i]
-    lib.pygat_set_gemm_mode.argtypes = [i]
-    lib.pygat_get_gemm_mode.argtypes = []
+    lib.pygat_default_gemm_mode.argtypes = []
     lib.pygat_dense_row_counts.argtypes = [p, i, i64, i, p, p]
     lib.pygat_scan_workspace_bytes.argtypes = [i64]
     lib.pygat_scan_workspace_bytes.restype = sz
@@ -70,11 +72,11 @@ def _load():
     lib.pygat_csr_symmetric_perm.argtypes = [i, p, p, p, p, p]
     lib.pygat_gemm_workspace_bytes.argtypes = [i, i, i]
     lib.pygat_gemm_workspace_bytes.restype = sz
-    lib.pygat_gemm_f32.argtypes = [i, i, i, i, i64, p, i64, p, i64, C.POINTER(OutSegments), i, i, p, p]
+    lib.pygat_gemm_f32.argtypes = [i, i, i, i, i64, p, i64, p, i64, C.POINTER(OutSegments), i, i, p, i, p]
     lib.pygat_pack_params.argtypes = [i, i, i, p, p, p, p, i64, p, p]
     lib.pygat_unpack_wgrad.argtypes = [i, i, i, p, i64, i, p, p]
     lib.pygat_attn_scores.argtypes = [i, i, i, p, p, p, p, p]
-    lib.pygat_project.argtypes = [i, i, i, i, p, i64, p, i64, p, p, p, p, i, p, p]
+    lib.pygat_project.argtypes = [i, i, i, i, p, i64, p, i64, p, p, p, p, i, p, i, p]
     lib.pygat_edge_pairs.argtypes = [i, p, p, p, p]
     lib.pygat_slot_bounds.argtypes = [i, i64, p, p, i, p, p]
     lib.pygat_partials_bytes.argtypes = [i64, i, i, i]
@@ -98,7 +100,7 @@ def _load():
     u32 = C.c_uint32
     lib.pygat_wgrad_workspace_bytes.argtypes = [i, i, i, i]
     lib.pygat_wgrad_workspace_bytes.restype = sz
-    lib.pygat_wgrad.argtypes = [i, i, i, i, p, i64, p, p, p, p, i, p, i, i, p]
+    lib.pygat_wgrad.argtypes = [i, i, i, i, p, i64, p, p, p, p, i, p, i, i, i, p]
     lib.pygat_dropout_mask.argtypes = [i64, f, p, u32, p, p]
     lib.pygat_dropout_expand.argtypes = [i, i, i, p, i64, p, f, p, u32, p, i64, p]
     lib.pygat_dropout_head_sum.argtypes = [i, i, i, p, i64, p, f, p, u32, p, i64, i, p]
@@ -115,7 +117,7 @@ def _load():
     lib.pygat_dropout_head_sum_bits.argtypes = [i, i, i, p, i64, p, f, p, i64, i, p]
     for s in SYMBOLS:
         fn = getattr(lib, s)
-        if fn.restype is C.c_int or s in ("pygat_abi_version", "pygat_padded_width", "pygat_device_count"):
+        if fn.restype is C.c_int or s in ("pygat_abi_version", "pygat_padded_width", "pygat_device_count", "pygat_default_gemm_mode"):
             fn.restype = i
     if lib.pygat_abi_version() != ABI_VERSION:
         raise ImportError(f"pygat_amd: ABI version {lib.pygat_abi_version()} != {ABI_VERSION}")

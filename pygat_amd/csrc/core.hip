@@ -12,20 +12,13 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-// PYGAT_GEMM_F32=1 in the environment starts the process on the fp32 MFMA kernels
-static int g_gemm_split = [] { const char* e = getenv("PYGAT_GEMM_F32"); return (e && atoi(e) != 0) ? 0 : 1; }();
-int gemm_split_mode() { return g_gemm_split; }
+// PYGAT_GEMM_F32=1 in the environment makes fp32 MFMA the default product mode of the process.  Read once at load
+// and never written again: the mode of a call is an ARGUMENT of the entry points that run GEMMs (include/pygat_amd.h).
+static const int g_default_split = [] { const char* e = getenv("PYGAT_GEMM_F32"); return (e && atoi(e) != 0) ? 0 : 1; }();
+bool gemm_split(int mode) { return mode == PYGAT_GEMM_DEFAULT ? g_default_split != 0 : mode == PYGAT_GEMM_SPLIT_BF16; }
 }  // namespace pygat
 
-extern "C" int pygat_get_gemm_mode(void) { return pygat::g_gemm_split ? PYGAT_GEMM_SPLIT_BF16 : PYGAT_GEMM_FP32_MFMA; }
-extern "C" int pygat_set_gemm_mode(int mode) {
-  if (mode != PYGAT_GEMM_SPLIT_BF16 && mode != PYGAT_GEMM_FP32_MFMA) {
-    pygat::set_error("set_gemm_mode: unknown mode %d", mode);
-    return PYGAT_EINVAL;
-  }
-  pygat::g_gemm_split = (mode == PYGAT_GEMM_SPLIT_BF16);
-  return PYGAT_OK;
-}
+extern "C" int pygat_default_gemm_mode(void) { return pygat::g_default_split ? PYGAT_GEMM_SPLIT_BF16 : PYGAT_GEMM_FP32_MFMA; }
 
 extern "C" int pygat_abi_version(void) { return PYGAT_ABI_VERSION; }
 extern "C" const char* pygat_last_error(void) { return pygat::g_err; }

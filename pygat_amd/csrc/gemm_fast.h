@@ -59,21 +59,21 @@ __device__ __forceinline__ float* out_segment(const pygat_out_segments& out, int
   float* p = out.ptr[0];
   int c0 = 0;
 #pragma unroll
-  for (int q = 1; q < 4; ++q)
+  for (int q = 1; q < PYGAT_MAX_SEGMENTS; ++q)
     if (q < out.nseg && col >= out.col_start[q]) { ld = out.ld[q]; p = out.ptr[q]; c0 = out.col_start[q]; }
   return p + (col - c0);
 }
 #endif
 
-// 0: every fp32 GEMM product on v_mfma_f32_32x32x2_f32; 1 (default): the streamed fast paths split each operand
-// exactly into three bf16 pieces and sum all nine piece products in fp32 (pygat_set_gemm_mode)
-int gemm_split_mode();
+// product mode of a call (include/pygat_amd.h, PYGAT_GEMM_*) -> true: the streamed fast paths split each operand exactly
+// into three bf16 pieces and sum all nine piece products in fp32; false: every product on v_mfma_f32_32x32x2_f32
+bool gemm_split(int mode);
 
 // each returns 1 (or the slab count) if it took the call, 0 if the shape does not qualify, < 0 on a launch error
 int try_gemm_smallk_x3(const SmallKArgs& g, int NT, dim3 grid, hipStream_t st);
 // [Wh | s] of a projection whose heads are 8 or 16 columns wide: s from the accumulators (SmallKArgs::sr_a)
 int try_project_x3(int n, int Fin, int H, int Fp, const float* X, int64_t ldx, const float* Wcat, int64_t ldw, float* Wh,
-                   float* s, const float* a_pad, hipStream_t st);
+                   float* s, const float* a_pad, bool split, hipStream_t st);
 int try_gemm_tn_x3(const TnArgs& g, int splits, hipStream_t st);
 
 }  // namespace pygat

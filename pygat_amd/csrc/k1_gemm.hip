@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     } else {
       int s = 0;
 #pragma unroll
-      for (int q = 1; q < 4; ++q)
+      for (int q = 1; q < PYGAT_MAX_SEGMENTS; ++q)
         if (q < g.out.nseg && col >= g.out.col_start[q]) s = q;
       base = g.out.ptr[s] + (col - g.out.col_start[s]);
       ld = g.out.ld[s];
@@ -588,13 +588,13 @@ static int launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
 }
 
 int try_gemm_smallk(int transB, int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
-                    const pygat_out_segments* out, int accumulate, hipStream_t st, const float* svec = nullptr,
+                    const pygat_out_segments* out, int accumulate, bool split, hipStream_t st, const float* svec = nullptr,
                     int64_t sv_ld = 0, int sv_n = 0, float* s_out = nullptr, int64_t s_ld = 0);
 int try_gemm_tn_stream(int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
-                       int max_splits, float* ws, hipStream_t st, int N1, const float* B2, int64_t ldb2);
+                       int max_splits, float* ws, bool split, hipStream_t st, int N1, const float* B2, int64_t ldb2);
 int try_project_x3(int n, int Fin, int H, int Fp, const float* X, int64_t ldx, const float* Wcat, int64_t ldw, float* Wh,
-                   float* s, const float* a_pad, hipStream_t st);
-int gemm_split_mode();
+                   float* s, const float* a_pad, bool split, hipStream_t st);
+bool gemm_split(int mode);
 
 }  // namespace pygat
 
@@ -607,10 +607,12 @@ extern "C" size_t pygat_gemm_workspace_bytes(int M, int N, int split_k) {
 
 extern "C" int pygat_gemm_f32(int transA, int transB, int M, int N, int64_t K, const float* A, int64_t lda,
                               const float* B, int64_t ldb, const pygat_out_segments* out, int accumulate,
-                              int split_k, void* ws, void* stream) {
+                              int split_k, void* ws, int gemm_mode, void* stream) {
   PYGAT_REQUIRE(A && B && out, "gemm: null pointer");
+  PYGAT_REQUIRE(gemm_mode >= PYGAT_GEMM_DEFAULT && gemm_mode <= PYGAT_GEMM_FP32_MFMA, "gemm: unknown product mode %d", gemm_mode);
+  const bool split = gemm_split(gemm_mode);
   PYGAT_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad sizes M=%d N=%d K=%lld", M, N, (long long)K);
-  PYGAT_REQUIRE(out->nseg >= 1 && out->nseg <= 4 && out->col_start[0] == 0 && out->col_start[out->nseg] == N,
+  PYGAT_REQUIRE(out->nseg >= 1 && out->nseg <= PYGAT_MAX_SEGMENTS && out->col_start[0] == 0 && out->col_start[out->nseg] == N,
                 "gemm: output segments must cover [0,N) (nseg=%d)", out->nseg);
   for (int s = 0; s < out->nseg; ++s)
     PYGAT_REQUIRE(out->ptr[s] && out->col_start[s + 1] > out->col_start[s] &&
@@ -621,12 +623,12 @@ extern "C" int pygat_gemm_f32(int transA, int transB, int M, int N, int64_t K, c
   PYGAT_REQUIRE(split_k == 1 || ws, "gemm: split_k > 1 needs a workspace");
   hipStream_t st = (hipStream_t)stream;
   if (!transA && split_k == 1) {  // tall-skinny, small K: B resident in LDS, A streamed through registers
-    int r = try_gemm_smallk(transB, M, N, K, A, lda, B, ldb, out, accumulate, st);
+    int r = try_gemm_smallk(transB, M, N, K, A, lda, B, ldb, out, accumulate, split, st);
     if (r < 0) return r;
     if (r == 1) return PYGAT_OK;
   }
   if (transA && !transB && split_k > 1) {  // weight gradient: huge K, small M x N, no LDS
-    int r = try_gemm_tn_stream(M, N, K, A, lda, B, ldb, split_k, (float*)ws, st, N, nullptr, 0);
+    int r = try_gemm_tn_stream(M, N, K, A, lda, B, ldb, split_k, (float*)ws, split, st, N, nullptr, 0);
     if (r < 0) return r;
     if (r >= 1) {
       int64_t tot = (int64_t)M * N;
@@ -668,20 +670,23 @@ extern "C" int pygat_gemm_f32(int transA, int transB, int M, int N, int64_t K, c
 // a head is 8 / 16 LANES of one MFMA tile, its sum four DPP adds per row register (round 1 tried this with
 // ds_bpermute reductions over whole tiles, which cost more than the fifth tile they saved).
 extern "C" int pygat_project(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const float* Wcat, int64_t ldw,
-                             const float* a_pad, float* Wh, float* Sk, float* s, int split_k, void* ws, void* stream) {
+                             const float* a_pad, float* Wh, float* Sk, float* s, int split_k, void* ws, int gemm_mode,
+                             void* stream) {
   const int Fp = padded_width(Fo);
   PYGAT_REQUIRE(n > 0 && Fin > 0 && H > 0 && Fp > 0 && X && Wcat && Wh && s, "project: bad arguments");
+  PYGAT_REQUIRE(gemm_mode >= PYGAT_GEMM_DEFAULT && gemm_mode <= PYGAT_GEMM_FP32_MFMA, "project: unknown product mode %d", gemm_mode);
+  const bool split = gemm_split(gemm_mode);
   const int R = H * Fp, nw = R * (Sk ? 2 : 1), ncols = nw + H;
   PYGAT_REQUIRE(ldw >= nw + 2 * H && ldx >= Fin, "project: leading dimension too small");
   pygat_out_segments seg;
   int k = 0;
   if (a_pad && split_k <= 1) {   // heads of 8 / 16 columns, Fin 64 / 128: s = Wh . a_src from the accumulators (k1_gemm_x3.hip)
-    const int r = try_project_x3(n, Fin, H, Fp, X, ldx, Wcat, ldw, Wh, s, a_pad, (hipStream_t)stream);
+    const int r = try_project_x3(n, Fin, H, Fp, X, ldx, Wcat, ldw, Wh, s, a_pad, split, (hipStream_t)stream);
     if (r < 0) return r;
     if (r == 1) {
       if (!Sk) return PYGAT_OK;
       seg.nseg = 1; seg.col_start[0] = 0; seg.col_start[1] = R; seg.ptr[0] = Sk; seg.ld[0] = R;
-      return pygat_gemm_f32(0, 0, n, R, Fin, X, ldx, Wcat + R, ldw, &seg, 0, 1, nullptr, stream);
+      return pygat_gemm_f32(0, 0, n, R, Fin, X, ldx, Wcat + R, ldw, &seg, 0, 1, nullptr, gemm_mode, stream);
     }
   }
   seg.col_start[0] = 0; seg.ptr[k] = Wh; seg.ld[k] = R; ++k;
@@ -689,14 +694,14 @@ extern "C" int pygat_project(int n, int Fin, int H, int Fo, const float* X, int6
   static const bool sv_off = getenv("PYGAT_K1_NO_SV") != nullptr;   // development knob: s as GEMM columns everywhere
   if (H <= 8 && split_k <= 1 && !sv_off) {   // s on the VALU of the small-K kernel, no MFMA tile for it
     seg.col_start[k] = nw; seg.nseg = k;
-    const int r = try_gemm_smallk(0, n, nw, Fin, X, ldx, Wcat, ldw, &seg, 0, (hipStream_t)stream, Wcat + nw, ldw, H, s, H);
+    const int r = try_gemm_smallk(0, n, nw, Fin, X, ldx, Wcat, ldw, &seg, 0, split, (hipStream_t)stream, Wcat + nw, ldw, H, s, H);
     if (r < 0) return r;
     if (r == 1) return PYGAT_OK;
   }
   seg.col_start[k] = nw; seg.ptr[k] = s; seg.ld[k] = H; ++k;
   seg.col_start[k] = ncols;
   seg.nseg = k;
-  return pygat_gemm_f32(0, 0, n, ncols, Fin, X, ldx, Wcat, ldw, &seg, 0, split_k, ws, stream);
+  return pygat_gemm_f32(0, 0, n, ncols, Fin, X, ldx, Wcat, ldw, &seg, 0, split_k, ws, gemm_mode, stream);
 }
 
 // Weight gradient of one level (autograd of layers.py:35,134):  dW_h = X^T dWh_h, all heads in one GEMM.
@@ -728,8 +733,11 @@ extern "C" size_t pygat_wgrad_workspace_bytes(int Fin, int H, int Fo, int split_
 }
 
 extern "C" int pygat_wgrad(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const float* dWh, const float* ds,
-                           const float* a_pad, float* dW, int split_k, void* ws, int h_first, int h_count, void* stream) {
+                           const float* a_pad, float* dW, int split_k, void* ws, int h_first, int h_count, int gemm_mode,
+                           void* stream) {
   const int Fp = padded_width(Fo);
+  PYGAT_REQUIRE(gemm_mode >= PYGAT_GEMM_DEFAULT && gemm_mode <= PYGAT_GEMM_FP32_MFMA, "wgrad: unknown product mode %d", gemm_mode);
+  const bool split = gemm_split(gemm_mode);
   PYGAT_REQUIRE(n > 0 && Fin > 0 && H > 0 && Fp > 0 && X && dWh && dW && ws && ldx >= Fin, "wgrad: bad arguments");
   PYGAT_REQUIRE(!ds || a_pad, "wgrad: ds needs a_pad");
   if (h_count == 0 && h_first == 0) h_count = H;
@@ -750,11 +758,11 @@ extern "C" int pygat_wgrad(int n, int Fin, int H, int Fo, const float* X, int64_
   pygat_out_segments seg;
   seg.nseg = 1; seg.col_start[0] = 0; seg.ptr[0] = dWc; seg.ld[0] = ldc;
   bool done = false;
-  if (ds && split_k > 1 && gemm_split_mode() && R > 64 && Fin > 64) {
+  if (ds && split_k > 1 && split && R > 64 && Fin > 64) {
     // split-bf16 mode: the wide part on the split kernel (it takes one B operand), the H columns of ds in a second,
     // narrow streamed-K pass over X -- 0.1 ms of extra reading against 45 % fewer MFMA cycles on the R columns
     seg.col_start[1] = R;
-    int r = try_gemm_tn_stream(Fin, R, n, X, ldx, dWh, ldd, split_k, slabs, st, R, nullptr, 0);
+    int r = try_gemm_tn_stream(Fin, R, n, X, ldx, dWh, ldd, split_k, slabs, split, st, R, nullptr, 0);
     if (r < 0) return r;
     if (r >= 1) {
       hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)cdiv((int64_t)Fin * R, 64)), dim3(512), 0, st, Fin, R, r,
@@ -764,14 +772,14 @@ extern "C" int pygat_wgrad(int n, int Fin, int H, int Fo, const float* X, int64_
       seg2.nseg = 1; seg2.col_start[0] = 0; seg2.col_start[1] = H; seg2.ptr[0] = dWc + R; seg2.ld[0] = ldc;
       int64_t sk2 = (int64_t)split_k * (R + H) / H;   // slabs of the narrow pass that fit the same workspace
       if (sk2 > 256) sk2 = 256;
-      const int r2 = try_gemm_tn_stream(Fin, H, n, X, ldx, ds, lds, (int)sk2, slabs, st, H, nullptr, 0);
+      const int r2 = try_gemm_tn_stream(Fin, H, n, X, ldx, ds, lds, (int)sk2, slabs, split, st, H, nullptr, 0);
       if (r2 < 0) return r2;
       if (r2 >= 1) {
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)cdiv((int64_t)Fin * H, 64)), dim3(512), 0, st, Fin, H, r2,
                            (const float*)slabs, seg2, 0);
         PYGAT_CHECK_LAUNCH("wgrad(reduce ds)");
       } else {
-        const int rc = pygat_gemm_f32(1, 0, Fin, H, n, X, ldx, ds, lds, &seg2, 0, split_k, slabs, stream);
+        const int rc = pygat_gemm_f32(1, 0, Fin, H, n, X, ldx, ds, lds, &seg2, 0, split_k, slabs, gemm_mode, stream);
         if (rc) return rc;
       }
       done = true;
@@ -779,7 +787,7 @@ extern "C" int pygat_wgrad(int n, int Fin, int H, int Fo, const float* X, int64_
   }
   if (!done && ds && split_k > 1) {                 // one streamed-K GEMM over [dWh | ds]
     seg.col_start[1] = R + H;
-    int r = try_gemm_tn_stream(Fin, R + H, n, X, ldx, dWh, ldd, split_k, slabs, st, R, ds, lds);
+    int r = try_gemm_tn_stream(Fin, R + H, n, X, ldx, dWh, ldd, split_k, slabs, split, st, R, ds, lds);
     if (r < 0) return r;
     if (r >= 1) {
       const int64_t tot = (int64_t)Fin * (R + H);
@@ -791,11 +799,11 @@ extern "C" int pygat_wgrad(int n, int Fin, int H, int Fo, const float* X, int64_
   }
   if (!done) {                                      // any shape: the general path, once per operand
     seg.col_start[1] = R;
-    int rc = pygat_gemm_f32(1, 0, Fin, R, n, X, ldx, dWh, ldd, &seg, 0, split_k, slabs, stream);
+    int rc = pygat_gemm_f32(1, 0, Fin, R, n, X, ldx, dWh, ldd, &seg, 0, split_k, slabs, gemm_mode, stream);
     if (rc) return rc;
     if (ds) {
       seg.col_start[1] = H; seg.ptr[0] = dWc + R;
-      rc = pygat_gemm_f32(1, 0, Fin, H, n, X, ldx, ds, lds, &seg, 0, split_k, slabs, stream);
+      rc = pygat_gemm_f32(1, 0, Fin, H, n, X, ldx, ds, lds, &seg, 0, split_k, slabs, gemm_mode, stream);
       if (rc) return rc;
     }
   }

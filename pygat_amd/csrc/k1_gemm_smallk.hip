@@ -254,7 +254,7 @@ static hipError_t launch_smallk(const SmallKArgs& g, int NT, dim3 grid, size_t l
 
 // returns 1 if the fast path took the call, 0 if the shape does not qualify, <0 on launch error
 int try_gemm_smallk(int transB, int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
-                    const pygat_out_segments* out, int accumulate, hipStream_t st, const float* svec, int64_t sv_ld,
+                    const pygat_out_segments* out, int accumulate, bool split, hipStream_t st, const float* svec, int64_t sv_ld,
                     int sv_n, float* s_out, int64_t s_ld) {
   if (K < 32 || K > 256 || (K % 32) != 0 || M < 8192) return 0;
   if (!aligned16(A) || (lda % 4) != 0) return 0;
@@ -274,7 +274,7 @@ int try_gemm_smallk(int transB, int M, int N, int64_t K, const float* A, int64_t
   if (gx < 1) gx = 1;
   if (gx > g.tiles_m) gx = g.tiles_m;
   dim3 grid((unsigned)gx, (unsigned)tiles_n, 1);
-  if (gemm_split_mode()) {   // the same GEMM on the bf16 MFMA pipe from exactly split operands (k1_gemm_x3.hip)
+  if (split) {   // the same GEMM on the bf16 MFMA pipe from exactly split operands (k1_gemm_x3.hip)
     const int r = try_gemm_smallk_x3(g, NT, grid, st);
     if (r != 0) return r;
   }
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void gemm_tn_wide_kernel(TnArgs g) {
 // picks the slab count, launches; returns the number of slabs written to ws (>= 1), 0 if the shape
 // does not qualify, < 0 on error.  ws must hold max_splits * M * N floats.
 int try_gemm_tn_stream(int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
-                       int max_splits, float* ws, hipStream_t st, int N1, const float* B2, int64_t ldb2) {
+                       int max_splits, float* ws, bool split, hipStream_t st, int N1, const float* B2, int64_t ldb2) {
   if (K < 4096 || (int64_t)M * N > 512 * 512 || max_splits < 1 || !ws) return 0;
   if (!B2) N1 = N;
   if (B2 && (N1 <= 0 || N1 >= N || (N1 % 32) != 0)) return 0;
@@ -506,7 +506,7 @@ int try_gemm_tn_stream(int M, int N, int64_t K, const float* A, int64_t lda, con
   g.N1 = N1; g.B2 = B2; g.ldb2 = ldb2;
   // the wide-load variant re-fetches A four times (once per wave) and measured slower (3.5 GB of HBM
   // reads for a 1 GB problem); it stays selectable for experiments
-  if (gemm_split_mode()) {
+  if (split) {
     const int64_t kps16 = cdiv(cdiv(K, max_splits), 48) * 48;
     TnArgs gx = g;
     gx.k_per_split = kps16;

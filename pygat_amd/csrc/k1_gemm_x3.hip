@@ -473,9 +473,9 @@ int try_gemm_smallk_x3(const SmallKArgs& g, int NT, dim3 grid, hipStream_t st) {
 }
 
 int try_project_x3(int n, int Fin, int H, int Fp, const float* X, int64_t ldx, const float* Wcat, int64_t ldw, float* Wh,
-                   float* s, const float* a_pad, hipStream_t st) {
+                   float* s, const float* a_pad, bool split, hipStream_t st) {
   const int R = H * Fp;
-  if (!gemm_split_mode() || !a_pad || (Fp != 8 && Fp != 16) || (R % 32) != 0 || (Fin != 64 && Fin != 128) || n < 8192) return 0;
+  if (!split || !a_pad || (Fp != 8 && Fp != 16) || (R % 32) != 0 || (Fin != 64 && Fin != 128) || n < 8192) return 0;
   if (!aligned16(X) || (ldx % 4) != 0) return 0;
   const int nt_r = R / 32;
   if (nt_r > 4 && (nt_r % 4) != 0) return 0;   // (whole 128-column tiles only: narrower ones re-read X once per tile)

@@ -36,7 +36,7 @@ import os
 from . import _lib, ops
 from ._lib import lib, check, padded_width
 from .graph import CSRGraph, slot_edges_for
-from .ops import _Level, _ptr, _span, _stream, gemm
+from .ops import _Level, _ptr, _span, _stream, gemm, gemm_mode, get_gemm_mode
 
 
 STREAM_X, STREAM_WH, STREAM_ATT = 1, 2, 3     # Philox stream ids of the three masks drawn from one seed
@@ -92,6 +92,7 @@ class GATLevelDropoutFn(torch.autograd.Function):
         HF, R, E = H * Fin, L.R, graph.nnz
         ncb = R * (2 if skip else 1)
         p = float(p)
+        ctx.gemm_mode = get_gemm_mode()     # the backward (an autograd thread) forms its GEMM products the same way
         with torch.cuda.device(dev):
             st = _stream()
             if explicit:
@@ -171,7 +172,7 @@ class GATLevelDropoutFn(torch.autograd.Function):
         G = G.contiguous().float()
         HF, R, Fin = H * L.Fin, L.R, L.Fin
         ncb = Bp.shape[1]
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), gemm_mode(ctx.gemm_mode):
             st = _stream()
             RW = R + 4 * H
             GR = torch.empty(L.N, RW, dtype=f32, device=dev)

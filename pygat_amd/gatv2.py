@@ -20,7 +20,7 @@ import torch.nn as nn
 from . import _lib
 from ._lib import lib, check
 from .graph import CSRGraph, as_graph
-from .ops import _Level, _ptr, _stream, gemm, gat_level
+from .ops import _Level, _ptr, _stream, gemm, gat_level, gemm_mode, get_gemm_mode
 
 
 class GATv2LevelFn(torch.autograd.Function):
@@ -57,6 +57,7 @@ class GATv2LevelFn(torch.autograd.Function):
         a2 = torch.zeros(H, Fp, dtype=f32, device=dev)
         a2[:, :Fo] = a
         need_grad = any(ctx.needs_input_grad[:4])
+        ctx.gemm_mode = get_gemm_mode()     # the backward (an autograd thread) forms its GEMM products the same way
         with torch.cuda.device(dev):
             st = _stream()
             WW = torch.empty(L.N, 2 * R, dtype=f32, device=dev)
@@ -104,7 +105,7 @@ class GATv2LevelFn(torch.autograd.Function):
         R, Fp = L.R, L.Fp
         dev, f32 = x.device, torch.float32
         G = G.contiguous().float()
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), gemm_mode(ctx.gemm_mode):
             st = _stream()
             LG = 2 * R + 4 * H
             GRW = torch.empty(L.N, LG, dtype=f32, device=dev)

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Optional, Sequence
 
 import torch
@@ -134,7 +135,7 @@ def _segments(cols_ptr_ld) -> _lib.OutSegments:
     return seg
 
 
-def _split_k(M: int, N: int, K: int, streamed_k: bool = False) -> int:
+def _split_k(M: int, N: int, K: int, streamed_k: bool = False, mode: Optional[str] = None) -> int:
     """K slabs of a GEMM.  General kernel: up to ~4 work-groups per CU, slabs of >= 256, at most 256 of them,
     and the partial sums (written + re-read) below a quarter of the operand bytes -- the dropout projection
     [N, H*Fin] x [H*Fin, R] streams a 100+ MB operand through few output tiles and wants 5-20 slabs, not the 2
@@ -142,7 +143,7 @@ def _split_k(M: int, N: int, K: int, streamed_k: bool = False) -> int:
     exactly one work-group per CU is the optimum at every width -- slabs x column tiles = 256 (128 columns:
     256 slabs 0.37 ms; 512 columns: 64 slabs 1.41 ms against 2.68 ms with 256; 1024 columns: 32 slabs)."""
     nt = -(-N // 32)
-    if streamed_k and K >= 4096 and M * N <= 512 * 512 and get_gemm_mode() == "split-bf16" and M > 64 and N > 64 \
+    if streamed_k and K >= 4096 and M * N <= 512 * 512 and (mode or get_gemm_mode()) == "split-bf16" and M > 64 and N > 64 \
             and M % 4 == 0 and N % 4 == 0:
         # the split-bf16 kernel (128 x 128 tiles through 60 KB of LDS): two work-groups per CU
         tiles = -(-M // 128) * -(-N // 128)
@@ -160,31 +161,60 @@ def _split_k(M: int, N: int, K: int, streamed_k: bool = False) -> int:
     return max(1, min(256, 1024 // tiles, K // 256, max(by_traffic, want))) if tiles < 1024 else 1
 
 
-GEMM_MODES = {"split-bf16": 0, "fp32-mfma": 1}
+GEMM_MODES = {"split-bf16": 0, "fp32-mfma": 1}     # PYGAT_GEMM_SPLIT_BF16 / PYGAT_GEMM_FP32_MFMA
+_mode_tls = threading.local()                        # the calling thread's choice; None = the library's default
 
 
-def set_gemm_mode(mode: str) -> None:
-    """'split-bf16' (default): the streamed GEMMs cut every fp32 operand exactly into three bf16 pieces and sum all
-    nine piece products in fp32 on the bf16 MFMA pipe; 'fp32-mfma': fp32 MFMA throughout (include/pygat_amd.h)."""
-    check(lib.pygat_set_gemm_mode(GEMM_MODES[mode]), "set_gemm_mode")
+def _mode_code(mode: Optional[str] = None) -> int:
+    """The `gemm_mode` argument of a C call: an explicit name, else this thread's set_gemm_mode choice, else
+    PYGAT_GEMM_DEFAULT (-1: split-bf16 unless PYGAT_GEMM_F32=1 was in the environment when the library was loaded)."""
+    mode = mode or getattr(_mode_tls, "mode", None)
+    return -1 if mode is None else GEMM_MODES[mode]
+
+
+def set_gemm_mode(mode: Optional[str]) -> None:
+    """'split-bf16': the GEMMs cut every fp32 operand exactly into three bf16 pieces and sum all nine piece products
+    in fp32 on the bf16 MFMA pipe; 'fp32-mfma': fp32 MFMA throughout; None: back to the library default
+    (include/pygat_amd.h).  The C library holds no mode: this is the CALLING THREAD's choice, handed to every GEMM
+    entry point as an argument; a level's backward uses the mode its forward ran with."""
+    if mode is not None and mode not in GEMM_MODES:
+        raise ValueError(f"gemm mode {mode!r}: expected one of {sorted(GEMM_MODES)}")
+    _mode_tls.mode = mode
 
 
 def get_gemm_mode() -> str:
-    m = lib.pygat_get_gemm_mode()
-    return next(k for k, v in GEMM_MODES.items() if v == m)
+    code = _mode_code()
+    if code < 0:
+        code = lib.pygat_default_gemm_mode()
+    return next(k for k, v in GEMM_MODES.items() if v == code)
+
+
+class gemm_mode:
+    """with pygat_amd.gemm_mode("fp32-mfma"): ...  -- the product mode of the calls made inside, this thread only."""
+
+    def __init__(self, mode: Optional[str]):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = getattr(_mode_tls, "mode", None)
+        set_gemm_mode(self.mode)
+
+    def __exit__(self, *exc):
+        _mode_tls.mode = self.prev
+        return False
 
 
 def gemm(transA: bool, transB: bool, M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor,
-         ldb: int, segments, accumulate: bool = False, split_k: Optional[int] = None) -> None:
-    """C = op(A) op(B), fp32 in / fp32 accumulate (see set_gemm_mode); `segments` = [(ncols, tensor, ld), ...]."""
+         ldb: int, segments, accumulate: bool = False, split_k: Optional[int] = None, mode: Optional[str] = None) -> None:
+    """C = op(A) op(B), fp32 in / fp32 accumulate; `segments` = [(ncols, tensor, ld), ...]; mode: see set_gemm_mode."""
     if split_k is None:
-        split_k = _split_k(M, N, K, streamed_k=transA and not transB)
+        split_k = _split_k(M, N, K, streamed_k=transA and not transB, mode=mode)
     ws = None
     if split_k > 1:
         ws = torch.empty(lib.pygat_gemm_workspace_bytes(M, N, split_k) // 4, dtype=torch.float32, device=A.device)
     seg = _segments(segments)
     check(lib.pygat_gemm_f32(int(transA), int(transB), M, N, K, A.data_ptr(), lda, B.data_ptr(), ldb,
-                             C.byref(seg), int(accumulate), split_k, _ptr(ws), _stream()), "gemm_f32")
+                             C.byref(seg), int(accumulate), split_k, _ptr(ws), _mode_code(mode), _stream()), "gemm_f32")
 
 
 class _Level:
@@ -243,6 +273,7 @@ class GATLevelFn(torch.autograd.Function):
             Wskip = Wskip.contiguous().float()
         L = _Level(x, H, Fo, skip)
         L.ts = slot_edges_for(L.R, graph.slot_edges)
+        L.mode = get_gemm_mode()     # this thread's product mode, fixed for the level: its backward (another thread) uses it too
         dev, f32 = x.device, torch.float32
         need_grad = any(ctx.needs_input_grad[:4])
         with torch.cuda.device(dev):
@@ -263,7 +294,7 @@ class GATLevelFn(torch.autograd.Function):
                 if split_k > 1 else None
             with _span("k1_project"):
                 check(lib.pygat_project(L.N, Fin, H, Fo, x.data_ptr(), Fin, Wcat.data_ptr(), L.ldw, a_pad.data_ptr(), Wh.data_ptr(),
-                                        _ptr(Sk), s.data_ptr(), split_k, _ptr(ws), st), "project")
+                                        _ptr(Sk), s.data_ptr(), split_k, _ptr(ws), GEMM_MODES[L.mode], st), "project")
             # K2
             flags = (_lib.F_ELU if concat else 0) | (_lib.F_SKIP if skip else 0)
             hattn = torch.empty(L.N, L.R, dtype=f32, device=dev) if not concat else None
@@ -378,28 +409,28 @@ class GATLevelFn(torch.autograd.Function):
             # dW = x^T dWh (split-K over the nodes), dWskip = x^T Gp
             dW = dWs = dx = None
             if ctx.needs_input_grad[1]:
-                split_k = _split_k(L.Fin, Hb * L.Fp + (Hb if fold_ds else 0), L.N, streamed_k=True)
+                split_k = _split_k(L.Fin, Hb * L.Fp + (Hb if fold_ds else 0), L.N, streamed_k=True, mode=L.mode)
                 wsw = torch.empty(lib.pygat_wgrad_workspace_bytes(L.Fin, H, Fo, split_k) // 4, dtype=f32, device=dev)
                 dW = (torch.zeros if ranged else torch.empty)(H, L.Fin, Fo, dtype=f32, device=dev)
                 with _span("k5_wgrad"):
                     check(lib.pygat_wgrad(L.N, L.Fin, H, Fo, x.data_ptr(), L.Fin, dWh.data_ptr(),
                                           ds.data_ptr() if fold_ds else None, a_pad.data_ptr(), dW.data_ptr(), split_k,
-                                          wsw.data_ptr(), hb, hr, st), "wgrad")
+                                          wsw.data_ptr(), hb, hr, GEMM_MODES[L.mode], st), "wgrad")
             if L.skip and ctx.needs_input_grad[3]:
                 dSc = torch.empty(L.Fin, L.R, dtype=f32, device=dev)
                 for c0, w, g0 in L.gp_windows():
-                    gemm(True, False, L.Fin, w, L.N, x, L.Fin, GR[:, g0:], RW, [(w, dSc[:, c0:], L.R)])
+                    gemm(True, False, L.Fin, w, L.N, x, L.Fin, GR[:, g0:], RW, [(w, dSc[:, c0:], L.R)], mode=L.mode)
                 dWs = torch.empty(H, L.Fin, Fo, dtype=f32, device=dev)
                 check(lib.pygat_unpack_wgrad(H, L.Fin, Fo, dSc.data_ptr(), L.R, 0, dWs.data_ptr(), st), "unpack")
             # dx = dWh Wcat[:, :R]^T (+ Gp Wcat[:, R:2R]^T)
             if ctx.needs_input_grad[0]:
                 dx = torch.empty(L.N, L.Fin, dtype=f32, device=dev)
                 with _span("k5_xgrad"):
-                    gemm(False, True, L.N, L.Fin, L.R, dWh, L.R, Wcat, L.ldw, [(L.Fin, dx, L.Fin)])
+                    gemm(False, True, L.N, L.Fin, L.R, dWh, L.R, Wcat, L.ldw, [(L.Fin, dx, L.Fin)], mode=L.mode)
                     if L.skip:
                         for c0, w, g0 in L.gp_windows():
                             gemm(False, True, L.N, L.Fin, w, GR[:, g0:], RW, Wcat[:, L.R + c0:], L.ldw,
-                                 [(L.Fin, dx, L.Fin)], accumulate=True, split_k=1)
+                                 [(L.Fin, dx, L.Fin)], accumulate=True, split_k=1, mode=L.mode)
             if fork:
                 main.wait_stream(side)
         cast = lambda g_, k: g_ if g_ is None or g_.dtype == ctx.in_dtypes[k] else g_.to(ctx.in_dtypes[k])  # noqa: E731

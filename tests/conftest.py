@@ -12,6 +12,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
+    from oracle import c_oracle
+    c_oracle.build_for_host()     # before any test initialises the GPU
 
 
 @pytest.fixture(scope="session")

@@ -48,11 +48,12 @@ def oracle_levels(model, dtype):
     return levels
 
 
-def oracle_run(model, x, rowptr, col, G, dtype):
-    """Logits and every gradient from the oracle (autograd through oracle.model_forward) in `dtype`."""
+def oracle_run(model, x, rowptr, col, G, dtype, flips=None):
+    """Logits and every gradient from the oracle (autograd through oracle.model_forward) in `dtype`.
+    flips: per level None or [H,E] bool, LeakyReLU branch overrides (oracle._leaky; tests/parity.py)."""
     levels = oracle_levels(model, dtype)
     xx = torch.as_tensor(x).to(dtype).requires_grad_(True)
-    y = O.model_forward(xx, (rowptr, col), levels, model.alpha, "sparse")
+    y = O.model_forward(xx, (rowptr, col), levels, model.alpha, "sparse", flips=flips)
     y.backward(torch.as_tensor(G).to(dtype))
     grads = {}
     for li, lv in enumerate(levels, start=1):

@@ -57,7 +57,7 @@ def test_argument_validation_returns_einval(lib):
     # null pointers / bad sizes are rejected before anything is launched
     assert L.pygat_dense_row_counts(None, 4, 4, 0, None, None) == -1
     assert b"bad arguments" in L.pygat_last_error()
-    assert L.pygat_gemm_f32(0, 0, 4, 4, 4, None, 4, None, 4, None, 0, 1, None, None) == -1
+    assert L.pygat_gemm_f32(0, 0, 4, 4, 4, None, 4, None, 4, None, 0, 1, None, -1, None) == -1
     g = lib.Graph(0, 0, None, None, 64, None, None, 0, 0)
     assert L.pygat_gat_forward(C.byref(g), 8, 16, 0.2, 1, None, None, None, None, None, None, None, None, None, None, None, None, None) == -1
     assert b"graph" in L.pygat_last_error()
@@ -76,18 +76,36 @@ QUERIES = {"pygat_abi_version", "pygat_last_error", "pygat_padded_width", "pygat
            "pygat_scan_workspace_bytes", "pygat_gemm_workspace_bytes", "pygat_partials_bytes", "pygat_head_group",
            "pygat_agrad_workspace_bytes", "pygat_gatv2_workspace_bytes", "pygat_wgrad_workspace_bytes",
            "pygat_headmask_supported", "pygat_project_dropout_workspace_bytes", "pygat_wgrad_dropout_workspace_bytes",
-           "pygat_set_gemm_mode", "pygat_get_gemm_mode"}
+           "pygat_default_gemm_mode"}
 
 
-def test_gemm_mode_switch(lib):
-    """Default: the exact three-way bf16 split; the fp32-MFMA kernels stay selectable; unknown modes are refused."""
+def test_gemm_mode_is_a_call_argument(lib, monkeypatch):
+    """The product mode of a GEMM is an ARGUMENT of the entry points that run one (ABI 11): the library exports no
+    setter -- no process-global mutable state besides the thread-local error string -- only the immutable default
+    (split-bf16 unless PYGAT_GEMM_F32=1 was in the environment at load).  Unknown modes are refused per call.  The
+    Python mirror keeps the choice per THREAD and hands it down with every call."""
+    import threading
     L = lib.lib
-    start = L.pygat_get_gemm_mode()
-    assert start in (0, 1)
-    assert L.pygat_set_gemm_mode(1) == 0 and L.pygat_get_gemm_mode() == 1
-    assert L.pygat_set_gemm_mode(0) == 0 and L.pygat_get_gemm_mode() == 0
-    assert L.pygat_set_gemm_mode(7) == -1 and b"unknown mode" in L.pygat_last_error()
-    assert L.pygat_set_gemm_mode(start) == 0
+    assert not hasattr(L, "pygat_set_gemm_mode") and not hasattr(L, "pygat_get_gemm_mode")
+    assert L.pygat_default_gemm_mode() in (0, 1)
+    seg = lib.OutSegments()
+    assert L.pygat_gemm_f32(0, 0, 4, 4, 4, 1, 4, 1, 4, C.byref(seg), 0, 1, None, 7, None) == -1
+    assert b"unknown product mode" in L.pygat_last_error()
+    assert L.pygat_project(4, 4, 1, 4, 1, 4, 1, 8, None, 1, None, 1, 1, None, -2, None) == -1
+    assert b"unknown product mode" in L.pygat_last_error()
+    assert L.pygat_wgrad(4, 4, 1, 4, 1, 4, 1, None, None, 1, 1, 1, 0, 0, 2, None) == -1
+    assert b"unknown product mode" in L.pygat_last_error()
+    from pygat_amd import ops
+    ops.set_gemm_mode(None)
+    assert ops._mode_code() == -1 and ops.get_gemm_mode() == ("split-bf16", "fp32-mfma")[L.pygat_default_gemm_mode()]
+    seen = {}
+    with ops.gemm_mode("fp32-mfma"):
+        assert ops.get_gemm_mode() == "fp32-mfma" and ops._mode_code() == 1 and ops._mode_code("split-bf16") == 0
+        t = threading.Thread(target=lambda: seen.setdefault("other", ops._mode_code()))   # another thread: its own choice
+        t.start(); t.join()
+    assert seen["other"] == -1 and ops._mode_code() == -1
+    with pytest.raises(ValueError):
+        ops.set_gemm_mode("fp16")
 
 
 def test_every_launcher_rejects_null_arguments(lib):

@@ -8,7 +8,8 @@ import pytest
 import torch
 
 from oracle import gat_oracle as O
-from test_gpu_parity import close, params, pg  # noqa: F401
+from parity import check_autograd, close_grad
+from test_gpu_parity import params, pg  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
@@ -34,10 +35,11 @@ def test_dropout_explicit_masks(pg, monkeypatch, two_gather, H, Fin, Fo, skip, c
     keep = lambda *s: (torch.rand(*s, generator=gen) >= p).double() / (1 - p)  # noqa: E731
     mx, mwh, matt = keep(H, N, Fin), keep(H, N, Fo), keep(E, H)
     # oracle (sparse formulation, masks per head; att mask is [H,E] there)
-    leaves = [t.clone().requires_grad_(True) for t in (x, W, a)] + ([Sk.clone().requires_grad_(True)] if skip else [])
-    y = O.level_forward(leaves[0], (rowptr, col), leaves[1], leaves[2], 0.2, concat, leaves[3] if skip else None,
-                        "sparse", dict(x=mx, wh=mwh, att=matt.t().contiguous()))
-    gr = torch.autograd.grad(y, leaves, G)
+    leaves = [x, W, a] + ([Sk] if skip else [])
+
+    def oracle(*lv):
+        mk = dict(x=mx.to(lv[0].dtype), wh=mwh.to(lv[0].dtype), att=matt.t().contiguous().to(lv[0].dtype))
+        return O.level_forward(lv[0], (rowptr, col), lv[1], lv[2], 0.2, concat, lv[3] if skip else None, "sparse", mk)
     dev = "cuda:0"
     g = pg.CSRGraph(torch.as_tensor(rowptr, device=dev), torch.as_tensor(col, device=dev), slot_edges=16)
     xd = x.float().to(dev).requires_grad_(True)
@@ -47,12 +49,10 @@ def test_dropout_explicit_masks(pg, monkeypatch, two_gather, H, Fin, Fo, skip, c
     masks = dict(x=mx.float().to(dev), wh=mwh.float().to(dev), att=matt.float().to(dev))
     out = gat_level_dropout(xd, g, Ws, As, Ss, 0.2, concat, p, masks=masks)
     out.backward(G.float().to(dev))
-    close(out, y.detach().numpy(), "out")
-    close(xd.grad, gr[0].numpy(), "dX")
-    close(torch.stack([w.grad for w in Ws]), gr[1].numpy(), "dW")
-    close(torch.stack([w.grad.reshape(-1) for w in As]), gr[2].numpy(), "da")
+    got = [xd.grad, torch.stack([w.grad for w in Ws]), torch.stack([w.grad.reshape(-1) for w in As])]
     if skip:
-        close(torch.stack([w.grad for w in Ss]), gr[3].numpy(), "dW_skip")
+        got.append(torch.stack([w.grad for w in Ss]))
+    check_autograd(out, got, oracle, leaves, G, ["dX", "dW", "da", "dW_skip"], what=f"dropout[{H},{Fin},{Fo},{skip},{concat}]")
 
 
 def test_dropout_statistics_and_model_train_mode(pg, topologies):  # noqa: F811
@@ -213,12 +213,12 @@ def test_headmask_projection_and_weight_gradient(pg, N, Fin, H, Fo, skip):  # no
         xm = x.double() * Mc[h]
         ref = xm @ W[h].double()
         got = Wh.view(N, H, Fp)[:, h, :Fo].double().cpu()
-        assert float((got - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), (fsplit, h)
+        close_grad(got, ref, (xm.float() @ W[h]).double(), f"Wh fsplit {fsplit} head {h}")
         if Fp > Fo:
             assert float(Wh.view(N, H, Fp)[:, h, Fo:].abs().max()) == 0.0
         if skip:
             refs = xm @ Ws[h].double()
-            assert float((Sk.view(N, H, Fp)[:, h, :Fo].double().cpu() - refs).abs().max()) <= 1e-5 * max(1.0, float(refs.abs().max()))
+            close_grad(Sk.view(N, H, Fp)[:, h, :Fo], refs, (xm.float() @ Ws[h]).double(), f"Sk fsplit {fsplit} head {h}")
     # weight gradient: dWc [Fin, R (+R)] = (x o m_h)^T [dWh_h | Gp_h]
     dWh = torch.randn(N, R, generator=gen).to(dev)
     RW = R + 4 * H
@@ -231,16 +231,18 @@ def test_headmask_projection_and_weight_gradient(pg, N, Fin, H, Fo, skip):  # no
                                       GR.data_ptr() if skip else None, RW, dWc.data_ptr(), split_k, ws.data_ptr(), None))
         for h in range(H):
             xm = x.double() * Mc[h]
-            ref = xm.t() @ dWh.view(N, H, Fp)[:, h].double().cpu()
+            d_h = dWh.view(N, H, Fp)[:, h].cpu()
+            ref = xm.t() @ d_h.double()
             got = dWc[:, h * Fp:(h + 1) * Fp].double().cpu()
-            assert float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), (split_k, h)
+            close_grad(got, ref, (xm.float().t() @ d_h).double(), f"dWc split_k {split_k} head {h}")
             if skip:
-                refs = xm.t() @ GR[:, h * Fp:(h + 1) * Fp].double().cpu()
+                g_h = GR[:, h * Fp:(h + 1) * Fp].cpu()
+                refs = xm.t() @ g_h.double()
                 gots = dWc[:, R + h * Fp:R + (h + 1) * Fp].double().cpu()
-                assert float((gots - refs).abs().max()) <= 2e-5 * max(1.0, float(refs.abs().max())), (split_k, h)
+                close_grad(gots, refs, (xm.float().t() @ g_h).double(), f"dWc skip split_k {split_k} head {h}")
     # head sum under the same bytes
     dxe = torch.randn(N, H * Fin, generator=gen).to(dev)
     dx = torch.empty(N, Fin, device=dev)
     check(lib.pygat_dropout_head_sum_bits(N, Fin, H, dxe.data_ptr(), H * Fin, bits.data_ptr(), p, dx.data_ptr(), Fin, 0, None))
     ref = (Mc.permute(1, 0, 2) * dxe.view(N, H, Fin).double().cpu()).sum(1)
-    assert float((dx.double().cpu() - ref).abs().max()) < 1e-4
+    close_grad(dx, ref, (Mc.permute(1, 0, 2).float() * dxe.view(N, H, Fin).cpu()).sum(1).double(), "head sum under the mask bytes")

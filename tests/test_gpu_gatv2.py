@@ -4,7 +4,8 @@ import pytest
 import torch
 
 from oracle import gat_oracle as O
-from test_gpu_parity import close, pg  # noqa: F401
+from parity import check_autograd, close_fwd
+from test_gpu_parity import pg  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
@@ -34,9 +35,8 @@ def test_sparse_v2_level(pg, H, Fin, Fo, skip, concat, slot, symmetric):  # noqa
     gen = torch.Generator().manual_seed(5)
     x = torch.randn(N, Fin, dtype=torch.float64, generator=gen)
     G = torch.randn(N, H * Fo if concat else Fo, dtype=torch.float64, generator=gen)
-    leaves = [t.clone().requires_grad_(True) for t in (x, W, a)] + ([Sk.clone().requires_grad_(True)] if skip else [])
-    y = O.level_forward_v2(leaves[0], (rowptr, col), leaves[1], leaves[2], 0.2, concat, leaves[3] if skip else None)
-    gr = torch.autograd.grad(y, leaves, G)
+    leaves = [x, W, a] + ([Sk] if skip else [])
+    oracle = lambda *lv: O.level_forward_v2(lv[0], (rowptr, col), lv[1], lv[2], 0.2, concat, lv[3] if skip else None)  # noqa: E731
     dev = "cuda:0"
     g = pg.CSRGraph(torch.as_tensor(rowptr, device=dev), torch.as_tensor(col, device=dev), slot_edges=slot)
     xd = x.float().to(dev).requires_grad_(True)
@@ -45,10 +45,8 @@ def test_sparse_v2_level(pg, H, Fin, Fo, skip, concat, slot, symmetric):  # noqa
     Sd = Sk.float().to(dev).requires_grad_(True) if skip else None
     out = pg.GATv2LevelFn.apply(xd, Wd, ad, Sd, g, 0.2, concat)
     out.backward(G.float().to(dev))
-    close(out, y.detach().numpy(), "out")
-    close(xd.grad, gr[0].numpy(), "dX"); close(Wd.grad, gr[1].numpy(), "dW"); close(ad.grad, gr[2].numpy(), "da")
-    if skip:
-        close(Sd.grad, gr[3].numpy(), "dW_skip")
+    check_autograd(out, [xd.grad, Wd.grad, ad.grad] + ([Sd.grad] if skip else []), oracle, leaves, G,
+                   ["dX", "dW", "da", "dW_skip"], what=f"v2[{H},{Fin},{Fo},{skip},{concat},slot {slot},sym {symmetric}]")
 
 
 def test_v2_dropin_layers_and_model(pg, topologies):  # noqa: F811
@@ -62,7 +60,8 @@ def test_v2_dropin_layers_and_model(pg, topologies):  # noqa: F811
     yd = d(x.cuda(), adj.cuda())
     ref = O.dense_head_forward_v2(x.double(), adj.double(), d.W.detach().double().cpu(), d.a.detach().double().cpu(), 0.2,
                                   True, d.skip_projection.detach().double().cpu())
-    close(yd, ref.numpy(), "dense V2")
+    ref32 = O.dense_head_forward_v2(x, adj, d.W.detach().cpu(), d.a.detach().cpu(), 0.2, True, d.skip_projection.detach().cpu())
+    close_fwd(yd, ref.numpy(), "dense V2", ref32.double().numpy())
     yd.sum().backward()
     assert d.a.grad is not None and float(d.a.grad.abs().max()) == 0.0
     assert float(d.W.grad[:Fin].abs().max()) == 0.0 and float(d.W.grad[Fin:].abs().max()) > 0.0
@@ -71,7 +70,8 @@ def test_v2_dropin_layers_and_model(pg, topologies):  # noqa: F811
     s = pg.SpGraphAttentionLayerV2(Fin, Fo, 0.0, 0.2, concat=False).cuda()
     ys = s(x.cuda(), adj.cuda())
     ref = O.sparse_head_forward_v2(x.double(), rowptr, col, s.W.detach().double().cpu(), s.a.detach().double().cpu(), 0.2, False)
-    close(ys, ref.numpy(), "sparse V2")
+    ref32 = O.sparse_head_forward_v2(x, rowptr, col, s.W.detach().cpu(), s.a.detach().cpu(), 0.2, False)
+    close_fwd(ys, ref.numpy(), "sparse V2", ref32.double().numpy())
     # model: --model GATv2_sparse (train.py:117), 8 heads then 1
     torch.manual_seed(4)
     m = pg.GAT([Fin, 8, 7], [8, 1], 2, 0.0, 0.2, pg.SpGraphAttentionLayerV2).cuda()
@@ -84,7 +84,11 @@ def test_v2_dropin_layers_and_model(pg, topologies):  # noqa: F811
                            0.2, True)
     ref = O.level_forward_v2(h, (rowptr, col), sd["attention_layer_2_head_1.W"].double().cpu()[None],
                              sd["attention_layer_2_head_1.a"].double().cpu().reshape(1, -1), 0.2, False)
-    close(y, ref.numpy(), "GATv2_sparse model")
+    h32 = O.level_forward_v2(x, (rowptr, col), torch.stack([sd[f"attention_layer_1_head_{j}.W"].cpu() for j in range(1, 9)]),
+                             torch.stack([sd[f"attention_layer_1_head_{j}.a"].cpu().reshape(-1) for j in range(1, 9)]), 0.2, True)
+    ref32 = O.level_forward_v2(h32, (rowptr, col), sd["attention_layer_2_head_1.W"].cpu()[None],
+                               sd["attention_layer_2_head_1.a"].cpu().reshape(1, -1), 0.2, False)
+    close_fwd(y, ref.numpy(), "GATv2_sparse model", ref32.double().numpy())
     y.sum().backward()
     assert all(p.grad is not None for p in m.parameters())
     # dense V2 in train mode (train.py:54,116 default for --model GATv2): runs (parity: test_dense_v2_dropout_explicit_masks)
@@ -114,11 +118,13 @@ def test_sparse_v2_dropout_explicit_masks(pg, H, Fin, Fo, skip, concat):  # noqa
     G = torch.randn(N, H * Fo if concat else Fo, dtype=torch.float64, generator=gen)
     keep = lambda *s: (torch.rand(*s, generator=gen) >= p).double() / (1 - p)  # noqa: E731
     mx, mi, mj, matt = keep(H, N, Fin), keep(H, N, Fo), keep(H, N, Fo), keep(E, H)
-    leaves = [t.clone().requires_grad_(True) for t in (x, W, a)] + ([Sk.clone().requires_grad_(True)] if skip else [])
-    outs = [O.sparse_head_forward_v2(leaves[0], rowptr, col, leaves[1][h], leaves[2][h], 0.2, concat,
-                                     leaves[3][h] if skip else None, mx[h], mi[h], mj[h], matt[:, h]) for h in range(H)]
-    y = torch.cat(outs, 1) if concat else torch.mean(torch.stack(outs, 1), 1)
-    gr = torch.autograd.grad(y, leaves, G)
+    leaves = [x, W, a] + ([Sk] if skip else [])
+
+    def oracle(*lv):
+        c = lambda m: m.to(lv[0].dtype)  # noqa: E731
+        outs = [O.sparse_head_forward_v2(lv[0], rowptr, col, lv[1][h], lv[2][h], 0.2, concat, lv[3][h] if skip else None,
+                                         c(mx[h]), c(mi[h]), c(mj[h]), c(matt[:, h])) for h in range(H)]
+        return torch.cat(outs, 1) if concat else torch.mean(torch.stack(outs, 1), 1)
     dev = "cuda:0"
     g = pg.CSRGraph(torch.as_tensor(rowptr, device=dev), torch.as_tensor(col, device=dev), slot_edges=16)
     xd = x.float().to(dev).requires_grad_(True)
@@ -128,11 +134,10 @@ def test_sparse_v2_dropout_explicit_masks(pg, H, Fin, Fo, skip, concat):  # noqa
     masks = dict(x=mx.float().to(dev), whi=mi.float().to(dev), whj=mj.float().to(dev), att=matt.float().to(dev))
     out = gatv2_level(xd, g, Ws, As, Ss, 0.2, concat, p, masks=masks)
     out.backward(G.float().to(dev))
-    close(out, y.detach().numpy(), "out"); close(xd.grad, gr[0].numpy(), "dX")
-    close(torch.stack([w.grad for w in Ws]), gr[1].numpy(), "dW")
-    close(torch.stack([w.grad.reshape(-1) for w in As]), gr[2].numpy(), "da")
+    got = [xd.grad, torch.stack([w.grad for w in Ws]), torch.stack([w.grad.reshape(-1) for w in As])]
     if skip:
-        close(torch.stack([w.grad for w in Ss]), gr[3].numpy(), "dW_skip")
+        got.append(torch.stack([w.grad for w in Ss]))
+    check_autograd(out, got, oracle, leaves, G, ["dX", "dW", "da", "dW_skip"], what=f"v2 dropout[{H},{Fin},{Fo},{skip},{concat}]")
 
 
 @pytest.mark.parametrize("skip,concat", [(False, True), (True, True), (True, False)])
@@ -155,26 +160,24 @@ def test_dense_v2_dropout_explicit_masks(pg, skip, concat):  # noqa: F811
     layer = pg.GraphAttentionLayerV2(Fin, Fo, p, 0.2, concat=concat, skip_connection=skip).to("cuda:0").train()
     x = torch.randn(N, Fin, generator=gen, dtype=torch.float64)
     G = torch.randn(N, Fo, generator=gen, dtype=torch.float64)
-    leaves = [x.clone().requires_grad_(True), layer.W.detach().double().cpu().requires_grad_(True),
-              layer.a.detach().double().cpu().requires_grad_(True)]
+    leaves = [x, layer.W.detach().double().cpu(), layer.a.detach().double().cpu()]
     if skip:
-        leaves.append(layer.skip_projection.detach().double().cpu().requires_grad_(True))
-    y = O.dense_head_forward_v2(leaves[0], adj, leaves[1], leaves[2], 0.2, concat, leaves[3] if skip else None,
-                                mask_x=mx, mask_wh1=mwh1, mask_wh2=mwh2, mask_att=matt)
-    gr = torch.autograd.grad(y, leaves, G, allow_unused=True)
+        leaves.append(layer.skip_projection.detach().double().cpu())
+
+    def oracle(*lv):
+        c = lambda m: m.to(lv[0].dtype)  # noqa: E731
+        return O.dense_head_forward_v2(lv[0], c(adj), lv[1], lv[2], 0.2, concat, lv[3] if skip else None,
+                                       mask_x=c(mx), mask_wh1=c(mwh1), mask_wh2=c(mwh2), mask_att=c(matt))
     dev = "cuda:0"
     g = pg.CSRGraph(torch.as_tensor(rowptr, device=dev), torch.as_tensor(col, device=dev))
     xd = x.float().to(dev).requires_grad_(True)
     masks = {"x": mx.float().to(dev)[None], "wh": mwh2.float().to(dev)[None], "att": matt_e.float().to(dev)[:, None]}
     out = layer(xd, g, masks=masks)
     out.backward(G.float().to(dev))
-    close(out, y.detach().numpy(), "out")
-    close(xd.grad, gr[0].numpy(), "dX")
-    close(layer.W.grad, gr[1].numpy(), "dW")
+    _, (_, gr) = check_autograd(out, [xd.grad, layer.W.grad, None] + ([layer.skip_projection.grad] if skip else []), oracle,
+                                leaves, G, ["dX", "dW", "da", "dW_skip"], what=f"dense v2 dropout[{skip},{concat}]")
     assert float(layer.W.grad[:Fin].abs().max()) == 0.0 and float(layer.a.grad.abs().max()) == 0.0
     assert gr[2] is None or float(gr[2].abs().max()) < 1e-10      # mathematically zero (uniform attention)
-    if skip:
-        close(layer.skip_projection.grad, gr[3].numpy(), "dW_skip")
     # in-kernel masks: runs, finite, differs from eval
     out2 = layer(xd, g)
     assert torch.isfinite(out2).all() and float((out2 - layer.eval()(xd, g)).abs().max()) > 1e-3

@@ -1,4 +1,4 @@
-"""The streamed GEMMs in their two arithmetic modes (include/pygat_amd.h, pygat_set_gemm_mode).
+"""The streamed GEMMs in their two arithmetic modes (include/pygat_amd.h: the `gemm_mode` argument of the GEMM entry points).
 
 'split-bf16' cuts every fp32 operand exactly into three bf16 pieces and sums all nine piece products into fp32
 accumulators on the bf16 MFMA pipe (pygat_amd/csrc/k1_gemm_x3.hip); 'fp32-mfma' is v_mfma_f32_32x32x2_f32 throughout.
@@ -22,9 +22,8 @@ def pg():
 
 
 def _run(pg, mode, tA, tB, M, N, K, A, B, **kw):
-    pg.set_gemm_mode(mode)
     C = torch.full((M, N), float("nan"), device="cuda")
-    pg.gemm(tA, tB, M, N, K, A, A.shape[1], B, B.shape[1], [(N, C, N)], **kw)
+    pg.gemm(tA, tB, M, N, K, A, A.shape[1], B, B.shape[1], [(N, C, N)], mode=mode, **kw)
     torch.cuda.synchronize()
     return C
 
@@ -132,10 +131,9 @@ def test_projection_with_s_columns_both_modes(pg, n, Fin, H, Fo, with_a):
     s64 = torch.einsum("nhf,hf->nh", Wh64, a[:, :Fo].double())
     res = {}
     for mode in ("fp32-mfma", "split-bf16"):
-        pg.set_gemm_mode(mode)
         Wh = torch.full((n, R), float("nan"), device="cuda"); s = torch.full((n, H), float("nan"), device="cuda")
         check(lib.pygat_project(n, Fin, H, Fo, x.data_ptr(), Fin, Wcat.data_ptr(), ldw, a_pad.data_ptr() if with_a else None,
-                                Wh.data_ptr(), None, s.data_ptr(), 1, None, None), "project")
+                                Wh.data_ptr(), None, s.data_ptr(), 1, None, pg.ops.GEMM_MODES[mode], None), "project")
         torch.cuda.synchronize()
         eW = float((Wh.view(n, H, Fp)[:, :, :Fo].double() - Wh64).abs().max() / Wh64.abs().max())
         eS = float((s.double() - s64).abs().max() / s64.abs().max())
@@ -165,11 +163,10 @@ def test_projection_with_skip_both_modes(pg):
     Sk64 = torch.einsum("nk,hkf->nhf", x.double(), Ws.double())
     s64 = torch.einsum("nhf,hf->nh", Wh64, a[:, :Fo].double())
     for mode in ("fp32-mfma", "split-bf16"):
-        pg.set_gemm_mode(mode)
         Wh = torch.full((n, R), float("nan"), device="cuda"); Sk = torch.full((n, R), float("nan"), device="cuda")
         s = torch.full((n, H), float("nan"), device="cuda")
         check(lib.pygat_project(n, Fin, H, Fo, x.data_ptr(), Fin, Wcat.data_ptr(), ldw, a_pad.data_ptr(), Wh.data_ptr(), Sk.data_ptr(),
-                                s.data_ptr(), 1, None, None), "project")
+                                s.data_ptr(), 1, None, pg.ops.GEMM_MODES[mode], None), "project")
         torch.cuda.synchronize()
         for got, ref, what in ((Wh.view(n, H, Fp)[:, :, :Fo], Wh64, "Wh"), (Sk.view(n, H, Fp)[:, :, :Fo], Sk64, "Sk"), (s, s64, "s")):
             err = float((got.double() - ref).abs().max() / ref.abs().max())

@@ -23,13 +23,12 @@ for Fin, H, Fo in [(128, 8, 16), (128, 8, 8), (128, 4, 16), (128, 2, 16), (128, 
     Wh = torch.empty(n, R, device="cuda"); s = torch.empty(n, H, device="cuda")
     res = {}
     for mode in ("fp32-mfma", "split-bf16"):
-        pg.set_gemm_mode(mode)
         ts = []
         for _ in range(12):
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
             check(lib.pygat_project(n, Fin, H, Fo, x.data_ptr(), Fin, Wcat.data_ptr(), ldw, a_pad.data_ptr(), Wh.data_ptr(), None,
-                                    s.data_ptr(), 1, None, None), "project")
+                                    s.data_ptr(), 1, None, pg.ops.GEMM_MODES[mode], None), "project")
             e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
         res[mode] = float(np.median(ts[3:]))
     gb = 4.0 * n * (Fin + R + H) / 1e9

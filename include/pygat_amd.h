@@ -342,7 +342,10 @@ int pygat_unpack_blockdiag(int H, int Fin, int Fo, const float* dBp, int64_t ldb
  * in LDS with its mask bytes and the heads are an inner loop over the MFMA fragments (a_h = bit_h ? x : 0):
  *   pygat_project_dropout     [Wh | Sk] = 1/(1-p) (X .* m_h) [W_h | Wskip_h]           Wcat from pygat_pack_params;
  *                             split_k K slabs over Fin for graphs with few 128-row tiles
- *   pygat_wgrad_dropout       dWc [Fin x R (+R)] = 1/(1-p) (X .* m_h)^T [dWh_h | Gp_h]  (then pygat_unpack_wgrad)
+ *   pygat_wgrad_dropout       dWc [Fin x R (+R)] = 1/(1-p) (X .* m_h)^T [dWh_h | Gp_h]  (then pygat_unpack_wgrad);
+ *                             split_k K slabs over the nodes: a slab is ONE fp32 accumulator chain per output, so give
+ *                             slabs of a few hundred rows (pygat_amd/dropout.py: >= 64 rows until the chip is full) when
+ *                             the result should match a blocked CPU product to its last bits
  *   pygat_dropout_head_sum_bits  dx[i,k] (+)= 1/(1-p) sum_h bit_h[i,k] dxe[i, h*Fin + k]
  * Memory: N*Fin bytes instead of N*H*Fin*4 (Citeseer: 12 MB instead of 394 MB); no products with zero blocks.
  * X must be dense (ldx == Fin).  Explicit masks (tests) are packed into the same bytes by the caller. */

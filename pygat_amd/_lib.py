@@ -9,6 +9,12 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch FIRST: it brings its own HIP runtime (torch/lib/libamdhip64.so); libpygat_amd.so must bind to that one.  Loaded
+# before torch, the library pulls in /opt/rocm/lib/libamdhip64.so.7 instead, the process then holds two HIP runtimes and
+# the library's launches fail with "no ROCm-capable device is detected" while torch sees the GPU (met on the GPU box when
+# __graft_entry__.build() imported the package before anything had imported torch).
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpygat_amd.so")
 

@@ -172,11 +172,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   const int64_t kend = (kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 
-  f32x16 acc[NT];
+  // Two-level accumulation.  An MFMA accumulator is ONE fp32 summation chain over k: after n additions its rounding
+  // error has grown like n (every addition rounds at the size of the running sum), where a CPU BLAS -- 64 and more
+  // independent partial sums -- stays near sqrt(n): a K = 384 input gradient sat at 4.5 x, a K = 9001 chain at 7.5 x
+  // the error of the fp32 CPU product (tests/parity.py prices every result at <= 4 x).  So the chain is cut: every
+  // FLUSH k the running tile is added into a second register set and restarted from zero (chains of FLUSH / 2 small
+  // sums + K / FLUSH large ones; K = 1024: a third of the error).  Costs 16 NT registers, which is why the
+  // 192- and 256-column tiles of the first version are gone (launch_gemm: at most 160 columns per tile).
+  constexpr int FLUSH_TILES = 64 / BK;
+  f32x16 acc[NT], acc2[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; acc2[i][r] = 0.f; }
+  auto flush = [&]() {
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc2[i][r] += acc[i][r]; acc[i][r] = 0.f; }
+  };
 
   constexpr bool EXACT = (BN * BK / 4) % 256 == 0;      // the B tile is a whole number of float4 per thread
   // branch-free staging loads (see load_*_fast): uniform in the launch
@@ -265,6 +279,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
           if (kt + 2 < nkt) sstore(0);
           __syncthreads();
         }
+        if (((kt >> 1) % (FLUSH_TILES / 2)) == FLUSH_TILES / 2 - 1) flush();
       }
     } else {
       if (nkt > 0) {
@@ -278,11 +293,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         mma_tile(buf);
         if (kt + 1 < nkt) sstore(buf ^ 1);
         __syncthreads();
+        if ((kt % FLUSH_TILES) == FLUSH_TILES - 1) flush();
       }
     }
   };
   if (interior) kloop(std::true_type{});
   else kloop(std::false_type{});
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] += acc2[i][r];
 
   // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -552,8 +572,7 @@ static int launch_headmask(const HeadMaskArgs& g, int splits, hipStream_t st) {
 template <bool TA, bool TB>
 static int launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
   const int nt_needed = (int)cdiv(g.N, 32);
-  int NT = nt_needed <= 1 ? 1 : nt_needed <= 2 ? 2 : nt_needed <= 3 ? 3 : nt_needed <= 4 ? 4
-         : nt_needed <= 5 ? 5 : nt_needed <= 6 ? 6 : nt_needed <= 8 ? 8 : 4;
+  int NT = nt_needed <= 1 ? 1 : nt_needed <= 2 ? 2 : nt_needed <= 3 ? 3 : nt_needed <= 4 ? 4 : nt_needed <= 5 ? 5 : 4;
   dim3 grid((unsigned)cdiv(g.M, BM), (unsigned)cdiv(g.N, 32 * NT), (unsigned)splits);
   // 32-deep k-tiles for the 128-column tile: PYGAT_GEMM_BK=32 (development knob; measured on the PPI level-2
   // projection 3144 x 2056 x 1024: 189 us with 16-deep tiles, 219 us with 32-deep ones -- 66 KB of LDS leave two
@@ -580,9 +599,7 @@ static int launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
         hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 4, 16>), grid, dim3(256), lds(4, 16), st, g);
       }
       break;
-    case 5: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 5, 16>), grid, dim3(256), lds(5, 16), st, g); break;
-    case 6: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 6, 16>), grid, dim3(256), lds(6, 16), st, g); break;
-    default: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 8, 16>), grid, dim3(256), lds(8, 16), st, g); break;
+    default: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 5, 16>), grid, dim3(256), lds(5, 16), st, g); break;
   }
   return 0;
 }
@@ -594,6 +611,8 @@ int try_gemm_tn_stream(int M, int N, int64_t K, const float* A, int64_t lda, con
                        int max_splits, float* ws, bool split, hipStream_t st, int N1, const float* B2, int64_t ldb2);
 int try_project_x3(int n, int Fin, int H, int Fp, const float* X, int64_t ldx, const float* Wcat, int64_t ldw, float* Wh,
                    float* s, const float* a_pad, bool split, hipStream_t st);
+int try_gemm_x3g(int transA, int transB, int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                 const pygat_out_segments* out, int accumulate, int splits, int64_t k_per_split, float* ws, hipStream_t st);
 bool gemm_split(int mode);
 
 }  // namespace pygat
@@ -635,6 +654,20 @@ extern "C" int pygat_gemm_f32(int transA, int transB, int M, int N, int64_t K, c
       hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)cdiv(tot, 64)), dim3(512), 0, st, M, N, r,
                          (const float*)ws, *out, accumulate);
       PYGAT_CHECK_LAUNCH("gemm_splitk_reduce");
+      return PYGAT_OK;
+    }
+  }
+  if (split) {   // any layout on the bf16 pipe from exactly split operands (gemm_x3g_kernel); odd shapes fall through
+    const int64_t kps16 = cdiv(cdiv(K, split_k), 16) * 16;
+    const int sp = (int)cdiv(K, kps16);
+    const int r = try_gemm_x3g(transA, transB, M, N, K, A, lda, B, ldb, out, accumulate, sp, kps16, (float*)ws, st);
+    if (r < 0) return r;
+    if (r == 1) {
+      if (sp > 1) {
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)cdiv((int64_t)M * N, 64)), dim3(512), 0, st, M, N, sp,
+                           (const float*)ws, *out, accumulate);
+        PYGAT_CHECK_LAUNCH("gemm_splitk_reduce");
+      }
       return PYGAT_OK;
     }
   }

@@ -668,4 +668,260 @@ int try_gemm_tn_x3(const TnArgs& g, int splits, hipStream_t st) {
   return splits;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same pipeline for ANY operand layout: C[M x N] = op(A) op(B) with every product formed from the exact three-way
+// bf16 split (projections with K > 256 or few rows: the PPI levels' 1024 -> 1024 GEMMs, layers.py:35,134,48,166; their
+// input gradients dX = dWh W^T; GATv2's projections; weight gradients the streamed-K kernel above does not take).
+// gemm_tn_x3_kernel is the (k-strided, k-strided) case of it and stays as tuned for the headline's dW.
+//
+// An operand is either K-STRIDED ([K x cols], cols contiguous: A of a transA call, B of a plain one) and staged as
+// above -- thread (kp, c4) loads rows 2 kp, 2 kp + 1 x 4 columns and writes the packed (k even, k odd) pieces as dwords --
+// or K-CONTIGUOUS ([rows x K]: A of a plain call, B of a transB one): thread (h = (tid >> 4) & 1, row = (tid & 15) +
+// 16 (tid >> 5)) loads the 8 floats k0 + 8 h .. + 7 of its row (two 16-byte loads; a row's 16 k of a step are one
+// 64-byte sector), splits the four (k, k + 1) pairs and writes each piece's four dwords as two ds_write_b64 into the
+// SAME image layout ([row or column][16 k], 40-byte rows): the 16 lanes of a ds_write_b64 group hold 16 consecutive
+// rows of one h, 16 x 40 bytes hit the 16 even banks, the pair fills the odd ones -- conflict-free like the dword
+// writes of the k-strided stage.  Consumer side, scheduling (split + LDS writes of step i + 1 between the MFMAs of
+// step i, 9-MFMA regions), the three-slot load ring and the two LDS stages are those of the kernel above.
+//
+// Two-level accumulation (see gemm_f32_kernel): every 96 k the running 64 x 64 block is added into a second register
+// set.  DIRECT output (ws == nullptr): rows / columns routed to the output segments, optional accumulate; otherwise
+// slab blockIdx.x of the split-K workspace.
+// Needs 16-byte aligned rows: ld % 4 == 0 for both operands, K % 4 == 0 and 4-aligned slabs for a k-contiguous one,
+// the contiguous extent (M or N) % 4 == 0 for a k-strided one.
+struct X3gArgs {
+  int M, N;
+  int64_t K;
+  const float* A;
+  int64_t lda;
+  const float* B;
+  int64_t ldb;
+  int64_t k_per_split;
+  float* ws;
+  pygat_out_segments out;
+  int accumulate;
+};
+
+struct X3gSlot {      // one step of both operands, in flight
+  float4 a0, a1, b0, b1;
+};
+
+template <bool KCA, bool KCB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_x3g_kernel(X3gArgs g) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_xg[];   // [2 * TNX_STAGE]: 60 KB, two work-groups per CU
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.z * 128;
+  const int64_t kbeg = (int64_t)blockIdx.x * g.k_per_split;
+  const int64_t kend = (kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K;
+  const int nsteps = (int)((kend - kbeg + 15) / 16);
+  // loader roles
+  const int kp = tid & 7, c4 = tid >> 3;                                  // k-strided
+  const int lh = (tid >> 4) & 1, lrow = (tid & 15) + 16 * (tid >> 5);     // k-contiguous
+  const float* la;
+  const float* lb;
+  if constexpr (KCA) la = g.A + (int64_t)((m0 + lrow < g.M) ? m0 + lrow : g.M - 1) * g.lda;   // rows past M: the last row
+  else la = g.A + ((m0 + 4 * c4 + 3 < g.M) ? m0 + 4 * c4 : 0);                                 // columns past M: column 0
+  if constexpr (KCB) lb = g.B + (int64_t)((n0 + lrow < g.N) ? n0 + lrow : g.N - 1) * g.ldb;
+  else lb = g.B + ((n0 + 4 * c4 + 3 < g.N) ? n0 + 4 * c4 : 0);
+  // (their products only reach rows / columns of C that are never stored)
+
+  auto load = [&](X3gSlot& r, int step) {
+    const int st = step < nsteps ? step : nsteps - 1;
+    const int64_t ks = kbeg + 16 * (int64_t)st;
+    {   // k-strided addressing (rows 2 kp, 2 kp + 1 of the step)
+      const int64_t k = ks + 2 * kp;
+      const int64_t k0 = k < kend ? k : kend - 1, k1 = k + 1 < kend ? k + 1 : kend - 1;
+      if constexpr (!KCA) { r.a0 = ld4(la + k0 * g.lda); r.a1 = ld4(la + k1 * g.lda); }
+      if constexpr (!KCB) { r.b0 = ld4(lb + k0 * g.ldb); r.b1 = ld4(lb + k1 * g.ldb); }
+    }
+    {   // k-contiguous addressing (floats 8 lh .. + 7 of the step)
+      const int64_t k = ks + 8 * lh;
+      const int64_t k0 = k < kend ? k : kend - 4, k1 = k + 4 < kend ? k + 4 : kend - 4;
+      if constexpr (KCA) { r.a0 = ld4(la + k0); r.a1 = ld4(la + k1); }
+      if constexpr (KCB) { r.b0 = ld4(lb + k0); r.b1 = ld4(lb + k1); }
+    }
+  };
+  // half H (0 / 1) of one operand's split + LDS writes: two of the step's eight "put units"
+  auto put_strided = [&](uint32_t* img, const float4& x0, const float4& x1, float z0, float z1, auto half_tag) {
+    constexpr int HALF = decltype(half_tag)::value;
+    float p0, p1, q0, q1;
+    if constexpr (HALF == 0) { p0 = x0.x; p1 = x1.x; q0 = x0.y; q1 = x1.y; } else { p0 = x0.z; p1 = x1.z; q0 = x0.w; q1 = x1.w; }
+    uint32_t h, m, l;
+    split_pair(p0 * z0, p1 * z1, h, m, l);
+    uint32_t* d = img + (4 * c4 + 2 * HALF) * TNX_RS + kp;
+    d[0] = h; d[TNX_IMG] = m; d[2 * TNX_IMG] = l;
+    split_pair(q0 * z0, q1 * z1, h, m, l);
+    d += TNX_RS;
+    d[0] = h; d[TNX_IMG] = m; d[2 * TNX_IMG] = l;
+  };
+  auto put_contig = [&](uint32_t* img, const float4& x, float z) {   // one float4 = two (k, k + 1) pairs
+    uint32_t h0, m0_, l0, h1, m1, l1;
+    split_pair(x.x * z, x.y * z, h0, m0_, l0);
+    split_pair(x.z * z, x.w * z, h1, m1, l1);
+    return [=](uint32_t* d) {
+      *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(d + TNX_IMG) = make_uint2(m0_, m1);
+      *reinterpret_cast<uint2*>(d + 2 * TNX_IMG) = make_uint2(l0, l1);
+    }(img);
+  };
+  // A's copy of k positions past the slab is zeroed (only the last step of a slab has any): step index -> 1 / 0 factors
+  // of the thread's two rows (k-strided) or two float4 (k-contiguous), recomputed here instead of riding in the ring
+  auto put_a = [&](const X3gSlot& r, int stage, int step_of_r, auto half_tag) {
+    constexpr int HALF = decltype(half_tag)::value;
+    uint32_t* img = lds_xg + stage * TNX_STAGE;
+    const int64_t ks = kbeg + 16 * (int64_t)step_of_r;
+    if constexpr (KCA) {
+      const int64_t k = ks + 8 * lh + 4 * HALF;
+      put_contig(img + lrow * TNX_RS + 4 * lh + 2 * HALF, HALF == 0 ? r.a0 : r.a1, k < kend ? 1.f : 0.f);
+    } else {
+      const int64_t k = ks + 2 * kp;
+      put_strided(img, r.a0, r.a1, k < kend ? 1.f : 0.f, k + 1 < kend ? 1.f : 0.f, half_tag);
+    }
+  };
+  auto put_b = [&](const X3gSlot& r, int stage, auto half_tag) {
+    constexpr int HALF = decltype(half_tag)::value;
+    uint32_t* img = lds_xg + stage * TNX_STAGE + 3 * TNX_IMG;
+    if constexpr (KCB) put_contig(img + lrow * TNX_RS + 4 * lh + 2 * HALF, HALF == 0 ? r.b0 : r.b1, 1.f);
+    else put_strided(img, r.b0, r.b1, 1.f, 1.f, half_tag);
+  };
+
+  f32x16 acc[2][2], acc2[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acc2[i][j][r] = 0.f; }
+  // consumer role: wave (w >> 1, w & 1) owns rows 64 (w >> 1) .., columns 64 (w & 1) .. of the tile
+  const uint32_t* fa = lds_xg + (64 * (w >> 1) + fr) * TNX_RS + 4 * fh;
+  const uint32_t* fb = lds_xg + 3 * TNX_IMG + (64 * (w & 1) + fr) * TNX_RS + 4 * fh;
+
+  using H0 = std::integral_constant<int, 0>;
+  using H1 = std::integral_constant<int, 1>;
+  // one step: global loads of step i + 2, fragment reads of stage i & 1 (FIRST in program order, see the kernel
+  // above), then per 32 x 32 tile of the wave's block its nine MFMAs with a quarter of step i + 1's split between them
+  auto step = [&](const X3gSlot& rs, X3gSlot& rl, int i) {
+    load(rl, i + 2);
+    uint4 fq[4][3];
+    {
+      const uint32_t* a_ = fa + (i & 1) * TNX_STAGE;
+      const uint32_t* b_ = fb + (i & 1) * TNX_STAGE;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        fq[0][p] = ld_frag(a_ + p * TNX_IMG);
+        fq[1][p] = ld_frag(a_ + p * TNX_IMG + 32 * TNX_RS);
+        fq[2][p] = ld_frag(b_ + p * TNX_IMG);
+        fq[3][p] = ld_frag(b_ + p * TNX_IMG + 32 * TNX_RS);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int sn = (i + 1) & 1;   // (past the last step: clamped data into the idle stage)
+    auto quarter = [&](auto tm_tag, auto tn_tag) {
+      constexpr int TM = decltype(tm_tag)::value, TN = decltype(tn_tag)::value;
+      Frag3 af;
+      af.h = __builtin_bit_cast(U4, fq[TM][0]); af.m = __builtin_bit_cast(U4, fq[TM][1]); af.l = __builtin_bit_cast(U4, fq[TM][2]);
+      acc[TM][TN] = mma9(af, fq[2 + TN][0], fq[2 + TN][1], fq[2 + TN][2], acc[TM][TN]);
+#pragma unroll
+      for (int m = 0; m < 9; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        if (m < 6) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    put_a(rs, sn, i + 1, H0{}); quarter(H0{}, H0{});
+    put_a(rs, sn, i + 1, H1{}); quarter(H0{}, H1{});
+    put_b(rs, sn, H0{}); quarter(H1{}, H0{});
+    put_b(rs, sn, H1{}); quarter(H1{}, H1{});
+    __syncthreads();
+  };
+
+  // two-slot load ring (the streamed-K kernel above keeps three: here the second accumulator set takes the registers,
+  // and two co-resident work-groups x two steps x 16 KB are 64 KB in flight per CU): step i splits the slot loaded
+  // during step i - 1 and refills the other one with step i + 2
+  X3gSlot r0, r1;
+  load(r0, 0);
+  __builtin_amdgcn_sched_barrier(0);   // (issue order = wait order)
+  load(r1, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  put_a(r0, 0, 0, H0{}); put_a(r0, 0, 0, H1{}); put_b(r0, 0, H0{}); put_b(r0, 0, H1{});
+  __syncthreads();
+  for (int i = 0; i < nsteps; i += 2) {
+    step(r1, r0, i);
+    if (i + 1 < nsteps) step(r0, r1, i + 1);
+    if (((i >> 1) % 3) == 2) {      // every 6 steps = 96 k
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { acc2[a][b][r] += acc[a][b][r]; acc[a][b][r] = 0.f; }
+    }
+  }
+  const int wm0 = m0 + 64 * (w >> 1), wn0 = n0 + 64 * (w & 1);
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int col = wn0 + 32 * tn + fr;
+      if (col >= g.N) continue;
+      float* base;
+      int64_t ld;
+      if (g.ws) { base = g.ws + (int64_t)blockIdx.x * g.M * g.N + col; ld = g.N; }
+      else base = out_segment(g.out, col, ld);
+      const bool add = !g.ws && g.accumulate;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm0 + 32 * tm + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (row < g.M) {
+          float* p = base + (int64_t)row * ld;
+          const float v = acc[tm][tn][r] + acc2[tm][tn][r];
+          *p = add ? *p + v : v;
+        }
+      }
+    }
+}
+
+// 1: took the call (slabs, if any, are in ws: the caller reduces them); 0: shape does not qualify; < 0: launch error
+int try_gemm_x3g(int transA, int transB, int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                 const pygat_out_segments* out, int accumulate, int splits, int64_t k_per_split, float* ws, hipStream_t st) {
+  if (M <= 64 || N <= 64 || K < 32) return 0;
+  if (!aligned16(A) || !aligned16(B) || (lda % 4) != 0 || (ldb % 4) != 0) return 0;
+  const bool kca = !transA, kcb = transB != 0;
+  if ((kca || kcb) && ((K % 4) != 0 || (k_per_split % 4) != 0)) return 0;
+  if ((!kca && (M % 4) != 0) || (!kcb && (N % 4) != 0)) return 0;
+  if (splits > 1 && (!ws || (k_per_split % 16) != 0)) return 0;
+  X3gArgs g;
+  g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb;
+  g.k_per_split = splits > 1 ? k_per_split : K;
+  g.ws = splits > 1 ? ws : nullptr;
+  g.out = *out; g.accumulate = accumulate;
+  dim3 grid((unsigned)splits, (unsigned)cdiv(M, 128), (unsigned)cdiv(N, 128));
+  constexpr size_t lds = 2 * TNX_STAGE * sizeof(uint32_t);
+#define PYGAT_X3G_LAUNCH(KA, KB)                                                                                          \
+  do {                                                                                                                    \
+    int dev = -1;                                                                                                         \
+    (void)hipGetDevice(&dev);                                                                                             \
+    static bool attr_set[64] = {};                                                                                        \
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3g_kernel<KA, KB>),                                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                    \
+      if (dev >= 0 && dev < 64) attr_set[dev] = true;                                                                     \
+    }                                                                                                                     \
+    hipLaunchKernelGGL((gemm_x3g_kernel<KA, KB>), grid, dim3(256), lds, st, g);                                           \
+  } while (0)
+  if (kca && kcb) PYGAT_X3G_LAUNCH(true, true);
+  else if (kca) PYGAT_X3G_LAUNCH(true, false);
+  else if (kcb) PYGAT_X3G_LAUNCH(false, true);
+  else PYGAT_X3G_LAUNCH(false, false);
+#undef PYGAT_X3G_LAUNCH
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("gemm_x3g: %s", hipGetErrorString(e));
+    return PYGAT_EHIP;
+  }
+  return 1;
+}
+
 }  // namespace pygat

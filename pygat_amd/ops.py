@@ -135,7 +135,14 @@ def _segments(cols_ptr_ld) -> _lib.OutSegments:
     return seg
 
 
-def _split_k(M: int, N: int, K: int, streamed_k: bool = False, mode: Optional[str] = None) -> int:
+def _x3g_takes(transA: bool, transB: bool, M: int, N: int, K: int) -> bool:
+    """Shapes the general split-bf16 kernel takes (csrc/k1_gemm_x3.hip try_gemm_x3g; rows are assumed 16-byte aligned)."""
+    kca, kcb = not transA, transB
+    return (M > 64 and N > 64 and K >= 32 and ((K % 4) == 0 or not (kca or kcb)) and (kca or M % 4 == 0)
+            and (kcb or N % 4 == 0))
+
+
+def _split_k(M: int, N: int, K: int, streamed_k: bool = False, mode: Optional[str] = None, transB: bool = False) -> int:
     """K slabs of a GEMM.  General kernel: up to ~4 work-groups per CU, slabs of >= 256, at most 256 of them,
     and the partial sums (written + re-read) below a quarter of the operand bytes -- the dropout projection
     [N, H*Fin] x [H*Fin, R] streams a 100+ MB operand through few output tiles and wants 5-20 slabs, not the 2
@@ -151,7 +158,15 @@ def _split_k(M: int, N: int, K: int, streamed_k: bool = False, mode: Optional[st
     if streamed_k and K >= 4096 and M * N <= 512 * 512:
         tiles = -(-M // 128) * -(-N // (32 * min(nt, 5 if nt == 5 else 4)))
         return max(1, min(256 // tiles, K // 256)) if tiles < 256 else 1
-    bn = 32 * (nt if nt <= 8 else 4)
+    if (mode or get_gemm_mode()) == "split-bf16" and _x3g_takes(streamed_k, transB, M, N, K) and not (not streamed_k and K <= 256 and M >= 8192):
+        # general split kernel, 128 x 128 tiles, two work-groups per CU.  Its partial sums are expensive (written and
+        # re-read by the reduce launch): measured on PPI level 2 (tools/gemm_bench.py --splits), projection 3144 x 2056 x
+        # 1024 (425 tiles) 145 / 221 us at 1 / 2 slabs, input gradient 3144 x 1024 x 1024 (200 tiles) 82 / 115 us, weight
+        # gradient 1024 x 1024 x 3144 (64 tiles) 217 / 140 / 105 / 89 / 82 us at 1 / 2 / 3 / 4 / 8: slabs only when the
+        # tiles alone leave most of the chip idle, then up to 512 work-groups
+        tiles = -(-M // 128) * -(-N // 128)
+        return 1 if tiles >= 96 else max(1, min(K // 256, 512 // tiles))
+    bn = 32 * (nt if nt <= 5 else 4)
     tiles = -(-M // 128) * -(-N // bn)
     by_traffic = int(0.125 * K * (M + N) / (M * N))
     # weight-gradient shapes of the general kernel (K = nodes, few output tiles) want ~2 work-groups per CU: the PPI
@@ -208,7 +223,7 @@ def gemm(transA: bool, transB: bool, M: int, N: int, K: int, A: torch.Tensor, ld
          ldb: int, segments, accumulate: bool = False, split_k: Optional[int] = None, mode: Optional[str] = None) -> None:
     """C = op(A) op(B), fp32 in / fp32 accumulate; `segments` = [(ncols, tensor, ld), ...]; mode: see set_gemm_mode."""
     if split_k is None:
-        split_k = _split_k(M, N, K, streamed_k=transA and not transB, mode=mode)
+        split_k = _split_k(M, N, K, streamed_k=transA and not transB, mode=mode, transB=transB)
     ws = None
     if split_k > 1:
         ws = torch.empty(lib.pygat_gemm_workspace_bytes(M, N, split_k) // 4, dtype=torch.float32, device=A.device)

@@ -130,14 +130,38 @@ def _kink_deltas(ref, X, W, a, rowptr, col, alpha, with_dx):
 
 
 def _explain(resid, cols, names):
-    """0/1 flip vector that best explains the residual (all tensors jointly, each scaled to unit maximum)."""
+    """0/1 flip vector that best explains the residual, all tensors jointly.  Every tensor is scaled to unit maximum
+    of its RESIDUAL (a tensor no candidate touches -- an upper level's parameters in a multi-level model -- then simply
+    does not take part, instead of having its rounding noise blown up).  Start: rounded least squares and the empty
+    set; then single toggles are accepted while they lower |resid - A sigma|^2 by at least 0.1 %: the result never
+    explains less than "no flips" does."""
     if not cols:
         return np.zeros(0)
-    sc = {n: 1.0 / max(np.abs(np.stack([c[n] for c in cols])).max(), 1e-300) for n in names}
+    sc = {n: 1.0 / max(float(np.abs(resid[n]).max()), 1e-300) for n in names}
     A = np.stack([np.concatenate([(c[n] * sc[n]).ravel() for n in names]) for c in cols], 1)
     b = np.concatenate([(resid[n] * sc[n]).ravel() for n in names])
-    sig, *_ = np.linalg.lstsq(A, b, rcond=None)
-    return (sig > 0.5).astype(np.float64)
+    Gm, cb, bb = A.T @ A, A.T @ b, float(b @ b)
+    cost = lambda s_: bb - 2.0 * float(s_ @ cb) + float(s_ @ Gm @ s_)  # noqa: E731
+    lsq, *_ = np.linalg.lstsq(A, b, rcond=None)
+    best, best_cost = None, None
+    for start in (np.zeros(len(cols)), (lsq > 0.5).astype(np.float64)):
+        s_ = start.copy()
+        cur = cost(s_)
+        improved = True
+        while improved:
+            improved = False
+            gs = Gm @ s_
+            for k in range(len(cols)):
+                d = 1.0 - 2.0 * s_[k]                                   # +1: switch flip k on, -1: off
+                delta = d * (2.0 * gs[k] - 2.0 * cb[k]) + Gm[k, k]       # change of the cost (d^2 = 1)
+                if delta < -1e-3 * max(cur, 1e-300):
+                    s_[k] += d
+                    cur += delta
+                    gs = Gm @ s_
+                    improved = True
+        if best is None or cur < best_cost:
+            best, best_cost = s_, cur
+    return best
 
 
 def close_level_grads(got, X, rowptr, col, W, a, alpha, concat, G, Wskip=None, what="level", factor=4.0, floor=ATOL):

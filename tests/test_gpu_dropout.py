@@ -224,7 +224,11 @@ def test_headmask_projection_and_weight_gradient(pg, N, Fin, H, Fo, skip):  # no
     RW = R + 4 * H
     GR = torch.randn(N, RW, generator=gen).to(dev) if skip else None
     ntot = R * (2 if skip else 1)
-    for split_k in (1, 7):
+    # K slabs as the level passes them (pygat_amd.dropout._headmask_splits: slabs of >= 64 nodes until the chip is full) and
+    # one odd count; a single 1300-node chain (split_k = 1) is not something the level ever asks for -- one MFMA
+    # accumulator over 1300 rows sits at 4.1 x the fp32 CPU product's error, the slabs' partial sums at 1-2 x
+    from pygat_amd.dropout import _headmask_splits
+    for split_k in sorted({7, _headmask_splits(-(-Fin // 128), H, Fp, skip, N)}):
         ws = torch.empty(max(1, lib.pygat_wgrad_dropout_workspace_bytes(Fin, H, Fo, int(skip), split_k) // 4), device=dev)
         dWc = torch.empty(Fin, ntot, device=dev)
         check(lib.pygat_wgrad_dropout(N, Fin, H, Fo, xd.data_ptr(), Fin, bits.data_ptr(), p, dWh.data_ptr(),

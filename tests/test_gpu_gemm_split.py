@@ -36,6 +36,12 @@ SHAPES = [
     (False, True, 10007, 100, 64), (False, True, 70001, 100, 64), (False, False, 70001, 72, 128), (False, False, 300000, 128, 64),
     (True, False, 128, 128, 100000), (True, False, 100, 200, 65537), (True, False, 72, 130, 50001),
     (True, False, 256, 256, 20011),
+    # the general split kernel (gemm_x3g_kernel: any layout, K > 256 or few rows): the PPI levels' projections, input and
+    # weight gradients, ragged M / N, K tails of a step (K % 16 != 0) and of the accumulator flush period
+    (False, False, 3144, 2056, 1024), (False, True, 3144, 1024, 1024), (True, False, 1024, 1024, 3144),
+    (False, False, 1612, 1548, 1024), (False, True, 1000, 1024, 768), (True, False, 1024, 260, 3144),
+    (False, False, 131, 132, 36), (False, True, 65, 67, 100), (True, False, 68, 72, 333), (False, False, 4097, 520, 260),
+    (False, True, 20000, 128, 512),
 ]
 
 
@@ -95,6 +101,47 @@ def test_split_mode_is_exact_where_fp32_is(pg, tA, big):
     for mode in ("fp32-mfma", "split-bf16"):
         C = _run(pg, mode, tA, False, M, N, K, As, Bf)
         assert torch.equal(C, ref), mode
+
+
+@pytest.mark.parametrize("tA,tB", [(False, False), (False, True), (True, False)])
+def test_general_split_kernel_is_exact_where_fp32_is(pg, tA, tB):
+    """The same bit-exactness argument for the general split kernel (K = 1024, a PPI-sized operand), every operand layout:
+    full-mantissa values on one side against a signed power-of-two selection matrix on the other, both ways round, plus
+    split-K slabs and accumulation onto an existing C (exact as long as C holds a multiple of the result's ulp: 0 here)."""
+    M, N, K = 1612, 1028, 1024
+    g = torch.Generator(device="cuda").manual_seed(17)
+
+    def full(r, c):
+        return ((torch.randint(0, 2, (r, c), device="cuda", generator=g).float() * 2 - 1) *
+                torch.randint(1 << 23, 1 << 24, (r, c), device="cuda", generator=g).float() *
+                torch.exp2(torch.randint(-20, 21, (r, c), device="cuda", generator=g).float()))
+
+    def select(rows, cols, along_rows):
+        """one nonzero (a signed power of two) per row (along_rows) or per column of a [rows, cols] matrix"""
+        S = torch.zeros(rows, cols, device="cuda")
+        n = rows if along_rows else cols
+        val = torch.exp2(torch.randint(-8, 9, (n,), device="cuda", generator=g).float()) * \
+            (torch.randint(0, 2, (n,), device="cuda", generator=g).float() * 2 - 1)
+        if along_rows:
+            S[torch.arange(rows, device="cuda"), torch.randint(0, cols, (rows,), device="cuda", generator=g)] = val
+        else:
+            S[torch.randint(0, rows, (cols,), device="cuda", generator=g), torch.arange(cols, device="cuda")] = val
+        return S
+    opA = lambda T: T.t().contiguous() if tA else T      # noqa: E731  stored form of a logical [M, K] / [K, N] operand
+    opB = lambda T: T.t().contiguous() if tB else T      # noqa: E731
+    cases = [(full(M, K), select(K, N, False)),           # every output = one full-mantissa A value x a power of two
+             (select(M, K, True), full(K, N))]
+    for Al, Bl in cases:
+        ref = (Al.double() @ Bl.double()).float()
+        A, B = opA(Al), opB(Bl)
+        for mode in ("fp32-mfma", "split-bf16"):
+            for sk in (1, 3):
+                C = _run(pg, mode, tA, tB, M, N, K, A, B, split_k=sk)
+                assert torch.equal(C, ref), (mode, sk)
+        C = torch.zeros(M, N, device="cuda")
+        pg.gemm(tA, tB, M, N, K, A, A.shape[1], B, B.shape[1], [(N // 2, C, N), (N - N // 2, C[:, N // 2:], N)], accumulate=True,
+                split_k=1, mode="split-bf16")
+        assert torch.equal(C, ref)
 
 
 def test_small_integers_sum_exactly(pg):

@@ -688,7 +688,7 @@ int try_gemm_tn_x3(const TnArgs& g, int splits, hipStream_t st) {
 // set.  DIRECT output (ws == nullptr): rows / columns routed to the output segments, optional accumulate; otherwise
 // slab blockIdx.x of the split-K workspace.
 // Needs 16-byte aligned rows: ld % 4 == 0 for both operands, K % 4 == 0 and 4-aligned slabs for a k-contiguous one,
-// the contiguous extent (M or N) % 4 == 0 for a k-strided one.
+// the contiguous extent (M or N) of a k-strided one a multiple of 4 or its rows padded to one.
 struct X3gArgs {
   int M, N;
   int64_t K;
@@ -721,9 +721,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const float* la;
   const float* lb;
   if constexpr (KCA) la = g.A + (int64_t)((m0 + lrow < g.M) ? m0 + lrow : g.M - 1) * g.lda;   // rows past M: the last row
-  else la = g.A + ((m0 + 4 * c4 + 3 < g.M) ? m0 + 4 * c4 : 0);                                 // columns past M: column 0
+  else la = g.A + ((m0 + 4 * c4 < g.M) ? m0 + 4 * c4 : 0);   // columns past M: column 0 (a float4 may run up to 3 columns into the row's padding)
   if constexpr (KCB) lb = g.B + (int64_t)((n0 + lrow < g.N) ? n0 + lrow : g.N - 1) * g.ldb;
-  else lb = g.B + ((n0 + 4 * c4 + 3 < g.N) ? n0 + 4 * c4 : 0);
+  else lb = g.B + ((n0 + 4 * c4 < g.N) ? n0 + 4 * c4 : 0);
   // (their products only reach rows / columns of C that are never stored)
 
   auto load = [&](X3gSlot& r, int step) {
@@ -890,7 +890,9 @@ int try_gemm_x3g(int transA, int transB, int M, int N, int64_t K, const float* A
   if (!aligned16(A) || !aligned16(B) || (lda % 4) != 0 || (ldb % 4) != 0) return 0;
   const bool kca = !transA, kcb = transB != 0;
   if ((kca || kcb) && ((K % 4) != 0 || (k_per_split % 4) != 0)) return 0;
-  if ((!kca && (M % 4) != 0) || (!kcb && (N % 4) != 0)) return 0;
+  // a k-strided operand is read four columns at a time: its extent is a multiple of 4, or the rows are padded to one
+  // (the projection's Wcat: 2 R + H columns in rows of ldw = the next multiple of 4)
+  if ((!kca && (M % 4) != 0 && lda < (M + 3) / 4 * 4) || (!kcb && (N % 4) != 0 && ldb < (N + 3) / 4 * 4)) return 0;
   if (splits > 1 && (!ws || (k_per_split % 16) != 0)) return 0;
   X3gArgs g;
   g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb;

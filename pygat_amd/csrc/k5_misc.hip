@@ -130,14 +130,39 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(int n, int H, int Fp, 
 }
 
 // ------------------------------------------------------------- parameter packing
+// Blocks [0, copy_blocks): one element of Wcat (or of a_pad) per thread -- the padded head columns of W and W_skip.
+// Blocks behind them: one WAVE per (k, h) forms the two columns (W_h a_src_h)[k], (W_h a_dst_h)[k]: coalesced reads of the
+// F' weights of row k, two DPP sums.  (The first version let one thread loop over F' for each of those 2 H columns: 8
+// lanes per row walking 256 strided floats each -- 25 us for the PPI levels, a fifth of their projection GEMM.)
 __global__ __launch_bounds__(256) void pack_params_kernel(int H, int Fin, int Fo, int Fp,
                                                           const float* __restrict__ W,
                                                           const float* __restrict__ a,
                                                           const float* __restrict__ w_skip,
                                                           float* __restrict__ Wcat, int64_t ldw,
-                                                          float* __restrict__ a_pad) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+                                                          float* __restrict__ a_pad, int copy_blocks) {
   const int R = H * Fp, Rs = w_skip ? R : 0;
+  if ((int)blockIdx.x >= copy_blocks) {
+    const int64_t wv = ((int64_t)blockIdx.x - copy_blocks) * 4 + (threadIdx.x >> 6);
+    if (wv >= (int64_t)Fin * H) return;
+    const int k = (int)(wv / H), h = (int)(wv % H), lane = threadIdx.x & 63;
+    const float* wr = W + ((int64_t)h * Fin + k) * Fo;
+    const float* ar = a + (int64_t)h * 2 * Fo;
+    float vs = 0.f, vd = 0.f;
+    for (int f = lane; f < Fo; f += 64) {
+      const float w = wr[f];
+      vs = fmaf(w, ar[f], vs);
+      vd = fmaf(w, ar[Fo + f], vd);
+    }
+    vs = group_sum<64>(vs);
+    vd = group_sum<64>(vd);
+    if (lane == 0) {
+      float* o = Wcat + (int64_t)k * ldw + R + Rs;
+      o[h] = vs;
+      o[H + h] = vd;
+    }
+    return;
+  }
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx < (int64_t)H * 2 * Fp) {  // a_pad[h][which][f]
     const int h = (int)(idx / (2 * Fp)), r = (int)(idx % (2 * Fp)), which = r / Fp, f = r % Fp;
     a_pad[idx] = f < Fo ? a[(int64_t)h * 2 * Fo + which * Fo + f] : 0.f;
@@ -152,10 +177,7 @@ __global__ __launch_bounds__(256) void pack_params_kernel(int H, int Fin, int Fo
     const int h = (col - R) / Fp, f = (col - R) % Fp;
     if (f < Fo) v = w_skip[((int64_t)h * Fin + k) * Fo + f];
   } else if (col < R + Rs + 2 * H) {
-    const int c = col - R - Rs, h = c % H, which = c / H;
-    const float* wr = W + ((int64_t)h * Fin + k) * Fo;
-    const float* ar = a + (int64_t)h * 2 * Fo + which * Fo;
-    for (int f = 0; f < Fo; ++f) v = fmaf(wr[f], ar[f], v);
+    return;                         // the W_h a columns: written by the waves of the second block range
   }
   Wcat[idx] = v;
 }
@@ -229,8 +251,9 @@ extern "C" int pygat_pack_params(int H, int Fin, int Fo, const float* W, const f
   PYGAT_REQUIRE(ldw >= need && ldw % 4 == 0, "pack_params: ldw=%lld must be a multiple of 4 and >= %d", (long long)ldw, need);
   int64_t tot = (int64_t)Fin * ldw;
   if (tot < (int64_t)H * 2 * Fp) tot = (int64_t)H * 2 * Fp;
-  hipLaunchKernelGGL(pack_params_kernel, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, H, Fin, Fo,
-                     Fp, W, a, w_skip, Wcat, ldw, a_pad);
+  const int copy_blocks = (int)cdiv(tot, 256);
+  hipLaunchKernelGGL(pack_params_kernel, dim3((unsigned)(copy_blocks + cdiv((int64_t)Fin * H, 4))), dim3(256), 0,
+                     (hipStream_t)stream, H, Fin, Fo, Fp, W, a, w_skip, Wcat, ldw, a_pad, copy_blocks);
   PYGAT_CHECK_LAUNCH("pack_params");
   return PYGAT_OK;
 }

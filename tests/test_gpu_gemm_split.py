@@ -144,6 +144,33 @@ def test_general_split_kernel_is_exact_where_fp32_is(pg, tA, tB):
         assert torch.equal(C, ref)
 
 
+def test_general_split_kernel_padded_rows(pg):
+    """A k-strided operand whose extent is not a multiple of 4 but whose rows are padded to one (the projection's Wcat: 2 R + H
+    = 1542 columns of PPI level 3 in rows of 1544): the kernel reads up to 3 columns into the padding, whatever it holds --
+    NaN here -- without it reaching C."""
+    g = torch.Generator(device="cuda").manual_seed(23)
+    M, N, K, ldb = 3144, 1542, 1024, 1544
+    A = torch.randn(M, K, device="cuda", generator=g)
+    Bp = torch.full((K, ldb), float("nan"), device="cuda")
+    Bp[:, :N] = torch.randn(K, N, device="cuda", generator=g)
+    ref = A.double() @ Bp[:, :N].double()
+    err = {}
+    for mode in ("fp32-mfma", "split-bf16"):
+        C = torch.full((M, N + 3), 7.0, device="cuda")
+        pg.gemm(False, False, M, N, K, A, K, Bp, ldb, [(N, C, N + 3)], mode=mode)
+        assert torch.isfinite(C).all() and bool((C[:, N:] == 7.0).all()), mode
+        err[mode] = float((C[:, :N].double() - ref).abs().max() / ref.abs().max())
+    assert err["fp32-mfma"] < 1e-5 and err["split-bf16"] <= 2.0 * err["fp32-mfma"] + 1e-7, err
+    # the transposed-A form (weight gradient of a 121-wide head table): M = 726 + 2 rows of padding
+    Mt, ldat = 726 + 1, 728
+    At = torch.full((K, ldat), float("nan"), device="cuda"); At[:, :Mt] = torch.randn(K, Mt, device="cuda", generator=g)
+    Bt = torch.randn(K, 256, device="cuda", generator=g)
+    reft = At[:, :Mt].double().t() @ Bt.double()
+    Ct = torch.empty(Mt, 256, device="cuda")
+    pg.gemm(True, False, Mt, 256, K, At, ldat, Bt, 256, [(256, Ct, 256)], mode="split-bf16", split_k=1)
+    assert float((Ct.double() - reft).abs().max() / reft.abs().max()) < 1e-6
+
+
 def test_small_integers_sum_exactly(pg):
     """Integer operands whose dot products stay below 2^24: any summation order is exact, both modes must give the
     integer result."""

@@ -175,6 +175,11 @@ typedef struct {
      outputs travel over xGMI while chunk k+1 is computed).  Every other entry point needs 0, 0. */
   int64_t slot_first;
   int64_t slot_count;
+  /* NULL, or [n_slots][4] = (first edge, end edge, row of the first edge, flags) of every slot, flags bit 0: the slot's
+     first row began in an earlier slot, bit 1: its last row continues in a later one (pygat_slot_meta).  One 16-byte load
+     then replaces the slot's start-up chain slot_begin -> edge_rc -> rowptr and the rowptr load at its end: what a slot
+     costs in DEPENDENT memory round trips is what bounds the attention kernels on small graphs and on narrow rows. */
+  const int32_t* slot_meta;
 } pygat_graph;
 
 /* edge_rc[k] = (i, col[k]) for rowptr[i] <= k < rowptr[i+1] */
@@ -185,6 +190,10 @@ int pygat_edge_pairs(int n, const int32_t* rowptr, const int32_t* col, int32_t* 
  * slot_edges/2 are ever cut); slot_begin[n_slots] = nnz, n_slots = ceil(nnz / slot_edges). */
 int pygat_slot_bounds(int n, int64_t nnz, const int32_t* rowptr, const int32_t* edge_rc, int slot_edges,
                       int32_t* slot_begin, void* stream);
+/* slot_meta[k] = (first edge, end edge, row of the first edge, flags) for the slots of `slot_begin` (NULL: uniform
+ * slots of slot_edges) -- see pygat_graph.slot_meta.  slot_meta: [n_slots][4] int32, 16-byte aligned. */
+int pygat_slot_meta(int n, int64_t nnz, const int32_t* rowptr, const int32_t* edge_rc, int slot_edges,
+                    const int32_t* slot_begin, int32_t* slot_meta, void* stream);
 
 /* bytes of `part` workspace needed by forward / column backward for this graph and row width */
 size_t pygat_partials_bytes(int64_t nnz, int slot_edges, int H, int Fp);

@@ -29,7 +29,7 @@ SYMBOLS = [
     "pygat_exclusive_scan_i32", "pygat_dense_fill_cols", "pygat_csr_symmetric_perm",
     "pygat_gemm_workspace_bytes", "pygat_gemm_f32", "pygat_pack_params", "pygat_project", "pygat_attn_scores",
     "pygat_unpack_wgrad",
-    "pygat_edge_pairs", "pygat_slot_bounds", "pygat_partials_bytes", "pygat_head_group", "pygat_gat_forward", "pygat_head_mean",
+    "pygat_edge_pairs", "pygat_slot_bounds", "pygat_slot_meta", "pygat_partials_bytes", "pygat_head_group", "pygat_gat_forward", "pygat_head_mean",
     "pygat_gat_backward_prepare", "pygat_gat_backward_row", "pygat_gat_backward_col", "pygat_gat_backward_rowsum",
     "pygat_agrad_workspace_bytes", "pygat_a_grad", "pygat_wgrad_workspace_bytes", "pygat_wgrad",
     "pygat_gatv2_forward", "pygat_gatv2_backward_prepare", "pygat_gatv2_workspace_bytes", "pygat_gatv2_backward",
@@ -52,7 +52,8 @@ class OutSegments(C.Structure):
 class Graph(C.Structure):
     _fields_ = [("n", C.c_int), ("nnz", C.c_int64), ("rowptr", C.c_void_p), ("edge_rc", C.c_void_p),
                 ("slot_edges", C.c_int), ("slot_begin", C.c_void_p), ("cut_rows", C.c_void_p),
-                ("n_cut", C.c_int), ("n_cut_wide", C.c_int), ("slot_first", C.c_int64), ("slot_count", C.c_int64)]
+                ("n_cut", C.c_int), ("n_cut_wide", C.c_int), ("slot_first", C.c_int64), ("slot_count", C.c_int64),
+                ("slot_meta", C.c_void_p)]
 
 
 def _load():
@@ -85,6 +86,7 @@ def _load():
     lib.pygat_project.argtypes = [i, i, i, i, p, i64, p, i64, p, p, p, p, i, p, i, p]
     lib.pygat_edge_pairs.argtypes = [i, p, p, p, p]
     lib.pygat_slot_bounds.argtypes = [i, i64, p, p, i, p, p]
+    lib.pygat_slot_meta.argtypes = [i, i64, p, p, i, p, p, p]
     lib.pygat_partials_bytes.argtypes = [i64, i, i, i]
     lib.pygat_partials_bytes.restype = sz
     lib.pygat_head_group.argtypes = [i, i, i]

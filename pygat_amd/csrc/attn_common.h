@@ -121,6 +121,7 @@ struct GraphDev {  // device view of pygat_graph
   const int2* rc;   // (row, col) per edge
   int ts;           // nominal edges per slot
   const int32_t* sb;  // row-snapped slot borders [nslots+1] or nullptr (uniform slots)
+  const int4* meta;   // [nslots] (e0, e1, first row, flags) or nullptr (pygat_graph.slot_meta)
   const int32_t* cut;  // [n_cut][3] (slot, row, pieces) or nullptr
   int n_cut, n_cut_wide;
   int64_t k0, kn;   // active slot range [k0, k0 + kn) (the forward can work on a range of whole rows)
@@ -140,7 +141,11 @@ static inline int check_graph(const pygat_graph* g, GraphDev* d, bool allow_slot
     return PYGAT_EINVAL;
   }
   d->n = g->n; d->nnz = g->nnz; d->rowptr = g->rowptr; d->rc = reinterpret_cast<const int2*>(g->edge_rc);
-  d->ts = g->slot_edges; d->sb = g->slot_begin;
+  d->ts = g->slot_edges; d->sb = g->slot_begin; d->meta = reinterpret_cast<const int4*>(g->slot_meta);
+  if (g->slot_meta && !aligned16(g->slot_meta)) {
+    set_error("graph: slot_meta must be 16-byte aligned");
+    return PYGAT_EINVAL;
+  }
   d->cut = g->cut_rows; d->n_cut = g->cut_rows ? g->n_cut : 0; d->n_cut_wide = g->cut_rows ? g->n_cut_wide : 0;
   if (d->n_cut < 0 || d->n_cut_wide < 0 || d->n_cut_wide > d->n_cut) {
     set_error("graph: bad cut-row list (n_cut=%d n_cut_wide=%d)", g->n_cut, g->n_cut_wide);

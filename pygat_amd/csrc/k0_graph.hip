@@ -164,9 +164,35 @@ __global__ __launch_bounds__(256) void slot_bounds_kernel(int64_t nnz, int ts, i
   sb[k] = (int32_t)b;
 }
 
+// (first edge, end edge, first row, flags) of every slot: what a slot's start-up otherwise fetches through the chain
+// slot_begin -> edge_rc -> rowptr, and the rowptr load at its end, in one 16-byte record
+__global__ __launch_bounds__(256) void slot_meta_kernel(int64_t nnz, int ts, int64_t nslots, const int32_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ edge_rc, const int32_t* __restrict__ sb,
+                                                        int4* __restrict__ meta) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= nslots) return;
+  int64_t e0, e1;
+  if (sb) { e0 = sb[k]; e1 = sb[k + 1]; }
+  else { e0 = k * ts; e1 = (e0 + ts < nnz) ? e0 + ts : nnz; }
+  const int rf = edge_rc[2 * e0], rl = edge_rc[2 * (e1 - 1)];
+  const int flags = (rowptr[rf] < e0 ? 1 : 0) | (rowptr[rl + 1] > e1 ? 2 : 0);
+  meta[k] = make_int4((int)e0, (int)e1, rf, flags);
+}
+
 }  // namespace pygat
 
 using namespace pygat;
+
+extern "C" int pygat_slot_meta(int n, int64_t nnz, const int32_t* rowptr, const int32_t* edge_rc, int slot_edges,
+                               const int32_t* slot_begin, int32_t* slot_meta, void* stream) {
+  PYGAT_REQUIRE(n > 0 && nnz > 0 && nnz < ((int64_t)1 << 31) && rowptr && edge_rc && slot_meta && slot_edges >= 4 &&
+                    (slot_edges & 3) == 0 && aligned16(slot_meta), "slot_meta: bad arguments");
+  const int64_t nslots = cdiv(nnz, slot_edges);
+  hipLaunchKernelGGL(slot_meta_kernel, dim3((unsigned)cdiv(nslots, 256)), dim3(256), 0, (hipStream_t)stream, nnz, slot_edges,
+                     nslots, rowptr, edge_rc, slot_begin, reinterpret_cast<int4*>(slot_meta));
+  PYGAT_CHECK_LAUNCH("slot_meta");
+  return PYGAT_OK;
+}
 
 extern "C" int pygat_dense_row_counts(const float* adj, int n, int64_t ld, int mode, int32_t* counts,
                                       void* stream) {

@@ -230,23 +230,40 @@ __device__ __forceinline__ void fwd_flush(const FwdArgs& a, const LaneCols<VEC>&
 // 9-10 VGPRs less, which is what keeps the training forward (AUX) at 5 waves per SIMD.
 // LPH > 0: lanes per head known at compile time (0: read from the shape) -- the per-edge head sums are DPP chains whose
 // length otherwise costs a scalar branch per step, six per edge.
+#ifndef PYGAT_K2_NARROW_U
+#define PYGAT_K2_NARROW_U 4   // (8 was measured: 0.32 -> 0.30 ms at one head of 16, 140 registers)
+#endif
 template <int LPR, int VEC, bool V2, bool AUX, bool FAST, int LPH = 0, int CR = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((AUX && FAST && VEC == 1) ? 5 : 1))) void gat_fwd_kernel(FwdArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((AUX && FAST && VEC == 1 && LPR > 8) ? 5 : 1))) void gat_fwd_kernel(FwdArgs a) {
   constexpr int EPW = 64 / LPR;
-  constexpr int U = (VEC == 1) ? 4 : 2;
+  // Narrow rows (LPR <= 8: at most 32 floats -- one or two 16-float heads, the shard of an 8- or 4-GPU head-parallel run):
+  // a gather is one or two sectors, a wave carries 8-16 slots and the whole grid is ~20 waves per SIMD, so the kernel is
+  // bound by the chain of dependent memory round trips a slot walks through (SQ counters at one head: 12 % VALU-active,
+  // 60 % waiting, 3.4 waves per SIMD).  There: 8 edges per round instead of 4, and the edge records of the NEXT round
+  // are fetched while this round's rows are in flight -- 1 serial round trip per 8 edges instead of 2 per 4.
+  constexpr bool NARROW = (VEC == 1 && LPR <= 8);
+  constexpr int U = (VEC == 1) ? (NARROW ? PYGAT_K2_NARROW_U : 4) : 2;
   const int lane = threadIdx.x & 63;
-  const int64_t kl = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * EPW + lane / LPR;
+  const int64_t kl = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * EPW + lane / LPR;
   if (kl >= a.g.kn) return;  // lane groups are independent: no cross-lane op below
   const int64_t k = a.g.k0 + kl;  // slot id
   int64_t e0, e1;
-  slot_range(a.g, k, &e0, &e1);
+  const int2* __restrict__ rc = a.g.rc;
+  int r_first;
+  bool head_partial, tail_known = false, tail_flag = false;
+  if (a.g.meta) {   // (wave-uniform) one record instead of the chain slot_begin -> edge_rc -> rowptr
+    const int4 mt = a.g.meta[k];
+    e0 = mt.x; e1 = mt.y; r_first = mt.z;
+    head_partial = (mt.w & 1) != 0; tail_known = true; tail_flag = (mt.w & 2) != 0;
+  } else {
+    slot_range(a.g, k, &e0, &e1);
+    r_first = rc[e0].x;
+    head_partial = a.g.rowptr[r_first] < e0;
+  }
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
   const int R = CR ? CR : a.rs.R;
   const int64_t ldh = CR ? CR / (4 * (LPH ? LPH : 1)) : a.rs.ldh;
-  const int2* __restrict__ rc = a.g.rc;
 
-  const int r_first = rc[e0].x;
-  const bool head_partial = a.g.rowptr[r_first] < e0;
   int cur = r_first;
   const int lph = LPH > 0 ? LPH : (a.rs.lph < 64 ? a.rs.lph : 64);
   float4 adst[VEC];  // this lane's slice of a_dst (zero on padded / invalid chunks)
@@ -260,10 +277,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((AUX && FAS
   RowState<VEC, AUX> st;
   st.reset();
 
+  int2 pn[NARROW ? U : 1];
+  if constexpr (NARROW) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) pn[u] = rc[(e0 + u < e1) ? e0 + u : e1 - 1];
+  }
   for (int64_t e = e0; e < e1; e += U) {
     int2 p[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) p[u] = rc[(e + u < e1) ? e + u : e1 - 1];
+    for (int u = 0; u < U; ++u) {
+      if constexpr (NARROW) p[u] = pn[u];
+      else p[u] = rc[(e + u < e1) ? e + u : e1 - 1];
+    }
     float sv[U][VEC], tv[U][VEC], mk[U][VEC];
     float4 wv[U][VEC];
 #pragma unroll
@@ -289,6 +314,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((AUX && FAS
           sv[u][v] = a.s[(int64_t)p[u].x * ldh + lc.head[v]];
         }
       }
+    if constexpr (NARROW) {   // next round's edge records: in flight together with this round's rows
+#pragma unroll
+      for (int u = 0; u < U; ++u) pn[u] = rc[(e + U + u < e1) ? e + U + u : e1 - 1];
+    }
     // per-head sums over the lanes of a head (all lanes of the group are active here):
     // V1: t_j = Wh_j . a_dst from the row just gathered; V2: the logit e_ij itself
 #pragma unroll
@@ -315,7 +344,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((AUX && FAS
       }
     }
   }
-  const bool tail_partial = a.g.rowptr[cur + 1] > e1;
+  const bool tail_partial = tail_known ? tail_flag : a.g.rowptr[cur + 1] > e1;
   fwd_flush<LPR, VEC, AUX, LPH, CR>(a, lc, k, cur, cur == r_first && head_partial, tail_partial, st);
 }
 
@@ -516,7 +545,11 @@ static int launch_forward(const pygat_graph* g, int H, int Fo, float alpha, int 
     a.part = (float*)part;   // reused by the windows: the launches are ordered on the stream
     int lpr, vec;
     pick_lanes(a.rs, &lpr, &vec);
-    const unsigned blocks = (unsigned)cdiv(cdiv(nslots, 64 / lpr), 4);
+    // narrow rows (a wave carries 8-64 slots, the whole grid is a few ten waves per SIMD): one-wave work-groups, so that a
+    // SIMD slot is refilled as soon as ITS wave ends instead of when the slowest of four does
+    static const int narrow_bt = [] { const char* e = getenv("PYGAT_NARROW_BLOCK"); return e ? atoi(e) : 64; }();   // development knob
+    const unsigned bt = (vec == 1 && lpr <= 8) ? (unsigned)narrow_bt : 256u;
+    const unsigned blocks = (unsigned)cdiv(cdiv(nslots, 64 / lpr), bt / 64);
     const bool aux = aneg != nullptr;
     // 32-bit element offsets: the gathered table and s below 2^32 bytes
     // measured (config 5, same box): the training forward 1.147 -> 1.114 ms (5 instead of 4 waves per SIMD), the plain
@@ -524,13 +557,13 @@ static int launch_forward(const pygat_graph* g, int H, int Fo, float alpha, int 
     const bool fast = aux && !att_mask && (int64_t)a.g.n * a.ldwh * 4 < ((int64_t)1 << 32);
 #define PYGAT_FWD(V2V, AUXV, FASTV)                                                                                   \
     PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_fwd_kernel<LPR, VEC, V2V, AUXV, FASTV>), dim3(blocks),    \
-                                                      dim3(256), 0, st, a))
+                                                      dim3(bt), 0, st, a))
     if (v2) PYGAT_FWD(true, false, false);
     else if (aux && fast && lpr == 32 && vec == 1 && a.rs.lph == 4 && !getenv("PYGAT_K2_NO_LPH"))   // 8 heads x 16: the headline shape
       if (a.rs.R == 128 && a.rs.ldr == 128 && a.rs.ldh == 8 && a.rs.ldo == 128 && a.rs.Fo == 16 && a.ldwh == 128 && !(flags & PYGAT_F_SKIP))
-        hipLaunchKernelGGL((gat_fwd_kernel<32, 1, false, true, true, 4, 128>), dim3(blocks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((gat_fwd_kernel<32, 1, false, true, true, 4, 128>), dim3(blocks), dim3(bt), 0, st, a);
       else
-        hipLaunchKernelGGL((gat_fwd_kernel<32, 1, false, true, true, 4>), dim3(blocks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((gat_fwd_kernel<32, 1, false, true, true, 4>), dim3(blocks), dim3(bt), 0, st, a);
     else if (aux && fast) PYGAT_FWD(false, true, true);
     else if (aux) PYGAT_FWD(false, true, false);
     else PYGAT_FWD(false, false, false);

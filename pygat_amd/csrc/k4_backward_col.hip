@@ -92,36 +92,55 @@ __device__ __forceinline__ T pick(const T (&x)[U], int u) {
 template <int LPR, int VEC, bool WRITE_DZ, int LPH = 0, int CR = 0>
 __global__ __launch_bounds__(256) void gat_bwd_col_kernel(ColArgs a) {
   constexpr int EPW = 64 / LPR;
+  // narrow rows: next round's edge records prefetched (see gat_fwd_kernel; 8 edges per round were measured too: two rows
+  // per edge in registers leave 2 waves per SIMD at U = 8, 0.30 -> 0.35 ms at one head of 16)
+  constexpr bool NARROW = (VEC == 1 && LPR <= 8);
   constexpr int U = (VEC == 1) ? 4 : 2;
   const int lane = threadIdx.x & 63;
-  const int64_t k = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * EPW + lane / LPR;
+  const int64_t k = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * EPW + lane / LPR;
   if (k >= num_slots(a.g)) return;
   int64_t e0, e1;
-  slot_range(a.g, k, &e0, &e1);
+  int r_first;
+  bool head_partial, tail_known = false, tail_flag = false;
+  const int2* __restrict__ rc = a.g.rc;
+  if (a.g.meta) {   // (wave-uniform) one record instead of the chain slot_begin -> edge_rc -> rowptr
+    const int4 mt = a.g.meta[k];
+    e0 = mt.x; e1 = mt.y; r_first = mt.z;
+    head_partial = (mt.w & 1) != 0; tail_known = true; tail_flag = (mt.w & 2) != 0;
+  } else {
+    slot_range(a.g, k, &e0, &e1);
+    r_first = rc[e0].x;
+    head_partial = a.g.rowptr[r_first] < e0;
+  }
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
   const int R = CR ? CR : a.rs.R;
   constexpr int HC = CR / (4 * (LPH ? LPH : 1));   // heads, when CR > 0
   const int64_t RW = CR ? CR + 4 * HC : a.ldgr, ldr = CR ? CR : a.rs.ldr, ldh = CR ? HC : a.rs.ldh;
   const int lph = LPH > 0 ? LPH : (a.rs.lph < 64 ? a.rs.lph : 64);
-  const int2* __restrict__ rc = a.g.rc;
   float4 adst[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
     adst[v] = ld4(a.a_pad + (int64_t)lc.head[v] * 2 * a.rs.Fp + a.rs.Fp + (lc.cofs[v] & (a.rs.Fp - 1)));
     if (!lc.valid[v]) adst[v] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  const int r_first = rc[e0].x;
-  const bool head_partial = a.g.rowptr[r_first] < e0;
   int cur = r_first;
   float4 acc[VEC];
   float dt[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) { acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); dt[v] = 0.f; }
 
+  int2 pn[NARROW ? U : 1];
+  if constexpr (NARROW) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) pn[u] = rc[(e0 + u < e1) ? e0 + u : e1 - 1];
+  }
   for (int64_t e = e0; e < e1; e += U) {
     int2 p[U];  // (j, i): j = this (transposed) row, i = the forward row that attends to j
 #pragma unroll
-    for (int u = 0; u < U; ++u) p[u] = rc[(e + u < e1) ? e + u : e1 - 1];
+    for (int u = 0; u < U; ++u) {
+      if constexpr (NARROW) p[u] = pn[u];
+      else p[u] = rc[(e + u < e1) ? e + u : e1 - 1];
+    }
     float4 rt[U][VEC], gv[U][VEC], wv[U][VEC];
     float mk[U][VEC];
 #pragma unroll
@@ -142,6 +161,10 @@ __global__ __launch_bounds__(256) void gat_bwd_col_kernel(ColArgs a) {
         mk[u][v] = 1.f;
         if (a.mask) mk[u][v] = a.mask[(int64_t)a.perm[(e + u < e1) ? e + u : e1 - 1] * ldh + lc.head[v]];
       }
+    if constexpr (NARROW) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) pn[u] = rc[(e + U + u < e1) ? e + U + u : e1 - 1];
+    }
     float al[U][VEC], dz[U][VEC];
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -183,7 +206,7 @@ __global__ __launch_bounds__(256) void gat_bwd_col_kernel(ColArgs a) {
       }
     }
   }
-  const bool tail_partial = a.g.rowptr[cur + 1] > e1;
+  const bool tail_partial = tail_known ? tail_flag : a.g.rowptr[cur + 1] > e1;
   col_flush<VEC, LPH, CR>(a, lc, k, cur, cur == r_first && head_partial, tail_partial, acc, dt);
 }
 
@@ -401,19 +424,23 @@ extern "C" int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm
     a.dWh = dWh + (int64_t)gh * Fp; a.dt = dt + gh; a.part = (float*)part;
     int lpr, vec;
     pick_lanes(a.rs, &lpr, &vec);
-    const unsigned blocks = (unsigned)cdiv(cdiv(nslots, 64 / lpr), 4);
+    // narrow rows (a wave carries 8-64 slots, the whole grid is a few ten waves per SIMD): one-wave work-groups, so that a
+    // SIMD slot is refilled as soon as ITS wave ends instead of when the slowest of four does
+    static const int narrow_bt = [] { const char* e = getenv("PYGAT_NARROW_BLOCK"); return e ? atoi(e) : 64; }();   // development knob
+    const unsigned bt = (vec == 1 && lpr <= 8) ? (unsigned)narrow_bt : 256u;
+    const unsigned blocks = (unsigned)cdiv(cdiv(nslots, 64 / lpr), bt / 64);
     if (dz_t) {
       PYGAT_DISPATCH_LANES(lpr, vec,
-                           hipLaunchKernelGGL((gat_bwd_col_kernel<LPR, VEC, true>), dim3(blocks), dim3(256), 0, st, a));
+                           hipLaunchKernelGGL((gat_bwd_col_kernel<LPR, VEC, true>), dim3(blocks), dim3(bt), 0, st, a));
     } else if (lpr == 32 && vec == 1 && a.rs.lph == 4) {   // 8 heads x 16: the headline shape
       if (a.rs.R == 128 && a.rs.ldr == 128 && a.rs.ldh == 8 && a.ldgr == 160 && a.rs.H == 8 && !att_mask &&
           (int64_t)a.g.n * 160 * 4 < ((int64_t)1 << 32) && !getenv("PYGAT_K4_NO_CONST"))   // (development knob)
-        hipLaunchKernelGGL((gat_bwd_col_kernel<32, 1, false, 4, 128>), dim3(blocks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((gat_bwd_col_kernel<32, 1, false, 4, 128>), dim3(blocks), dim3(bt), 0, st, a);
       else
-        hipLaunchKernelGGL((gat_bwd_col_kernel<32, 1, false, 4>), dim3(blocks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((gat_bwd_col_kernel<32, 1, false, 4>), dim3(blocks), dim3(bt), 0, st, a);
     } else {
       PYGAT_DISPATCH_LANES(lpr, vec,
-                           hipLaunchKernelGGL((gat_bwd_col_kernel<LPR, VEC, false>), dim3(blocks), dim3(256), 0, st, a));
+                           hipLaunchKernelGGL((gat_bwd_col_kernel<LPR, VEC, false>), dim3(blocks), dim3(bt), 0, st, a));
     }
     PYGAT_CHECK_LAUNCH("gat_backward_col");
     const size_t fix_lds = (a.g.cut ? FIX_LIST_WAVES : 4) * (size_t)(a.rs.R + 2 * a.rs.H) * sizeof(float);

@@ -96,9 +96,14 @@ class _Pattern:
                     order = torch.argsort(pieces, descending=True, stable=True)
                     cut = torch.stack([k, r_last[k], pieces], 1)[order].to(torch.int32).contiguous()
                     n_cut, n_wide = int(k.numel()), int((pieces > 32).sum().item())
+            # one 16-byte record per slot (first edge, end edge, first row, cut flags): the kernels' start-up in one load
+            meta = torch.empty(-(-self.nnz // slot_edges), 4, dtype=torch.int32, device=self.rowptr.device)
+            with torch.cuda.device(self.rowptr.device):
+                check(lib.pygat_slot_meta(self.n, self.nnz, self.rowptr.data_ptr(), self.edge_rc.data_ptr(), slot_edges, _ptr(sb),
+                                          meta.data_ptr(), _stream()), "slot_meta")
             st = _lib.Graph(self.n, self.nnz, _ptr(self.rowptr), _ptr(self.edge_rc), slot_edges, _ptr(sb), _ptr(cut),
-                            n_cut, n_wide)
-            self._alt[key] = (st, sb, cut)
+                            n_cut, n_wide, 0, 0, _ptr(meta))
+            self._alt[key] = (st, sb, cut, meta)
         return self._alt[key][0]
 
     def row_chunks(self, nchunks: int, slot_edges: Optional[int] = None):
@@ -109,7 +114,7 @@ class _Pattern:
         key = ("chunks", ts, nchunks)
         if key not in self._alt:
             base = self._make(ts, True)
-            _, sb, cut = self._alt[(ts, True)]
+            _, sb, cut, meta = self._alt[(ts, True)]
             nslots = sb.numel() - 1
             sbl, rp = sb.long(), self.rowptr.long()
             first_row = self.edge_rc[sbl[:-1], 0].long()                 # row of the first edge of every slot
@@ -134,7 +139,7 @@ class _Pattern:
                     if n_cut == 0:
                         sub = cut[:1].contiguous()                       # a non-NULL list with n_cut = 0: nothing to fix up
                 st = _lib.Graph(self.n, self.nnz, _ptr(self.rowptr), _ptr(self.edge_rc), ts, _ptr(sb), _ptr(sub), n_cut,
-                                n_wide, b0, b1 - b0)
+                                n_wide, b0, b1 - b0, _ptr(meta))
                 out.append((st, r0, r1))
                 keep.append(sub)
             self._alt[key] = (out, keep)

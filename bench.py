@@ -147,7 +147,8 @@ def epoch_ms(pg, dev, name, epochs=200):
         y = torch.randint(0, c["nfeats"][-1], (N,), generator=g).to(dev)
         it = torch.arange(c["ntrain"], device=dev)
         graph = pg.CSRGraph(torch.as_tensor(rowptr, device=dev), torch.as_tensor(col, device=dev))
-        loss_fn = lambda out: F.nll_loss(F.log_softmax(F.elu(out), dim=1)[it], y[it])      # noqa: E731  train.py:151-152,159
+        # train.py:151-152,159: nll_loss(log_softmax(elu(out))[idx_train], labels[idx_train]) -- one launch forward, one backward
+        loss_fn = pg.EluLogSoftmaxNLL(it, y, N)
     torch.manual_seed(72)
     model = pg.GAT(c["nfeats"], c["nheads"], len(c["nheads"]), c["dropout"], 0.2, pg.SpGraphAttentionLayer,
                    skip_connection=(name == "ppi")).to(dev)

@@ -130,6 +130,16 @@ int pygat_gemm_f32(int transA, int transB, int M, int N, int64_t K,
 int pygat_pack_params(int H, int Fin, int Fo, const float* W, const float* a,
                       const float* w_skip, float* Wcat, int64_t ldw, float* a_pad,
                       void* stream);
+/* The same with the parameters where the reference keeps them: one W [Fin x F'], a (2F' values) and skip_projection
+ * [Fin x F'] tensor PER HEAD module (layers.py:21-28,111-119; models.py:15-27).  W, a, w_skip (or NULL): HOST arrays of H
+ * device pointers, H <= PYGAT_MAX_HEADS_TABLE (they travel as kernel arguments) -- no stacking copy before the level. */
+#define PYGAT_MAX_HEADS_TABLE 16
+int pygat_pack_params_heads(int H, int Fin, int Fo, const float* const* W, const float* const* a,
+                            const float* const* w_skip, float* Wcat, int64_t ldw, float* a_pad, void* stream);
+/* torch.stack of the per-head parameters in ONE launch: W_out [H x nW], a_out [H x nA], skip_out [H x nS] (or NULL) from host
+ * arrays of H device pointers (the level flavours that take stacked parameters: dropout, GATv2). */
+int pygat_stack_heads(int H, int64_t nW, int nA, int64_t nS, const float* const* W, const float* const* a,
+                      const float* const* w_skip, float* W_out, float* a_out, float* skip_out, void* stream);
 /* Projection of one level in one GEMM: [Wh | Sk | s] = X * Wcat[:, :R (+R) + H]; the H columns behind the
  * heads are W_h a_src_h (pygat_pack_params), so s_i = Wh_i . a_src (layers.py:60) comes out of the same pass.
  * a_pad (pygat_pack_params; may be NULL): lets the kernel form s from the Wh accumulators themselves -- the
@@ -368,6 +378,19 @@ int pygat_wgrad_dropout(int n, int Fin, int H, int Fo, const float* X, int64_t l
                         const float* dWh, const float* Gp, int64_t ldgp, float* dWc, int split_k, void* ws, void* stream);
 int pygat_dropout_head_sum_bits(int n, int Fin, int H, const float* dxe, int64_t lde, const unsigned char* bits, float p,
                                 float* dx, int64_t ldx, int accumulate, void* stream);
+
+/* ------------------------------------------------ the citation scripts' training loss (next row 8(f)-2: fused epoch)
+ * train.py:151-152,159: loss = nll_loss(log_softmax(elu(out), dim=1)[idx], labels[idx]), forward and backward as ONE
+ * launch each (ATen: 17).  The index set is given as per-row weights: weight[r] = (multiplicity of r in idx) / len(idx),
+ * label[r] the class of row r (any value where weight[r] == 0).
+ *   forward:  loss[0] = sum_r weight[r] * -log_softmax(elu(out[r, :]))[label[r]]     (deterministic two-stage sum inside
+ *             the launch; ws >= pygat_nll_workspace_bytes(n), ZEROED once by the caller, left zeroed by every launch)
+ *   backward: dout[r, c] = gscale[0] * d loss / d out[r, c]   (every row written; gscale = the upstream gradient, on the device) */
+size_t pygat_nll_workspace_bytes(int n);
+int pygat_elu_logsoftmax_nll(int n, int C, const float* out, int64_t ldo, const int32_t* label, const float* weight,
+                             void* ws, float* loss, void* stream);
+int pygat_elu_logsoftmax_nll_backward(int n, int C, const float* out, int64_t ldo, const int32_t* label, const float* weight,
+                                      const float* gscale, float* dout, int64_t ldd, void* stream);
 
 #ifdef __cplusplus
 }

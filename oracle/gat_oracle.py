@@ -322,6 +322,16 @@ def csr_layer_fwd_bwd(X, rowptr, col, Ws, As, alpha, concat, G, W_skips=None, fl
 
 
 # --------------------------------------------------------------------------
+# the citation scripts' training loss -- train.py:151-152,159
+# --------------------------------------------------------------------------
+def train_loss(out, idx, labels):
+    """output = F.log_softmax(F.elu(model(features, adj)), dim=1)   (train.py:151-152)
+    loss = F.nll_loss(output[idx], labels[idx])                       (train.py:159; idx_val / idx_test at 169, 186)"""
+    idx = torch.as_tensor(idx, dtype=torch.int64)
+    return F.nll_loss(F.log_softmax(F.elu(out), dim=1)[idx], torch.as_tensor(labels, dtype=torch.int64)[idx])
+
+
+# --------------------------------------------------------------------------
 # graph helpers used by tests and by bench.py's CPU leg
 # --------------------------------------------------------------------------
 def dense_from_csr(rowptr, col, N, dtype=torch.float32):

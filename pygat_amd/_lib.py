@@ -27,7 +27,7 @@ SYMBOLS = [
     "pygat_abi_version", "pygat_last_error", "pygat_padded_width", "pygat_device_count",
     "pygat_device_name", "pygat_default_gemm_mode", "pygat_dense_row_counts", "pygat_scan_workspace_bytes",
     "pygat_exclusive_scan_i32", "pygat_dense_fill_cols", "pygat_csr_symmetric_perm",
-    "pygat_gemm_workspace_bytes", "pygat_gemm_f32", "pygat_pack_params", "pygat_project", "pygat_attn_scores",
+    "pygat_gemm_workspace_bytes", "pygat_gemm_f32", "pygat_pack_params", "pygat_pack_params_heads", "pygat_stack_heads", "pygat_project", "pygat_attn_scores",
     "pygat_unpack_wgrad",
     "pygat_edge_pairs", "pygat_slot_bounds", "pygat_slot_meta", "pygat_partials_bytes", "pygat_head_group", "pygat_gat_forward", "pygat_head_mean",
     "pygat_gat_backward_prepare", "pygat_gat_backward_row", "pygat_gat_backward_col", "pygat_gat_backward_rowsum",
@@ -38,6 +38,7 @@ SYMBOLS = [
     "pygat_headmask_supported", "pygat_dropout_bits", "pygat_project_dropout_workspace_bytes", "pygat_project_dropout",
     "pygat_wgrad_dropout_workspace_bytes",
     "pygat_wgrad_dropout", "pygat_dropout_head_sum_bits",
+    "pygat_nll_workspace_bytes", "pygat_elu_logsoftmax_nll", "pygat_elu_logsoftmax_nll_backward",
 ]
 
 
@@ -81,6 +82,8 @@ def _load():
     lib.pygat_gemm_workspace_bytes.restype = sz
     lib.pygat_gemm_f32.argtypes = [i, i, i, i, i64, p, i64, p, i64, C.POINTER(OutSegments), i, i, p, i, p]
     lib.pygat_pack_params.argtypes = [i, i, i, p, p, p, p, i64, p, p]
+    lib.pygat_pack_params_heads.argtypes = [i, i, i, p, p, p, p, i64, p, p]
+    lib.pygat_stack_heads.argtypes = [i, i64, i, i64, p, p, p, p, p, p, p]
     lib.pygat_unpack_wgrad.argtypes = [i, i, i, p, i64, i, p, p]
     lib.pygat_attn_scores.argtypes = [i, i, i, p, p, p, p, p]
     lib.pygat_project.argtypes = [i, i, i, i, p, i64, p, i64, p, p, p, p, i, p, i, p]
@@ -123,6 +126,10 @@ def _load():
     lib.pygat_wgrad_dropout_workspace_bytes.restype = sz
     lib.pygat_wgrad_dropout.argtypes = [i, i, i, i, p, i64, p, f, p, p, i64, p, i, p, p]
     lib.pygat_dropout_head_sum_bits.argtypes = [i, i, i, p, i64, p, f, p, i64, i, p]
+    lib.pygat_nll_workspace_bytes.argtypes = [i]
+    lib.pygat_nll_workspace_bytes.restype = sz
+    lib.pygat_elu_logsoftmax_nll.argtypes = [i, i, p, i64, p, p, p, p, p]
+    lib.pygat_elu_logsoftmax_nll_backward.argtypes = [i, i, p, i64, p, p, p, p, i64, p]
     for s in SYMBOLS:
         fn = getattr(lib, s)
         if fn.restype is C.c_int or s in ("pygat_abi_version", "pygat_padded_width", "pygat_device_count", "pygat_default_gemm_mode"):

@@ -134,19 +134,31 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(int n, int H, int Fp, 
 // Blocks behind them: one WAVE per (k, h) forms the two columns (W_h a_src_h)[k], (W_h a_dst_h)[k]: coalesced reads of the
 // F' weights of row k, two DPP sums.  (The first version let one thread loop over F' for each of those 2 H columns: 8
 // lanes per row walking 256 strided floats each -- 25 us for the PPI levels, a fifth of their projection GEMM.)
+// TABLE: the parameters of head h come from their own tensors (pygat_pack_params_heads: pointers as kernel arguments), else
+// from the stacked arrays W [H x Fin x F'], a [H x 2F'], w_skip [H x Fin x F']
+constexpr int MAX_HEADS_TABLE = PYGAT_MAX_HEADS_TABLE;
+struct HeadPtrs {
+  const float* w[MAX_HEADS_TABLE];
+  const float* a[MAX_HEADS_TABLE];
+  const float* s[MAX_HEADS_TABLE];
+};
+template <bool TABLE>
 __global__ __launch_bounds__(256) void pack_params_kernel(int H, int Fin, int Fo, int Fp,
-                                                          const float* __restrict__ W,
-                                                          const float* __restrict__ a,
-                                                          const float* __restrict__ w_skip,
+                                                          const float* __restrict__ W_,
+                                                          const float* __restrict__ a_,
+                                                          const float* __restrict__ w_skip_, HeadPtrs tab, int has_skip,
                                                           float* __restrict__ Wcat, int64_t ldw,
                                                           float* __restrict__ a_pad, int copy_blocks) {
-  const int R = H * Fp, Rs = w_skip ? R : 0;
+  const int R = H * Fp, Rs = has_skip ? R : 0;
+  auto Wp = [&](int h) { return TABLE ? tab.w[h] : W_ + (int64_t)h * Fin * Fo; };        // [Fin x F'] of head h
+  auto Ap = [&](int h) { return TABLE ? tab.a[h] : a_ + (int64_t)h * 2 * Fo; };          // [2F']
+  auto Sp = [&](int h) { return TABLE ? tab.s[h] : w_skip_ + (int64_t)h * Fin * Fo; };
   if ((int)blockIdx.x >= copy_blocks) {
     const int64_t wv = ((int64_t)blockIdx.x - copy_blocks) * 4 + (threadIdx.x >> 6);
     if (wv >= (int64_t)Fin * H) return;
     const int k = (int)(wv / H), h = (int)(wv % H), lane = threadIdx.x & 63;
-    const float* wr = W + ((int64_t)h * Fin + k) * Fo;
-    const float* ar = a + (int64_t)h * 2 * Fo;
+    const float* wr = Wp(h) + (int64_t)k * Fo;
+    const float* ar = Ap(h);
     float vs = 0.f, vd = 0.f;
     for (int f = lane; f < Fo; f += 64) {
       const float w = wr[f];
@@ -165,17 +177,17 @@ __global__ __launch_bounds__(256) void pack_params_kernel(int H, int Fin, int Fo
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx < (int64_t)H * 2 * Fp) {  // a_pad[h][which][f]
     const int h = (int)(idx / (2 * Fp)), r = (int)(idx % (2 * Fp)), which = r / Fp, f = r % Fp;
-    a_pad[idx] = f < Fo ? a[(int64_t)h * 2 * Fo + which * Fo + f] : 0.f;
+    a_pad[idx] = f < Fo ? Ap(h)[which * Fo + f] : 0.f;
   }
   if (idx >= (int64_t)Fin * ldw) return;
   const int k = (int)(idx / ldw), col = (int)(idx % ldw);
   float v = 0.f;
   if (col < R) {
     const int h = col / Fp, f = col % Fp;
-    if (f < Fo) v = W[((int64_t)h * Fin + k) * Fo + f];
+    if (f < Fo) v = Wp(h)[(int64_t)k * Fo + f];
   } else if (col < R + Rs) {
     const int h = (col - R) / Fp, f = (col - R) % Fp;
-    if (f < Fo) v = w_skip[((int64_t)h * Fin + k) * Fo + f];
+    if (f < Fo) v = Sp(h)[(int64_t)k * Fo + f];
   } else if (col < R + Rs + 2 * H) {
     return;                         // the W_h a columns: written by the waves of the second block range
   }
@@ -252,9 +264,65 @@ extern "C" int pygat_pack_params(int H, int Fin, int Fo, const float* W, const f
   int64_t tot = (int64_t)Fin * ldw;
   if (tot < (int64_t)H * 2 * Fp) tot = (int64_t)H * 2 * Fp;
   const int copy_blocks = (int)cdiv(tot, 256);
-  hipLaunchKernelGGL(pack_params_kernel, dim3((unsigned)(copy_blocks + cdiv((int64_t)Fin * H, 4))), dim3(256), 0,
-                     (hipStream_t)stream, H, Fin, Fo, Fp, W, a, w_skip, Wcat, ldw, a_pad, copy_blocks);
+  HeadPtrs none = {};
+  hipLaunchKernelGGL(pack_params_kernel<false>, dim3((unsigned)(copy_blocks + cdiv((int64_t)Fin * H, 4))), dim3(256), 0,
+                     (hipStream_t)stream, H, Fin, Fo, Fp, W, a, w_skip, none, w_skip ? 1 : 0, Wcat, ldw, a_pad, copy_blocks);
   PYGAT_CHECK_LAUNCH("pack_params");
+  return PYGAT_OK;
+}
+
+// The per-head parameter tensors of a level copied into stacked arrays W [H x nW], a [H x nA], w_skip [H x nW] in ONE
+// launch (torch.stack: one cat launch per parameter kind).  For the level flavours that still take stacked parameters.
+namespace pygat {
+__global__ __launch_bounds__(256) void stack_heads_kernel(int H, int64_t nW, int nA, int64_t nS, HeadPtrs tab, float* __restrict__ W,
+                                                          float* __restrict__ a, float* __restrict__ S) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t per = nW + nA + nS;
+  if (idx >= per * H) return;
+  const int h = (int)(idx / per);
+  const int64_t r = idx % per;
+  if (r < nW) W[h * nW + r] = tab.w[h][r];
+  else if (r < nW + nA) a[(int64_t)h * nA + (r - nW)] = tab.a[h][r - nW];
+  else S[h * nS + (r - nW - nA)] = tab.s[h][r - nW - nA];
+}
+}  // namespace pygat
+
+extern "C" int pygat_stack_heads(int H, int64_t nW, int nA, int64_t nS, const float* const* W, const float* const* a,
+                                 const float* const* w_skip, float* W_out, float* a_out, float* skip_out, void* stream) {
+  if (!w_skip) nS = 0;
+  PYGAT_REQUIRE(H > 0 && H <= MAX_HEADS_TABLE && nW > 0 && nA > 0 && nS >= 0 && W && a && W_out && a_out && (!w_skip || (skip_out && nS > 0)),
+                "stack_heads: bad arguments (1 <= H <= %d)", MAX_HEADS_TABLE);
+  HeadPtrs tab = {};
+  for (int h = 0; h < H; ++h) {
+    PYGAT_REQUIRE(W[h] && a[h] && (!w_skip || w_skip[h]), "stack_heads: null parameter pointer of head %d", h);
+    tab.w[h] = W[h]; tab.a[h] = a[h]; tab.s[h] = w_skip ? w_skip[h] : nullptr;
+  }
+  const int64_t tot = (nW + nA + nS) * H;
+  hipLaunchKernelGGL(stack_heads_kernel, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, H, nW, nA, nS, tab,
+                     W_out, a_out, skip_out);
+  PYGAT_CHECK_LAUNCH("stack_heads");
+  return PYGAT_OK;
+}
+
+extern "C" int pygat_pack_params_heads(int H, int Fin, int Fo, const float* const* W, const float* const* a,
+                                       const float* const* w_skip, float* Wcat, int64_t ldw, float* a_pad, void* stream) {
+  int Fp = padded_width(Fo);
+  PYGAT_REQUIRE(H > 0 && H <= MAX_HEADS_TABLE && Fin > 0 && Fp > 0 && W && a && Wcat && a_pad,
+                "pack_params_heads: bad arguments (1 <= H <= %d)", MAX_HEADS_TABLE);
+  const int need = H * Fp * (w_skip ? 2 : 1) + 2 * H;
+  PYGAT_REQUIRE(ldw >= need && ldw % 4 == 0, "pack_params_heads: ldw=%lld must be a multiple of 4 and >= %d", (long long)ldw, need);
+  HeadPtrs tab = {};
+  for (int h = 0; h < H; ++h) {
+    PYGAT_REQUIRE(W[h] && a[h] && (!w_skip || w_skip[h]), "pack_params_heads: null parameter pointer of head %d", h);
+    tab.w[h] = W[h]; tab.a[h] = a[h]; tab.s[h] = w_skip ? w_skip[h] : nullptr;
+  }
+  int64_t tot = (int64_t)Fin * ldw;
+  if (tot < (int64_t)H * 2 * Fp) tot = (int64_t)H * 2 * Fp;
+  const int copy_blocks = (int)cdiv(tot, 256);
+  hipLaunchKernelGGL(pack_params_kernel<true>, dim3((unsigned)(copy_blocks + cdiv((int64_t)Fin * H, 4))), dim3(256), 0,
+                     (hipStream_t)stream, H, Fin, Fo, Fp, nullptr, nullptr, nullptr, tab, w_skip ? 1 : 0, Wcat, ldw, a_pad,
+                     copy_blocks);
+  PYGAT_CHECK_LAUNCH("pack_params_heads");
   return PYGAT_OK;
 }
 

@@ -1,0 +1,113 @@
+// K8 -- the training loss of the reference's citation-network script as two launches (gfx950).
+//
+// train.py:151-152,159:  output = F.log_softmax(F.elu(model(features, adj)), dim=1)
+//                        loss   = F.nll_loss(output[idx_train], labels[idx_train])
+// ATen runs that as elu, log_softmax, two index kernels, nll_loss and -- in the backward -- nll_loss_backward, three fills,
+// an index_put with accumulate (five index-arithmetic kernels and a radix sort), log_softmax_backward and elu_backward:
+// 17 launches of 2-5 us each in an epoch whose attention kernels take 7-10 us (tools/epoch_sequence.py).  Here:
+//   forward   loss = sum_r w_r * (-log softmax(elu(out_r))[y_r]),   w_r = (multiplicity of r in the index set) / |index set|
+//   backward  dOut[r, c] = g * w_r * (softmax(elu(out_r))[c] - [c == y_r]) * elu'(out[r, c])      (0 where w_r == 0)
+// one thread per row (C is 3-7 classes), partial sums per block, the LAST block to finish adds them in block order
+// (a counter in the workspace, left at zero again): deterministic, no second launch.
+#include "common.h"
+
+namespace pygat {
+
+__device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expm1f(x); }
+
+__global__ __launch_bounds__(256) void nll_fwd_kernel(int n, int C, const float* __restrict__ out, int64_t ldo,
+                                                      const int32_t* __restrict__ label, const float* __restrict__ weight,
+                                                      float* __restrict__ ws, float* __restrict__ loss) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  float v = 0.f;
+  if (r < n) {
+    const float w = weight[r];
+    if (w != 0.f) {
+      const float* o = out + (int64_t)r * ldo;
+      float mx = -INFINITY;
+      for (int c = 0; c < C; ++c) mx = fmaxf(mx, elu_f(o[c]));
+      float se = 0.f;
+      for (int c = 0; c < C; ++c) se += expf(elu_f(o[c]) - mx);
+      v = w * (mx + logf(se) - elu_f(o[label[r]]));
+    }
+  }
+  // block sum in a fixed order: lanes by DPP / shuffles, waves through LDS
+  v = group_sum<64>(v);
+  __shared__ float sm[4];
+  __shared__ int last;
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  unsigned int* counter = reinterpret_cast<unsigned int*>(ws);
+  float* part = ws + 4;
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    __threadfence();
+    last = (atomicAdd(counter, 1u) == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (last) {   // the last block to arrive: every partial is visible (fence above, fence below)
+    __threadfence();
+    float t = 0.f;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) t += __builtin_nontemporal_load(part + b);
+    t = group_sum<64>(t);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      loss[0] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+      *counter = 0u;   // ready for the next launch (a replayed HIP graph included)
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void nll_bwd_kernel(int n, int C, const float* __restrict__ out, int64_t ldo,
+                                                      const int32_t* __restrict__ label, const float* __restrict__ weight,
+                                                      const float* __restrict__ gscale, float* __restrict__ dout, int64_t ldd) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  const float w = weight[r] * gscale[0];
+  float* d = dout + (int64_t)r * ldd;
+  if (w == 0.f) {
+    for (int c = 0; c < C; ++c) d[c] = 0.f;
+    return;
+  }
+  const float* o = out + (int64_t)r * ldo;
+  float mx = -INFINITY;
+  for (int c = 0; c < C; ++c) mx = fmaxf(mx, elu_f(o[c]));
+  float se = 0.f;
+  for (int c = 0; c < C; ++c) se += expf(elu_f(o[c]) - mx);
+  const float rse = 1.f / se;
+  const int y = label[r];
+  for (int c = 0; c < C; ++c) {
+    const float x = o[c];
+    const float p = expf(elu_f(x) - mx) * rse;
+    d[c] = w * (p - (c == y ? 1.f : 0.f)) * (x > 0.f ? 1.f : expf(x));
+  }
+}
+
+}  // namespace pygat
+
+using namespace pygat;
+
+extern "C" size_t pygat_nll_workspace_bytes(int n) {
+  if (n <= 0) return 0;
+  return (size_t)(4 + cdiv(n, 256)) * sizeof(float);
+}
+
+extern "C" int pygat_elu_logsoftmax_nll(int n, int C, const float* out, int64_t ldo, const int32_t* label, const float* weight,
+                                        void* ws, float* loss, void* stream) {
+  PYGAT_REQUIRE(n > 0 && C > 0 && out && label && weight && ws && loss && ldo >= C, "elu_logsoftmax_nll: bad arguments");
+  hipLaunchKernelGGL(nll_fwd_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n, C, out, ldo, label,
+                     weight, (float*)ws, loss);
+  PYGAT_CHECK_LAUNCH("elu_logsoftmax_nll");
+  return PYGAT_OK;
+}
+
+extern "C" int pygat_elu_logsoftmax_nll_backward(int n, int C, const float* out, int64_t ldo, const int32_t* label,
+                                                 const float* weight, const float* gscale, float* dout, int64_t ldd, void* stream) {
+  PYGAT_REQUIRE(n > 0 && C > 0 && out && label && weight && gscale && dout && ldo >= C && ldd >= C,
+                "elu_logsoftmax_nll_backward: bad arguments");
+  hipLaunchKernelGGL(nll_bwd_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n, C, out, ldo, label,
+                     weight, gscale, dout, ldd);
+  PYGAT_CHECK_LAUNCH("elu_logsoftmax_nll_backward");
+  return PYGAT_OK;
+}

@@ -36,7 +36,7 @@ import os
 from . import _lib, ops
 from ._lib import lib, check, padded_width
 from .graph import CSRGraph, slot_edges_for
-from .ops import _Level, _ptr, _span, _stream, gemm, gemm_mode, get_gemm_mode
+from .ops import _Level, _ptr, _span, _stream, gemm, gemm_mode, get_gemm_mode, stack_heads
 
 
 STREAM_X, STREAM_WH, STREAM_ATT = 1, 2, 3     # Philox stream ids of the three masks drawn from one seed
@@ -152,9 +152,9 @@ class GATLevelDropoutFn(torch.autograd.Function):
             with _span("k2_forward"):
                 check(lib.pygat_gat_forward(graph.fwd.ref(L.ts), H, Fo, float(alpha), flags, Wh.data_ptr(), s.data_ptr(),
                                             a_pad.data_ptr(), _ptr(Sk), matt.data_ptr(),
-                                            out.data_ptr() if concat else None, _ptr(hattn), m.data_ptr(), Z.data_ptr(),
+                                            out.data_ptr() if (concat or H == 1) else None, _ptr(hattn), m.data_ptr(), Z.data_ptr(),
                                             _ptr(aneg), _ptr(qneg), part.data_ptr(), st), "gat_forward")
-            if not concat:
+            if not concat and H > 1:     # (the mean over one head is that head: K2 wrote `out` itself, see ops._level_forward)
                 check(lib.pygat_head_mean(L.N, H, Fo, hattn.data_ptr(), _ptr(Sk), out.data_ptr(), st), "head_mean")
         ctx.save_for_backward(x if use_bits else Ae, bits if use_bits else Bp, a_pad, Wh, s, Sk, out if concat else hattn, m, Z,
                               mask_x if explicit else seed, mwh, matt, aneg, qneg, Wcat if use_bits else None)
@@ -289,9 +289,7 @@ def gat_level_dropout(x, graph: CSRGraph, Ws: Sequence[torch.Tensor], As: Sequen
     """One level in training mode with dropout p.  `masks` (tests) = {"x","wh","att"} pre-scaled; without them the
     masks are drawn in-kernel from one int64 seed taken from torch's (graph-safe) generator."""
     del head_mean  # implied by `concat` (models.py:23): concat=False <=> last level <=> head mean
-    W = torch.stack(list(Ws), 0)
-    a = torch.stack([q.reshape(-1) for q in As], 0)
-    Wskip = torch.stack(list(Wskips), 0) if Wskips is not None else None
+    W, a, Wskip = stack_heads(list(Ws), list(As), None if Wskips is None else list(Wskips))   # one launch, not a cat per kind
     if masks is not None:
         return GATLevelDropoutFn.apply(x, W, a, Wskip, graph, alpha, concat, p, masks["x"], masks["wh"], masks["att"], None)
     seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=x.device, generator=generator)

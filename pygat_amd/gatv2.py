@@ -20,7 +20,7 @@ import torch.nn as nn
 from . import _lib
 from ._lib import lib, check
 from .graph import CSRGraph, as_graph
-from .ops import _Level, _ptr, _stream, gemm, gat_level, gemm_mode, get_gemm_mode
+from .ops import _Level, _ptr, _stream, gemm, gat_level, gemm_mode, get_gemm_mode, stack_heads
 
 
 class GATv2LevelFn(torch.autograd.Function):
@@ -181,9 +181,7 @@ def gatv2_level(x, graph: CSRGraph, Ws: Sequence[torch.Tensor], As: Sequence[tor
                 masks: Optional[dict] = None) -> torch.Tensor:
     """All heads of one SpGraphAttentionLayerV2 level.  Ws: H tensors [2Fin,F']; As: H tensors of F' elements.
     dropout > 0 (training): per-head masks are drawn here unless given (`masks`, tests)."""
-    W = torch.stack(list(Ws), 0)
-    a = torch.stack([q.reshape(-1) for q in As], 0)
-    Wskip = torch.stack(list(Wskips), 0) if Wskips is not None else None
+    W, a, Wskip = stack_heads(list(Ws), list(As), None if Wskips is None else list(Wskips))   # one launch, not a cat per kind
     if masks is None and dropout > 0.0:
         H, Fin2, Fo = W.shape
         masks = draw_masks_v2(dropout, H, x.shape[0], Fin2 // 2, Fo, graph.nnz, x.device)

@@ -54,7 +54,11 @@ class _Replay(torch.autograd.Function):
         if G.data_ptr() != lvl.G.data_ptr():
             lvl.G.copy_(G)
         lvl.g_bwd.replay()
-        return (None,) + tuple(None if g is None else g.detach() for g in lvl.grads)
+        # copies: the static buffers are overwritten by the next replay, and autograd may adopt a returned tensor as
+        # param.grad (then accumulate into it in place)
+        if ctx.needs_input_grad[1] and lvl.grads[0] is None:
+            raise RuntimeError("GraphedLevel: x requires grad but the level was captured with need_dx=False")
+        return (None,) + tuple(None if g is None else g.detach().clone() for g in lvl.grads)
 
 
 class GraphedLevel:
@@ -141,6 +145,7 @@ class FusedEpoch:
         self.loss_fn, self.eval_fn, self.evaluate = loss_fn, (eval_fn or loss_fn), evaluate
         self.epochs = 0
         self.g = None
+        self._one = torch.ones((), dtype=torch.float32, device=x.device)   # d loss / d loss, made once (backward() would fill one per step)
         if capture:                                       # capture=False: the same epoch body, launched eagerly
             with torch.cuda.device(x.device):
                 _side_warmup(self._eager_epoch, warmup)   # NOTE: these warm-up epochs DO train the model
@@ -153,7 +158,7 @@ class FusedEpoch:
         self.model.train()
         self.opt.zero_grad(set_to_none=True)     # no fill kernels; the first gradient of a step is adopted, not added
         loss = self.loss_fn(self.model(self.x, self.graph))
-        loss.backward()
+        loss.backward(self._one if loss.dtype == torch.float32 and loss.dim() == 0 else None)
         self.opt.step()
         val = loss
         if self.evaluate:

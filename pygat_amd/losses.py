@@ -1,0 +1,66 @@
+"""The training loss of the reference's citation-network script as two HIP launches.
+
+train.py:151-152,159 computes `F.nll_loss(F.log_softmax(F.elu(model(x, adj)), dim=1)[idx_train], labels[idx_train])`;
+ATen spends 17 launches on it per training step (an index_put with a radix sort among them) in an epoch whose attention
+kernels take microseconds.  `EluLogSoftmaxNLL(idx, labels, n)(out)` is the same value and the same gradient in one launch
+forward, one backward (csrc/k8_loss.hip).  No CPU path: the tensors must live on the GPU.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import lib, check
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _NLLFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out, crit):
+        if not out.is_cuda:
+            raise RuntimeError("pygat_amd: EluLogSoftmaxNLL needs GPU tensors; there is no CPU path")
+        out = out.contiguous().float()
+        n, C = out.shape
+        if n != crit.n:
+            raise ValueError(f"EluLogSoftmaxNLL: built for {crit.n} rows, got {n}")
+        loss = torch.empty(1, dtype=torch.float32, device=out.device)
+        with torch.cuda.device(out.device):
+            check(lib.pygat_elu_logsoftmax_nll(n, C, out.data_ptr(), C, crit.label.data_ptr(), crit.weight.data_ptr(),
+                                               crit.ws.data_ptr(), loss.data_ptr(), _stream()), "elu_logsoftmax_nll")
+        ctx.save_for_backward(out)
+        ctx.crit = crit
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        crit = ctx.crit
+        n, C = out.shape
+        g = g.reshape(1).float().contiguous()
+        dout = torch.empty_like(out)
+        with torch.cuda.device(out.device):
+            check(lib.pygat_elu_logsoftmax_nll_backward(n, C, out.data_ptr(), C, crit.label.data_ptr(), crit.weight.data_ptr(),
+                                                        g.data_ptr(), dout.data_ptr(), C, _stream()),
+                  "elu_logsoftmax_nll_backward")
+        return dout, None
+
+
+class EluLogSoftmaxNLL:
+    """loss(out) == F.nll_loss(F.log_softmax(F.elu(out), dim=1)[idx], labels[idx])  (train.py:151-152,159).
+
+    idx: the rows the loss is taken over (idx_train / idx_val / idx_test; repeats count as often as they occur),
+    labels: [n] class per row, n: rows of the model output."""
+
+    def __init__(self, idx: torch.Tensor, labels: torch.Tensor, n: int):
+        if not (idx.is_cuda and labels.is_cuda):
+            raise RuntimeError("pygat_amd: EluLogSoftmaxNLL needs GPU tensors; there is no CPU path")
+        self.n = int(n)
+        idx = idx.long()
+        self.weight = (torch.bincount(idx, minlength=self.n).float() / max(1, idx.numel())).contiguous()
+        self.label = labels.to(torch.int32).contiguous()
+        self.ws = torch.zeros(lib.pygat_nll_workspace_bytes(self.n) // 4, dtype=torch.float32, device=idx.device)
+
+    def __call__(self, out: torch.Tensor) -> torch.Tensor:
+        return _NLLFn.apply(out, self)

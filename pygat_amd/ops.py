@@ -281,176 +281,288 @@ class GATLevelFn(torch.autograd.Function):
         H, Fin, Fo = W.shape
         if x.shape[1] != Fin or a.shape != (H, 2 * Fo):
             raise ValueError(f"shape mismatch: x {tuple(x.shape)}, W {tuple(W.shape)}, a {tuple(a.shape)}")
-        if x.shape[0] != graph.n:
-            raise ValueError(f"x has {x.shape[0]} rows but the graph has {graph.n} nodes")
         skip = Wskip is not None
         if skip:
             Wskip = Wskip.contiguous().float()
-        L = _Level(x, H, Fo, skip)
-        L.ts = slot_edges_for(L.R, graph.slot_edges)
-        L.mode = get_gemm_mode()     # this thread's product mode, fixed for the level: its backward (another thread) uses it too
-        dev, f32 = x.device, torch.float32
-        need_grad = any(ctx.needs_input_grad[:4])
-        with torch.cuda.device(dev):
-            st = _stream()
-            Wcat = torch.empty(Fin, L.ldw, dtype=f32, device=dev)
-            a_pad = torch.empty(H, 2, L.Fp, dtype=f32, device=dev)
-            check(lib.pygat_pack_params(H, Fin, Fo, W.data_ptr(), a.data_ptr(), _ptr(Wskip), Wcat.data_ptr(), L.ldw,
+
+        def pack(Wcat, ldw, a_pad, st):
+            check(lib.pygat_pack_params(H, Fin, Fo, W.data_ptr(), a.data_ptr(), _ptr(Wskip), Wcat.data_ptr(), ldw,
                                         a_pad.data_ptr(), st), "pack_params")
-            # K1: [Wh | Sk | s | t] = x @ Wcat
-            Wh = torch.empty(L.N, L.R, dtype=f32, device=dev)
-            Sk = torch.empty(L.N, L.R, dtype=f32, device=dev) if skip else None
-            s = torch.empty(L.N, H, dtype=f32, device=dev)
-            ncols = L.R * (2 if skip else 1) + H
-            tiles = -(-L.N // 128) * -(-ncols // 128)
-            # few row tiles (Cora: 22): K slabs of >= 128 until ~1.5 work-groups per CU (PYGAT_K1_SPLIT_MIN_K: slab floor)
-            split_k = max(1, min(-(-384 // tiles), Fin // _K1_SLAB)) if tiles < 256 else 1
-            ws = torch.empty(lib.pygat_gemm_workspace_bytes(L.N, ncols, split_k) // 4, dtype=f32, device=dev) \
-                if split_k > 1 else None
-            with _span("k1_project"):
-                check(lib.pygat_project(L.N, Fin, H, Fo, x.data_ptr(), Fin, Wcat.data_ptr(), L.ldw, a_pad.data_ptr(), Wh.data_ptr(),
-                                        _ptr(Sk), s.data_ptr(), split_k, _ptr(ws), GEMM_MODES[L.mode], st), "project")
-            # K2
-            flags = (_lib.F_ELU if concat else 0) | (_lib.F_SKIP if skip else 0)
-            hattn = torch.empty(L.N, L.R, dtype=f32, device=dev) if not concat else None
-            m = torch.empty(L.N, H, dtype=f32, device=dev) if need_grad else None
-            Z = torch.empty(L.N, H, dtype=f32, device=dev) if need_grad else None
-            flavour = backward_flavour(L.R) if need_grad else None
-            aneg = torch.empty(L.N, L.R, dtype=f32, device=dev) if flavour == "rowlocal" else None
-            qneg = torch.empty(L.N, H, dtype=f32, device=dev) if flavour == "rowlocal" else None
-            out = torch.empty(L.N, H * Fo if concat else Fo, dtype=f32, device=dev)
-            part = torch.empty(lib.pygat_partials_bytes(graph.nnz, L.ts, H, L.Fp) // 4, dtype=f32,
-                               device=dev)
-            chunks = [(graph.fwd.ref(L.ts), 0, L.N)]
-            if pipeline is not None and concat and pipeline[0] > 1:
-                chunks = graph.fwd.row_chunks(int(pipeline[0]), L.ts)
-            for c, (gref, r0, r1) in enumerate(chunks):
-                with _span("k2_forward"):
-                    check(lib.pygat_gat_forward(gref, H, Fo, float(alpha), flags, Wh.data_ptr(), s.data_ptr(),
-                                                a_pad.data_ptr(), _ptr(Sk), None, out.data_ptr() if concat else None,
-                                                _ptr(hattn), _ptr(m), _ptr(Z), _ptr(aneg), _ptr(qneg), part.data_ptr(), st),
-                          "gat_forward")
-                if pipeline is not None and concat:
-                    pipeline[1](c, r0, r1, out)
-            if not concat:
-                check(lib.pygat_head_mean(L.N, H, Fo, hattn.data_ptr(), _ptr(Sk), out.data_ptr(), st), "head_mean")
-        if need_grad:
-            # concat: the backward recovers hattn from `out` (no second [N,R] table is written)
-            ctx.save_for_backward(x, Wcat, a_pad, Wh, s, Sk, out if concat else hattn, m, Z, aneg, qneg)
-            ctx.graph, ctx.L, ctx.alpha, ctx.concat, ctx.flags = graph, L, float(alpha), concat, flags
-            ctx.flavour = flavour
-            ctx.bwd_heads = None
-            if bwd_heads is not None:
-                hb, hr = int(bwd_heads[0]), int(bwd_heads[1])
-                if not (0 <= hb and 0 < hr and hb + hr <= H):
-                    raise ValueError(f"bwd_heads {bwd_heads} outside the {H} heads of the level")
-                if skip or ctx.needs_input_grad[0]:
-                    raise ValueError("pygat_amd: bwd_heads supports neither a skip projection nor a gradient into x")
-                ctx.bwd_heads = (hb, hr)
-        return out
+        return _level_forward(ctx, tuple(ctx.needs_input_grad[:4]), x, H, Fo, skip, pack, graph, alpha, concat, bwd_heads, pipeline)
 
     @staticmethod
     def backward(ctx, G):
-        x, Wcat, a_pad, Wh, s, Sk, y, m, Z, aneg, qneg = ctx.saved_tensors
-        graph, L, H, Fo = ctx.graph, ctx.L, ctx.L.H, ctx.L.Fo
-        dev, f32 = x.device, torch.float32
-        G = G.contiguous().float()
-        ranged = ctx.bwd_heads is not None
-        hb, hr = ctx.bwd_heads if ranged else (0, 0)       # (0, 0) = all heads in the C ABI
-        Hb = hr if ranged else H                            # heads this backward covers
-        with torch.cuda.device(dev):
-            st = _stream()
-            RW = Hb * (L.Fp + 4)                            # GR is compact for the covered heads
-            GR = torch.empty(L.N, RW, dtype=f32, device=dev)      # per head window: [Gp | (s, m, 1/Z, D) per head]
-            ds = torch.empty(L.N, H, dtype=f32, device=dev)
-            dt = torch.empty(L.N, H, dtype=f32, device=dev)
-            dWh = torch.empty(L.N, L.R, dtype=f32, device=dev)
-            part = torch.empty(lib.pygat_partials_bytes(graph.nnz, L.ts, H, L.Fp) // 4, dtype=f32,
-                               device=dev)
-            rowlocal = ctx.flavour == "rowlocal"
-            with _span("k3a_prepare"):
-                check(lib.pygat_gat_backward_prepare(L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(),
-                                                     y.data_ptr(), _ptr(Sk), s.data_ptr(), m.data_ptr(), Z.data_ptr(),
-                                                     GR.data_ptr(), _ptr(aneg), _ptr(qneg), ctx.alpha,
-                                                     ds.data_ptr() if rowlocal else None, hb, hr, st), "gat_backward_prepare")
-            two_gather = ctx.flavour == "two-gather"
-            if rowlocal:        # ds is known: the column pass finishes dWh on its own
-                with _span("k4_backward_col"):
-                    check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), None, H, Fo, ctx.alpha, Wh.data_ptr(),
-                                                     a_pad.data_ptr(), GR.data_ptr(), None, ds.data_ptr(),
-                                                     dWh.data_ptr(), dt.data_ptr(), None, part.data_ptr(), hb, hr, st),
-                          "gat_backward_col")
-            elif two_gather:
-                with _span("k3b_row"):
-                    check(lib.pygat_gat_backward_row(graph.fwd.ref(L.ts), H, Fo, ctx.alpha, Wh.data_ptr(),
-                                                     a_pad.data_ptr(), GR.data_ptr(), None, ds.data_ptr(),
-                                                     part.data_ptr(), hb, hr, st), "gat_backward_row")
-                with _span("k4_backward_col"):
-                    check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), None, H, Fo, ctx.alpha, Wh.data_ptr(),
-                                                     a_pad.data_ptr(), GR.data_ptr(), None, ds.data_ptr(),
-                                                     dWh.data_ptr(), dt.data_ptr(), None, part.data_ptr(), hb, hr, st),
-                          "gat_backward_col")
-            else:
-                dz_t = torch.empty(graph.nnz, H, dtype=f32, device=dev)
-                with _span("k4_backward_col"):
-                    check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), None, H, Fo, ctx.alpha, Wh.data_ptr(),
-                                                     a_pad.data_ptr(), GR.data_ptr(), None, None,
-                                                     dWh.data_ptr(), dt.data_ptr(), dz_t.data_ptr(), part.data_ptr(), hb, hr, st),
-                          "gat_backward_col")
-                with _span("k3c_rowsum"):
-                    check(lib.pygat_gat_backward_rowsum(graph.fwd.ref(L.ts), graph.perm_f.data_ptr(), H, Fo,
-                                                        dz_t.data_ptr(), ds.data_ptr(), part.data_ptr(), hb, hr, st),
-                          "gat_backward_rowsum")
-            # da; after the row-sum flavour the same stream also finishes dWh_i += ds_i a_src
-            da = (torch.zeros if ranged else torch.empty)(H, 2 * Fo, dtype=f32, device=dev)
-            ws = torch.empty(lib.pygat_agrad_workspace_bytes(H, Fo) // 4, dtype=f32, device=dev)
-            # ... unless nothing but the weight-gradient GEMM consumes dWh: there ds rides along as extra columns
-            # (pygat_wgrad) and dWh is never rewritten
-            rowsum = ctx.flavour == "rowsum"
-            fold_ds = (rowsum and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]
-                       and (Hb * L.Fp) % 32 == 0 and L.N >= 4096)   # the streamed-K GEMM takes [dWh | ds] in one pass
-            finish = rowsum and not fold_ds
-            # when a_grad does not rewrite dWh, nothing downstream depends on it: run it on the side stream,
-            # beside the weight-gradient GEMM (TIMER spans stay on the main stream: no fork while timing kernels)
-            fork = OVERLAP_BACKWARD and not finish and TIMER is None and ctx.needs_input_grad[1]
-            if fork:
-                main, side = torch.cuda.current_stream(), _side_stream(dev)
-                side.wait_stream(main)      # the tensors it touches stay referenced until the join below
-            with _span("k5_agrad"):
-                check(lib.pygat_a_grad(L.N, H, Fo, Wh.data_ptr(), ds.data_ptr(), dt.data_ptr(), da.data_ptr(),
-                                       ws.data_ptr(), a_pad.data_ptr() if finish else None,
-                                       dWh.data_ptr() if finish else None, hb, hr,
-                                       side.cuda_stream if fork else st), "a_grad")
-            # dW = x^T dWh (split-K over the nodes), dWskip = x^T Gp
-            dW = dWs = dx = None
-            if ctx.needs_input_grad[1]:
-                split_k = _split_k(L.Fin, Hb * L.Fp + (Hb if fold_ds else 0), L.N, streamed_k=True, mode=L.mode)
-                wsw = torch.empty(lib.pygat_wgrad_workspace_bytes(L.Fin, H, Fo, split_k) // 4, dtype=f32, device=dev)
-                dW = (torch.zeros if ranged else torch.empty)(H, L.Fin, Fo, dtype=f32, device=dev)
-                with _span("k5_wgrad"):
-                    check(lib.pygat_wgrad(L.N, L.Fin, H, Fo, x.data_ptr(), L.Fin, dWh.data_ptr(),
-                                          ds.data_ptr() if fold_ds else None, a_pad.data_ptr(), dW.data_ptr(), split_k,
-                                          wsw.data_ptr(), hb, hr, GEMM_MODES[L.mode], st), "wgrad")
-            if L.skip and ctx.needs_input_grad[3]:
-                dSc = torch.empty(L.Fin, L.R, dtype=f32, device=dev)
-                for c0, w, g0 in L.gp_windows():
-                    gemm(True, False, L.Fin, w, L.N, x, L.Fin, GR[:, g0:], RW, [(w, dSc[:, c0:], L.R)], mode=L.mode)
-                dWs = torch.empty(H, L.Fin, Fo, dtype=f32, device=dev)
-                check(lib.pygat_unpack_wgrad(H, L.Fin, Fo, dSc.data_ptr(), L.R, 0, dWs.data_ptr(), st), "unpack")
-            # dx = dWh Wcat[:, :R]^T (+ Gp Wcat[:, R:2R]^T)
-            if ctx.needs_input_grad[0]:
-                dx = torch.empty(L.N, L.Fin, dtype=f32, device=dev)
-                with _span("k5_xgrad"):
-                    gemm(False, True, L.N, L.Fin, L.R, dWh, L.R, Wcat, L.ldw, [(L.Fin, dx, L.Fin)], mode=L.mode)
-                    if L.skip:
-                        for c0, w, g0 in L.gp_windows():
-                            gemm(False, True, L.N, L.Fin, w, GR[:, g0:], RW, Wcat[:, L.R + c0:], L.ldw,
-                                 [(L.Fin, dx, L.Fin)], accumulate=True, split_k=1, mode=L.mode)
-            if fork:
-                main.wait_stream(side)
+        dx, dW, da, dWs = _level_backward(ctx, G)
         cast = lambda g_, k: g_ if g_ is None or g_.dtype == ctx.in_dtypes[k] else g_.to(ctx.in_dtypes[k])  # noqa: E731
-        return (cast(dx, 0), cast(dW, 1), (cast(da, 2) if ctx.needs_input_grad[2] else None), cast(dWs, 3), None, None, None,
-                None, None)
+        return (cast(dx, 0), cast(dW, 1), cast(da, 2), cast(dWs, 3), None, None, None, None, None)
+
+
+MAX_HEAD_TABLE = 16     # PYGAT_MAX_HEADS_TABLE: heads whose parameter pointers travel as kernel arguments
+
+
+class GATLevelHeadsFn(torch.autograd.Function):
+    """The same level with its parameters given as they live in the model -- one W [Fin,F'], a (2F' values) and
+    skip_projection [Fin,F'] tensor PER HEAD (layers.py:21-28,111-119; models.py:15-27) -- instead of stacked: the packing
+    kernel reads them through a pointer table (pygat_pack_params_heads), so no torch.stack (a cat launch per parameter
+    kind, level and forward: a tenth of a small graph's epoch) precedes the level.
+    forward(x, graph, alpha, concat, pipeline, H, skip, *Ws, *As[, *Wskips]) -> out."""
+
+    @staticmethod
+    def forward(ctx, x, graph: CSRGraph, alpha: float, concat: bool, pipeline, H: int, skip: bool, *params):
+        if not x.is_cuda:
+            raise RuntimeError("pygat_amd: inputs must be on the GPU; the hot path has no CPU fallback")
+        Ws, As = params[:H], params[H:2 * H]
+        Ss = params[2 * H:3 * H] if skip else ()
+        Fin, Fo = Ws[0].shape
+        ctx.in_dtype_x = x.dtype
+        ctx.param_shapes = [tuple(p.shape) for p in params]
+        ctx.param_dtypes = [p.dtype for p in params]
+        x = x.contiguous().float()
+        Ws = [w.contiguous().float() for w in Ws]; As = [v.contiguous().float() for v in As]; Ss = [w.contiguous().float() for w in Ss]
+        if x.shape[1] != Fin or any(w.shape != (Fin, Fo) for w in Ws) or any(v.numel() != 2 * Fo for v in As):
+            raise ValueError(f"shape mismatch: x {tuple(x.shape)}, W {tuple(Ws[0].shape)}, a {tuple(As[0].shape)}")
+        PT = C.c_void_p * H
+        wp, ap = PT(*[w.data_ptr() for w in Ws]), PT(*[v.data_ptr() for v in As])
+        sp = PT(*[w.data_ptr() for w in Ss]) if skip else None
+
+        def pack(Wcat, ldw, a_pad, st):
+            check(lib.pygat_pack_params_heads(H, Fin, Fo, wp, ap, sp, Wcat.data_ptr(), ldw, a_pad.data_ptr(), st), "pack_params_heads")
+        n = ctx.needs_input_grad
+        need = (n[0], any(n[7:7 + H]), any(n[7 + H:7 + 2 * H]), skip and any(n[7 + 2 * H:7 + 3 * H]))
+        ctx.H, ctx.skip = H, skip
+        return _level_forward(ctx, need, x, H, Fo, skip, pack, graph, alpha, concat, None, pipeline)
+
+    @staticmethod
+    def backward(ctx, G):
+        dx, dW, da, dWs = _level_backward(ctx, G)
+        H = ctx.H
+        if dx is not None and dx.dtype != ctx.in_dtype_x:
+            dx = dx.to(ctx.in_dtype_x)
+        outs = []
+        for k in range(H):
+            outs.append(None if dW is None else dW[k])
+        for k in range(H):
+            outs.append(None if da is None else da[k].reshape(ctx.param_shapes[H + k]))
+        if ctx.skip:
+            for k in range(H):
+                outs.append(None if dWs is None else dWs[k])
+        outs = [g_ if g_ is None or g_.dtype == dt else g_.to(dt) for g_, dt in zip(outs, ctx.param_dtypes)]
+        return (dx, None, None, None, None, None, None) + tuple(outs)
+
+
+def _level_forward(ctx, need, x, H, Fo, skip, pack, graph: CSRGraph, alpha: float, concat: bool, bwd_heads, pipeline):
+    """Body of the level's forward, shared by GATLevelFn (stacked parameters) and GATLevelHeadsFn (one tensor per head).
+    need = (x, W, a, Wskip) gradient flags; pack(Wcat, ldw, a_pad, stream) launches the parameter packing."""
+    Fin = x.shape[1]
+    if x.shape[0] != graph.n:
+        raise ValueError(f"x has {x.shape[0]} rows but the graph has {graph.n} nodes")
+    L = _Level(x, H, Fo, skip)
+    L.ts = slot_edges_for(L.R, graph.slot_edges)
+    L.mode = get_gemm_mode()     # this thread's product mode, fixed for the level: its backward (another thread) uses it too
+    dev, f32 = x.device, torch.float32
+    need_grad = any(need)
+    ctx.need = need
+    with torch.cuda.device(dev):
+        st = _stream()
+        Wcat = torch.empty(Fin, L.ldw, dtype=f32, device=dev)
+        a_pad = torch.empty(H, 2, L.Fp, dtype=f32, device=dev)
+        pack(Wcat, L.ldw, a_pad, st)
+        # K1: [Wh | Sk | s | t] = x @ Wcat
+        Wh = torch.empty(L.N, L.R, dtype=f32, device=dev)
+        Sk = torch.empty(L.N, L.R, dtype=f32, device=dev) if skip else None
+        s = torch.empty(L.N, H, dtype=f32, device=dev)
+        ncols = L.R * (2 if skip else 1) + H
+        tiles = -(-L.N // 128) * -(-ncols // 128)
+        # few row tiles (Cora: 22): K slabs of >= 128 until ~1.5 work-groups per CU (PYGAT_K1_SPLIT_MIN_K: slab floor)
+        split_k = max(1, min(-(-384 // tiles), Fin // _K1_SLAB)) if tiles < 256 else 1
+        ws = torch.empty(lib.pygat_gemm_workspace_bytes(L.N, ncols, split_k) // 4, dtype=f32, device=dev) \
+            if split_k > 1 else None
+        with _span("k1_project"):
+            check(lib.pygat_project(L.N, Fin, H, Fo, x.data_ptr(), Fin, Wcat.data_ptr(), L.ldw, a_pad.data_ptr(), Wh.data_ptr(),
+                                    _ptr(Sk), s.data_ptr(), split_k, _ptr(ws), GEMM_MODES[L.mode], st), "project")
+        # K2
+        flags = (_lib.F_ELU if concat else 0) | (_lib.F_SKIP if skip else 0)
+        # mean over ONE head = that head (Cora / Citeseer output level, train.py:55,66): K2 writes `out` itself (its epilogue
+        # adds the skip rows, no ELU), no head-mean launch; hattn is then only kept for the backward
+        single = (not concat) and H == 1
+        hattn = torch.empty(L.N, L.R, dtype=f32, device=dev) if (not concat and (need_grad or not single)) else None
+        m = torch.empty(L.N, H, dtype=f32, device=dev) if need_grad else None
+        Z = torch.empty(L.N, H, dtype=f32, device=dev) if need_grad else None
+        flavour = backward_flavour(L.R) if need_grad else None
+        aneg = torch.empty(L.N, L.R, dtype=f32, device=dev) if flavour == "rowlocal" else None
+        qneg = torch.empty(L.N, H, dtype=f32, device=dev) if flavour == "rowlocal" else None
+        out = torch.empty(L.N, H * Fo if concat else Fo, dtype=f32, device=dev)
+        part = torch.empty(lib.pygat_partials_bytes(graph.nnz, L.ts, H, L.Fp) // 4, dtype=f32,
+                           device=dev)
+        chunks = [(graph.fwd.ref(L.ts), 0, L.N)]
+        if pipeline is not None and concat and pipeline[0] > 1:
+            chunks = graph.fwd.row_chunks(int(pipeline[0]), L.ts)
+        for c, (gref, r0, r1) in enumerate(chunks):
+            with _span("k2_forward"):
+                check(lib.pygat_gat_forward(gref, H, Fo, float(alpha), flags, Wh.data_ptr(), s.data_ptr(),
+                                            a_pad.data_ptr(), _ptr(Sk), None, out.data_ptr() if (concat or single) else None,
+                                            _ptr(hattn), _ptr(m), _ptr(Z), _ptr(aneg), _ptr(qneg), part.data_ptr(), st),
+                      "gat_forward")
+            if pipeline is not None and concat:
+                pipeline[1](c, r0, r1, out)
+        if not concat and not single:
+            check(lib.pygat_head_mean(L.N, H, Fo, hattn.data_ptr(), _ptr(Sk), out.data_ptr(), st), "head_mean")
+    if need_grad:
+        # concat: the backward recovers hattn from `out` (no second [N,R] table is written)
+        ctx.save_for_backward(x, Wcat, a_pad, Wh, s, Sk, out if concat else hattn, m, Z, aneg, qneg)
+        ctx.graph, ctx.L, ctx.alpha, ctx.concat, ctx.flags = graph, L, float(alpha), concat, flags
+        ctx.flavour = flavour
+        ctx.bwd_heads = None
+        if bwd_heads is not None:
+            hb, hr = int(bwd_heads[0]), int(bwd_heads[1])
+            if not (0 <= hb and 0 < hr and hb + hr <= H):
+                raise ValueError(f"bwd_heads {bwd_heads} outside the {H} heads of the level")
+            if skip or need[0]:
+                raise ValueError("pygat_amd: bwd_heads supports neither a skip projection nor a gradient into x")
+            ctx.bwd_heads = (hb, hr)
+    return out
+
+def _level_backward(ctx, G):
+    """Body of the level's backward: -> (dx | None, dW [H,Fin,F'] | None, da [H,2F'] | None, dWskip | None)."""
+    x, Wcat, a_pad, Wh, s, Sk, y, m, Z, aneg, qneg = ctx.saved_tensors
+    graph, L, H, Fo = ctx.graph, ctx.L, ctx.L.H, ctx.L.Fo
+    dev, f32 = x.device, torch.float32
+    G = G.contiguous().float()
+    ranged = ctx.bwd_heads is not None
+    hb, hr = ctx.bwd_heads if ranged else (0, 0)       # (0, 0) = all heads in the C ABI
+    Hb = hr if ranged else H                            # heads this backward covers
+    with torch.cuda.device(dev):
+        st = _stream()
+        RW = Hb * (L.Fp + 4)                            # GR is compact for the covered heads
+        GR = torch.empty(L.N, RW, dtype=f32, device=dev)      # per head window: [Gp | (s, m, 1/Z, D) per head]
+        ds = torch.empty(L.N, H, dtype=f32, device=dev)
+        dt = torch.empty(L.N, H, dtype=f32, device=dev)
+        dWh = torch.empty(L.N, L.R, dtype=f32, device=dev)
+        part = torch.empty(lib.pygat_partials_bytes(graph.nnz, L.ts, H, L.Fp) // 4, dtype=f32,
+                           device=dev)
+        rowlocal = ctx.flavour == "rowlocal"
+        with _span("k3a_prepare"):
+            check(lib.pygat_gat_backward_prepare(L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(),
+                                                 y.data_ptr(), _ptr(Sk), s.data_ptr(), m.data_ptr(), Z.data_ptr(),
+                                                 GR.data_ptr(), _ptr(aneg), _ptr(qneg), ctx.alpha,
+                                                 ds.data_ptr() if rowlocal else None, hb, hr, st), "gat_backward_prepare")
+        two_gather = ctx.flavour == "two-gather"
+        if rowlocal:        # ds is known: the column pass finishes dWh on its own
+            with _span("k4_backward_col"):
+                check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), None, H, Fo, ctx.alpha, Wh.data_ptr(),
+                                                 a_pad.data_ptr(), GR.data_ptr(), None, ds.data_ptr(),
+                                                 dWh.data_ptr(), dt.data_ptr(), None, part.data_ptr(), hb, hr, st),
+                      "gat_backward_col")
+        elif two_gather:
+            with _span("k3b_row"):
+                check(lib.pygat_gat_backward_row(graph.fwd.ref(L.ts), H, Fo, ctx.alpha, Wh.data_ptr(),
+                                                 a_pad.data_ptr(), GR.data_ptr(), None, ds.data_ptr(),
+                                                 part.data_ptr(), hb, hr, st), "gat_backward_row")
+            with _span("k4_backward_col"):
+                check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), None, H, Fo, ctx.alpha, Wh.data_ptr(),
+                                                 a_pad.data_ptr(), GR.data_ptr(), None, ds.data_ptr(),
+                                                 dWh.data_ptr(), dt.data_ptr(), None, part.data_ptr(), hb, hr, st),
+                      "gat_backward_col")
+        else:
+            dz_t = torch.empty(graph.nnz, H, dtype=f32, device=dev)
+            with _span("k4_backward_col"):
+                check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), None, H, Fo, ctx.alpha, Wh.data_ptr(),
+                                                 a_pad.data_ptr(), GR.data_ptr(), None, None,
+                                                 dWh.data_ptr(), dt.data_ptr(), dz_t.data_ptr(), part.data_ptr(), hb, hr, st),
+                      "gat_backward_col")
+            with _span("k3c_rowsum"):
+                check(lib.pygat_gat_backward_rowsum(graph.fwd.ref(L.ts), graph.perm_f.data_ptr(), H, Fo,
+                                                    dz_t.data_ptr(), ds.data_ptr(), part.data_ptr(), hb, hr, st),
+                      "gat_backward_rowsum")
+        # da; after the row-sum flavour the same stream also finishes dWh_i += ds_i a_src
+        da = (torch.zeros if ranged else torch.empty)(H, 2 * Fo, dtype=f32, device=dev)
+        ws = torch.empty(lib.pygat_agrad_workspace_bytes(H, Fo) // 4, dtype=f32, device=dev)
+        # ... unless nothing but the weight-gradient GEMM consumes dWh: there ds rides along as extra columns
+        # (pygat_wgrad) and dWh is never rewritten
+        rowsum = ctx.flavour == "rowsum"
+        fold_ds = (rowsum and ctx.need[1] and not ctx.need[0]
+                   and (Hb * L.Fp) % 32 == 0 and L.N >= 4096)   # the streamed-K GEMM takes [dWh | ds] in one pass
+        finish = rowsum and not fold_ds
+        # when a_grad does not rewrite dWh, nothing downstream depends on it: run it on the side stream,
+        # beside the weight-gradient GEMM (TIMER spans stay on the main stream: no fork while timing kernels)
+        fork = OVERLAP_BACKWARD and not finish and TIMER is None and ctx.need[1]
+        if fork:
+            main, side = torch.cuda.current_stream(), _side_stream(dev)
+            side.wait_stream(main)      # the tensors it touches stay referenced until the join below
+        with _span("k5_agrad"):
+            check(lib.pygat_a_grad(L.N, H, Fo, Wh.data_ptr(), ds.data_ptr(), dt.data_ptr(), da.data_ptr(),
+                                   ws.data_ptr(), a_pad.data_ptr() if finish else None,
+                                   dWh.data_ptr() if finish else None, hb, hr,
+                                   side.cuda_stream if fork else st), "a_grad")
+        # dW = x^T dWh (split-K over the nodes), dWskip = x^T Gp
+        dW = dWs = dx = None
+        if ctx.need[1]:
+            split_k = _split_k(L.Fin, Hb * L.Fp + (Hb if fold_ds else 0), L.N, streamed_k=True, mode=L.mode)
+            wsw = torch.empty(lib.pygat_wgrad_workspace_bytes(L.Fin, H, Fo, split_k) // 4, dtype=f32, device=dev)
+            dW = (torch.zeros if ranged else torch.empty)(H, L.Fin, Fo, dtype=f32, device=dev)
+            with _span("k5_wgrad"):
+                check(lib.pygat_wgrad(L.N, L.Fin, H, Fo, x.data_ptr(), L.Fin, dWh.data_ptr(),
+                                      ds.data_ptr() if fold_ds else None, a_pad.data_ptr(), dW.data_ptr(), split_k,
+                                      wsw.data_ptr(), hb, hr, GEMM_MODES[L.mode], st), "wgrad")
+        if L.skip and ctx.need[3]:
+            dSc = torch.empty(L.Fin, L.R, dtype=f32, device=dev)
+            for c0, w, g0 in L.gp_windows():
+                gemm(True, False, L.Fin, w, L.N, x, L.Fin, GR[:, g0:], RW, [(w, dSc[:, c0:], L.R)], mode=L.mode)
+            dWs = torch.empty(H, L.Fin, Fo, dtype=f32, device=dev)
+            check(lib.pygat_unpack_wgrad(H, L.Fin, Fo, dSc.data_ptr(), L.R, 0, dWs.data_ptr(), st), "unpack")
+        # dx = dWh Wcat[:, :R]^T (+ Gp Wcat[:, R:2R]^T)
+        if ctx.need[0]:
+            dx = torch.empty(L.N, L.Fin, dtype=f32, device=dev)
+            with _span("k5_xgrad"):
+                gemm(False, True, L.N, L.Fin, L.R, dWh, L.R, Wcat, L.ldw, [(L.Fin, dx, L.Fin)], mode=L.mode)
+                if L.skip:
+                    for c0, w, g0 in L.gp_windows():
+                        gemm(False, True, L.N, L.Fin, w, GR[:, g0:], RW, Wcat[:, L.R + c0:], L.ldw,
+                             [(L.Fin, dx, L.Fin)], accumulate=True, split_k=1, mode=L.mode)
+        if fork:
+            main.wait_stream(side)
+    return dx, dW, (da if ctx.need[2] else None), dWs
+
+
+class StackHeads(torch.autograd.Function):
+    """(W [H,Fin,F'], a [H,2F'], Wskip [H,Fin,F'] | None) from the per-head parameter tensors in ONE launch (torch.stack: a
+    cat launch per parameter kind); backward: views of the stacked gradients.  forward(H, skip, *Ws, *As[, *Wskips])."""
+
+    @staticmethod
+    def forward(ctx, H: int, skip: bool, *params):
+        Ws, As = params[:H], params[H:2 * H]
+        Ss = params[2 * H:3 * H] if skip else ()
+        dev, f32 = Ws[0].device, torch.float32
+        ctx.shapes = [tuple(p.shape) for p in params]
+        ctx.H, ctx.skip = H, skip
+        ok = Ws[0].is_cuda and H <= MAX_HEAD_TABLE and all(p.dtype == f32 and p.is_contiguous() for p in params)
+        if not ok:
+            return (torch.stack(list(Ws), 0), torch.stack([q.reshape(-1) for q in As], 0),
+                    torch.stack(list(Ss), 0) if skip else None)
+        W = torch.empty(H, *Ws[0].shape, dtype=f32, device=dev)
+        a = torch.empty(H, As[0].numel(), dtype=f32, device=dev)
+        S = torch.empty(H, *Ss[0].shape, dtype=f32, device=dev) if skip else None     # (GATv2: W is [2 Fin, F'], the skip [Fin, F'])
+        PT = C.c_void_p * H
+        with torch.cuda.device(dev):
+            check(lib.pygat_stack_heads(H, Ws[0].numel(), As[0].numel(), Ss[0].numel() if skip else 0,
+                                        PT(*[w.data_ptr() for w in Ws]), PT(*[v.data_ptr() for v in As]),
+                                        PT(*[w.data_ptr() for w in Ss]) if skip else None, W.data_ptr(), a.data_ptr(), _ptr(S),
+                                        _stream()), "stack_heads")
+        return W, a, S
+
+    @staticmethod
+    def backward(ctx, dW, da, dS):
+        H = ctx.H
+        outs = [None if dW is None else dW[k] for k in range(H)]
+        outs += [None if da is None else da[k].reshape(ctx.shapes[H + k]) for k in range(H)]
+        if ctx.skip:
+            outs += [None if dS is None else dS[k] for k in range(H)]
+        return (None, None) + tuple(outs)
+
+
+def stack_heads(Ws, As, Wskips):
+    """-> (W, a, Wskip) stacked; one launch."""
+    return StackHeads.apply(len(Ws), Wskips is not None, *Ws, *As, *(Wskips if Wskips is not None else ()))
 
 
 def gat_level(x: torch.Tensor, graph: CSRGraph, Ws: Sequence[torch.Tensor], As: Sequence[torch.Tensor],
@@ -458,6 +570,10 @@ def gat_level(x: torch.Tensor, graph: CSRGraph, Ws: Sequence[torch.Tensor], As: 
     """All heads of one level. Ws: H tensors [Fin,F']; As: H tensors with 2F' elements
     ([2F',1] as in GraphAttentionLayer, layers.py:23, or [1,2F'] as in SpGraphAttentionLayer,
     layers.py:114); Wskips: H tensors [Fin,F'] or None.  pipeline: see GATLevelFn."""
+    H = len(Ws)
+    if H <= MAX_HEAD_TABLE:        # parameters read in place through a pointer table: no torch.stack launches
+        return GATLevelHeadsFn.apply(x, graph, alpha, concat, pipeline, H, Wskips is not None, *Ws, *As,
+                                     *(Wskips if Wskips is not None else ()))
     W = torch.stack(list(Ws), 0)
     a = torch.stack([p.reshape(-1) for p in As], 0)
     Wskip = torch.stack(list(Wskips), 0) if Wskips is not None else None

@@ -23,6 +23,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("name", choices=["cora", "pubmed", "ppi"])
 ap.add_argument("--epochs", type=int, default=30)
 ap.add_argument("--spans", action="store_true")
+ap.add_argument("--aten-loss", action="store_true", help="the loss as the ATen sequence of train.py instead of the fused kernels")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 c = bench.EPOCH_CFG[args.name]
@@ -41,18 +42,23 @@ else:
     y = torch.randint(0, c["nfeats"][-1], (N,), generator=g).to(dev)
     it = torch.arange(c["ntrain"], device=dev)
     graph = pg.CSRGraph(torch.as_tensor(z["rowptr"], device=dev), torch.as_tensor(z["col"], device=dev))
-    loss_fn = lambda out: F.nll_loss(F.log_softmax(F.elu(out), dim=1)[it], y[it])   # noqa: E731
+    # train.py:151-152,159: nll_loss(log_softmax(elu(out))[idx_train], labels[idx_train]) -- one launch forward, one backward
+    loss_fn = pg.EluLogSoftmaxNLL(it, y, N) if "--aten-loss" not in sys.argv else \
+        (lambda out: F.nll_loss(F.log_softmax(F.elu(out), dim=1)[it], y[it]))
 torch.manual_seed(72)
 model = pg.GAT(c["nfeats"], c["nheads"], len(c["nheads"]), c["dropout"], 0.2, pg.SpGraphAttentionLayer,
                skip_connection=(args.name == "ppi")).to(dev)
 opt = torch.optim.Adam(model.parameters(), lr=c["lr"], weight_decay=c["wd"], capturable=True, fused=True)
 
 
+one = torch.ones((), device=dev)
+
+
 def epoch():
     model.train()
     opt.zero_grad(set_to_none=True)
     loss = loss_fn(model(x, graph))
-    loss.backward()
+    loss.backward(one)
     opt.step()
     model.eval()
     with torch.no_grad():

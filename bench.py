@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--hip-graph", action="store_true", help="replay the level from captured HIP graphs (pygat_amd.GraphedLevel)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-epoch", action="store_true", help="skip the Cora / Pubmed epoch_ms leg")
+    ap.add_argument("--no-v2", action="store_true", help="skip the GATv2 level leg")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--verify", action="store_true", help="check the gathered sharded output against the unsharded level")
     ap.add_argument("--forward-exchange", choices=["allgather", "replicate"], default="allgather",
@@ -104,8 +105,10 @@ def cpu_baseline(args, rowptr, col, X, W, a, G):
 # second half of BASELINE.json's metric: epoch time on the reference's small configurations
 # ---------------------------------------------------------------------------------------------------------
 EPOCH_CFG = {  # train.py:47-87, train_ppi.py:43-57
-    "cora": dict(nheads=[8, 1], nfeats=[1433, 8, 7], dropout=0.6, lr=5e-3, wd=5e-4, ntrain=140),
-    "pubmed": dict(nheads=[8, 8], nfeats=[500, 8, 3], dropout=0.6, lr=1e-2, wd=1e-3, ntrain=60),
+    # density: share of non-zero input features of the real dataset (bag of words; Cora 49 216 of 2708 x 1433, Pubmed
+    # 988 031 of 19 717 x 500 TF-IDF values): the synthetic features are drawn at that density
+    "cora": dict(nheads=[8, 1], nfeats=[1433, 8, 7], dropout=0.6, lr=5e-3, wd=5e-4, ntrain=140, density=0.0127),
+    "pubmed": dict(nheads=[8, 8], nfeats=[500, 8, 3], dropout=0.6, lr=1e-2, wd=1e-3, ntrain=60, density=0.1002),
     "ppi": dict(nheads=[4, 4, 6], nfeats=[50, 256, 256, 121], dropout=0.0, lr=5e-3, wd=0.0),
 }
 
@@ -142,7 +145,7 @@ def epoch_ms(pg, dev, name, epochs=200):
         z = np.load(os.path.join(ROOT, "tests", "golden", f"{name}_csr.npz"), allow_pickle=False)
         rowptr, col = z["rowptr"], z["col"]
         N, E = len(rowptr) - 1, int(len(col))
-        x = (torch.rand(N, c["nfeats"][0], generator=g) < 0.013).float()
+        x = (torch.rand(N, c["nfeats"][0], generator=g) < c["density"]).float()
         x = (x / x.sum(1, keepdim=True).clamp(min=1)).to(dev)          # utils.normalize_features
         y = torch.randint(0, c["nfeats"][-1], (N,), generator=g).to(dev)
         it = torch.arange(c["ntrain"], device=dev)
@@ -168,7 +171,58 @@ def epoch_ms(pg, dev, name, epochs=200):
             "config": f"{shape}{', skip connections' if name == 'ppi' else ''}, dropout {c['dropout']}, Adam (fused kernel), train step + "
                       f"eval forward, one HIP-graph replay per epoch",
             "data": ("two synthetic graphs with real PPI node counts, block-diagonal batch, synthetic features/labels"
-                     if name == "ppi" else "real topology, synthetic features/labels")}
+                     if name == "ppi" else f"real topology, synthetic row-normalised features at the dataset's density "
+                                           f"({c['density']:.2%} non-zero), synthetic labels")}
+
+
+def gatv2_level_record(pg, ops, graph, X, H, Fo, steps=10):
+    """one SpGraphAttentionLayerV2 level (layers.py:234-316) forward + backward on the same graph and
+    input, same head count and width: step time and HIP-event spans of its launches against their algorithmic bytes.
+    The V2 score a . LeakyReLU(W_l h_i + W_r h_j) needs the gathered node's whole F'-vector and the layer aggregates
+    Whi_j, so every edge gathers a 2R-float row [Whi_j | Whj_j] (forward, backward row pass) or [Gp_i | m, 1/Z, D | Whi_i]
+    (backward column pass): 2.7 x the bytes of the v1 level per edge."""
+    N, E, Fin = graph.n, graph.nnz, X.shape[1]
+    dev = X.device
+    g = torch.Generator(device=dev).manual_seed(5)
+    W = (torch.randn(H, 2 * Fin, Fo, generator=g, device=dev) * (1.414 * (2.0 / (2 * Fin + Fo)) ** 0.5)).requires_grad_(True)
+    a = (torch.randn(H, Fo, generator=g, device=dev) * (1.414 * (2.0 / (1 + Fo)) ** 0.5)).requires_grad_(True)
+    G = torch.randn(N, H * Fo, generator=g, device=dev)
+
+    def step():
+        W.grad = a.grad = None
+        pg.GATv2LevelFn.apply(X, W, a, None, graph, 0.2, True, None).backward(G)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    timer = ops.KernelTimer()
+    ops.TIMER = timer
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ops.TIMER = None
+    R = H * pg.padded_width(Fo)
+    model = {
+        "v2_project": 4.0 * N * (Fin + 2 * R),
+        "v2_forward": E * (8 + 8 * R) + N * (4 + 8 * R + 8 * H),
+        "v2_prepare": N * (12 * R + 8 * H + 4 * (2 * R + 4 * H)),
+        "v2_backward_row_col": E * (8 + 8 * R) + N * (4 * (2 * R + 4 * H) + 4 * R) + E * (8 + 4 * (2 * R + 4 * H)) + N * (20 * R),
+        "v2_wgrad": 4.0 * N * (Fin + 2 * R),
+    }
+    kernels = []
+    for name, v in timer.times_ms().items():
+        t = float(np.mean(v))
+        b = model.get(name)
+        kernels.append({"kernel": name, "avg_ms": t, "algorithmic_bytes": None if b is None else int(b),
+                        "frac_of_8TBps": None if b is None else b / (t * 1e-3) / 1e9 / HBM_PEAK_GBPS})
+    return {"layer": "SpGraphAttentionLayerV2 (layers.py:234-316)", "ms_per_step": ms, "edges_per_s": E / (ms * 1e-3),
+            "heads": H, "f_out": Fo, "kernels": kernels,
+            "note": "v2_backward_row_col = row pass (gathers [Whi_j | Whj_j]) + column pass (gathers [Gp_i | m,1/Z,D | Whi_i]) + "
+                    "their fix-ups, one C call; per-kernel times: profiles/ rocprof summary of tools/v2_bench.py"}
 
 
 def main():
@@ -479,6 +533,11 @@ def main():
             except Exception as ex:  # the GPU number stays valid without the CPU leg
                 line["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": os.cpu_count(), "kind": "port",
                                         "cpu": cpu_model(), "sample": f"failed: {ex!r}"}
+        if world == 1 and model_world == 1 and not args.no_v2 and not args.dx:
+            try:
+                line["gatv2"] = gatv2_level_record(pg, ops, graph, X, H, Fo)
+            except Exception as ex:
+                line["gatv2"] = {"ms_per_step": None, "error": repr(ex)}
         if world == 1 and model_world == 1 and not args.no_epoch:
             line["epoch_ms"] = {}
             for name in ("cora", "pubmed", "ppi"):

@@ -392,6 +392,23 @@ int pygat_elu_logsoftmax_nll(int n, int C, const float* out, int64_t ldo, const 
 int pygat_elu_logsoftmax_nll_backward(int n, int C, const float* out, int64_t ldo, const int32_t* label, const float* weight,
                                       const float* gscale, float* dout, int64_t ldd, void* stream);
 
+/* ------------------------------------------------ sparse input features (level 1 of the citation configurations)
+ * The reference densifies its bag-of-words features (utils.py:38-41,60) and multiplies the zeros (Cora: 98.7 % of X).
+ * With the non-zero pattern of X extracted once -- CSR (rowptr, col, val) for the projection, its transpose (colptr, row,
+ * val) for the weight gradient -- these two replace pygat_project / pygat_project_dropout and pygat_wgrad /
+ * pygat_wgrad_dropout for a first level (no gradient into X is formed):
+ *   pygat_project_sparse   [Wh | Sk | s] = scale * (X .* m_h) Wcat      Wcat from pygat_pack_params; Sk, s may be NULL
+ *   pygat_wgrad_sparse     dW_h = scale * (X .* m_h)^T dWh_h, dWskip_h = ... Gp_h   written as [H x Fin x F'] directly
+ * p = 0: no dropout (m = 1, scale = 1).  p > 0: per-head input dropout with the decisions of pygat_dropout_bits -- drawn
+ * from (seed, stream_id) per non-zero, or read from explicit `bits` [n x Fin] (H <= 8) -- and scale = 1 / (1 - p); s must
+ * be NULL then (scores come from the masked Wh, pygat_attn_scores).  At most 512 output columns (2 R + H). */
+int pygat_project_sparse(int n, int Fin, int H, int Fo, const int32_t* rowptr, const int32_t* col, const float* val,
+                         const float* Wcat, int64_t ldw, float p, const void* seed, int stream_id, const unsigned char* bits,
+                         float* Wh, float* Sk, float* s, void* stream);
+int pygat_wgrad_sparse(int n, int Fin, int H, int Fo, const int32_t* colptr, const int32_t* row, const float* val, float p,
+                       const void* seed, int stream_id, const unsigned char* bits, const float* dWh, const float* Gp, int64_t ldg,
+                       float* dW, float* dWskip, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

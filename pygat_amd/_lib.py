@@ -39,6 +39,7 @@ SYMBOLS = [
     "pygat_wgrad_dropout_workspace_bytes",
     "pygat_wgrad_dropout", "pygat_dropout_head_sum_bits",
     "pygat_nll_workspace_bytes", "pygat_elu_logsoftmax_nll", "pygat_elu_logsoftmax_nll_backward",
+    "pygat_project_sparse", "pygat_wgrad_sparse",
 ]
 
 
@@ -126,6 +127,8 @@ def _load():
     lib.pygat_wgrad_dropout_workspace_bytes.restype = sz
     lib.pygat_wgrad_dropout.argtypes = [i, i, i, i, p, i64, p, f, p, p, i64, p, i, p, p]
     lib.pygat_dropout_head_sum_bits.argtypes = [i, i, i, p, i64, p, f, p, i64, i, p]
+    lib.pygat_project_sparse.argtypes = [i, i, i, i, p, p, p, p, i64, f, p, i, p, p, p, p, p]
+    lib.pygat_wgrad_sparse.argtypes = [i, i, i, i, p, p, p, f, p, i, p, p, p, i64, p, p, p]
     lib.pygat_nll_workspace_bytes.argtypes = [i]
     lib.pygat_nll_workspace_bytes.restype = sz
     lib.pygat_elu_logsoftmax_nll.argtypes = [i, i, p, i64, p, p, p, p, p]

@@ -80,6 +80,7 @@ __device__ __forceinline__ float group_sum_rt(float x, int g) {
   return x;
 }
 
+__device__ __forceinline__ int ilog2_dev(int x) { return 31 - __clz(x); }   // x a power of two
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float dot4(float4 a, float4 b) {

@@ -74,7 +74,7 @@ class GATLevelDropoutFn(torch.autograd.Function):
     is, and the masks are drawn in-kernel (csrc/k7_dropout.hip)."""
 
     @staticmethod
-    def forward(ctx, x, W, a, Wskip, graph: CSRGraph, alpha, concat, p, mask_x, mask_wh, mask_att, seed):
+    def forward(ctx, x, W, a, Wskip, graph: CSRGraph, alpha, concat, p, mask_x, mask_wh, mask_att, seed, xs=None):
         if not x.is_cuda:
             raise RuntimeError("pygat_amd: inputs must be on the GPU; the hot path has no CPU fallback")
         ctx.in_dtypes = (x.dtype, W.dtype, a.dtype, None if Wskip is None else Wskip.dtype)
@@ -114,7 +114,19 @@ class GATLevelDropoutFn(torch.autograd.Function):
             Sk = torch.empty(L.N, R, dtype=f32, device=dev) if skip else None   # mm(h, skip) uses the dropped h (layers.py:48,166)
             use_bits = (not FORCE_WIDE) and bool(lib.pygat_headmask_supported(H, Fo, int(skip))) and L.hg == H
             Ae = Bp = bits = None
-            if use_bits:
+            # sparse input features (features.py): the projection on the non-zeros of x, same per-head decisions (drawn per
+            # non-zero from the seed, or the explicit masks' bit bytes); no gradient into x is formed on this path
+            sparse = xs is not None and use_bits and not ctx.needs_input_grad[0] and (not explicit or H <= 8)
+            ctx.xs = xs if sparse else None
+            if sparse:
+                bits = _pack_bits(mask_x) if explicit else None
+                with _span("k1_project"):
+                    check(lib.pygat_project_sparse(L.N, Fin, H, Fo, xs.rowptr.data_ptr(), xs.col.data_ptr(), xs.val.data_ptr(),
+                                                   Wcat.data_ptr(), L.ldw, p, None if explicit else seed.data_ptr(), STREAM_X,
+                                                   _ptr(bits), Wh.data_ptr(), _ptr(Sk), None, st), "project_sparse")
+                if bits is None:
+                    bits = torch.empty(0, dtype=torch.uint8, device=dev)     # (placeholder among the saved tensors)
+            elif use_bits:
                 # per-head input masks as one byte per element; all heads in one launch, x read once (layers.py:34,132)
                 if explicit:
                     bits = _pack_bits(mask_x)
@@ -171,7 +183,7 @@ class GATLevelDropoutFn(torch.autograd.Function):
         dev, f32 = Ae.device, torch.float32
         G = G.contiguous().float()
         HF, R, Fin = H * L.Fin, L.R, L.Fin
-        ncb = Bp.shape[1]
+        ncb = Bp.shape[1] if Bp.dim() == 2 else 0     # (wide path only: Bp is the block-diagonal weight stack there)
         with torch.cuda.device(dev), gemm_mode(ctx.gemm_mode):
             st = _stream()
             RW = R + 4 * H
@@ -212,10 +224,21 @@ class GATLevelDropoutFn(torch.autograd.Function):
                                    None if two_gather else a_pad.data_ptr(), None if two_gather else dWh.data_ptr(), 0, 0, st),
                   "a_grad")
             dWh.mul_(mwh)                          # back through the Wh dropout
+            xs = getattr(ctx, "xs", None)
+            if xs is not None:   # weight gradients on the non-zeros of x under the same decisions (forward: project_sparse)
+                dW = torch.empty(H, Fin, Fo, dtype=f32, device=dev)
+                dWs = torch.empty(H, Fin, Fo, dtype=f32, device=dev) if L.skip else None
+                with _span("k5_wgrad"):
+                    check(lib.pygat_wgrad_sparse(L.N, Fin, H, Fo, xs.colptr.data_ptr(), xs.trow.data_ptr(), xs.tval.data_ptr(), p,
+                                                 None if ctx.explicit else mx_or_seed.data_ptr(), STREAM_X,
+                                                 Bp.data_ptr() if ctx.explicit else None, dWh.data_ptr(),
+                                                 GR.data_ptr() if L.skip else None, RW, dW.data_ptr(), _ptr(dWs), st), "wgrad_sparse")
+                cast = lambda g_, k: g_ if g_ is None or g_.dtype == ctx.in_dtypes[k] else g_.to(ctx.in_dtypes[k])  # noqa: E731
+                return (None, cast(dW, 1), cast(da, 2), cast(dWs, 3), None, None, None, None, None, None, None, None, None)
             if ctx.use_bits:     # Ae is x and Bp the mask bytes on this path
                 dx, dW, dWs = _backward_bits(ctx, Ae, Bp, Wcat, dWh, GR, RW, st)
                 cast = lambda g_, k: g_ if g_ is None or g_.dtype == ctx.in_dtypes[k] else g_.to(ctx.in_dtypes[k])  # noqa: E731
-                return cast(dx, 0), cast(dW, 1), cast(da, 2), cast(dWs, 3), None, None, None, None, None, None, None, None
+                return cast(dx, 0), cast(dW, 1), cast(da, 2), cast(dWs, 3), None, None, None, None, None, None, None, None, None
             # dW_h = (x o m_h)^T dWh_h: the diagonal blocks of A'^T dWh
             dBp = torch.empty(HF, R, dtype=f32, device=dev)
             with _span("k5_wgrad"):
@@ -243,7 +266,7 @@ class GATLevelDropoutFn(torch.autograd.Function):
                                                  None if ctx.explicit else mx_or_seed.data_ptr(), STREAM_X,
                                                  dx.data_ptr(), Fin, 0, st), "dropout_head_sum")
         cast = lambda g_, k: g_ if g_ is None or g_.dtype == ctx.in_dtypes[k] else g_.to(ctx.in_dtypes[k])  # noqa: E731
-        return cast(dx, 0), cast(dW, 1), cast(da, 2), cast(dWs, 3), None, None, None, None, None, None, None, None
+        return cast(dx, 0), cast(dW, 1), cast(da, 2), cast(dWs, 3), None, None, None, None, None, None, None, None, None
 
 
 def _backward_bits(ctx, x, bits, Wcat, dWh, GR, RW, st):
@@ -285,12 +308,12 @@ def _backward_bits(ctx, x, bits, Wcat, dWh, GR, RW, st):
 
 def gat_level_dropout(x, graph: CSRGraph, Ws: Sequence[torch.Tensor], As: Sequence[torch.Tensor],
                       Wskips: Optional[Sequence[torch.Tensor]], alpha: float, concat: bool, p: float,
-                      head_mean: bool = False, masks: Optional[dict] = None, generator=None) -> torch.Tensor:
+                      head_mean: bool = False, masks: Optional[dict] = None, generator=None, xs=None) -> torch.Tensor:
     """One level in training mode with dropout p.  `masks` (tests) = {"x","wh","att"} pre-scaled; without them the
     masks are drawn in-kernel from one int64 seed taken from torch's (graph-safe) generator."""
     del head_mean  # implied by `concat` (models.py:23): concat=False <=> last level <=> head mean
     W, a, Wskip = stack_heads(list(Ws), list(As), None if Wskips is None else list(Wskips))   # one launch, not a cat per kind
     if masks is not None:
-        return GATLevelDropoutFn.apply(x, W, a, Wskip, graph, alpha, concat, p, masks["x"], masks["wh"], masks["att"], None)
+        return GATLevelDropoutFn.apply(x, W, a, Wskip, graph, alpha, concat, p, masks["x"], masks["wh"], masks["att"], None, xs)
     seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=x.device, generator=generator)
-    return GATLevelDropoutFn.apply(x, W, a, Wskip, graph, alpha, concat, p, None, None, None, seed)
+    return GATLevelDropoutFn.apply(x, W, a, Wskip, graph, alpha, concat, p, None, None, None, seed, xs)

@@ -20,7 +20,7 @@ import torch.nn as nn
 from . import _lib
 from ._lib import lib, check
 from .graph import CSRGraph, as_graph
-from .ops import _Level, _ptr, _stream, gemm, gat_level, gemm_mode, get_gemm_mode, stack_heads
+from .ops import _Level, _ptr, _span, _stream, gemm, gat_level, gemm_mode, get_gemm_mode, stack_heads
 
 
 class GATv2LevelFn(torch.autograd.Function):
@@ -65,7 +65,8 @@ class GATv2LevelFn(torch.autograd.Function):
             mask_x = mww = matt = None
             if masks is None:
                 segs = [(2 * R, WW, 2 * R)] + ([(R, Sk, R)] if skip else [])
-                gemm(False, False, L.N, ncols, Fin, x, Fin, Wcat, ncols, segs)
+                with _span("v2_project"):
+                    gemm(False, False, L.N, ncols, Fin, x, Fin, Wcat, ncols, segs)
             else:
                 mask_x = masks["x"].to(f32).contiguous()
                 matt = masks["att"].to(f32).contiguous()
@@ -88,9 +89,10 @@ class GATv2LevelFn(torch.autograd.Function):
             Z = torch.empty(L.N, H, dtype=f32, device=dev) if need_grad else None
             out = torch.empty(L.N, H * Fo if concat else Fo, dtype=f32, device=dev)
             part = torch.empty(lib.pygat_partials_bytes(graph.nnz, L.ts, H, Fp) // 4, dtype=f32, device=dev)
-            check(lib.pygat_gatv2_forward(graph.fwd.ref(L.ts), H, Fo, float(alpha), flags, WW.data_ptr(), a2.data_ptr(),
-                                          _ptr(Sk), _ptr(matt), out.data_ptr() if concat else None, _ptr(hattn), _ptr(m),
-                                          _ptr(Z), part.data_ptr(), st), "gatv2_forward")
+            with _span("v2_forward"):
+                check(lib.pygat_gatv2_forward(graph.fwd.ref(L.ts), H, Fo, float(alpha), flags, WW.data_ptr(), a2.data_ptr(),
+                                              _ptr(Sk), _ptr(matt), out.data_ptr() if concat else None, _ptr(hattn), _ptr(m),
+                                              _ptr(Z), part.data_ptr(), st), "gatv2_forward")
             if not concat:
                 check(lib.pygat_head_mean(L.N, H, Fo, hattn.data_ptr(), _ptr(Sk), out.data_ptr(), st), "head_mean")
         if need_grad:
@@ -110,17 +112,19 @@ class GATv2LevelFn(torch.autograd.Function):
             LG = 2 * R + 4 * H
             GRW = torch.empty(L.N, LG, dtype=f32, device=dev)
             Gp = GRW[:, :R]
-            check(lib.pygat_gatv2_backward_prepare(L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(), y.data_ptr(),
-                                                   _ptr(Sk), m.data_ptr(), Z.data_ptr(), WW.data_ptr(), GRW.data_ptr(), st),
-                  "gatv2_backward_prepare")
+            with _span("v2_prepare"):
+                check(lib.pygat_gatv2_backward_prepare(L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(), y.data_ptr(),
+                                                       _ptr(Sk), m.data_ptr(), Z.data_ptr(), WW.data_ptr(), GRW.data_ptr(), st),
+                      "gatv2_backward_prepare")
             dwr = torch.empty(L.N, R, dtype=f32, device=dev)
             dWW = torch.empty(L.N, 2 * R, dtype=f32, device=dev)
             da_p = torch.empty(H, Fo, dtype=f32, device=dev)
             ws = torch.empty(lib.pygat_gatv2_workspace_bytes(graph.nnz, L.ts, H, Fo) // 4 + 4, dtype=f32, device=dev)
-            check(lib.pygat_gatv2_backward(graph.fwd.ref(L.ts), graph.bwd.ref(L.ts),
-                                           graph.perm_t.data_ptr() if matt is not None else None, H, Fo, ctx.alpha,
-                                           WW.data_ptr(), a2.data_ptr(), GRW.data_ptr(), _ptr(matt), dwr.data_ptr(),
-                                           dWW.data_ptr(), da_p.data_ptr(), ws.data_ptr(), st), "gatv2_backward")
+            with _span("v2_backward_row_col"):
+                check(lib.pygat_gatv2_backward(graph.fwd.ref(L.ts), graph.bwd.ref(L.ts),
+                                               graph.perm_t.data_ptr() if matt is not None else None, H, Fo, ctx.alpha,
+                                               WW.data_ptr(), a2.data_ptr(), GRW.data_ptr(), _ptr(matt), dwr.data_ptr(),
+                                               dWW.data_ptr(), da_p.data_ptr(), ws.data_ptr(), st), "gatv2_backward")
             ncols = Wcat.shape[1]
             dW = dWs = dx = None
             if mask_x is not None:   # dropout: back through the Whi/Whj masks, then per head through its input mask
@@ -152,7 +156,8 @@ class GATv2LevelFn(torch.autograd.Function):
                 return dx, dW, da_p, dWs, None, None, None, None
             # dWcat[:, :2R] = x^T dWW ; skip columns = x^T Gp
             dWc = torch.empty(Fin, 2 * R, dtype=f32, device=dev)
-            gemm(True, False, Fin, 2 * R, L.N, x, Fin, dWW, 2 * R, [(2 * R, dWc, 2 * R)])
+            with _span("v2_wgrad"):
+                gemm(True, False, Fin, 2 * R, L.N, x, Fin, dWW, 2 * R, [(2 * R, dWc, 2 * R)])
             dv = dWc.view(Fin, 2 * H, Fp)
             dW = torch.cat([dv[:, 0:H, :Fo].permute(1, 0, 2), dv[:, H:2 * H, :Fo].permute(1, 0, 2)], dim=1).contiguous()
             if L.skip:

@@ -19,6 +19,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from .features import as_sparse_features
 from .graph import as_graph
 from .layers import GraphAttentionLayer, SpGraphAttentionLayer
 from .ops import gat_level
@@ -67,11 +68,17 @@ class GAT(nn.Module):
                 x = gat_level_head_parallel(x, graph, Ws, As, Sk, self.alpha, concat, p_drop, level_fn=fn)
             elif fn is not None:
                 x = fn(x, graph, Ws, As, Sk, self.alpha, concat)
-            elif p_drop > 0.0:
-                from .dropout import gat_level_dropout
-                x = gat_level_dropout(x, graph, Ws, As, Sk, self.alpha, concat, p_drop)
             else:
-                x = gat_level(x, graph, Ws, As, Sk, self.alpha, concat)
+                # a first level on sparse input features (bag-of-words X: features.py) multiplies the non-zeros only
+                xs = None
+                if lvl == 0:
+                    Fp = 1 << max(2, (heads[0].W.shape[1] - 1).bit_length())
+                    xs = as_sparse_features(x, len(heads) * Fp * (2 if self.skip_connection else 1) + len(heads))
+                if p_drop > 0.0:
+                    from .dropout import gat_level_dropout
+                    x = gat_level_dropout(x, graph, Ws, As, Sk, self.alpha, concat, p_drop, xs=xs)
+                else:
+                    x = gat_level(x, graph, Ws, As, Sk, self.alpha, concat, xs=xs)
         return x
 
     @torch.no_grad()

@@ -308,7 +308,7 @@ class GATLevelHeadsFn(torch.autograd.Function):
     forward(x, graph, alpha, concat, pipeline, H, skip, *Ws, *As[, *Wskips]) -> out."""
 
     @staticmethod
-    def forward(ctx, x, graph: CSRGraph, alpha: float, concat: bool, pipeline, H: int, skip: bool, *params):
+    def forward(ctx, x, graph: CSRGraph, alpha: float, concat: bool, pipeline, H: int, skip: bool, xs, *params):
         if not x.is_cuda:
             raise RuntimeError("pygat_amd: inputs must be on the GPU; the hot path has no CPU fallback")
         Ws, As = params[:H], params[H:2 * H]
@@ -328,9 +328,9 @@ class GATLevelHeadsFn(torch.autograd.Function):
         def pack(Wcat, ldw, a_pad, st):
             check(lib.pygat_pack_params_heads(H, Fin, Fo, wp, ap, sp, Wcat.data_ptr(), ldw, a_pad.data_ptr(), st), "pack_params_heads")
         n = ctx.needs_input_grad
-        need = (n[0], any(n[7:7 + H]), any(n[7 + H:7 + 2 * H]), skip and any(n[7 + 2 * H:7 + 3 * H]))
+        need = (n[0], any(n[8:8 + H]), any(n[8 + H:8 + 2 * H]), skip and any(n[8 + 2 * H:8 + 3 * H]))
         ctx.H, ctx.skip = H, skip
-        return _level_forward(ctx, need, x, H, Fo, skip, pack, graph, alpha, concat, None, pipeline)
+        return _level_forward(ctx, need, x, H, Fo, skip, pack, graph, alpha, concat, None, pipeline, xs=xs)
 
     @staticmethod
     def backward(ctx, G):
@@ -347,12 +347,13 @@ class GATLevelHeadsFn(torch.autograd.Function):
             for k in range(H):
                 outs.append(None if dWs is None else dWs[k])
         outs = [g_ if g_ is None or g_.dtype == dt else g_.to(dt) for g_, dt in zip(outs, ctx.param_dtypes)]
-        return (dx, None, None, None, None, None, None) + tuple(outs)
+        return (dx, None, None, None, None, None, None, None) + tuple(outs)
 
 
-def _level_forward(ctx, need, x, H, Fo, skip, pack, graph: CSRGraph, alpha: float, concat: bool, bwd_heads, pipeline):
+def _level_forward(ctx, need, x, H, Fo, skip, pack, graph: CSRGraph, alpha: float, concat: bool, bwd_heads, pipeline, xs=None):
     """Body of the level's forward, shared by GATLevelFn (stacked parameters) and GATLevelHeadsFn (one tensor per head).
-    need = (x, W, a, Wskip) gradient flags; pack(Wcat, ldw, a_pad, stream) launches the parameter packing."""
+    need = (x, W, a, Wskip) gradient flags; pack(Wcat, ldw, a_pad, stream) launches the parameter packing; xs: the
+    SparseFeatures of x (features.py) -- projection and weight gradient on the non-zeros only -- or None."""
     Fin = x.shape[1]
     if x.shape[0] != graph.n:
         raise ValueError(f"x has {x.shape[0]} rows but the graph has {graph.n} nodes")
@@ -377,9 +378,16 @@ def _level_forward(ctx, need, x, H, Fo, skip, pack, graph: CSRGraph, alpha: floa
         split_k = max(1, min(-(-384 // tiles), Fin // _K1_SLAB)) if tiles < 256 else 1
         ws = torch.empty(lib.pygat_gemm_workspace_bytes(L.N, ncols, split_k) // 4, dtype=f32, device=dev) \
             if split_k > 1 else None
+        if xs is not None and need[0]:
+            xs = None                                   # a gradient into x: the dense path forms it
         with _span("k1_project"):
-            check(lib.pygat_project(L.N, Fin, H, Fo, x.data_ptr(), Fin, Wcat.data_ptr(), L.ldw, a_pad.data_ptr(), Wh.data_ptr(),
-                                    _ptr(Sk), s.data_ptr(), split_k, _ptr(ws), GEMM_MODES[L.mode], st), "project")
+            if xs is not None:
+                check(lib.pygat_project_sparse(L.N, Fin, H, Fo, xs.rowptr.data_ptr(), xs.col.data_ptr(), xs.val.data_ptr(),
+                                               Wcat.data_ptr(), L.ldw, 0.0, None, 0, None, Wh.data_ptr(), _ptr(Sk), s.data_ptr(),
+                                               st), "project_sparse")
+            else:
+                check(lib.pygat_project(L.N, Fin, H, Fo, x.data_ptr(), Fin, Wcat.data_ptr(), L.ldw, a_pad.data_ptr(), Wh.data_ptr(),
+                                        _ptr(Sk), s.data_ptr(), split_k, _ptr(ws), GEMM_MODES[L.mode], st), "project")
         # K2
         flags = (_lib.F_ELU if concat else 0) | (_lib.F_SKIP if skip else 0)
         # mean over ONE head = that head (Cora / Citeseer output level, train.py:55,66): K2 writes `out` itself (its epilogue
@@ -411,6 +419,7 @@ def _level_forward(ctx, need, x, H, Fo, skip, pack, graph: CSRGraph, alpha: floa
         # concat: the backward recovers hattn from `out` (no second [N,R] table is written)
         ctx.save_for_backward(x, Wcat, a_pad, Wh, s, Sk, out if concat else hattn, m, Z, aneg, qneg)
         ctx.graph, ctx.L, ctx.alpha, ctx.concat, ctx.flags = graph, L, float(alpha), concat, flags
+        ctx.xs = xs
         ctx.flavour = flavour
         ctx.bwd_heads = None
         if bwd_heads is not None:
@@ -480,7 +489,9 @@ def _level_backward(ctx, G):
         # ... unless nothing but the weight-gradient GEMM consumes dWh: there ds rides along as extra columns
         # (pygat_wgrad) and dWh is never rewritten
         rowsum = ctx.flavour == "rowsum"
-        fold_ds = (rowsum and ctx.need[1] and not ctx.need[0]
+        xs = getattr(ctx, "xs", None)
+        sparse_w = xs is not None and not ranged and (not L.skip or L.hg >= H)    # weight gradients on the non-zeros of x
+        fold_ds = (rowsum and ctx.need[1] and not ctx.need[0] and not sparse_w
                    and (Hb * L.Fp) % 32 == 0 and L.N >= 4096)   # the streamed-K GEMM takes [dWh | ds] in one pass
         finish = rowsum and not fold_ds
         # when a_grad does not rewrite dWh, nothing downstream depends on it: run it on the side stream,
@@ -496,7 +507,15 @@ def _level_backward(ctx, G):
                                    side.cuda_stream if fork else st), "a_grad")
         # dW = x^T dWh (split-K over the nodes), dWskip = x^T Gp
         dW = dWs = dx = None
-        if ctx.need[1]:
+        if sparse_w and (ctx.need[1] or (L.skip and ctx.need[3])):
+            dW = torch.empty(H, L.Fin, Fo, dtype=f32, device=dev)
+            want_s = L.skip and ctx.need[3]
+            dWs = torch.empty(H, L.Fin, Fo, dtype=f32, device=dev) if want_s else None
+            with _span("k5_wgrad"):
+                check(lib.pygat_wgrad_sparse(L.N, L.Fin, H, Fo, xs.colptr.data_ptr(), xs.trow.data_ptr(), xs.tval.data_ptr(), 0.0,
+                                             None, 0, None, dWh.data_ptr(), GR.data_ptr() if want_s else None, RW, dW.data_ptr(),
+                                             _ptr(dWs), st), "wgrad_sparse")
+        elif ctx.need[1]:
             split_k = _split_k(L.Fin, Hb * L.Fp + (Hb if fold_ds else 0), L.N, streamed_k=True, mode=L.mode)
             wsw = torch.empty(lib.pygat_wgrad_workspace_bytes(L.Fin, H, Fo, split_k) // 4, dtype=f32, device=dev)
             dW = (torch.zeros if ranged else torch.empty)(H, L.Fin, Fo, dtype=f32, device=dev)
@@ -504,7 +523,7 @@ def _level_backward(ctx, G):
                 check(lib.pygat_wgrad(L.N, L.Fin, H, Fo, x.data_ptr(), L.Fin, dWh.data_ptr(),
                                       ds.data_ptr() if fold_ds else None, a_pad.data_ptr(), dW.data_ptr(), split_k,
                                       wsw.data_ptr(), hb, hr, GEMM_MODES[L.mode], st), "wgrad")
-        if L.skip and ctx.need[3]:
+        if L.skip and ctx.need[3] and not sparse_w:
             dSc = torch.empty(L.Fin, L.R, dtype=f32, device=dev)
             for c0, w, g0 in L.gp_windows():
                 gemm(True, False, L.Fin, w, L.N, x, L.Fin, GR[:, g0:], RW, [(w, dSc[:, c0:], L.R)], mode=L.mode)
@@ -566,13 +585,14 @@ def stack_heads(Ws, As, Wskips):
 
 
 def gat_level(x: torch.Tensor, graph: CSRGraph, Ws: Sequence[torch.Tensor], As: Sequence[torch.Tensor],
-              Wskips: Optional[Sequence[torch.Tensor]], alpha: float, concat: bool, pipeline=None) -> torch.Tensor:
+              Wskips: Optional[Sequence[torch.Tensor]], alpha: float, concat: bool, pipeline=None, xs=None) -> torch.Tensor:
     """All heads of one level. Ws: H tensors [Fin,F']; As: H tensors with 2F' elements
     ([2F',1] as in GraphAttentionLayer, layers.py:23, or [1,2F'] as in SpGraphAttentionLayer,
-    layers.py:114); Wskips: H tensors [Fin,F'] or None.  pipeline: see GATLevelFn."""
+    layers.py:114); Wskips: H tensors [Fin,F'] or None.  pipeline: see GATLevelFn.  xs: features.SparseFeatures of x
+    (a first level on sparse input features) or None."""
     H = len(Ws)
     if H <= MAX_HEAD_TABLE:        # parameters read in place through a pointer table: no torch.stack launches
-        return GATLevelHeadsFn.apply(x, graph, alpha, concat, pipeline, H, Wskips is not None, *Ws, *As,
+        return GATLevelHeadsFn.apply(x, graph, alpha, concat, pipeline, H, Wskips is not None, xs, *Ws, *As,
                                      *(Wskips if Wskips is not None else ()))
     W = torch.stack(list(Ws), 0)
     a = torch.stack([p.reshape(-1) for p in As], 0)

@@ -37,7 +37,7 @@ if args.name == "ppi":
 else:
     z = np.load(os.path.join(ROOT, "tests", "golden", f"{args.name}_csr.npz"), allow_pickle=False)
     N = len(z["rowptr"]) - 1
-    x = (torch.rand(N, c["nfeats"][0], generator=g) < 0.013).float()
+    x = (torch.rand(N, c["nfeats"][0], generator=g) < c["density"]).float()
     x = (x / x.sum(1, keepdim=True).clamp(min=1)).to(dev)
     y = torch.randint(0, c["nfeats"][-1], (N,), generator=g).to(dev)
     it = torch.arange(c["ntrain"], device=dev)

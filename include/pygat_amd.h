@@ -321,12 +321,14 @@ int pygat_gatv2_forward(const pygat_graph* g, int H, int Fo, float alpha, int fl
 int pygat_gatv2_backward_prepare(int n, int H, int Fo, int flags, int mean_mode,
                                  const float* G, const float* y, const float* sk,
                                  const float* m, const float* Z, const float* WW, float* GRW, void* stream);
-/* Row pass over g + column pass over gT (perm_t only indexes att_mask, may be NULL without one):
- *   dWW [n x 2R] = [dWhi | dWhj], da [H x F'];  dwhi_row [n x R] is scratch.  ws >= pygat_gatv2_workspace_bytes. */
+/* Column pass over gT, then row pass over g:
+ *   dWW [n x 2R] = [dWhi | dWhj], da [H x F'].  perm_t (transposed position -> forward edge) only indexes att_mask and may
+ *   be NULL without one; perm_f (forward edge -> transposed position; the same array for a symmetric pattern) lets the row
+ *   pass fetch the de_ij the column pass left per transposed edge.  ws >= pygat_gatv2_workspace_bytes. */
 size_t pygat_gatv2_workspace_bytes(int64_t nnz, int slot_edges, int H, int Fo);
-int pygat_gatv2_backward(const pygat_graph* g, const pygat_graph* gT, const int32_t* perm_t, int H, int Fo,
-                         float alpha, const float* WW, const float* a2, const float* GRW,
-                         const float* att_mask, float* dwhi_row, float* dWW, float* da, void* ws, void* stream);
+int pygat_gatv2_backward(const pygat_graph* g, const pygat_graph* gT, const int32_t* perm_t, const int32_t* perm_f,
+                         int H, int Fo, float alpha, const float* WW, const float* a2, const float* GRW,
+                         const float* att_mask, float* dWW, float* da, void* ws, void* stream);
 
 /* ------------------------------------------------ K7: train-mode dropout around the projection
  * The reference drops out inside every head, each head with its own masks (models.py:32,34 call the heads

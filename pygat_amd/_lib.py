@@ -108,7 +108,7 @@ def _load():
     lib.pygat_gatv2_backward_prepare.argtypes = [i, i, i, i, i, p, p, p, p, p, p, p, p]
     lib.pygat_gatv2_workspace_bytes.argtypes = [i64, i, i, i]
     lib.pygat_gatv2_workspace_bytes.restype = sz
-    lib.pygat_gatv2_backward.argtypes = [C.POINTER(Graph), C.POINTER(Graph), p, i, i, f, p, p, p, p, p, p, p, p, p]
+    lib.pygat_gatv2_backward.argtypes = [C.POINTER(Graph), C.POINTER(Graph), p, p, i, i, f, p, p, p, p, p, p, p, p]
     u32 = C.c_uint32
     lib.pygat_wgrad_workspace_bytes.argtypes = [i, i, i, i]
     lib.pygat_wgrad_workspace_bytes.restype = sz

@@ -6,9 +6,12 @@
 //   q_ij = de_ij * a (.) LeakyReLU'(Whi_i + Whj_j)          (an F'-vector per edge, never stored)
 //   dWhi_i += sum_j q_ij (row sums)     dWhj_j += sum_i q_ij (column sums)     dWhi_j += sum_i alpha~_ij Gp_i
 //   da = sum_ij de_ij LeakyReLU(Whi_i + Whj_j)
-// Same nnz-split structure as K3b/K4: the row pass walks the forward pattern (GRW_i row-local,
-// WW_j = [Whi_j | Whj_j] gathered), the column pass the transposed pattern (GRW_i = [Gp | m,1/Z,D | Whi]
-// gathered as one contiguous row, WW_j row-local); both recompute e, alpha and de per edge.
+// Same nnz-split structure as K3b/K4.  The COLUMN pass runs first, over the transposed pattern (GRW_i = [Gp | m,1/Z,D | Whi]
+// gathered as one contiguous row, WW_j = [Whi_j | Whj_j] row-local): it recomputes e, alpha and de per edge, sums dWhj_j
+// and the aggregation part of dWhi_j, and leaves de_ij per transposed edge (H floats, sequential).  The ROW pass (forward
+// pattern) then needs neither Gp nor Whi_j: it fetches de_ij through perm_f and gathers only the Whj HALF of WW_j to form
+// q_ij = de_ij a (.) LeakyReLU'(Whi_i + Whj_j) -- 0.6 KB per edge instead of the 1 KB [Whi_j | Whj_j] row it used to
+// gather to recompute de (round 3: 1.97 -> see DESIGN.md) -- adds the row sums into dWhi_i and forms da.
 #include "attn_common.h"
 
 namespace pygat {
@@ -17,7 +20,8 @@ struct V2Args {
   GraphDev g;
   RowShape rs;
   float alpha;
-  const int32_t* perm;  // column pass only: transposed position -> forward edge (mask index)
+  const int32_t* perm;  // column pass: transposed position -> forward edge (mask index); row pass: forward edge -> transposed position
+  float* de_t;          // [nnz][H] de_ij per TRANSPOSED edge: written by the column pass, read by the row pass
   const float* mask;    // [nnz][H] forward order or nullptr
   const float* WW;      // [n][2R]
   const float* GRW;     // [n][2R + 4H]
@@ -59,7 +63,6 @@ __global__ __launch_bounds__(256) void gat2_bwd_row_kernel(V2Args a) {
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
   const int H = a.rs.H, R = a.rs.R;
   const int64_t LW = 2 * (int64_t)R, LG = 2 * (int64_t)R + 4 * H;
-  const int lph = a.rs.lph < 64 ? a.rs.lph : 64;
   float4 a4[VEC], dacc[VEC], acc[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
@@ -75,27 +78,45 @@ __global__ __launch_bounds__(256) void gat2_bwd_row_kernel(V2Args a) {
     const int r_first = rc[e0].x;
     const bool head_partial = a.g.rowptr[r_first] < e0;
     int cur = r_first;
-    auto flush = [&](int i, bool is_head, bool is_tail) {
-      float* dst = (is_head || is_tail) ? a.part + (2 * k + (is_head ? 0 : 1)) * (int64_t)R : a.out + (int64_t)i * R;
+    auto flush = [&](int i, bool is_head, bool is_tail) {   // a whole row: added into dWhi_i = dWW[i, :R] (the column pass wrote it)
+      if (is_head || is_tail) {
+        float* dst = a.part + (2 * k + (is_head ? 0 : 1)) * (int64_t)R;
 #pragma unroll
-      for (int v = 0; v < VEC; ++v)
-        if (lc.valid[v]) st4(dst + lc.cofs[v], acc[v]);
+        for (int v = 0; v < VEC; ++v)
+          if (lc.valid[v]) st4(dst + lc.cofs[v], acc[v]);
+      } else {
+        float* dst = a.out + (int64_t)i * LW;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+          if (lc.valid[v]) {
+            const float4 o = ld4(dst + lc.cofs[v]);
+            st4(dst + lc.cofs[v], make_float4(o.x + acc[v].x, o.y + acc[v].y, o.z + acc[v].z, o.w + acc[v].w));
+          }
+      }
     };
     for (int64_t e = e0; e < e1; e += U) {
       int2 p[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) p[u] = rc[(e + u < e1) ? e + u : e1 - 1];
-      EdgeOut eo[U][VEC];
+      // de_ij comes from the column pass (transposed position of this edge: perm); only the Whj half of row j is gathered
+      float dev[U][VEC];
+      float4 qv[U][VEC], lv[U][VEC];
 #pragma unroll
-      for (int u = 0; u < U; ++u)
+      for (int u = 0; u < U; ++u) {
+        const int64_t ee = (e + u < e1) ? e + u : e1 - 1;
+        const int64_t pt = a.perm[ee];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-          const float* gi = a.GRW + (int64_t)p[u].x * LG;   // row-local
-          const float* wj = a.WW + (int64_t)p[u].y * LW;    // gathered
-          const float mk = a.mask ? a.mask[((e + u < e1) ? e + u : e1 - 1) * H + lc.head[v]] : 1.f;
-          eo[u][v] = v2_edge(ld4(gi + R + 4 * H + lc.cofs[v]), ld4(wj + lc.cofs[v]), ld4(wj + R + lc.cofs[v]),
-                             ld4(gi + lc.cofs[v]), ld4(gi + R + 4 * lc.head[v]), a4[v], mk, a.alpha, lc.valid[v], lph);
+          const float4 wi = ld4(a.GRW + (int64_t)p[u].x * LG + R + 4 * H + lc.cofs[v]);   // Whi_i, row-local
+          const float4 wj = ld4(a.WW + (int64_t)p[u].y * LW + R + lc.cofs[v]);            // Whj_j, gathered
+          const float de = a.de_t[pt * H + lc.head[v]];
+          const float4 h = make_float4(wi.x + wj.x, wi.y + wj.y, wi.z + wj.z, wi.w + wj.w);
+          dev[u][v] = de;
+          lv[u][v] = make_float4(lrelu2(h.x, a.alpha), lrelu2(h.y, a.alpha), lrelu2(h.z, a.alpha), lrelu2(h.w, a.alpha));
+          qv[u][v] = make_float4(de * a4[v].x * (h.x > 0.f ? 1.f : a.alpha), de * a4[v].y * (h.y > 0.f ? 1.f : a.alpha),
+                                 de * a4[v].z * (h.z > 0.f ? 1.f : a.alpha), de * a4[v].w * (h.w > 0.f ? 1.f : a.alpha));
         }
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (e + u < e1) {
@@ -107,9 +128,9 @@ __global__ __launch_bounds__(256) void gat2_bwd_row_kernel(V2Args a) {
           }
 #pragma unroll
           for (int v = 0; v < VEC; ++v) {
-            acc[v].x += eo[u][v].q.x; acc[v].y += eo[u][v].q.y; acc[v].z += eo[u][v].q.z; acc[v].w += eo[u][v].q.w;
-            dacc[v].x = fmaf(eo[u][v].de, eo[u][v].l.x, dacc[v].x); dacc[v].y = fmaf(eo[u][v].de, eo[u][v].l.y, dacc[v].y);
-            dacc[v].z = fmaf(eo[u][v].de, eo[u][v].l.z, dacc[v].z); dacc[v].w = fmaf(eo[u][v].de, eo[u][v].l.w, dacc[v].w);
+            acc[v].x += qv[u][v].x; acc[v].y += qv[u][v].y; acc[v].z += qv[u][v].z; acc[v].w += qv[u][v].w;
+            dacc[v].x = fmaf(dev[u][v], lv[u][v].x, dacc[v].x); dacc[v].y = fmaf(dev[u][v], lv[u][v].y, dacc[v].y);
+            dacc[v].z = fmaf(dev[u][v], lv[u][v].z, dacc[v].z); dacc[v].w = fmaf(dev[u][v], lv[u][v].w, dacc[v].w);
           }
         }
       }
@@ -143,7 +164,7 @@ __global__ __launch_bounds__(256) void gat2_rowsum_fixup_kernel(V2Args a, int wi
   const int64_t k_e = slot_of(a.g, row_end - 1);
   float acc = a.part[(2 * k + 1) * (int64_t)width + c];
   for (int64_t kk = k + 1; kk <= k_e; ++kk) acc += a.part[(2 * kk) * (int64_t)width + c];
-  if (col_finish && c < a.rs.R) acc += add[(int64_t)r * a.rs.R + c];   // column pass: + row-side part of dWhi
+  if (col_finish == 2) acc += dst[(int64_t)r * ld_dst + c];             // row pass: added into dWhi_i
   dst[(int64_t)r * ld_dst + c] = acc;
 }
 
@@ -165,7 +186,7 @@ __global__ __launch_bounds__(256) void gat2_rowsum_fixup_list_kernel(V2Args a, i
       acc += x0; acc += x1; acc += x2; acc += x3;
     }
     for (; q < npieces; ++q) acc += a.part[(2 * (k + q)) * (int64_t)width + c];
-    if (col_finish && c < a.rs.R) acc += add[(int64_t)r * a.rs.R + c];
+    if (col_finish == 2) acc += dst[(int64_t)r * ld_dst + c];           // row pass: added into dWhi_i
     dst[(int64_t)r * ld_dst + c] = acc;
   }
 }
@@ -232,8 +253,7 @@ __global__ __launch_bounds__(256) void gat2_bwd_col_kernel(V2Args a) {
 #pragma unroll
       for (int v = 0; v < VEC; ++v)
         if (lc.valid[v]) {
-          const float4 r4 = ld4(a.dwhi_row + (int64_t)j * R + lc.cofs[v]);
-          st4(dst + lc.cofs[v], make_float4(accA[v].x + r4.x, accA[v].y + r4.y, accA[v].z + r4.z, accA[v].w + r4.w));
+          st4(dst + lc.cofs[v], accA[v]);          // the row pass adds its row sums to this half afterwards
           st4(dst + R + lc.cofs[v], accJ[v]);
         }
     }
@@ -255,6 +275,8 @@ __global__ __launch_bounds__(256) void gat2_bwd_col_kernel(V2Args a) {
         gv[u][v] = ld4(gi + lc.cofs[v]);
         eo[u][v] = v2_edge(ld4(gi + R + 4 * H + lc.cofs[v]), ld4(wj + lc.cofs[v]), ld4(wj + R + lc.cofs[v]), gv[u][v],
                            ld4(gi + R + 4 * lc.head[v]), a4[v], mk, a.alpha, lc.valid[v], lph);
+        // de_ij for the row pass: the first lane of a head stores it (every lane of the head holds the same value)
+        if (lc.valid[v] && e + u < e1 && ((lc.cofs[v] >> 2) & (lph - 1)) == 0) a.de_t[(e + u) * H + lc.head[v]] = eo[u][v].de;
       }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -287,65 +309,65 @@ extern "C" size_t pygat_gatv2_workspace_bytes(int64_t nnz, int slot_edges, int H
   if (nnz <= 0 || slot_edges <= 0 || Fp == 0) return 0;
   const int64_t nslots = (nnz + slot_edges - 1) / slot_edges;
   const int64_t R = (int64_t)H * Fp;
-  // partial records of the column pass (2R floats each) + one da record per row-pass work-group
-  return (size_t)(2 * nslots * 2 * R + (nslots / 4 + 2) * R + DA_STAGE * R) * sizeof(float);
+  // partial records of the column pass (2R floats each) + one da record per row-pass work-group + de per transposed edge
+  return (size_t)(2 * nslots * 2 * R + (nslots / 4 + 2) * R + DA_STAGE * R + nnz * H + 4) * sizeof(float);
 }
 
-extern "C" int pygat_gatv2_backward(const pygat_graph* g, const pygat_graph* gT, const int32_t* perm_t, int H, int Fo,
-                                    float alpha, const float* WW, const float* a2, const float* GRW,
-                                    const float* att_mask, float* dwhi_row, float* dWW, float* da, void* ws,
-                                    void* stream) {
+extern "C" int pygat_gatv2_backward(const pygat_graph* g, const pygat_graph* gT, const int32_t* perm_t, const int32_t* perm_f,
+                                    int H, int Fo, float alpha, const float* WW, const float* a2, const float* GRW,
+                                    const float* att_mask, float* dWW, float* da, void* ws, void* stream) {
   V2Args a;
   int rc = check_graph(g, &a.g);
   if (rc) return rc;
   PYGAT_REQUIRE(make_row_shape(H, Fo, &a.rs), "gatv2_backward: unsupported H=%d F'=%d", H, Fo);
   PYGAT_REQUIRE(a.rs.R <= 1024, "gatv2_backward: row too wide");
-  PYGAT_REQUIRE(WW && a2 && GRW && dwhi_row && dWW && da && ws, "gatv2_backward: null pointer");
+  PYGAT_REQUIRE(WW && a2 && GRW && dWW && da && ws && perm_f, "gatv2_backward: null pointer");
   PYGAT_REQUIRE(!att_mask || perm_t, "gatv2_backward: an attention mask needs perm_t");
-  PYGAT_REQUIRE(aligned16(WW) && aligned16(a2) && aligned16(GRW) && aligned16(dwhi_row) && aligned16(dWW) && aligned16(ws),
+  PYGAT_REQUIRE(aligned16(WW) && aligned16(a2) && aligned16(GRW) && aligned16(dWW) && aligned16(ws),
                 "gatv2_backward: row tables must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int R = a.rs.R;
-  a.alpha = alpha; a.perm = nullptr; a.mask = att_mask; a.WW = WW; a.GRW = GRW; a.a2 = a2; a.dwhi_row = nullptr;
+  a.alpha = alpha; a.mask = att_mask; a.WW = WW; a.GRW = GRW; a.a2 = a2; a.dwhi_row = nullptr;
   int lpr, vec;
   pick_lanes(a.rs, &lpr, &vec);
   const int64_t nslots = num_slots(a.g);
   const unsigned blocks = (unsigned)cdiv(cdiv(nslots, 64 / lpr), 4);
   float* part = (float*)ws;
   float* da_part = part + 2 * nslots * 2 * (int64_t)R;
-  // row pass: dWhi_row, da
-  a.out = dwhi_row; a.part = part; a.da_part = da_part;
-  PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat2_bwd_row_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0, st, a));
-  PYGAT_CHECK_LAUNCH("gatv2_backward_row");
-  if (a.g.cut) {
-    if (a.g.n_cut > 0)
-      hipLaunchKernelGGL(gat2_rowsum_fixup_list_kernel, dim3((unsigned)a.g.n_cut), dim3(256), 0, st, a, R, dwhi_row, (int64_t)R,
-                         (const float*)nullptr, 0);
-  } else {
-    hipLaunchKernelGGL(gat2_rowsum_fixup_kernel, dim3((unsigned)cdiv(nslots * R, 256)), dim3(256), 0, st, a, R, dwhi_row,
-                       (int64_t)R, (const float*)nullptr, 0);
-  }
   float* da_stage = da_part + (nslots / 4 + 2) * (int64_t)R;
-  hipLaunchKernelGGL(gat2_da_stage_kernel, dim3(DA_STAGE), dim3(256), 0, st, R, (int)blocks, (const float*)da_part, da_stage);
-  hipLaunchKernelGGL(gat2_da_final_kernel, dim3((unsigned)cdiv(a.rs.H * a.rs.Fo, 256)), dim3(256), 0, st, a.rs, DA_STAGE,
-                     (const float*)da_stage, da);
-  PYGAT_CHECK_LAUNCH("gatv2_backward_row_fixup");
-  // column pass over the transposed pattern: dWW = [dWhi | dWhj]
+  float* de_t = da_stage + (int64_t)DA_STAGE * R;
+  // column pass over the transposed pattern: dWW = [aggregation part of dWhi | dWhj], de per transposed edge
   V2Args b = a;
   rc = check_graph(gT, &b.g);
   if (rc) return rc;
   PYGAT_REQUIRE(b.g.nnz == a.g.nnz && b.g.ts == a.g.ts, "gatv2_backward: g and gT differ in size / slot length");
-  b.perm = perm_t; b.dwhi_row = dwhi_row; b.out = dWW; b.part = part;
+  b.perm = perm_t; b.out = dWW; b.part = part; b.de_t = de_t; b.da_part = nullptr;
   PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat2_bwd_col_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0, st, b));
   PYGAT_CHECK_LAUNCH("gatv2_backward_col");
   if (b.g.cut) {
     if (b.g.n_cut > 0)
       hipLaunchKernelGGL(gat2_rowsum_fixup_list_kernel, dim3((unsigned)b.g.n_cut), dim3(256), 0, st, b, 2 * R, dWW,
-                         2 * (int64_t)R, (const float*)dwhi_row, 1);
+                         2 * (int64_t)R, (const float*)nullptr, 1);
   } else {
     hipLaunchKernelGGL(gat2_rowsum_fixup_kernel, dim3((unsigned)cdiv(nslots * 2 * R, 256)), dim3(256), 0, st, b, 2 * R, dWW,
-                       2 * (int64_t)R, (const float*)dwhi_row, 1);
+                       2 * (int64_t)R, (const float*)nullptr, 1);
   }
   PYGAT_CHECK_LAUNCH("gatv2_backward_col_fixup");
+  // row pass over the forward pattern: dWhi_i += sum_j q_ij (de through perm_f, only Whj_j gathered), da
+  a.perm = perm_f; a.out = dWW; a.part = part; a.da_part = da_part; a.de_t = de_t;
+  PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat2_bwd_row_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0, st, a));
+  PYGAT_CHECK_LAUNCH("gatv2_backward_row");
+  if (a.g.cut) {
+    if (a.g.n_cut > 0)
+      hipLaunchKernelGGL(gat2_rowsum_fixup_list_kernel, dim3((unsigned)a.g.n_cut), dim3(256), 0, st, a, R, dWW, 2 * (int64_t)R,
+                         (const float*)nullptr, 2);
+  } else {
+    hipLaunchKernelGGL(gat2_rowsum_fixup_kernel, dim3((unsigned)cdiv(nslots * R, 256)), dim3(256), 0, st, a, R, dWW,
+                       2 * (int64_t)R, (const float*)nullptr, 2);
+  }
+  hipLaunchKernelGGL(gat2_da_stage_kernel, dim3(DA_STAGE), dim3(256), 0, st, R, (int)blocks, (const float*)da_part, da_stage);
+  hipLaunchKernelGGL(gat2_da_final_kernel, dim3((unsigned)cdiv(a.rs.H * a.rs.Fo, 256)), dim3(256), 0, st, a.rs, DA_STAGE,
+                     (const float*)da_stage, da);
+  PYGAT_CHECK_LAUNCH("gatv2_backward_row_fixup");
   return PYGAT_OK;
 }

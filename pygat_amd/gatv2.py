@@ -116,14 +116,13 @@ class GATv2LevelFn(torch.autograd.Function):
                 check(lib.pygat_gatv2_backward_prepare(L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(), y.data_ptr(),
                                                        _ptr(Sk), m.data_ptr(), Z.data_ptr(), WW.data_ptr(), GRW.data_ptr(), st),
                       "gatv2_backward_prepare")
-            dwr = torch.empty(L.N, R, dtype=f32, device=dev)
             dWW = torch.empty(L.N, 2 * R, dtype=f32, device=dev)
             da_p = torch.empty(H, Fo, dtype=f32, device=dev)
             ws = torch.empty(lib.pygat_gatv2_workspace_bytes(graph.nnz, L.ts, H, Fo) // 4 + 4, dtype=f32, device=dev)
             with _span("v2_backward_row_col"):
                 check(lib.pygat_gatv2_backward(graph.fwd.ref(L.ts), graph.bwd.ref(L.ts),
-                                               graph.perm_t.data_ptr() if matt is not None else None, H, Fo, ctx.alpha,
-                                               WW.data_ptr(), a2.data_ptr(), GRW.data_ptr(), _ptr(matt), dwr.data_ptr(),
+                                               graph.perm_t.data_ptr() if matt is not None else None, graph.perm_f.data_ptr(),
+                                               H, Fo, ctx.alpha, WW.data_ptr(), a2.data_ptr(), GRW.data_ptr(), _ptr(matt),
                                                dWW.data_ptr(), da_p.data_ptr(), ws.data_ptr(), st), "gatv2_backward")
             ncols = Wcat.shape[1]
             dW = dWs = dx = None

@@ -263,7 +263,7 @@ def main():
 
     import pygat_amd as pg
     from pygat_amd import ops
-    from pygat_amd.dist import partition_heads, gather_columns_layout
+    from pygat_amd.dist import partition_heads
     from pygat_amd.rmat import rmat_csr
 
     H, Fo, Fin = args.heads, args.fout, args.fin
@@ -322,8 +322,8 @@ def main():
 
     # N > 1: the level runs row chunk by row chunk (GATLevelFn pipeline): chunk c's head outputs (models.py:32
     # torch.cat) are all-gathered on RCCL's own stream while chunk c+1 is computed; the rest of the exchange hides
-    # behind this level's backward, which does not depend on it, and is joined at the end of the step.  The gathered
-    # chunks stay rank-major [world, rows, w]: pygat_amd.dist copies them into their column slices as they land.
+    # behind this level's backward, which does not depend on it, and is joined at the end of the step, where the gathered
+    # rank-major chunks [world, rows, w] are copied into their column slices of the [N, H F'] activation (as pygat_amd.dist does).
     # The chunk borders are the level's own (GATLevelFn cuts with the slot length of ITS row width: 32-edge slots for a
     # one-head 64-byte row, graph.slot_edges otherwise), so the receive buffers are sized from the (r0, r1) the callback
     # gets: allocated on the first step, reused -- and checked -- on every later one.
@@ -340,6 +340,7 @@ def main():
         works.append(dist.all_gather_into_tensor(buf.view(world * (r1 - r0), h_loc * Fo), out[r0:r1], async_op=True))
 
     chunk_rows = {}
+    full_out = None
 
     def step():
         if use_pg:
@@ -349,9 +350,16 @@ def main():
                 Xb.grad = None
             out = pg.GATLevelFn.apply(Xb, W_loc, a_loc, None, graph, 0.2, True, None, (nchunks, on_chunk))
             out.backward(G_loc)
-            for wk in works:
+            # join the exchange and lay the gathered blocks out as the next level reads them ([N, H F'], models.py:32 torch.cat):
+            # what pygat_amd.dist._pipelined_concat_level does -- one strided copy per chunk, part of the step
+            nonlocal full_out
+            if full_out is None:
+                full_out = torch.empty(N, world * h_loc * Fo, device=dev)
+            for c, wk in enumerate(works):
                 wk.wait()
-            return [gbufs[c] for c in sorted(gbufs)]
+                r0, r1 = chunk_rows[c]
+                full_out[r0:r1].view(r1 - r0, world, h_loc * Fo).copy_(gbufs[c].permute(1, 0, 2))
+            return full_out
         out = level_fwd()
         level_bwd(out)
         return out
@@ -430,8 +438,6 @@ def main():
         full = step()
         if rank == 0:
             # the gathered concat output of the sharded run against the unsharded level on this rank
-            if use_pg:                                      # chunks of [world, rows, w] -> [N, world*w]
-                full = torch.cat([gather_columns_layout(b) for b in full], dim=0)
             ref = pg.GATLevelFn.apply(X, W, a, None, graph, 0.2, True)
             got = full if (use_pg or replicate or model_world == 1) else None
             if got is not None:

@@ -5,7 +5,7 @@ row-normalised bag of words on its citation datasets -- Cora 1.27 % non-zero, Ci
 it, zeros included, with every head's W in every epoch (layers.py:35,134).  The input never changes between epochs, so its
 pattern is extracted ONCE (cached on the tensor like the adjacency, graph.as_graph) as CSR for the projection and as its
 transpose for the weight gradient; csrc/k9_sparse.hip then does both products on the non-zeros only, under the same
-per-head dropout decisions as the dense kernels.  Dense inputs (density above MAX_DENSITY), inputs that require a gradient
+per-head dropout decisions as the dense kernels.  Dense inputs (density above MAX_DENSITY, or feature columns longer than MAX_COLUMN_NNZ on average), inputs that require a gradient
 and hidden levels keep the dense GEMMs.  PYGAT_SPARSE_X=0 switches the whole path off.
 """
 from __future__ import annotations
@@ -16,7 +16,10 @@ from typing import Optional
 
 import torch
 
-MAX_DENSITY = 0.25          # above this the dense MFMA GEMM wins
+MAX_DENSITY = 0.05          # above this the dense MFMA GEMM wins
+MAX_COLUMN_NNZ = 256        # mean non-zeros per feature column: the weight gradient runs one wave per column (Cora 34,
+                            # Citeseer 28; Pubmed's 500 TF-IDF columns hold 1976 each and stay on the dense kernels: measured
+                            # 1.22 ms per epoch sparse against 0.70 dense)
 MAX_COLUMNS = 512           # output columns 2 R + H the sparse kernels take (k9_sparse.hip SP_CPL)
 ENABLED = os.environ.get("PYGAT_SPARSE_X", "1") != "0"
 
@@ -56,7 +59,7 @@ def as_sparse_features(x: torch.Tensor, out_columns: int) -> Optional[SparseFeat
     if hit is not None and hit[0]() is x:
         return hit[1]
     density = float(torch.count_nonzero(x)) / max(1, x.numel())      # one device sync per feature tensor, then cached
-    xs = SparseFeatures(x) if 0.0 < density <= MAX_DENSITY else None
+    xs = SparseFeatures(x) if (0.0 < density <= MAX_DENSITY and density * x.shape[0] <= MAX_COLUMN_NNZ) else None
     if len(_cache) > 16:
         _cache.clear()
     _cache[key] = (weakref.ref(x), xs)

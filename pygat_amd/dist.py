@@ -95,7 +95,12 @@ class AllGatherColumns(torch.autograd.Function):
         return out[:, :widths[rank]].contiguous(), None
 
 
-PIPELINE_CHUNKS = 4          # row chunks of a pipelined hidden level (PYGAT_DIST_CHUNKS overrides; 1 = no pipeline)
+import os as _os
+
+# row chunks of a pipelined hidden level (1 = no pipeline).  PYGAT_DIST_CHUNKS is read ONCE, at import: every rank must issue
+# the same number and shapes of collectives, so the count may not change under a running job (a per-call read on each rank
+# could disagree and hang); set the environment identically on all ranks, or assign dist.PIPELINE_CHUNKS on all of them.
+PIPELINE_CHUNKS = int(_os.environ.get("PYGAT_DIST_CHUNKS", 4))
 PIPELINE_MIN_ROWS = 1 << 15  # below this a level is launch-bound and one blocking all-gather is cheaper
 
 
@@ -173,8 +178,7 @@ def gat_level_head_parallel(x, graph, Ws, As, Wskips, alpha: float, concat: bool
             level_fn = gat_level
     sk = None if Wskips is None else list(Wskips[s:e])
     widths = [(b - a) * Fo for a, b in parts]
-    import os
-    nchunks = int(os.environ.get("PYGAT_DIST_CHUNKS", PIPELINE_CHUNKS))
+    nchunks = PIPELINE_CHUNKS
     if (concat and hip_level and dropout == 0.0 and world > 1 and nchunks > 1 and x.shape[0] >= PIPELINE_MIN_ROWS
             and len(set(widths)) == 1 and e > s):
         return _pipelined_concat_level(x, graph, list(Ws[s:e]), list(As[s:e]), sk, alpha, widths, nchunks)

@@ -73,15 +73,15 @@ def main():
         json.dump(doc, fh, indent=1)
     if a.latest:
         spans = {   # bench.py span -> kernel name prefixes (pygat_amd/ops.py)
-            "k1_project": ("pygat::gemm_smallk_kernel", "pygat::gemm_smallk_x3_kernel"),
+            # (bench.py also runs its `alt` pass -- the fp32-MFMA kernels -- under the profiler: the default mode's kernels only)
+            "k1_project": ("pygat::gemm_smallk_x3_kernel",),
             "k2_forward": ("pygat::gat_fwd_",),
             "k3a_prepare": ("pygat::gat_bwd_prepare",),
             "k3b_row": ("pygat::gat_bwd_row_kernel",),
             "k4_backward_col": ("pygat::gat_bwd_col_",),
             "k3c_rowsum": ("pygat::gat_bwd_rowsum_kernel",),
             "k5_agrad": ("pygat::a_grad_",),
-            "k5_wgrad": ("pygat::gemm_tn_stream_kernel", "pygat::gemm_tn_x3_kernel", "pygat::gemm_splitk_reduce_kernel",
-                         "pygat::unpack_wgrad"),
+            "k5_wgrad": ("pygat::gemm_tn_x3_kernel", "pygat::gemm_splitk_reduce_kernel", "pygat::unpack_wgrad"),
         }
         traffic = {}
         for span, prefixes in spans.items():

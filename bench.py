@@ -210,7 +210,10 @@ def gatv2_level_record(pg, ops, graph, X, H, Fo, steps=10):
         "v2_project": 4.0 * N * (Fin + 2 * R),
         "v2_forward": E * (8 + 8 * R) + N * (4 + 8 * R + 8 * H),
         "v2_prepare": N * (12 * R + 8 * H + 4 * (2 * R + 4 * H)),
-        "v2_backward_row_col": E * (8 + 8 * R) + N * (4 * (2 * R + 4 * H) + 4 * R) + E * (8 + 4 * (2 * R + 4 * H)) + N * (20 * R),
+        # column pass: per edge (i, j) pair, the gathered [Gp_i | m,1/Z,D | Whi_i] row, the de record it writes; per node WW_j
+        # row-local and dWW_j written.  Row pass: per edge pair, perm, the Whj HALF of WW_j, the de record; per node Whi_i
+        # row-local and dWhi_i read-modify-written
+        "v2_backward_row_col": E * (8 + 4 * (2 * R + 4 * H) + 4 * H) + N * (16 * R) + E * (12 + 4 * R + 4 * H) + N * (12 * R),
         "v2_wgrad": 4.0 * N * (Fin + 2 * R),
     }
     kernels = []
@@ -221,8 +224,9 @@ def gatv2_level_record(pg, ops, graph, X, H, Fo, steps=10):
                         "frac_of_8TBps": None if b is None else b / (t * 1e-3) / 1e9 / HBM_PEAK_GBPS})
     return {"layer": "SpGraphAttentionLayerV2 (layers.py:234-316)", "ms_per_step": ms, "edges_per_s": E / (ms * 1e-3),
             "heads": H, "f_out": Fo, "kernels": kernels,
-            "note": "v2_backward_row_col = row pass (gathers [Whi_j | Whj_j]) + column pass (gathers [Gp_i | m,1/Z,D | Whi_i]) + "
-                    "their fix-ups, one C call; per-kernel times: profiles/ rocprof summary of tools/v2_bench.py"}
+            "note": "v2_backward_row_col = column pass (gathers [Gp_i | m,1/Z,D | Whi_i], leaves de per transposed edge) + row pass "
+                    "(gathers the Whj half of [Whi_j | Whj_j], de through perm) + their fix-ups, one C call; per-kernel times: "
+                    "profiles/ rocprof summary of tools/v2_bench.py"}
 
 
 def main():

@@ -101,6 +101,8 @@ class _Pattern:
             with torch.cuda.device(self.rowptr.device):
                 check(lib.pygat_slot_meta(self.n, self.nnz, self.rowptr.data_ptr(), self.edge_rc.data_ptr(), slot_edges, _ptr(sb),
                                           meta.data_ptr(), _stream()), "slot_meta")
+            if os.environ.get("PYGAT_NO_SLOT_META") == "1":      # development knob (A/B of the slot records)
+                meta = None
             st = _lib.Graph(self.n, self.nnz, _ptr(self.rowptr), _ptr(self.edge_rc), slot_edges, _ptr(sb), _ptr(cut),
                             n_cut, n_wide, 0, 0, _ptr(meta))
             self._alt[key] = (st, sb, cut, meta)

@@ -147,9 +147,11 @@ int pygat_stack_heads(int H, int64_t nW, int nA, int64_t nS, const float* const*
  * Sk may be NULL (no skip).  split_k / ws as pygat_gemm_f32. */
 int pygat_project(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const float* Wcat, int64_t ldw, const float* a_pad,
                   float* Wh, float* Sk, float* s, int split_k, void* ws, int gemm_mode, void* stream);
-/* s[n x H], t[n x H] (t may be NULL) from an (already masked) Wh table: s_ih = Wh_ih . a_src_h, t_ih = Wh_ih . a_dst_h
- * (layers.py:60-61 after the Wh dropout of layers.py:37,136).  a_pad as written by pygat_pack_params. */
-int pygat_attn_scores(int n, int H, int Fo, const float* Wh, const float* a_pad,
+/* s[n x H], t[n x H] (t may be NULL) from the masked Wh table: s_ih = Wh_ih . a_src_h, t_ih = Wh_ih . a_dst_h
+ * (layers.py:60-61 after the Wh dropout of layers.py:37,136).  wh_mask [n x R] (pre-scaled) non-NULL: that dropout is
+ * applied HERE, in place (Wh *= wh_mask), instead of by a launch of its own; NULL: Wh is taken as it is.
+ * a_pad as written by pygat_pack_params. */
+int pygat_attn_scores(int n, int H, int Fo, float* Wh, const float* wh_mask, const float* a_pad,
                       float* s, float* t, void* stream);
 /* Inverse for gradients: dW[H x Fin x F'] (+)= columns of dWcat [Fin x ld]. */
 int pygat_unpack_wgrad(int H, int Fin, int Fo, const float* dWcat, int64_t ld,
@@ -292,8 +294,11 @@ int pygat_gat_backward_rowsum(const pygat_graph* g, const int32_t* perm_f, int H
 /* da[H x 2F'] : da_src = sum_i ds_i Wh_i, da_dst = sum_j dt_j Wh_j (per head).
  * ws >= pygat_agrad_workspace_bytes(H, Fo).  dWh (with a_pad) non-NULL: also dWh_i += ds_i a_src, see above. */
 size_t pygat_agrad_workspace_bytes(int H, int Fo);
+/* dwh_mask [n x R] (pre-scaled; needs dWh): dWh is also taken back through the Wh dropout of layers.py:37,136 in the same
+ * pass (after the finishing term), instead of by a launch of its own. */
 int pygat_a_grad(int n, int H, int Fo, const float* Wh, const float* ds, const float* dt,
-                 float* da, void* ws, const float* a_pad, float* dWh, int h_first, int h_count, void* stream);
+                 float* da, void* ws, const float* a_pad, float* dWh, const float* dwh_mask, int h_first, int h_count,
+                 void* stream);
 
 /* Weight gradient of one level, the backward counterpart of pygat_project (autograd of layers.py:35,134):
  *   dW[h] = X^T dWh[:, head h]                       dW [H x Fin x F'], X [n x Fin], dWh [n x R]
@@ -346,6 +351,9 @@ int pygat_gatv2_backward(const pygat_graph* g, const pygat_graph* gT, const int3
  *                           stream_id as the expand call)
  */
 int pygat_dropout_mask(int64_t count, float p, const void* seed, uint32_t stream_id, float* out, void* stream);
+/* two of them (a level's Wh and attention masks) in one launch */
+int pygat_dropout_mask2(float p, const void* seed, int64_t count1, uint32_t stream1, float* out1, int64_t count2,
+                        uint32_t stream2, float* out2, void* stream);
 int pygat_dropout_expand(int n, int Fin, int H, const float* x, int64_t ldx, const float* mask, float p,
                          const void* seed, uint32_t stream_id, float* out, int64_t ldo, void* stream);
 int pygat_dropout_head_sum(int n, int Fin, int H, const float* dxe, int64_t lde, const float* mask, float p,

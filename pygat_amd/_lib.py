@@ -33,7 +33,7 @@ SYMBOLS = [
     "pygat_gat_backward_prepare", "pygat_gat_backward_row", "pygat_gat_backward_col", "pygat_gat_backward_rowsum",
     "pygat_agrad_workspace_bytes", "pygat_a_grad", "pygat_wgrad_workspace_bytes", "pygat_wgrad",
     "pygat_gatv2_forward", "pygat_gatv2_backward_prepare", "pygat_gatv2_workspace_bytes", "pygat_gatv2_backward",
-    "pygat_dropout_mask", "pygat_dropout_expand", "pygat_dropout_head_sum", "pygat_pack_blockdiag",
+    "pygat_dropout_mask", "pygat_dropout_mask2", "pygat_dropout_expand", "pygat_dropout_head_sum", "pygat_pack_blockdiag",
     "pygat_unpack_blockdiag",
     "pygat_headmask_supported", "pygat_dropout_bits", "pygat_project_dropout_workspace_bytes", "pygat_project_dropout",
     "pygat_wgrad_dropout_workspace_bytes",
@@ -86,7 +86,7 @@ def _load():
     lib.pygat_pack_params_heads.argtypes = [i, i, i, p, p, p, p, i64, p, p]
     lib.pygat_stack_heads.argtypes = [i, i64, i, i64, p, p, p, p, p, p, p]
     lib.pygat_unpack_wgrad.argtypes = [i, i, i, p, i64, i, p, p]
-    lib.pygat_attn_scores.argtypes = [i, i, i, p, p, p, p, p]
+    lib.pygat_attn_scores.argtypes = [i, i, i, p, p, p, p, p, p]
     lib.pygat_project.argtypes = [i, i, i, i, p, i64, p, i64, p, p, p, p, i, p, i, p]
     lib.pygat_edge_pairs.argtypes = [i, p, p, p, p]
     lib.pygat_slot_bounds.argtypes = [i, i64, p, p, i, p, p]
@@ -103,7 +103,7 @@ def _load():
     lib.pygat_gat_backward_rowsum.argtypes = [C.POINTER(Graph), p, i, i, p, p, p, i, i, p]
     lib.pygat_agrad_workspace_bytes.argtypes = [i, i]
     lib.pygat_agrad_workspace_bytes.restype = sz
-    lib.pygat_a_grad.argtypes = [i, i, i, p, p, p, p, p, p, p, i, i, p]
+    lib.pygat_a_grad.argtypes = [i, i, i, p, p, p, p, p, p, p, p, i, i, p]
     lib.pygat_gatv2_forward.argtypes = [C.POINTER(Graph), i, i, f, i, p, p, p, p, p, p, p, p, p, p]
     lib.pygat_gatv2_backward_prepare.argtypes = [i, i, i, i, i, p, p, p, p, p, p, p, p]
     lib.pygat_gatv2_workspace_bytes.argtypes = [i64, i, i, i]
@@ -114,6 +114,7 @@ def _load():
     lib.pygat_wgrad_workspace_bytes.restype = sz
     lib.pygat_wgrad.argtypes = [i, i, i, i, p, i64, p, p, p, p, i, p, i, i, i, p]
     lib.pygat_dropout_mask.argtypes = [i64, f, p, u32, p, p]
+    lib.pygat_dropout_mask2.argtypes = [f, p, i64, u32, p, i64, u32, p, p]
     lib.pygat_dropout_expand.argtypes = [i, i, i, p, i64, p, f, p, u32, p, i64, p]
     lib.pygat_dropout_head_sum.argtypes = [i, i, i, p, i64, p, f, p, u32, p, i64, i, p]
     lib.pygat_pack_blockdiag.argtypes = [i, i, i, p, p, p, i64, p]

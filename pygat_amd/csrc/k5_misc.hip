@@ -18,7 +18,9 @@ __global__ __launch_bounds__(256) void a_grad_partial_kernel(int n, int nblocks,
                                                              const float* __restrict__ ds,
                                                              const float* __restrict__ dt,
                                                              float* __restrict__ ws, const float* __restrict__ a_pad,
-                                                             float* __restrict__ dWh) {
+                                                             float* __restrict__ dWh, const float* __restrict__ dmask) {
+  // dWh != nullptr: the rows of dWh are rewritten in the same pass -- finished (+= ds_i a_src, when a_pad is given) and / or
+  // taken back through the Wh dropout (x dmask: layers.py:37,136's mask, pre-scaled), which used to be a launch of its own
   // TPR threads per row (power of two >= NCH, <= 256), 256/TPR rows in flight per block
   int tpr = 1;
   while (tpr < rs.NCH) tpr <<= 1;
@@ -30,8 +32,8 @@ __global__ __launch_bounds__(256) void a_grad_partial_kernel(int n, int nblocks,
   const int64_t r0 = blockIdx.x * rows_per_block;
   const int64_t r1 = (r0 + rows_per_block < n) ? r0 + rows_per_block : n;
   float4 as = make_float4(0.f, 0.f, 0.f, 0.f), ad = as;
-  float4 asrc = as;
-  if (dWh) asrc = ld4(a_pad + (int64_t)h * 2 * rs.Fp + (co & (rs.Fp - 1)));
+  float4 asrc = as;     // (zero without a_pad: the finishing term vanishes)
+  if (dWh && a_pad) asrc = ld4(a_pad + (int64_t)h * 2 * rs.Fp + (co & (rs.Fp - 1)));
   int64_t i = r0 + rg;
   for (; i + 3 * rpb < r1; i += 4 * rpb) {  // 4 rows in flight per thread: the kernel is a pure stream
     float4 w[4], d[4];
@@ -49,6 +51,10 @@ __global__ __launch_bounds__(256) void a_grad_partial_kernel(int n, int nblocks,
       for (int q = 0; q < 4; ++q) {
         d[q].x = fmaf(a1[q], asrc.x, d[q].x); d[q].y = fmaf(a1[q], asrc.y, d[q].y);
         d[q].z = fmaf(a1[q], asrc.z, d[q].z); d[q].w = fmaf(a1[q], asrc.w, d[q].w);
+        if (dmask) {
+          const float4 mk = ld4(dmask + (i + q * rpb) * rs.ldr + co);
+          d[q].x *= mk.x; d[q].y *= mk.y; d[q].z *= mk.z; d[q].w *= mk.w;
+        }
         st4(dWh + (i + q * rpb) * rs.ldr + co, d[q]);
       }
     }
@@ -64,6 +70,10 @@ __global__ __launch_bounds__(256) void a_grad_partial_kernel(int n, int nblocks,
     if (dWh && valid) {
       float4 d = ld4(dWh + i * rs.ldr + co);
       d.x = fmaf(a1, asrc.x, d.x); d.y = fmaf(a1, asrc.y, d.y); d.z = fmaf(a1, asrc.z, d.z); d.w = fmaf(a1, asrc.w, d.w);
+      if (dmask) {
+        const float4 mk = ld4(dmask + i * rs.ldr + co);
+        d.x *= mk.x; d.y *= mk.y; d.z *= mk.z; d.w *= mk.w;
+      }
       st4(dWh + i * rs.ldr + co, d);
     }
     as.x = fmaf(a1, w.x, as.x); as.y = fmaf(a1, w.y, as.y); as.z = fmaf(a1, w.z, as.z); as.w = fmaf(a1, w.w, as.w);
@@ -110,18 +120,25 @@ __global__ __launch_bounds__(256) void a_grad_final_kernel(RowShape rs, int nblo
   if (ok && q == 0) da[idx] = acc;
 }
 
-// s, t from a (masked) Wh table: one thread per (node, head)
-__global__ __launch_bounds__(256) void attn_scores_kernel(int n, int H, int Fp, const float* __restrict__ Wh,
-                                                          const float* __restrict__ a_pad, float* __restrict__ s,
-                                                          float* __restrict__ t) {
+// s, t from a (masked) Wh table: one thread per (node, head).  wh_mask != nullptr: the Wh dropout (layers.py:37,136) is applied
+// here, in place, instead of by a launch of its own
+__global__ __launch_bounds__(256) void attn_scores_kernel(int n, int H, int Fp, float* __restrict__ Wh,
+                                                          const float* __restrict__ wh_mask, const float* __restrict__ a_pad,
+                                                          float* __restrict__ s, float* __restrict__ t) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (int64_t)n * H) return;
   const int h = (int)(idx % H);
-  const float* w = Wh + idx * Fp;               // row i, head h: offset (i*H + h)*Fp
+  float* w = Wh + idx * Fp;               // row i, head h: offset (i*H + h)*Fp
   const float* as = a_pad + (int64_t)h * 2 * Fp;
   float x = 0.f, y = 0.f;
   for (int f = 0; f < Fp; f += 4) {
-    const float4 w4 = ld4(w + f), a4 = ld4(as + f), d4 = ld4(as + Fp + f);
+    float4 w4 = ld4(w + f);
+    if (wh_mask) {
+      const float4 mk = ld4(wh_mask + idx * Fp + f);
+      w4.x *= mk.x; w4.y *= mk.y; w4.z *= mk.z; w4.w *= mk.w;
+      st4(w + f, w4);
+    }
+    const float4 a4 = ld4(as + f), d4 = ld4(as + Fp + f);
     x += dot4(w4, a4);
     y += dot4(w4, d4);
   }
@@ -216,14 +233,17 @@ extern "C" size_t pygat_agrad_workspace_bytes(int H, int Fo) {
 }
 
 extern "C" int pygat_a_grad(int n, int H, int Fo, const float* Wh, const float* ds, const float* dt, float* da,
-                            void* ws, const float* a_pad, float* dWh, int h_first, int h_count, void* stream) {
+                            void* ws, const float* a_pad, float* dWh, const float* dwh_mask, int h_first, int h_count,
+                            void* stream) {
   RowShape rs;
   const int Fp = padded_width(Fo);
   HeadRange rg;
   PYGAT_REQUIRE(H > 0 && Fp > 0 && Fp <= 1024, "a_grad: unsupported H=%d F'=%d", H, Fo);
   PYGAT_REQUIRE(make_head_range(H, h_first, h_count, &rg), "a_grad: bad head range [%d, +%d) of %d", h_first, h_count, H);
   PYGAT_REQUIRE(n > 0 && Wh && ds && dt && da && ws && aligned16(Wh) && aligned16(ws), "a_grad: bad arguments");
-  PYGAT_REQUIRE(!dWh || (a_pad && aligned16(dWh) && aligned16(a_pad)), "a_grad: dWh needs a_pad, both 16-byte aligned");
+  PYGAT_REQUIRE(!dWh || ((a_pad || dwh_mask) && aligned16(dWh) && (!a_pad || aligned16(a_pad)) && (!dwh_mask || aligned16(dwh_mask))),
+                "a_grad: dWh needs a_pad and / or dwh_mask, 16-byte aligned");
+  PYGAT_REQUIRE(!dwh_mask || dWh, "a_grad: dwh_mask needs dWh");
   hipStream_t st = (hipStream_t)stream;
   // a work-group streams rows of at most 1024 floats (256 threads x 16 B): wider levels go window by window
   const int hg = (rg.hr * Fp <= 1024) ? rg.hr : (1024 / Fp);
@@ -242,7 +262,7 @@ extern "C" int pygat_a_grad(int n, int H, int Fo, const float* Wh, const float* 
     PYGAT_REQUIRE(make_window_shape(H, Fo, hc, &rs), "a_grad: unsupported H=%d F'=%d", hc, Fo);
     hipLaunchKernelGGL(a_grad_partial_kernel, dim3(nblocks), dim3(256), 0, st, n, nblocks, rs, Wh + (int64_t)gh * Fp,
                        ds + gh, dt + gh, (float*)ws, a_pad ? a_pad + (int64_t)gh * 2 * Fp : nullptr,
-                       dWh ? dWh + (int64_t)gh * Fp : nullptr);
+                       dWh ? dWh + (int64_t)gh * Fp : nullptr, dwh_mask ? dwh_mask + (int64_t)gh * Fp : nullptr);
     hipLaunchKernelGGL(a_grad_final_kernel, dim3((unsigned)cdiv(rs.H * 2 * rs.Fo * 8, 256)), dim3(256), 0, st, rs, nblocks,
                        (const float*)ws, da + (int64_t)gh * 2 * Fo);
     PYGAT_CHECK_LAUNCH("a_grad");
@@ -250,13 +270,13 @@ extern "C" int pygat_a_grad(int n, int H, int Fo, const float* Wh, const float* 
   return PYGAT_OK;
 }
 
-extern "C" int pygat_attn_scores(int n, int H, int Fo, const float* Wh, const float* a_pad, float* s, float* t,
+extern "C" int pygat_attn_scores(int n, int H, int Fo, float* Wh, const float* wh_mask, const float* a_pad, float* s, float* t,
                                  void* stream) {
   int Fp = padded_width(Fo);
-  PYGAT_REQUIRE(n > 0 && H > 0 && Fp > 0 && Wh && a_pad && s && aligned16(Wh) && aligned16(a_pad),
+  PYGAT_REQUIRE(n > 0 && H > 0 && Fp > 0 && Wh && a_pad && s && aligned16(Wh) && aligned16(a_pad) && (!wh_mask || aligned16(wh_mask)),
                 "attn_scores: bad arguments");
   hipLaunchKernelGGL(attn_scores_kernel, dim3((unsigned)cdiv((int64_t)n * H, 256)), dim3(256), 0, (hipStream_t)stream, n,
-                     H, Fp, Wh, a_pad, s, t);
+                     H, Fp, Wh, wh_mask, a_pad, s, t);
   PYGAT_CHECK_LAUNCH("attn_scores");
   return PYGAT_OK;
 }

@@ -174,6 +174,42 @@ extern "C" int pygat_dropout_mask(int64_t count, float p, const void* seed, uint
   return PYGAT_OK;
 }
 
+// Two flat masks from one seed in ONE launch (the Wh mask and the attention mask of a level: streams 2 and 3 of its seed)
+namespace pygat {
+__global__ __launch_bounds__(256) void dropout_mask2_kernel(int64_t count1, DropRng g1, float* __restrict__ out1, int64_t count2,
+                                                            DropRng g2, float* __restrict__ out2, int64_t q1) {
+  int64_t q4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool second = q4 >= q1;
+  if (second) q4 -= q1;
+  const int64_t count = second ? count2 : count1;
+  const DropRng& g = second ? g2 : g1;
+  float* out = second ? out2 : out1;
+  const int64_t e0 = q4 * 4;
+  if (e0 >= count) return;
+  const uint64_t seed = *g.seed;
+  const uint4 w = draw4(g, seed, (uint32_t)(q4 >> 32), 0xFFFFFFFFu, (uint32_t)q4);
+  float v[4] = {w.x < g.thresh ? g.scale : 0.f, w.y < g.thresh ? g.scale : 0.f, w.z < g.thresh ? g.scale : 0.f,
+                w.w < g.thresh ? g.scale : 0.f};
+  if (e0 + 3 < count) {
+    st4(out + e0, make_float4(v[0], v[1], v[2], v[3]));
+  } else {
+    for (int q = 0; e0 + q < count; ++q) out[e0 + q] = v[q];
+  }
+}
+}  // namespace pygat
+
+extern "C" int pygat_dropout_mask2(float p, const void* seed, int64_t count1, uint32_t stream1, float* out1, int64_t count2,
+                                   uint32_t stream2, float* out2, void* stream) {
+  DropRng g1, g2;
+  PYGAT_REQUIRE(count1 > 0 && count2 > 0 && seed && out1 && out2 && aligned16(out1) && aligned16(out2), "dropout_mask2: bad arguments");
+  PYGAT_REQUIRE(make_rng(p, seed, stream1, &g1) && make_rng(p, seed, stream2, &g2), "dropout_mask2: p=%g outside [0,1]", (double)p);
+  const int64_t q1 = cdiv(cdiv(count1, 4), 256) * 256, q2 = cdiv(count2, 4);
+  hipLaunchKernelGGL(dropout_mask2_kernel, dim3((unsigned)cdiv(q1 + q2, 256)), dim3(256), 0, (hipStream_t)stream, count1, g1, out1,
+                     count2, g2, out2, q1);
+  PYGAT_CHECK_LAUNCH("dropout_mask2");
+  return PYGAT_OK;
+}
+
 extern "C" int pygat_dropout_expand(int n, int Fin, int H, const float* x, int64_t ldx, const float* mask, float p,
                                     const void* seed, uint32_t stream_id, float* out, int64_t ldo, void* stream) {
   DropRng g;

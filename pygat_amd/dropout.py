@@ -104,8 +104,8 @@ class GATLevelDropoutFn(torch.autograd.Function):
                 seed = seed.contiguous()
                 mwh = torch.empty(L.N, R, dtype=f32, device=dev)
                 matt = torch.empty(E, H, dtype=f32, device=dev)
-                check(lib.pygat_dropout_mask(L.N * R, p, seed.data_ptr(), STREAM_WH, mwh.data_ptr(), st), "dropout_mask")
-                check(lib.pygat_dropout_mask(E * H, p, seed.data_ptr(), STREAM_ATT, matt.data_ptr(), st), "dropout_mask")
+                check(lib.pygat_dropout_mask2(p, seed.data_ptr(), L.N * R, STREAM_WH, mwh.data_ptr(), E * H, STREAM_ATT,
+                                              matt.data_ptr(), st), "dropout_mask2")     # both masks, one launch
             Wcat = torch.empty(Fin, L.ldw, dtype=f32, device=dev)
             a_pad = torch.empty(H, 2, L.Fp, dtype=f32, device=dev)
             check(lib.pygat_pack_params(H, Fin, Fo, W.data_ptr(), a.data_ptr(), _ptr(Wskip), Wcat.data_ptr(), L.ldw,
@@ -149,9 +149,9 @@ class GATLevelDropoutFn(torch.autograd.Function):
                       "dropout_expand")
                 with _span("k1_project"):
                     gemm(False, False, L.N, ncb, HF, Ae, HF, Bp, ncb, [(R, Wh, R)] + ([(R, Sk, R)] if skip else []))
-            Wh.mul_(mwh)                           # layers.py:37,136
+            # the Wh dropout (layers.py:37,136) is applied in place by the score kernel: Wh *= mwh, then s, t from the masked rows
             s = torch.empty(L.N, H, dtype=f32, device=dev); t = torch.empty(L.N, H, dtype=f32, device=dev)
-            check(lib.pygat_attn_scores(L.N, H, Fo, Wh.data_ptr(), a_pad.data_ptr(), s.data_ptr(), t.data_ptr(), st),
+            check(lib.pygat_attn_scores(L.N, H, Fo, Wh.data_ptr(), mwh.data_ptr(), a_pad.data_ptr(), s.data_ptr(), t.data_ptr(), st),
                   "attn_scores")
             flags = (_lib.F_ELU if concat else 0) | (_lib.F_SKIP if skip else 0)
             hattn = torch.empty(L.N, R, dtype=f32, device=dev) if not concat else None
@@ -220,10 +220,10 @@ class GATLevelDropoutFn(torch.autograd.Function):
                                                     ds.data_ptr(), part.data_ptr(), 0, 0, st), "gat_backward_rowsum")
             da = torch.empty(H, 2 * Fo, dtype=f32, device=dev)
             ws = torch.empty(lib.pygat_agrad_workspace_bytes(H, Fo) // 4, dtype=f32, device=dev)
+            # the same pass takes dWh back through the Wh dropout (x mwh), after finishing it where the flavour asks for that
             check(lib.pygat_a_grad(L.N, H, Fo, Wh.data_ptr(), ds.data_ptr(), dt.data_ptr(), da.data_ptr(), ws.data_ptr(),
-                                   None if two_gather else a_pad.data_ptr(), None if two_gather else dWh.data_ptr(), 0, 0, st),
+                                   None if two_gather else a_pad.data_ptr(), dWh.data_ptr(), mwh.data_ptr(), 0, 0, st),
                   "a_grad")
-            dWh.mul_(mwh)                          # back through the Wh dropout
             xs = getattr(ctx, "xs", None)
             if xs is not None:   # weight gradients on the non-zeros of x under the same decisions (forward: project_sparse)
                 dW = torch.empty(H, Fin, Fo, dtype=f32, device=dev)

@@ -503,7 +503,7 @@ def _level_backward(ctx, G):
         with _span("k5_agrad"):
             check(lib.pygat_a_grad(L.N, H, Fo, Wh.data_ptr(), ds.data_ptr(), dt.data_ptr(), da.data_ptr(),
                                    ws.data_ptr(), a_pad.data_ptr() if finish else None,
-                                   dWh.data_ptr() if finish else None, hb, hr,
+                                   dWh.data_ptr() if finish else None, None, hb, hr,
                                    side.cuda_stream if fork else st), "a_grad")
         # dW = x^T dWh (split-K over the nodes), dWskip = x^T Gp
         dW = dWs = dx = None

@@ -366,7 +366,7 @@ int pygat_unpack_blockdiag(int H, int Fin, int Fo, const float* dBp, int64_t ldb
 
 /* Per-head input dropout WITHOUT the wide operand (default since ABI 9 where supported: H <= 8 and
  * (skip ? 2 : 1) * Fp <= 256, pygat_headmask_supported).  The decisions of all heads for x[i,k] are one byte,
- *   pygat_dropout_bits        bits[i,k] bit h = head h keeps x[i,k]   (Philox counter (k >> 2, i, stream_id, h))
+ *   pygat_dropout_bits        bits[i,k] bit h = head h keeps x[i,k]   (word h & 3 of Philox counter (k, i, stream_id, h >> 2))
  * and the projection and its weight gradient run for ALL heads in one launch with X read once -- the A tile is staged
  * in LDS with its mask bytes and the heads are an inner loop over the MFMA fragments (a_h = bit_h ? x : 0):
  *   pygat_project_dropout     [Wh | Sk] = 1/(1-p) (X .* m_h) [W_h | Wskip_h]           Wcat from pygat_pack_params;
@@ -388,6 +388,18 @@ int pygat_wgrad_dropout(int n, int Fin, int H, int Fo, const float* X, int64_t l
                         const float* dWh, const float* Gp, int64_t ldgp, float* dWc, int split_k, void* ws, void* stream);
 int pygat_dropout_head_sum_bits(int n, int Fin, int H, const float* dxe, int64_t lde, const unsigned char* bits, float p,
                                 float* dx, int64_t ldx, int accumulate, void* stream);
+/* NARROW levels (Fin <= 128, H <= 8, (skip ? 2 : 1) H F'p <= 128 -- the second level of the citation models: 64 inputs,
+ * 1 x 7 or 8 x 3 outputs; pygat_dropout_narrow says whether a shape qualifies): pygat_project_dropout and
+ * pygat_wgrad_dropout then run on the vector ALUs with the weight table in registers (csrc/k10_narrow.hip) -- split_k of
+ * the projection is ignored, split_k of the weight gradient is the number of row slabs (one wave each; a few rows per slab
+ * on a small graph, 8-32 on a large one) and its workspace is always used -- and the gradient into the level's input is one
+ * launch instead of a GEMM per head and a fold:
+ *   pygat_dx_dropout   dx[i,k] (+)= 1/(1-p) sum_h bit_h(i,k) ( dWh_h[i,:] . W_h[k,:] + Gp_h[i,:] . Wskip_h[k,:] )
+ * dWh [n x R], Gp rows of stride ldgp or NULL, Wcat from pygat_pack_params.  PYGAT_NARROW=0 (read when the library loads)
+ * switches the narrow kernels off. */
+int pygat_dropout_narrow(int Fin, int H, int Fo, int skip);
+int pygat_dx_dropout(int n, int Fin, int H, int Fo, const float* dWh, const float* Gp, int64_t ldgp, const unsigned char* bits,
+                     float p, const float* Wcat, int64_t ldw, float* dx, int64_t lddx, int accumulate, void* stream);
 
 /* ------------------------------------------------ the citation scripts' training loss (next row 8(f)-2: fused epoch)
  * train.py:151-152,159: loss = nll_loss(log_softmax(elu(out), dim=1)[idx], labels[idx]), forward and backward as ONE
@@ -405,7 +417,7 @@ int pygat_elu_logsoftmax_nll_backward(int n, int C, const float* out, int64_t ld
 /* ------------------------------------------------ sparse input features (level 1 of the citation configurations)
  * The reference densifies its bag-of-words features (utils.py:38-41,60) and multiplies the zeros (Cora: 98.7 % of X).
  * With the non-zero pattern of X extracted once -- CSR (rowptr, col, val) for the projection, its transpose (colptr, row,
- * val) for the weight gradient -- these two replace pygat_project / pygat_project_dropout and pygat_wgrad /
+ * val, cut into segments) for the weight gradient -- these two replace pygat_project / pygat_project_dropout and pygat_wgrad /
  * pygat_wgrad_dropout for a first level (no gradient into X is formed):
  *   pygat_project_sparse   [Wh | Sk | s] = scale * (X .* m_h) Wcat      Wcat from pygat_pack_params; Sk, s may be NULL
  *   pygat_wgrad_sparse     dW_h = scale * (X .* m_h)^T dWh_h, dWskip_h = ... Gp_h   written as [H x Fin x F'] directly
@@ -415,9 +427,16 @@ int pygat_elu_logsoftmax_nll_backward(int n, int C, const float* out, int64_t ld
 int pygat_project_sparse(int n, int Fin, int H, int Fo, const int32_t* rowptr, const int32_t* col, const float* val,
                          const float* Wcat, int64_t ldw, float p, const void* seed, int stream_id, const unsigned char* bits,
                          float* Wh, float* Sk, float* s, void* stream);
-int pygat_wgrad_sparse(int n, int Fin, int H, int Fo, const int32_t* colptr, const int32_t* row, const float* val, float p,
+/* The transpose is cut into nseg SEGMENTS of at most 128 entries, none crossing a feature column (a frequent word's column is
+ * thousands of entries long): segment s covers entries [seg_begin[s], seg_end[s]) of (row, val) -- which are in column
+ * order -- and belongs to column seg_col[s]; column k owns the segments [colseg[k], colseg[k+1]) (at least one each, so
+ * nseg >= Fin).  One wave per segment, then one per column adds its segments in order.  ws >=
+ * pygat_wgrad_sparse_workspace_bytes(nseg, H, F', skip). */
+size_t pygat_wgrad_sparse_workspace_bytes(int nseg, int H, int Fo, int skip);
+int pygat_wgrad_sparse(int n, int Fin, int H, int Fo, int nseg, const int32_t* colseg, const int32_t* seg_col,
+                       const int32_t* seg_begin, const int32_t* seg_end, const int32_t* row, const float* val, float p,
                        const void* seed, int stream_id, const unsigned char* bits, const float* dWh, const float* Gp, int64_t ldg,
-                       float* dW, float* dWskip, void* stream);
+                       void* ws, float* dW, float* dWskip, void* stream);
 
 #ifdef __cplusplus
 }

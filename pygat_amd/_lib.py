@@ -39,7 +39,7 @@ SYMBOLS = [
     "pygat_wgrad_dropout_workspace_bytes",
     "pygat_wgrad_dropout", "pygat_dropout_head_sum_bits",
     "pygat_nll_workspace_bytes", "pygat_elu_logsoftmax_nll", "pygat_elu_logsoftmax_nll_backward",
-    "pygat_project_sparse", "pygat_wgrad_sparse",
+    "pygat_project_sparse", "pygat_wgrad_sparse", "pygat_wgrad_sparse_workspace_bytes", "pygat_dropout_narrow", "pygat_dx_dropout",
 ]
 
 
@@ -129,7 +129,11 @@ def _load():
     lib.pygat_wgrad_dropout.argtypes = [i, i, i, i, p, i64, p, f, p, p, i64, p, i, p, p]
     lib.pygat_dropout_head_sum_bits.argtypes = [i, i, i, p, i64, p, f, p, i64, i, p]
     lib.pygat_project_sparse.argtypes = [i, i, i, i, p, p, p, p, i64, f, p, i, p, p, p, p, p]
-    lib.pygat_wgrad_sparse.argtypes = [i, i, i, i, p, p, p, f, p, i, p, p, p, i64, p, p, p]
+    lib.pygat_wgrad_sparse.argtypes = [i, i, i, i, i, p, p, p, p, p, p, f, p, i, p, p, p, i64, p, p, p, p]
+    lib.pygat_wgrad_sparse_workspace_bytes.argtypes = [i, i, i, i]
+    lib.pygat_dropout_narrow.argtypes = [i, i, i, i]
+    lib.pygat_dx_dropout.argtypes = [i, i, i, i, p, p, i64, p, f, p, i64, p, i64, i, p]
+    lib.pygat_wgrad_sparse_workspace_bytes.restype = sz
     lib.pygat_nll_workspace_bytes.argtypes = [i]
     lib.pygat_nll_workspace_bytes.restype = sz
     lib.pygat_elu_logsoftmax_nll.argtypes = [i, i, p, i64, p, p, p, p, p]

@@ -12,6 +12,7 @@
 // and all NT column blocks.  LDS images are k-major (As[k][m], Bs[k][n]) so a
 // fragment read is 32 consecutive floats per half-wave: conflict-free ds_read_b32.
 #include "common.h"
+#include "narrow.h"
 #include <type_traits>
 
 namespace pygat {
@@ -872,6 +873,8 @@ extern "C" int pygat_project_dropout(int n, int Fin, int H, int Fo, const float*
   PYGAT_REQUIRE(n > 0 && Fin > 0 && X && bits && Wcat && Wh && ldx == Fin, "project_dropout: bad arguments (X must be dense: ldx == Fin)");
   PYGAT_REQUIRE(pygat_headmask_supported(H, Fo, Sk != nullptr), "project_dropout: unsupported H=%d F'=%d", H, Fo);
   PYGAT_REQUIRE(p >= 0.f && p <= 1.f, "project_dropout: p=%g outside [0,1]", (double)p);
+  if (narrow_takes(Fin, H, Fo, Sk != nullptr))       // 64-feature levels: weights in registers (k10_narrow.hip), no slabs
+    return narrow_project(n, Fin, H, Fo, X, ldx, bits, p, Wcat, ldw, Wh, Sk, (hipStream_t)stream);
   if (split_k < 1) split_k = 1;
   PYGAT_REQUIRE(split_k == 1 || ws, "project_dropout: split_k > 1 needs a workspace");
   const int R = H * Fp, ntot = R * (Sk ? 2 : 1);
@@ -917,6 +920,10 @@ extern "C" int pygat_wgrad_dropout(int n, int Fin, int H, int Fo, const float* X
   PYGAT_REQUIRE(pygat_headmask_supported(H, Fo, Gp != nullptr), "wgrad_dropout: unsupported H=%d F'=%d", H, Fo);
   if (split_k < 1) split_k = 1;
   PYGAT_REQUIRE(split_k == 1 || ws, "wgrad_dropout: split_k > 1 needs a workspace");
+  if (narrow_takes(Fin, H, Fo, Gp != nullptr)) {     // k10_narrow.hip: the slabs are one wave's rows each, always through ws
+    PYGAT_REQUIRE(ws, "wgrad_dropout: the narrow kernels need the workspace (pygat_wgrad_dropout_workspace_bytes)");
+    return narrow_wgrad(n, Fin, H, Fo, X, ldx, bits, p, dWh, Gp, ldgp, dWc, split_k, ws, (hipStream_t)stream);
+  }
   const int R = H * Fp, ntot = R * (Gp ? 2 : 1);
   hipStream_t st = (hipStream_t)stream;
   int64_t kps = cdiv(cdiv(n, split_k), BK) * BK;

@@ -41,21 +41,16 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(int64_t count, DropRn
 }
 
 // Input-dropout decisions of all heads as ONE byte per input element: bit h of bits[i, k] = "head h keeps x[i,k]"
-// (word (k & 3) of Philox(counter = (k >> 2, i, stream_id, h), key = seed) < keep * 2^32).  Consumed by the
+// (rng.h draw_heads4: word (h & 3) of Philox(counter = (k, i, stream_id, h >> 2), key = seed) < keep * 2^32).  Consumed by the
 // head-masked GEMMs (k1_gemm.hip) and by dropout_head_sum_bits_kernel: 1 byte instead of 4H bytes per element.
 __global__ __launch_bounds__(256) void dropout_bits_kernel(int n, int Fin, int H, DropRng g, unsigned char* __restrict__ bits) {
-  const int q4 = (Fin + 3) / 4;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)n * q4) return;
-  const int i = (int)(idx / q4), c4 = (int)(idx % q4);
+  if (idx >= (int64_t)n * Fin) return;
+  const int i = (int)(idx / Fin), k = (int)(idx - (int64_t)i * Fin);
   const uint64_t seed = *g.seed;
-  uint32_t b[4] = {0, 0, 0, 0};
-  for (int h = 0; h < H; ++h) {
-    const uint4 w = draw4(g, seed, (uint32_t)i, (uint32_t)h, (uint32_t)c4);
-    b[0] |= (w.x < g.thresh ? 1u : 0u) << h; b[1] |= (w.y < g.thresh ? 1u : 0u) << h;
-    b[2] |= (w.z < g.thresh ? 1u : 0u) << h; b[3] |= (w.w < g.thresh ? 1u : 0u) << h;
-  }
-  for (int q = 0; q < 4 && 4 * c4 + q < Fin; ++q) bits[(int64_t)i * Fin + 4 * c4 + q] = (unsigned char)b[q];
+  uint32_t b = 0;
+  for (int hq = 0; 4 * hq < H; ++hq) b |= keep_nibble(g, draw_heads4(g, seed, (uint32_t)i, (uint32_t)k, (uint32_t)hq)) << (4 * hq);
+  bits[idx] = (unsigned char)(b & ((1u << H) - 1u));
 }
 
 // dx[i,k] (+)= scale * sum_h bit_h[i,k] * dxe[i, h*Fin + k]  -- back through the per-head input dropout (bits form)
@@ -271,7 +266,7 @@ extern "C" int pygat_dropout_bits(int n, int Fin, int H, float p, const void* se
   DropRng g;
   PYGAT_REQUIRE(n > 0 && Fin > 0 && H >= 1 && H <= 8 && seed && bits, "dropout_bits: bad arguments (H <= 8)");
   PYGAT_REQUIRE(make_rng(p, seed, (uint32_t)stream_id, &g), "dropout_bits: p=%g outside [0,1]", (double)p);
-  const int64_t tot = (int64_t)n * ((Fin + 3) / 4);
+  const int64_t tot = (int64_t)n * Fin;
   hipLaunchKernelGGL(dropout_bits_kernel, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, n, Fin, H, g, bits);
   PYGAT_CHECK_LAUNCH("dropout_bits");
   return PYGAT_OK;

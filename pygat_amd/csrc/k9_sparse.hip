@@ -24,6 +24,7 @@ struct SpArgs {
   const int32_t* idx;       // column index per non-zero (forward) / row index (backward)
   const float* val;
   int masked;               // 0: no dropout
+  int hq_shift;             // log2 of (quads of heads, rounded up to a power of two) (masked)
   DropRng g;                // masked, bits == nullptr
   const unsigned char* bits;  // [n x Fin] explicit decisions or nullptr
 };
@@ -31,19 +32,92 @@ struct SpArgs {
 // head of output column c: [0, R) W heads, [R, 2R) skip heads (has_skip), behind them the H score columns (never masked)
 __device__ __forceinline__ int sp_head(const SpArgs& a, int c, int fp_shift) { return (c < a.R ? c : c - a.R) >> fp_shift; }
 
-__device__ __forceinline__ bool sp_keep(const SpArgs& a, uint64_t seed, int i, int k, int h) {
-  if (a.bits) return (a.bits[(int64_t)i * a.Fin + k] >> h) & 1u;
-  const uint4 w = draw4(a.g, seed, (uint32_t)i, (uint32_t)h, (uint32_t)(k >> 2));
-  return word_of(w, k & 3) < a.g.thresh;
+// keep decisions of heads 4*hq .. 4*hq+3 for x[i, k], as a nibble
+__device__ __forceinline__ uint32_t sp_keep4(const SpArgs& a, uint64_t seed, int i, int k, int hq) {
+  if (a.bits) return ((uint32_t)a.bits[(int64_t)i * a.Fin + k] >> (4 * hq)) & 15u;
+  return keep_nibble(a.g, draw_heads4(a.g, seed, (uint32_t)i, (uint32_t)k, (uint32_t)hq));
 }
 
-template <int CPL>
+// The walk both kernels share.  `fixed` is the row (forward) / feature column (BWD) this wave owns, the non-zeros
+// [e0, e1) carry the other coordinate.  The 64 lanes fetch 64 (index, value) pairs at once; each pair is then handed to all
+// lanes through a scalar register (v_readlane with a uniform lane number: no LDS crossbar), eight gathered table rows in
+// flight.  Dropout decisions depend on (row, column, HEAD) only, not on the output column, and one Philox call yields four
+// heads (rng.h draw_heads4): a batch of 64 / Q pairs (Q = quads of heads, rounded up to a power of two) gets its decisions
+// from ONE call per lane -- lane = (pair, quad) -- collected with four ballots; every output column then picks the ballot
+// of its head's word, shifted by its quad, once per batch, and finds pair j's decision at the uniform bit j * Q.  (One call
+// per lane per pair, as the first version had it, made Pubmed's 50-word rows 25 x more Philox than needed: 158 us.)
+template <int CPL, bool BWD, bool MASKED>
+__device__ __forceinline__ void sp_walk(const SpArgs& a, uint64_t seed, int fixed, int e0, int e1, int lane, const int (&cc)[CPL],
+                                        const int (&hh)[CPL], float (&acc)[CPL], const float* __restrict__ T1, int64_t ld1,
+                                        const float* __restrict__ T2, int64_t ld2) {
+  constexpr int U = 8;
+  const int B = MASKED ? (64 >> a.hq_shift) : 64;                    // 64, 32, 16 or 8: a multiple of U
+  // byte offsets in 32 bits (sp_setup checks the tables stay below 4 GiB): one scalar multiply per pair, the gathered row's
+  // address is a uniform base plus a 32-bit lane offset
+  const char* __restrict__ B1 = (const char*)T1;
+  const char* __restrict__ B2 = (const char*)T2;
+  const uint32_t s1 = (uint32_t)ld1 * 4u, s2 = (uint32_t)ld2 * 4u;
+  uint32_t c4[CPL];
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) c4[q] = 4u * (uint32_t)((BWD && cc[q] >= a.R) ? cc[q] - a.R : cc[q]);
+  for (int eb = e0; eb < e1; eb += 64) {
+    const int cnt = (e1 - eb < 64) ? e1 - eb : 64;
+    const int li = eb + (lane < cnt ? lane : cnt - 1);
+    const int kk = a.idx[li];
+    const int vv = lane < cnt ? __float_as_int(a.val[li]) : 0;       // lanes past the end: a valid index with value 0
+    for (int jb = 0; jb < cnt; jb += B) {
+      uint32_t lo[CPL], hi[CPL];
+      if (MASKED) {
+        const int jl = jb + (lane >> a.hq_shift), ql = lane & ((1 << a.hq_shift) - 1);
+        const int other = __shfl(kk, jl < cnt ? jl : cnt - 1);
+        uint32_t nib = 0;
+        if (jl < cnt && 4 * ql < a.H) nib = BWD ? sp_keep4(a, seed, other, fixed, ql) : sp_keep4(a, seed, fixed, other, ql);
+        const uint64_t m0 = __ballot(nib & 1u), m1 = __ballot(nib & 2u), m2 = __ballot(nib & 4u), m3 = __ballot(nib & 8u);
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+          const int wd = hh[q] & 3;
+          const uint64_t sel = (wd == 0 ? m0 : wd == 1 ? m1 : wd == 2 ? m2 : m3) >> (hh[q] >> 2);
+          lo[q] = (uint32_t)sel; hi[q] = (uint32_t)(sel >> 32);
+        }
+      }
+      const int nb = (cnt - jb < B) ? cnt - jb : B;
+      // pairs j + u >= nb of a round exist only in the last batch (B is a multiple of U): lanes >= cnt, value 0
+      for (int j = 0; j < nb; j += U) {
+        float v[U], w[U][CPL];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t id = (uint32_t)__builtin_amdgcn_readlane(kk, jb + j + u);
+          v[u] = __int_as_float(__builtin_amdgcn_readlane(vv, jb + j + u));
+          const uint32_t o1 = id * s1, o2 = id * s2;
+#pragma unroll
+          for (int q = 0; q < CPL; ++q)
+            w[u][q] = (BWD && cc[q] >= a.R) ? *(const float*)(B2 + (o2 + c4[q])) : *(const float*)(B1 + (o1 + c4[q]));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int pos = ((j + u) << a.hq_shift) & 63;
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) {
+            float wq = w[u][q];
+            if (MASKED) {
+              const uint32_t mw = (pos & 32) ? hi[q] : lo[q];
+              wq = __int_as_float(__float_as_int(wq) & -(int)((mw >> (pos & 31)) & 1u));
+            }
+            acc[q] = fmaf(v[u], wq, acc[q]);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int CPL, bool MASKED>
 __global__ __launch_bounds__(256) void sparse_project_kernel(SpArgs a, const float* __restrict__ Wcat, int64_t ldw,
                                                              float* __restrict__ Wh, float* __restrict__ Sk, float* __restrict__ s) {
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
   if (i >= a.n) return;
   const int fp_shift = ilog2_dev(a.Fp);
-  const uint64_t seed = (a.masked && !a.bits) ? *a.g.seed : 0ull;
+  const uint64_t seed = (MASKED && !a.bits) ? *a.g.seed : 0ull;
   float acc[CPL];
   int cc[CPL], hh[CPL];
 #pragma unroll
@@ -51,35 +125,11 @@ __global__ __launch_bounds__(256) void sparse_project_kernel(SpArgs a, const flo
     acc[q] = 0.f;
     const int c = lane + 64 * q;
     cc[q] = c < a.ncols ? c : a.ncols - 1;           // clamped: loads stay unconditional, the value is not stored
-    hh[q] = sp_head(a, cc[q], fp_shift);
+    hh[q] = MASKED ? sp_head(a, cc[q], fp_shift) : 0;   // < H under a mask: no score columns then (sp_setup)
   }
-  const int e0 = a.ptr[i], e1 = a.ptr[i + 1];
-  for (int eb = e0; eb < e1; eb += 64) {
-    const int cnt = (e1 - eb < 64) ? e1 - eb : 64;
-    const int kk = a.idx[eb + (lane < cnt ? lane : cnt - 1)];
-    const float vv = a.val[eb + (lane < cnt ? lane : cnt - 1)];
-    for (int j = 0; j < cnt; j += 4) {
-      int k4[4];
-      float v4[4], w4[4][CPL];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int jj = (j + u < cnt) ? j + u : cnt - 1;
-        k4[u] = __shfl(kk, jj);
-        v4[u] = (j + u < cnt) ? __shfl(vv, jj) : 0.f;
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) w4[u][q] = Wcat[(int64_t)k4[u] * ldw + cc[q]];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) {
-          bool keep = true;
-          if (a.masked) keep = sp_keep(a, seed, i, k4[u], hh[q]);
-          acc[q] = keep ? fmaf(v4[u], w4[u][q], acc[q]) : acc[q];
-        }
-    }
-  }
-  const float scale = a.masked ? a.g.scale : 1.f;
+  const int e0 = __builtin_amdgcn_readfirstlane(a.ptr[i]), e1 = __builtin_amdgcn_readfirstlane(a.ptr[i + 1]);
+  sp_walk<CPL, false, MASKED>(a, seed, __builtin_amdgcn_readfirstlane(i), e0, e1, lane, cc, hh, acc, Wcat, ldw, nullptr, 0);
+  const float scale = MASKED ? a.g.scale : 1.f;
 #pragma unroll
   for (int q = 0; q < CPL; ++q) {
     const int c = lane + 64 * q;
@@ -91,14 +141,21 @@ __global__ __launch_bounds__(256) void sparse_project_kernel(SpArgs a, const flo
   }
 }
 
-// D1 = dWh [n x R]; D2 = Gp rows (the skip projection's upstream gradient) with row stride ld2, or nullptr
-template <int CPL>
-__global__ __launch_bounds__(256) void sparse_wgrad_kernel(SpArgs a, const float* __restrict__ D1, const float* __restrict__ D2,
-                                                           int64_t ld2, float* __restrict__ dW, float* __restrict__ dWs) {
-  const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (k >= a.Fin) return;
+// D1 = dWh [n x R]; D2 = Gp rows (the skip projection's upstream gradient) with row stride ld2, or nullptr.
+// A feature column's non-zeros are cut into SEGMENTS of at most SP_SEG entries (features.py): one wave per segment leaves its
+// partial sums, a second launch adds a column's segments in order -- a word that occurs in a third of the documents (a
+// 900-entry column of Cora, 6000 of Pubmed) is no longer one wave's serial walk.
+[[maybe_unused]] constexpr int SP_SEG = 128;   // features.py SEGMENT
+template <int CPL, bool MASKED>
+__global__ __launch_bounds__(256) void sparse_wgrad_kernel(SpArgs a, int nseg, const int32_t* __restrict__ seg_col,
+                                                           const int32_t* __restrict__ seg_begin, const int32_t* __restrict__ seg_end,
+                                                           const float* __restrict__ D1, const float* __restrict__ D2, int64_t ld2,
+                                                           float* __restrict__ part) {
+  const int sg = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  if (sg >= nseg) return;
+  const int k = __builtin_amdgcn_readfirstlane(seg_col[sg]);
   const int fp_shift = ilog2_dev(a.Fp);
-  const uint64_t seed = (a.masked && !a.bits) ? *a.g.seed : 0ull;
+  const uint64_t seed = (MASKED && !a.bits) ? *a.g.seed : 0ull;
   float acc[CPL];
   int cc[CPL], hh[CPL];
 #pragma unroll
@@ -106,44 +163,30 @@ __global__ __launch_bounds__(256) void sparse_wgrad_kernel(SpArgs a, const float
     acc[q] = 0.f;
     const int c = lane + 64 * q;
     cc[q] = c < a.ncols ? c : a.ncols - 1;
-    hh[q] = sp_head(a, cc[q], fp_shift);
+    hh[q] = MASKED ? sp_head(a, cc[q], fp_shift) : 0;   // < H under a mask: no score columns then (sp_setup)
   }
-  const int e0 = a.ptr[k], e1 = a.ptr[k + 1];
-  for (int eb = e0; eb < e1; eb += 64) {
-    const int cnt = (e1 - eb < 64) ? e1 - eb : 64;
-    const int ii = a.idx[eb + (lane < cnt ? lane : cnt - 1)];
-    const float vv = a.val[eb + (lane < cnt ? lane : cnt - 1)];
-    for (int j = 0; j < cnt; j += 4) {
-      int i4[4];
-      float v4[4], d4[4][CPL];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int jj = (j + u < cnt) ? j + u : cnt - 1;
-        i4[u] = __shfl(ii, jj);
-        v4[u] = (j + u < cnt) ? __shfl(vv, jj) : 0.f;
-#pragma unroll
-        for (int q = 0; q < CPL; ++q)
-          d4[u][q] = cc[q] < a.R ? D1[(int64_t)i4[u] * a.R + cc[q]] : D2[(int64_t)i4[u] * ld2 + (cc[q] - a.R)];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) {
-          bool keep = true;
-          if (a.masked) keep = sp_keep(a, seed, i4[u], k, hh[q]);
-          acc[q] = keep ? fmaf(v4[u], d4[u][q], acc[q]) : acc[q];
-        }
-    }
-  }
-  const float scale = a.masked ? a.g.scale : 1.f;
+  const int e0 = __builtin_amdgcn_readfirstlane(seg_begin[sg]), e1 = __builtin_amdgcn_readfirstlane(seg_end[sg]);
+  sp_walk<CPL, true, MASKED>(a, seed, k, e0, e1, lane, cc, hh, acc, D1, (int64_t)a.R, D2, ld2);
 #pragma unroll
   for (int q = 0; q < CPL; ++q) {
     const int c = lane + 64 * q;
-    if (c >= a.ncols) continue;
+    if (c < a.ncols) part[(int64_t)sg * a.ncols + c] = acc[q];
+  }
+}
+
+// column k = the sum of its segments' partial rows, in segment order; written straight into the [H x Fin x F'] layout
+__global__ __launch_bounds__(256) void sparse_wgrad_reduce_kernel(SpArgs a, const int32_t* __restrict__ colseg, const float* __restrict__ part,
+                                                                  float* __restrict__ dW, float* __restrict__ dWs) {
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (k >= a.Fin) return;
+  const int fp_shift = ilog2_dev(a.Fp);
+  const float scale = a.masked ? a.g.scale : 1.f;
+  const int s0 = colseg[k], s1 = colseg[k + 1];
+  for (int c = lane; c < a.ncols; c += 64) {
+    float t = 0.f;
+    for (int sg = s0; sg < s1; ++sg) t += part[(int64_t)sg * a.ncols + c];
     const int cr = c < a.R ? c : c - a.R, h = cr >> fp_shift, f = cr & (a.Fp - 1);
-    if (f >= a.Fo) continue;                                           // padding columns of a head
-    float* o = (c < a.R ? dW : dWs) + ((int64_t)h * a.Fin + k) * a.Fo + f;   // straight into the [H x Fin x F'] layout
-    *o = acc[q] * scale;
+    if (f < a.Fo) (c < a.R ? dW : dWs)[((int64_t)h * a.Fin + k) * a.Fo + f] = t * scale;
   }
 }
 
@@ -164,20 +207,30 @@ static int sp_setup(SpArgs* a, const char* what, int n, int Fin, int H, int Fo, 
     if (!seed && !bits) { set_error("%s: dropout needs a seed or explicit mask bits", what); return PYGAT_EINVAL; }
     if (!make_rng(p, seed, (uint32_t)stream_id, &a->g)) { set_error("%s: p=%g outside [0,1]", what, (double)p); return PYGAT_EINVAL; }
     if (H > 8 && bits) { set_error("%s: explicit mask bits hold 8 heads", what); return PYGAT_EINVAL; }
+    if (H > 32) { set_error("%s: dropout decisions are drawn for at most 32 heads", what); return PYGAT_EINVAL; }
+    a->hq_shift = 0;
+    while ((4 << a->hq_shift) < H) ++a->hq_shift;
   } else {
-    a->g.seed = nullptr; a->g.stream_id = 0; a->g.thresh = 0xFFFFFFFFu; a->g.scale = 1.f;
+    a->g.seed = nullptr; a->g.stream_id = 0; a->g.thresh = 0xFFFFFFFFu; a->g.scale = 1.f; a->hq_shift = 0;
   }
   return PYGAT_OK;
 }
 
-#define PYGAT_SP_DISPATCH(KERNEL, GRID, ...)                                                             \
+#define PYGAT_SP_DISPATCH_M(KERNEL, M, GRID, ...)                                                        \
   do {                                                                                                   \
     const int cpl__ = (int)cdiv(a.ncols, 64);                                                            \
-    if (cpl__ <= 1) hipLaunchKernelGGL((KERNEL<1>), GRID, dim3(256), 0, st, a, __VA_ARGS__);             \
-    else if (cpl__ <= 2) hipLaunchKernelGGL((KERNEL<2>), GRID, dim3(256), 0, st, a, __VA_ARGS__);        \
-    else if (cpl__ <= 4) hipLaunchKernelGGL((KERNEL<4>), GRID, dim3(256), 0, st, a, __VA_ARGS__);        \
-    else hipLaunchKernelGGL((KERNEL<SP_CPL>), GRID, dim3(256), 0, st, a, __VA_ARGS__);                   \
+    if (cpl__ <= 1) hipLaunchKernelGGL((KERNEL<1, M>), GRID, dim3(256), 0, st, a, __VA_ARGS__);          \
+    else if (cpl__ <= 2) hipLaunchKernelGGL((KERNEL<2, M>), GRID, dim3(256), 0, st, a, __VA_ARGS__);     \
+    else if (cpl__ <= 4) hipLaunchKernelGGL((KERNEL<4, M>), GRID, dim3(256), 0, st, a, __VA_ARGS__);     \
+    else hipLaunchKernelGGL((KERNEL<SP_CPL, M>), GRID, dim3(256), 0, st, a, __VA_ARGS__);                \
   } while (0)
+#define PYGAT_SP_DISPATCH(KERNEL, GRID, ...)                               \
+  do {                                                                     \
+    if (a.masked) PYGAT_SP_DISPATCH_M(KERNEL, true, GRID, __VA_ARGS__);    \
+    else PYGAT_SP_DISPATCH_M(KERNEL, false, GRID, __VA_ARGS__);            \
+  } while (0)
+
+static bool sp_fits_32bit(int64_t rows, int64_t ld) { return rows * ld * 4 < ((int64_t)1 << 32); }
 
 extern "C" int pygat_project_sparse(int n, int Fin, int H, int Fo, const int32_t* rowptr, const int32_t* col, const float* val,
                                     const float* Wcat, int64_t ldw, float p, const void* seed, int stream_id,
@@ -186,6 +239,7 @@ extern "C" int pygat_project_sparse(int n, int Fin, int H, int Fo, const int32_t
   int rc = sp_setup(&a, "project_sparse", n, Fin, H, Fo, rowptr, col, val, p, seed, stream_id, bits, Sk != nullptr, s != nullptr);
   if (rc) return rc;
   PYGAT_REQUIRE(Wcat && Wh && ldw >= a.ncols, "project_sparse: bad arguments (ldw=%lld, %d columns)", (long long)ldw, a.ncols);
+  PYGAT_REQUIRE(sp_fits_32bit(Fin, ldw), "project_sparse: the weight table exceeds 4 GiB");
   PYGAT_REQUIRE(!(a.masked && s), "project_sparse: the score columns are not formed under dropout (pygat_attn_scores does, on the masked Wh)");
   hipStream_t st = (hipStream_t)stream;
   PYGAT_SP_DISPATCH(sparse_project_kernel, dim3((unsigned)cdiv(n, 4)), Wcat, ldw, Wh, Sk, s);
@@ -193,15 +247,27 @@ extern "C" int pygat_project_sparse(int n, int Fin, int H, int Fo, const int32_t
   return PYGAT_OK;
 }
 
-extern "C" int pygat_wgrad_sparse(int n, int Fin, int H, int Fo, const int32_t* colptr, const int32_t* row, const float* val, float p,
+extern "C" size_t pygat_wgrad_sparse_workspace_bytes(int nseg, int H, int Fo, int skip) {
+  const int Fp = padded_width(Fo);
+  if (nseg <= 0 || H <= 0 || Fp == 0) return 0;
+  return (size_t)nseg * (size_t)(H * Fp * (skip ? 2 : 1)) * sizeof(float);
+}
+
+extern "C" int pygat_wgrad_sparse(int n, int Fin, int H, int Fo, int nseg, const int32_t* colseg, const int32_t* seg_col,
+                                  const int32_t* seg_begin, const int32_t* seg_end, const int32_t* row, const float* val, float p,
                                   const void* seed, int stream_id, const unsigned char* bits, const float* dWh, const float* Gp,
-                                  int64_t ldg, float* dW, float* dWskip, void* stream) {
+                                  int64_t ldg, void* ws, float* dW, float* dWskip, void* stream) {
   SpArgs a;
-  int rc = sp_setup(&a, "wgrad_sparse", n, Fin, H, Fo, colptr, row, val, p, seed, stream_id, bits, Gp != nullptr, false);
+  int rc = sp_setup(&a, "wgrad_sparse", n, Fin, H, Fo, colseg, row, val, p, seed, stream_id, bits, Gp != nullptr, false);
   if (rc) return rc;
-  PYGAT_REQUIRE(dWh && dW && (!Gp || (dWskip && ldg >= a.R)), "wgrad_sparse: bad arguments");
+  PYGAT_REQUIRE(nseg >= Fin && seg_col && seg_begin && seg_end && ws && dWh && dW && (!Gp || (dWskip && ldg >= a.R)),
+                "wgrad_sparse: bad arguments");
+  PYGAT_REQUIRE(sp_fits_32bit(n, a.R) && (!Gp || sp_fits_32bit(n, ldg)), "wgrad_sparse: the gradient tables exceed 4 GiB (n=%d)", n);
   hipStream_t st = (hipStream_t)stream;
-  PYGAT_SP_DISPATCH(sparse_wgrad_kernel, dim3((unsigned)cdiv(Fin, 4)), dWh, Gp, ldg, dW, dWskip);
+  float* part = (float*)ws;
+  PYGAT_SP_DISPATCH(sparse_wgrad_kernel, dim3((unsigned)cdiv(nseg, 4)), nseg, seg_col, seg_begin, seg_end, dWh, Gp, ldg, part);
   PYGAT_CHECK_LAUNCH("wgrad_sparse");
+  hipLaunchKernelGGL(sparse_wgrad_reduce_kernel, dim3((unsigned)cdiv(Fin, 4)), dim3(256), 0, st, a, colseg, (const float*)part, dW, dWskip);
+  PYGAT_CHECK_LAUNCH("wgrad_sparse(reduce)");
   return PYGAT_OK;
 }

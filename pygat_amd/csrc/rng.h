@@ -1,6 +1,11 @@
 // Counter-based dropout decisions shared by the dropout kernels (k7_dropout.hip) and the sparse-feature projection
-// (k9_sparse.hip): Philox-4x32-10 keyed by a seed in DEVICE memory.  Decision for element (row, col) of head h:
-// word (col & 3) of Philox(counter = (col >> 2, row, stream_id, h), key = seed) < keep * 2^32.  Not part of the C ABI.
+// (k9_sparse.hip): Philox-4x32-10 keyed by a seed in DEVICE memory.  Two counter layouts, neither part of the C ABI:
+//   draw4       one mask over a [rows x cols] table: decision (row, col) = word (col & 3) of
+//               Philox(counter = (col >> 2, row, stream_id, tag), key = seed) < keep * 2^32  -- four COLUMNS per call;
+//   draw_heads4 the per-head input masks (layers.py:34,132: every head drops its own copy of x): decision (row, col,
+//               head h) = word (h & 3) of Philox(counter = (col, row, stream_id, h >> 2)) -- four HEADS per call, so
+//               that the sparse kernels, which meet the non-zeros of x one (row, col) at a time, spend one call per
+//               non-zero and four heads instead of one per head (the first layout cost them 4 x the Philox work).
 #pragma once
 #include "common.h"
 
@@ -31,6 +36,14 @@ __device__ __forceinline__ uint32_t word_of(const uint4& w, int q) {
 // 4 decisions for (row, columns 4*c4 .. 4*c4+3)
 __device__ __forceinline__ uint4 draw4(const DropRng& g, uint64_t seed, uint32_t row_lo, uint32_t row_hi, uint32_t c4) {
   return philox4x32_10(make_uint4(c4, row_lo, g.stream_id, row_hi), make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+}
+
+// 4 decisions for (row, col, heads 4*hq .. 4*hq+3)
+__device__ __forceinline__ uint4 draw_heads4(const DropRng& g, uint64_t seed, uint32_t row, uint32_t col, uint32_t hq) {
+  return philox4x32_10(make_uint4(col, row, g.stream_id, hq), make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+}
+__device__ __forceinline__ uint32_t keep_nibble(const DropRng& g, const uint4& w) {
+  return (w.x < g.thresh ? 1u : 0u) | (w.y < g.thresh ? 2u : 0u) | (w.z < g.thresh ? 4u : 0u) | (w.w < g.thresh ? 8u : 0u);
 }
 
 static inline bool make_rng(float p, const void* seed, uint32_t stream_id, DropRng* g) {

@@ -50,6 +50,11 @@ def _headmask_splits(tiles_m: int, H: int, Fp: int, skip: bool, K: int) -> int:
     return max(1, min(-(-384 // (tiles_m * groups)), K // 64))
 
 
+def _narrow_slabs(n: int) -> int:
+    """Row slabs of the narrow weight gradient (one wave each): 4-32 rows, about a thousand waves on a large graph."""
+    return max(1, -(-n // max(4, min(32, n // 1024))))
+
+
 def _pack_bits(mask_x: torch.Tensor) -> torch.Tensor:
     """Explicit per-head input masks [H,N,Fin] (0 or 1/(1-p)) -> one byte per input element, bit h = head h keeps."""
     H = mask_x.shape[0]
@@ -228,11 +233,14 @@ class GATLevelDropoutFn(torch.autograd.Function):
             if xs is not None:   # weight gradients on the non-zeros of x under the same decisions (forward: project_sparse)
                 dW = torch.empty(H, Fin, Fo, dtype=f32, device=dev)
                 dWs = torch.empty(H, Fin, Fo, dtype=f32, device=dev) if L.skip else None
+                wss = torch.empty(lib.pygat_wgrad_sparse_workspace_bytes(xs.nseg, H, Fo, int(L.skip)) // 4 + 4, dtype=f32, device=dev)
                 with _span("k5_wgrad"):
-                    check(lib.pygat_wgrad_sparse(L.N, Fin, H, Fo, xs.colptr.data_ptr(), xs.trow.data_ptr(), xs.tval.data_ptr(), p,
-                                                 None if ctx.explicit else mx_or_seed.data_ptr(), STREAM_X,
+                    check(lib.pygat_wgrad_sparse(L.N, Fin, H, Fo, xs.nseg, xs.colseg.data_ptr(), xs.seg_col.data_ptr(),
+                                                 xs.seg_begin.data_ptr(), xs.seg_end.data_ptr(), xs.trow.data_ptr(),
+                                                 xs.tval.data_ptr(), p, None if ctx.explicit else mx_or_seed.data_ptr(), STREAM_X,
                                                  Bp.data_ptr() if ctx.explicit else None, dWh.data_ptr(),
-                                                 GR.data_ptr() if L.skip else None, RW, dW.data_ptr(), _ptr(dWs), st), "wgrad_sparse")
+                                                 GR.data_ptr() if L.skip else None, RW, wss.data_ptr(), dW.data_ptr(), _ptr(dWs), st),
+                          "wgrad_sparse")
                 cast = lambda g_, k: g_ if g_ is None or g_.dtype == ctx.in_dtypes[k] else g_.to(ctx.in_dtypes[k])  # noqa: E731
                 return (None, cast(dW, 1), cast(da, 2), cast(dWs, 3), None, None, None, None, None, None, None, None, None)
             if ctx.use_bits:     # Ae is x and Bp the mask bytes on this path
@@ -276,7 +284,8 @@ def _backward_bits(ctx, x, bits, Wcat, dWh, GR, RW, st):
     Fin, R = L.Fin, L.R
     ntot = R * (2 if L.skip else 1)
     # dW_h = (x o m_h)^T dWh_h, dWskip_h = (x o m_h)^T Gp_h: one launch for all heads, x read once; K slabs over the nodes
-    split_k = _headmask_splits(-(-Fin // 128), H, L.Fp, L.skip, L.N)
+    narrow = bool(lib.pygat_dropout_narrow(Fin, H, Fo, int(L.skip)))       # k10_narrow.hip: slabs = one wave's rows each
+    split_k = _narrow_slabs(L.N) if narrow else _headmask_splits(-(-Fin // 128), H, L.Fp, L.skip, L.N)
     ws = torch.empty(lib.pygat_wgrad_dropout_workspace_bytes(Fin, H, Fo, int(L.skip), split_k) // 4, dtype=f32, device=dev)
     dWc = torch.empty(Fin, ntot, dtype=f32, device=dev)
     with _span("k5_wgrad"):
@@ -290,7 +299,11 @@ def _backward_bits(ctx, x, bits, Wcat, dWh, GR, RW, st):
         dWs = torch.empty(H, Fin, Fo, dtype=f32, device=dev)
         check(lib.pygat_unpack_wgrad(H, Fin, Fo, dWc.data_ptr(), ntot, R, dWs.data_ptr(), st), "unpack_wgrad")
     dx = None
-    if ctx.needs_input_grad[0]:
+    if ctx.needs_input_grad[0] and narrow:
+        dx = torch.empty(L.N, Fin, dtype=f32, device=dev)
+        check(lib.pygat_dx_dropout(L.N, Fin, H, Fo, dWh.data_ptr(), GR.data_ptr() if L.skip else None, RW, bits.data_ptr(), p,
+                                   Wcat.data_ptr(), L.ldw, dx.data_ptr(), Fin, 0, st), "dx_dropout")
+    elif ctx.needs_input_grad[0]:
         # dxe[i, h*Fin + k] = dWh_h[i,:] . W_h[k,:] (+ Gp_h . Wskip_h), head by head, then folded under the mask bits
         HF = H * Fin
         dxe = torch.empty(L.N, HF, dtype=f32, device=dev)

@@ -5,7 +5,7 @@ row-normalised bag of words on its citation datasets -- Cora 1.27 % non-zero, Ci
 it, zeros included, with every head's W in every epoch (layers.py:35,134).  The input never changes between epochs, so its
 pattern is extracted ONCE (cached on the tensor like the adjacency, graph.as_graph) as CSR for the projection and as its
 transpose for the weight gradient; csrc/k9_sparse.hip then does both products on the non-zeros only, under the same
-per-head dropout decisions as the dense kernels.  Dense inputs (density above MAX_DENSITY, or feature columns longer than MAX_COLUMN_NNZ on average), inputs that require a gradient
+per-head dropout decisions as the dense kernels.  Dense inputs (density above MAX_DENSITY), inputs that require a gradient
 and hidden levels keep the dense GEMMs.  PYGAT_SPARSE_X=0 switches the whole path off.
 """
 from __future__ import annotations
@@ -16,10 +16,8 @@ from typing import Optional
 
 import torch
 
-MAX_DENSITY = 0.05          # above this the dense MFMA GEMM wins
-MAX_COLUMN_NNZ = 256        # mean non-zeros per feature column: the weight gradient runs one wave per column (Cora 34,
-                            # Citeseer 28; Pubmed's 500 TF-IDF columns hold 1976 each and stay on the dense kernels: measured
-                            # 1.22 ms per epoch sparse against 0.70 dense)
+MAX_DENSITY = float(os.environ.get("PYGAT_SPARSE_MAX_DENSITY", 0.15))   # above this the dense MFMA GEMMs win (Pubmed: 10 %)
+SEGMENT = 128               # entries per weight-gradient segment (k9_sparse.hip SP_SEG)
 MAX_COLUMNS = 512           # output columns 2 R + H the sparse kernels take (k9_sparse.hip SP_CPL)
 ENABLED = os.environ.get("PYGAT_SPARSE_X", "1") != "0"
 
@@ -41,8 +39,22 @@ class SparseFeatures:
         order = torch.argsort(cols, stable=True)           # by column, rows ascending inside a column
         self.trow = rows[order].to(torch.int32).contiguous()
         self.tval = self.val[order].contiguous()
-        self.colptr = torch.zeros(fin + 1, dtype=torch.int32, device=x.device)
-        self.colptr[1:] = torch.cumsum(torch.bincount(cols, minlength=fin), 0).to(torch.int32)
+        cnt = torch.bincount(cols, minlength=fin)
+        colptr = torch.zeros(fin + 1, dtype=torch.int64, device=x.device)
+        colptr[1:] = torch.cumsum(cnt, 0)
+        # segments of at most SEGMENT entries, none crossing a column, at least one per column (k9_sparse.hip: a wave each)
+        nseg_k = torch.clamp((cnt + SEGMENT - 1) // SEGMENT, min=1)
+        colseg = torch.zeros(fin + 1, dtype=torch.int64, device=x.device)
+        colseg[1:] = torch.cumsum(nseg_k, 0)
+        self.nseg = int(colseg[-1])
+        seg_col = torch.repeat_interleave(torch.arange(fin, device=x.device), nseg_k)
+        within = torch.arange(self.nseg, device=x.device) - colseg[seg_col]
+        seg_begin = colptr[seg_col] + SEGMENT * within
+        seg_end = torch.minimum(seg_begin + SEGMENT, colptr[seg_col + 1])
+        self.colseg = colseg.to(torch.int32).contiguous()
+        self.seg_col = seg_col.to(torch.int32).contiguous()
+        self.seg_begin = seg_begin.to(torch.int32).contiguous()
+        self.seg_end = seg_end.to(torch.int32).contiguous()
         self.density = self.nnz / max(1, n * fin)
 
 
@@ -59,7 +71,7 @@ def as_sparse_features(x: torch.Tensor, out_columns: int) -> Optional[SparseFeat
     if hit is not None and hit[0]() is x:
         return hit[1]
     density = float(torch.count_nonzero(x)) / max(1, x.numel())      # one device sync per feature tensor, then cached
-    xs = SparseFeatures(x) if (0.0 < density <= MAX_DENSITY and density * x.shape[0] <= MAX_COLUMN_NNZ) else None
+    xs = SparseFeatures(x) if 0.0 < density <= MAX_DENSITY else None
     if len(_cache) > 16:
         _cache.clear()
     _cache[key] = (weakref.ref(x), xs)

@@ -511,10 +511,12 @@ def _level_backward(ctx, G):
             dW = torch.empty(H, L.Fin, Fo, dtype=f32, device=dev)
             want_s = L.skip and ctx.need[3]
             dWs = torch.empty(H, L.Fin, Fo, dtype=f32, device=dev) if want_s else None
+            wss = torch.empty(lib.pygat_wgrad_sparse_workspace_bytes(xs.nseg, H, Fo, int(want_s)) // 4 + 4, dtype=f32, device=dev)
             with _span("k5_wgrad"):
-                check(lib.pygat_wgrad_sparse(L.N, L.Fin, H, Fo, xs.colptr.data_ptr(), xs.trow.data_ptr(), xs.tval.data_ptr(), 0.0,
-                                             None, 0, None, dWh.data_ptr(), GR.data_ptr() if want_s else None, RW, dW.data_ptr(),
-                                             _ptr(dWs), st), "wgrad_sparse")
+                check(lib.pygat_wgrad_sparse(L.N, L.Fin, H, Fo, xs.nseg, xs.colseg.data_ptr(), xs.seg_col.data_ptr(),
+                                             xs.seg_begin.data_ptr(), xs.seg_end.data_ptr(), xs.trow.data_ptr(), xs.tval.data_ptr(),
+                                             0.0, None, 0, None, dWh.data_ptr(), GR.data_ptr() if want_s else None, RW,
+                                             wss.data_ptr(), dW.data_ptr(), _ptr(dWs), st), "wgrad_sparse")
         elif ctx.need[1]:
             split_k = _split_k(L.Fin, Hb * L.Fp + (Hb if fold_ds else 0), L.N, streamed_k=True, mode=L.mode)
             wsw = torch.empty(lib.pygat_wgrad_workspace_bytes(L.Fin, H, Fo, split_k) // 4, dtype=f32, device=dev)

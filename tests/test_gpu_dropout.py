@@ -168,7 +168,8 @@ def test_dropout_p_one_and_float64_inputs(pg):  # noqa: F811
 
 
 @pytest.mark.parametrize("N,Fin,H,Fo,skip", [(3000, 1433, 8, 8, False), (700, 50, 4, 16, True), (1300, 77, 3, 64, True),
-                                            (900, 33, 1, 128, True), (5000, 64, 8, 3, False)])
+                                            (900, 33, 1, 128, True), (5000, 64, 8, 3, False), (2708, 64, 1, 7, False),
+                                            (800, 100, 2, 20, True)])
 def test_headmask_projection_and_weight_gradient(pg, N, Fin, H, Fo, skip):  # noqa: F811
     """The mask-byte projection (pygat_project_dropout) and its weight gradient (pygat_wgrad_dropout, K slabs over the
     nodes) through the C ABI against fp64 torch on the same decisions; and the statistics of pygat_dropout_bits
@@ -227,8 +228,12 @@ def test_headmask_projection_and_weight_gradient(pg, N, Fin, H, Fo, skip):  # no
     # K slabs as the level passes them (pygat_amd.dropout._headmask_splits: slabs of >= 64 nodes until the chip is full) and
     # one odd count; a single 1300-node chain (split_k = 1) is not something the level ever asks for -- one MFMA
     # accumulator over 1300 rows sits at 4.1 x the fp32 CPU product's error, the slabs' partial sums at 1-2 x
-    from pygat_amd.dropout import _headmask_splits
-    for split_k in sorted({7, _headmask_splits(-(-Fin // 128), H, Fp, skip, N)}):
+    # (the narrow kernels of k10_narrow.hip -- cases with Fin <= 128 and <= 128 output columns -- take slabs of a few rows, one
+    # wave each: pygat_amd.dropout._narrow_slabs, and a second count with ragged last slab)
+    from pygat_amd.dropout import _headmask_splits, _narrow_slabs
+    narrow = bool(lib.pygat_dropout_narrow(Fin, H, Fo, int(skip)))
+    assert narrow == (Fin <= 128 and R * (2 if skip else 1) <= 128 and Fp <= 64)
+    for split_k in sorted({_narrow_slabs(N), N // 37 + 1} if narrow else {7, _headmask_splits(-(-Fin // 128), H, Fp, skip, N)}):
         ws = torch.empty(max(1, lib.pygat_wgrad_dropout_workspace_bytes(Fin, H, Fo, int(skip), split_k) // 4), device=dev)
         dWc = torch.empty(Fin, ntot, device=dev)
         check(lib.pygat_wgrad_dropout(N, Fin, H, Fo, xd.data_ptr(), Fin, bits.data_ptr(), p, dWh.data_ptr(),
@@ -250,3 +255,22 @@ def test_headmask_projection_and_weight_gradient(pg, N, Fin, H, Fo, skip):  # no
     check(lib.pygat_dropout_head_sum_bits(N, Fin, H, dxe.data_ptr(), H * Fin, bits.data_ptr(), p, dx.data_ptr(), Fin, 0, None))
     ref = (Mc.permute(1, 0, 2) * dxe.view(N, H, Fin).double().cpu()).sum(1)
     close_grad(dx, ref, (Mc.permute(1, 0, 2).float() * dxe.view(N, H, Fin).cpu()).sum(1).double(), "head sum under the mask bytes")
+    if narrow:
+        # gradient into x in one launch (pygat_dx_dropout) = sum_h m_h o (dWh_h W_h^T + Gp_h Wskip_h^T)
+        dxn = torch.full((N, Fin), float("nan"), device=dev)
+        check(lib.pygat_dx_dropout(N, Fin, H, Fo, dWh.data_ptr(), GR.data_ptr() if skip else None, RW, bits.data_ptr(), p,
+                                   Wcat.data_ptr(), ldw, dxn.data_ptr(), Fin, 0, None))
+        ref64 = torch.zeros(N, Fin, dtype=torch.float64); ref32 = torch.zeros(N, Fin)
+        for h in range(H):
+            d_h = dWh.view(N, H, Fp)[:, h, :Fo].cpu()
+            t64 = d_h.double() @ W[h].double().t(); t32 = d_h @ W[h].t()
+            if skip:
+                g_h = GR[:, h * Fp:h * Fp + Fo].cpu()
+                t64 = t64 + g_h.double() @ Ws[h].double().t(); t32 = t32 + g_h @ Ws[h].t()
+            ref64 += Mc[h] * t64; ref32 += Mc[h].float() * t32
+        close_grad(dxn, ref64, ref32.double(), "dx under the mask bytes (narrow)")
+        base = torch.randn(N, Fin, generator=gen).to(dev)
+        acc = base.clone()
+        check(lib.pygat_dx_dropout(N, Fin, H, Fo, dWh.data_ptr(), GR.data_ptr() if skip else None, RW, bits.data_ptr(), p,
+                                   Wcat.data_ptr(), ldw, acc.data_ptr(), Fin, 1, None))
+        assert torch.allclose(acc, base + dxn, rtol=0, atol=1e-6 * float(dxn.abs().max()) + 1e-6)

@@ -30,6 +30,8 @@ def test_sparse_projection_and_weight_gradient(n, fin, H, Fo, skip, p):
     if R * (2 if skip else 1) + H > 512:
         pytest.skip("more output columns than the sparse kernels take")
     x = _features(n, fin, 0.02, n + fin)
+    x[:, 7] = torch.rand(n) + 0.1                    # a column every row has: several segments
+    x = x / x.sum(1, keepdim=True).clamp(min=1e-6)
     g = torch.Generator().manual_seed(H + Fo)
     W = torch.randn(H, fin, Fo, generator=g) * 0.3; a = torch.randn(H, 2 * Fo, generator=g) * 0.3
     Ws = torch.randn(H, fin, Fo, generator=g) * 0.3 if skip else None
@@ -39,7 +41,7 @@ def test_sparse_projection_and_weight_gradient(n, fin, H, Fo, skip, p):
     if M is not None:
         bits = sum((M[h].to(torch.int32) << h) for h in range(H)).to(torch.uint8).to(dev).contiguous()
     xd = x.to(dev); xs = SparseFeatures(xd)
-    assert xs.nnz == int((x != 0).sum()) and abs(xs.density - 0.02) < 0.01
+    assert xs.nnz == int((x != 0).sum()) and abs(xs.density - 0.02) < 0.02 and xs.nseg > fin
     ldw = -(-(R * (2 if skip else 1) + 2 * H) // 4) * 4
     Wcat = torch.empty(fin, ldw, device=dev); a_pad = torch.empty(H, 2, Fp, device=dev)
     Wd, ad, Wsd = W.to(dev).contiguous(), a.to(dev).contiguous(), (Ws.to(dev).contiguous() if skip else None)   # (kept alive)
@@ -68,9 +70,11 @@ def test_sparse_projection_and_weight_gradient(n, fin, H, Fo, skip, p):
     GR = torch.randn(n, RW, generator=g)
     dW = torch.full((H, fin, Fo), float("nan"), device=dev); dWs = torch.full((H, fin, Fo), float("nan"), device=dev) if skip else None
     dWh_d, GR_d = dWh.view(n, R).to(dev).contiguous(), GR.to(dev).contiguous()
-    check(lib.pygat_wgrad_sparse(n, fin, H, Fo, xs.colptr.data_ptr(), xs.trow.data_ptr(), xs.tval.data_ptr(), pe, None, 0,
+    wss = torch.empty(lib.pygat_wgrad_sparse_workspace_bytes(xs.nseg, H, Fo, int(skip)) // 4 + 4, device=dev)
+    check(lib.pygat_wgrad_sparse(n, fin, H, Fo, xs.nseg, xs.colseg.data_ptr(), xs.seg_col.data_ptr(), xs.seg_begin.data_ptr(),
+                                 xs.seg_end.data_ptr(), xs.trow.data_ptr(), xs.tval.data_ptr(), pe, None, 0,
                                  bits.data_ptr() if bits is not None else None, dWh_d.data_ptr(),
-                                 GR_d.data_ptr() if skip else None, RW, dW.data_ptr(),
+                                 GR_d.data_ptr() if skip else None, RW, wss.data_ptr(), dW.data_ptr(),
                                  dWs.data_ptr() if skip else None, None), "wgrad_sparse")
     torch.cuda.synchronize()
     for h in range(H):

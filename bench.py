@@ -155,9 +155,9 @@ def epoch_ms(pg, dev, name, epochs=200):
     torch.manual_seed(72)
     model = pg.GAT(c["nfeats"], c["nheads"], len(c["nheads"]), c["dropout"], 0.2, pg.SpGraphAttentionLayer,
                    skip_connection=(name == "ppi")).to(dev)
-    # torch's single-kernel Adam (same update rule as train.py's optim.Adam; the foreach form spends ~36 small launches
-    # per step on its per-parameter bias corrections: Cora epoch 0.60 -> 0.49 ms)
-    opt = torch.optim.Adam(model.parameters(), lr=c["lr"], weight_decay=c["wd"], capturable=True, fused=True)
+    # train.py:64-66's optim.Adam update as one launch over all parameters (pygat_amd.Adam, csrc/k11_adam.hip; torch's foreach
+    # form spends ~36 small launches per step, its fused capturable form two: 15 us of a 0.25 ms Cora epoch)
+    opt = pg.Adam(model.parameters(), lr=c["lr"], weight_decay=c["wd"])
     ep = pg.FusedEpoch(model, opt, x, graph, loss_fn)
     for _ in range(10):
         ep.run()
@@ -168,7 +168,7 @@ def epoch_ms(pg, dev, name, epochs=200):
     torch.cuda.synchronize()
     shape = f"{c['nfeats'][0]} -> " + " -> ".join(f"{h} x {f}" for h, f in zip(c["nheads"], c["nfeats"][1:]))
     return {"ms": (time.perf_counter() - t0) / epochs * 1e3, "nodes": N, "edges": E,
-            "config": f"{shape}{', skip connections' if name == 'ppi' else ''}, dropout {c['dropout']}, Adam (fused kernel), train step + "
+            "config": f"{shape}{', skip connections' if name == 'ppi' else ''}, dropout {c['dropout']}, Adam (pygat_adam_step), train step + "
                       f"eval forward, one HIP-graph replay per epoch",
             "data": ("two synthetic graphs with real PPI node counts, block-diagonal batch, synthetic features/labels"
                      if name == "ppi" else f"real topology, synthetic row-normalised features at the dataset's density "

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PYGAT_ABI_VERSION 11
+#define PYGAT_ABI_VERSION 12
 
 enum {
   PYGAT_OK = 0,
@@ -437,6 +437,23 @@ int pygat_wgrad_sparse(int n, int Fin, int H, int Fo, int nseg, const int32_t* c
                        const int32_t* seg_begin, const int32_t* seg_end, const int32_t* row, const float* val, float p,
                        const void* seed, int stream_id, const unsigned char* bits, const float* dWh, const float* Gp, int64_t ldg,
                        void* ws, float* dW, float* dWskip, void* stream);
+
+/* ---------------------------------------------- K11: optimiser step (csrc/k11_adam.hip)
+ * torch.optim.Adam's update (train.py:64-66,122: lr 0.005, weight_decay 5e-4; train_ppi.py:58-60) for up to
+ * PYGAT_ADAM_MAX_TENSORS parameter tensors in ONE launch:
+ *   g += wd p;  m += (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g^2;
+ *   p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+ * (hyper-parameters as doubles, like the Python floats torch holds: 1 - beta and the bias corrections are formed in double).
+ * params / grads / exp_avg / exp_avg_sq: HOST arrays of ntensors device pointers (fp32, contiguous), numel their sizes.
+ * state: PYGAT_ADAM_STATE_BYTES of DEVICE memory, 8-byte aligned ({int32 t, uint32 scratch, double beta1^t, double beta2^t}),
+ * zero before the first step; the kernel advances t itself, so a
+ * captured HIP graph replays successive steps.  More tensors: several calls must not share one state (each would advance
+ * it) -- give every group of 48 its own. */
+#define PYGAT_ADAM_MAX_TENSORS 48
+#define PYGAT_ADAM_STATE_BYTES 24
+int pygat_adam_step(int ntensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                    float* const* exp_avg_sq, const int64_t* numel, double lr, double beta1, double beta2, double eps,
+                    double weight_decay, void* state, void* stream);
 
 #ifdef __cplusplus
 }

@@ -12,8 +12,9 @@ from .layers import GraphAttentionLayer, SpGraphAttentionLayer  # noqa: F401
 from .models import GAT                                 # noqa: F401
 from .graphed import GraphedLevel, FusedEpoch           # noqa: F401
 from .losses import EluLogSoftmaxNLL                    # noqa: F401
+from .optim import Adam                                 # noqa: F401
 from .gatv2 import GraphAttentionLayerV2, SpGraphAttentionLayerV2, gatv2_level, GATv2LevelFn  # noqa: F401
 
-__all__ = ["CSRGraph", "as_graph", "gat_level", "GATLevelFn", "gemm", "set_gemm_mode", "get_gemm_mode", "gemm_mode", "GraphAttentionLayer",
+__all__ = ["Adam", "CSRGraph", "as_graph", "gat_level", "GATLevelFn", "gemm", "set_gemm_mode", "get_gemm_mode", "gemm_mode", "GraphAttentionLayer",
            "SpGraphAttentionLayer", "GAT", "padded_width", "LIB_PATH", "GraphAttentionLayerV2",
            "SpGraphAttentionLayerV2", "gatv2_level", "GATv2LevelFn", "GraphedLevel", "FusedEpoch", "EluLogSoftmaxNLL"]

@@ -18,7 +18,7 @@ import torch  # noqa: F401,E402
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpygat_amd.so")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 F_ELU = 1
 F_SKIP = 2
 
@@ -39,10 +39,11 @@ SYMBOLS = [
     "pygat_wgrad_dropout_workspace_bytes",
     "pygat_wgrad_dropout", "pygat_dropout_head_sum_bits",
     "pygat_nll_workspace_bytes", "pygat_elu_logsoftmax_nll", "pygat_elu_logsoftmax_nll_backward",
-    "pygat_project_sparse", "pygat_wgrad_sparse", "pygat_wgrad_sparse_workspace_bytes", "pygat_dropout_narrow", "pygat_dx_dropout",
+    "pygat_project_sparse", "pygat_wgrad_sparse", "pygat_wgrad_sparse_workspace_bytes", "pygat_dropout_narrow", "pygat_dx_dropout", "pygat_adam_step",
 ]
 
 
+MAX_ADAM_TENSORS = 48    # PYGAT_ADAM_MAX_TENSORS
 MAX_SEGMENTS = 4    # PYGAT_MAX_SEGMENTS
 
 
@@ -132,6 +133,7 @@ def _load():
     lib.pygat_wgrad_sparse.argtypes = [i, i, i, i, i, p, p, p, p, p, p, f, p, i, p, p, p, i64, p, p, p, p]
     lib.pygat_wgrad_sparse_workspace_bytes.argtypes = [i, i, i, i]
     lib.pygat_dropout_narrow.argtypes = [i, i, i, i]
+    lib.pygat_adam_step.argtypes = [i, p, p, p, p, p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, p, p]
     lib.pygat_dx_dropout.argtypes = [i, i, i, i, p, p, i64, p, f, p, i64, p, i64, i, p]
     lib.pygat_wgrad_sparse_workspace_bytes.restype = sz
     lib.pygat_nll_workspace_bytes.argtypes = [i]

@@ -177,51 +177,42 @@ __global__ __launch_bounds__(256) void narrow_wgrad_reduce_kernel(int total, int
   }
 }
 
-// lane = input feature k; w[c] = Wcat[k, c] over the NT (padded) columns of [W | Wskip]; heads are blocks of FP columns
+// lane = input feature k; w[c] = Wcat[k, c] over the NT (padded) columns of [W | Wskip]; heads are blocks of FP columns.
+// Row i of [dWh | Gp] is the same for every lane: its values arrive as scalar loads (uniform addresses), FMA operands straight
+// from scalar registers.
 template <int NT, int FPS>
 __global__ __launch_bounds__(256) void narrow_dx_kernel(NarrowArgs a, const float* __restrict__ D1, const float* __restrict__ D2,
                                                         int64_t ld2, const float* __restrict__ Wcat, int64_t ldw,
                                                         float* __restrict__ dx, int64_t lddx, int accumulate) {
-  constexpr int FP = 1 << FPS, NR = (NT + 63) / 64;
-  const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;   // uniform: scalar loop
+  constexpr int FP = 1 << FPS;
+  const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int r0 = wave * a.rpw;
   if (r0 >= a.n) return;
   const int r1 = (r0 + a.rpw < a.n) ? r0 + a.rpw : a.n;
   const int k = blockIdx.y * 64 + lane, kv = k < a.Fin ? k : a.Fin - 1;
+  const int nblk = a.ntot >> FPS;
   float w[NT];
 #pragma unroll
   for (int c = 0; c < NT; ++c) w[c] = c < a.ntot ? Wcat[(int64_t)kv * ldw + c] : 0.f;
-  auto load_d = [&](int i, float (&dr)[NR], int& b) {
-#pragma unroll
-    for (int j = 0; j < NR; ++j) {
-      const int c = lane + 64 * j;
-      dr[j] = c < a.R ? D1[(int64_t)i * a.R + c] : (c < a.ntot ? D2[(int64_t)i * ld2 + (c - a.R)] : 0.f);
-    }
-    b = (int)a.bits[(int64_t)i * a.Fin + kv];
-  };
-  float dr[NR], dn[NR];
-  int b, bnx;
-  load_d(r0, dr, b);
+  int b = (int)a.bits[(int64_t)r0 * a.Fin + kv];
   for (int i = r0; i < r1; ++i) {
-    load_d((i + 1 < r1) ? i + 1 : i, dn, bnx);
+    const int bnx = (int)a.bits[(int64_t)((i + 1 < r1) ? i + 1 : i) * a.Fin + kv];
     float acc = 0.f;
 #pragma unroll
     for (int blk = 0; blk < NT / FP; ++blk) {
-      float t = 0.f;
+      if (blk < nblk) {                                  // uniform
+        const int hb = blk < a.H ? blk : blk - a.H;      // W block, then the skip block of the same head
+        const float* __restrict__ src = blk < a.H ? D1 + (int64_t)i * a.R + blk * FP : D2 + (int64_t)i * ld2 + hb * FP;
+        float t = 0.f;
 #pragma unroll
-      for (int f = 0; f < FP; ++f) {
-        const int c = blk * FP + f;
-        t = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(dr[c >> 6]), c & 63)), w[c], t);
+        for (int f = 0; f < FP; ++f) t = fmaf(src[f], w[blk * FP + f], t);
+        acc += ((b >> hb) & 1) ? t : 0.f;
       }
-      const int hb = blk < a.H ? blk : blk - a.H;      // W block, then the skip block of the same head; padding blocks hold 0
-      acc += ((b >> hb) & 1) ? t : 0.f;
     }
     if (k < a.Fin) {
       float* o = dx + (int64_t)i * lddx + k;
       *o = accumulate ? *o + acc * a.scale : acc * a.scale;
     }
-#pragma unroll
-    for (int j = 0; j < NR; ++j) dr[j] = dn[j];
     b = bnx;
   }
 }

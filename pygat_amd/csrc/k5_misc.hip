@@ -247,13 +247,13 @@ extern "C" int pygat_a_grad(int n, int H, int Fo, const float* Wh, const float* 
   hipStream_t st = (hipStream_t)stream;
   // a work-group streams rows of at most 1024 floats (256 threads x 16 B): wider levels go window by window
   const int hg = (rg.hr * Fp <= 1024) ? rg.hr : (1024 / Fp);
-  // slabs: >= 256 rows per work-group on narrow rows (small graphs: few, short reductions), but a work-group holds only
+  // slabs: >= 64 rows per work-group on narrow rows (one round of four rows in flight per thread), but a work-group holds only
   // 256 / (threads per row) rows at a time -- ONE for rows of 1024 floats, where 256-row slabs meant 13 work-groups walking
   // the PPI batch (3144 x 4 KB) serially: 47 us for 13 MB.  At most 32 rounds of rows per work-group, at most AG_BLOCKS slabs.
   int tpr_h = 1;
   while (tpr_h < (hg * Fp) / 4) tpr_h <<= 1;
   const int64_t per_round = 256 / (tpr_h < 256 ? tpr_h : 256);
-  int64_t nb = cdiv(n, 256);
+  int64_t nb = cdiv(n, 64);     // (256-row slabs left Cora with 11 work-groups of four dependent rounds each: 12 us for 0.7 MB)
   if (cdiv(n, 32 * per_round) > nb) nb = cdiv(n, 32 * per_round);
   int nblocks = nb > AG_BLOCKS ? AG_BLOCKS : (int)nb;
   for (int h0 = 0; h0 < rg.hr; h0 += hg) {

@@ -120,7 +120,7 @@ def test_every_launcher_rejects_null_arguments(lib):
         for t in fn.argtypes:
             if t in (C.c_int, C.c_int64, C.c_size_t, C.c_uint32):
                 args.append(0)
-            elif t is C.c_float:
+            elif t in (C.c_float, C.c_double):
                 args.append(0.0)
             else:                      # void*, pygat_graph*, pygat_out_segments*
                 args.append(None)

@@ -48,7 +48,7 @@ else:
 torch.manual_seed(72)
 model = pg.GAT(c["nfeats"], c["nheads"], len(c["nheads"]), c["dropout"], 0.2, pg.SpGraphAttentionLayer,
                skip_connection=(args.name == "ppi")).to(dev)
-opt = torch.optim.Adam(model.parameters(), lr=c["lr"], weight_decay=c["wd"], capturable=True, fused=True)
+opt = pg.Adam(model.parameters(), lr=c["lr"], weight_decay=c["wd"])
 
 
 one = torch.ones((), device=dev)

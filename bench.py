@@ -140,7 +140,7 @@ def epoch_ms(pg, dev, name, epochs=200):
         N, E = graph.n, graph.nnz
         x = torch.randn(N, c["nfeats"][0], generator=g).to(dev)
         y = (torch.rand(N, c["nfeats"][-1], generator=g) < 0.3).float().to(dev)
-        loss_fn = lambda out: F.binary_cross_entropy_with_logits(out, y)                   # noqa: E731  train_ppi.py:104
+        loss_fn = pg.BCEWithLogits(y)            # train_ppi.py:114,157 BCEWithLogitsLoss(reduction='mean'): one launch each way
     else:
         z = np.load(os.path.join(ROOT, "tests", "golden", f"{name}_csr.npz"), allow_pickle=False)
         rowptr, col = z["rowptr"], z["col"]

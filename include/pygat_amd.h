@@ -140,6 +140,12 @@ int pygat_pack_params_heads(int H, int Fin, int Fo, const float* const* W, const
  * arrays of H device pointers (the level flavours that take stacked parameters: dropout, GATv2). */
 int pygat_stack_heads(int H, int64_t nW, int nA, int64_t nS, const float* const* W, const float* const* a,
                       const float* const* w_skip, float* W_out, float* a_out, float* skip_out, void* stream);
+/* The same with output blocks of nW_out >= nW (nS_out >= nS) elements per head, the tail zero: [Fin, F'] weights with zero
+ * rows appended, for a level whose Fin is not a multiple of 16 run on zero-padded input columns (PPI: 50 -> 64; the split-
+ * bf16 kernels take K in steps of 16, the fp32 fallback ran that level's three products at a sixth of their speed). */
+int pygat_stack_heads_padded(int H, int64_t nW, int64_t nW_out, int nA, int64_t nS, int64_t nS_out, const float* const* W,
+                             const float* const* a, const float* const* w_skip, float* W_out, float* a_out, float* skip_out,
+                             void* stream);
 /* Projection of one level in one GEMM: [Wh | Sk | s] = X * Wcat[:, :R (+R) + H]; the H columns behind the
  * heads are W_h a_src_h (pygat_pack_params), so s_i = Wh_i . a_src (layers.py:60) comes out of the same pass.
  * a_pad (pygat_pack_params; may be NULL): lets the kernel form s from the Wh accumulators themselves -- the
@@ -437,6 +443,14 @@ int pygat_wgrad_sparse(int n, int Fin, int H, int Fo, int nseg, const int32_t* c
                        const int32_t* seg_begin, const int32_t* seg_end, const int32_t* row, const float* val, float p,
                        const void* seed, int stream_id, const unsigned char* bits, const float* dWh, const float* Gp, int64_t ldg,
                        void* ws, float* dW, float* dWskip, void* stream);
+
+/* train_ppi.py:114,157: nn.BCEWithLogitsLoss(reduction='mean') over `total` logits / targets (fp32, contiguous), one launch
+ * each way: loss[0] = mean( max(x,0) - x y + log1p(exp(-|x|)) );  dlogits = gscale[0] / total * (sigmoid(x) - y).
+ * ws >= pygat_bce_workspace_bytes(total), zero before the first call (the kernel leaves its counter at zero). */
+size_t pygat_bce_workspace_bytes(int64_t total);
+int pygat_bce_with_logits(int64_t total, const float* logits, const float* targets, void* ws, float* loss, void* stream);
+int pygat_bce_with_logits_backward(int64_t total, const float* logits, const float* targets, const float* gscale, float* dlogits,
+                                   void* stream);
 
 /* ---------------------------------------------- K11: optimiser step (csrc/k11_adam.hip)
  * torch.optim.Adam's update (train.py:64-66,122: lr 0.005, weight_decay 5e-4; train_ppi.py:58-60) for up to

@@ -11,10 +11,10 @@ from .ops import gat_level, GATLevelFn, gemm, set_gemm_mode, get_gemm_mode, gemm
 from .layers import GraphAttentionLayer, SpGraphAttentionLayer  # noqa: F401
 from .models import GAT                                 # noqa: F401
 from .graphed import GraphedLevel, FusedEpoch           # noqa: F401
-from .losses import EluLogSoftmaxNLL                    # noqa: F401
+from .losses import EluLogSoftmaxNLL, BCEWithLogits                    # noqa: F401
 from .optim import Adam                                 # noqa: F401
 from .gatv2 import GraphAttentionLayerV2, SpGraphAttentionLayerV2, gatv2_level, GATv2LevelFn  # noqa: F401
 
-__all__ = ["Adam", "CSRGraph", "as_graph", "gat_level", "GATLevelFn", "gemm", "set_gemm_mode", "get_gemm_mode", "gemm_mode", "GraphAttentionLayer",
+__all__ = ["Adam", "BCEWithLogits", "CSRGraph", "as_graph", "gat_level", "GATLevelFn", "gemm", "set_gemm_mode", "get_gemm_mode", "gemm_mode", "GraphAttentionLayer",
            "SpGraphAttentionLayer", "GAT", "padded_width", "LIB_PATH", "GraphAttentionLayerV2",
            "SpGraphAttentionLayerV2", "gatv2_level", "GATv2LevelFn", "GraphedLevel", "FusedEpoch", "EluLogSoftmaxNLL"]

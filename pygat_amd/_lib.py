@@ -27,7 +27,7 @@ SYMBOLS = [
     "pygat_abi_version", "pygat_last_error", "pygat_padded_width", "pygat_device_count",
     "pygat_device_name", "pygat_default_gemm_mode", "pygat_dense_row_counts", "pygat_scan_workspace_bytes",
     "pygat_exclusive_scan_i32", "pygat_dense_fill_cols", "pygat_csr_symmetric_perm",
-    "pygat_gemm_workspace_bytes", "pygat_gemm_f32", "pygat_pack_params", "pygat_pack_params_heads", "pygat_stack_heads", "pygat_project", "pygat_attn_scores",
+    "pygat_gemm_workspace_bytes", "pygat_gemm_f32", "pygat_pack_params", "pygat_pack_params_heads", "pygat_stack_heads", "pygat_stack_heads_padded", "pygat_project", "pygat_attn_scores",
     "pygat_unpack_wgrad",
     "pygat_edge_pairs", "pygat_slot_bounds", "pygat_slot_meta", "pygat_partials_bytes", "pygat_head_group", "pygat_gat_forward", "pygat_head_mean",
     "pygat_gat_backward_prepare", "pygat_gat_backward_row", "pygat_gat_backward_col", "pygat_gat_backward_rowsum",
@@ -39,7 +39,7 @@ SYMBOLS = [
     "pygat_wgrad_dropout_workspace_bytes",
     "pygat_wgrad_dropout", "pygat_dropout_head_sum_bits",
     "pygat_nll_workspace_bytes", "pygat_elu_logsoftmax_nll", "pygat_elu_logsoftmax_nll_backward",
-    "pygat_project_sparse", "pygat_wgrad_sparse", "pygat_wgrad_sparse_workspace_bytes", "pygat_dropout_narrow", "pygat_dx_dropout", "pygat_adam_step",
+    "pygat_project_sparse", "pygat_wgrad_sparse", "pygat_wgrad_sparse_workspace_bytes", "pygat_dropout_narrow", "pygat_dx_dropout", "pygat_adam_step", "pygat_bce_workspace_bytes", "pygat_bce_with_logits", "pygat_bce_with_logits_backward",
 ]
 
 
@@ -86,6 +86,7 @@ def _load():
     lib.pygat_pack_params.argtypes = [i, i, i, p, p, p, p, i64, p, p]
     lib.pygat_pack_params_heads.argtypes = [i, i, i, p, p, p, p, i64, p, p]
     lib.pygat_stack_heads.argtypes = [i, i64, i, i64, p, p, p, p, p, p, p]
+    lib.pygat_stack_heads_padded.argtypes = [i, i64, i64, i, i64, i64, p, p, p, p, p, p, p]
     lib.pygat_unpack_wgrad.argtypes = [i, i, i, p, i64, i, p, p]
     lib.pygat_attn_scores.argtypes = [i, i, i, p, p, p, p, p, p]
     lib.pygat_project.argtypes = [i, i, i, i, p, i64, p, i64, p, p, p, p, i, p, i, p]
@@ -133,6 +134,10 @@ def _load():
     lib.pygat_wgrad_sparse.argtypes = [i, i, i, i, i, p, p, p, p, p, p, f, p, i, p, p, p, i64, p, p, p, p]
     lib.pygat_wgrad_sparse_workspace_bytes.argtypes = [i, i, i, i]
     lib.pygat_dropout_narrow.argtypes = [i, i, i, i]
+    lib.pygat_bce_workspace_bytes.argtypes = [i64]
+    lib.pygat_bce_workspace_bytes.restype = sz
+    lib.pygat_bce_with_logits.argtypes = [i64, p, p, p, p, p]
+    lib.pygat_bce_with_logits_backward.argtypes = [i64, p, p, p, p, p]
     lib.pygat_adam_step.argtypes = [i, p, p, p, p, p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, p, p]
     lib.pygat_dx_dropout.argtypes = [i, i, i, i, p, p, i64, p, f, p, i64, p, i64, i, p]
     lib.pygat_wgrad_sparse_workspace_bytes.restype = sz

@@ -300,34 +300,42 @@ extern "C" int pygat_pack_params(int H, int Fin, int Fo, const float* W, const f
 // The per-head parameter tensors of a level copied into stacked arrays W [H x nW], a [H x nA], w_skip [H x nW] in ONE
 // launch (torch.stack: one cat launch per parameter kind).  For the level flavours that still take stacked parameters.
 namespace pygat {
-__global__ __launch_bounds__(256) void stack_heads_kernel(int H, int64_t nW, int nA, int64_t nS, HeadPtrs tab, float* __restrict__ W,
-                                                          float* __restrict__ a, float* __restrict__ S) {
+__global__ __launch_bounds__(256) void stack_heads_kernel(int H, int64_t nW, int nA, int64_t nS, int64_t nWo, int64_t nSo, HeadPtrs tab,
+                                                          float* __restrict__ W, float* __restrict__ a, float* __restrict__ S) {
+  // output blocks of nWo >= nW (nSo >= nS) elements per head: the tail of a block is zero (rows appended to [Fin, F'])
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t per = nW + nA + nS;
+  const int64_t per = nWo + nA + nSo;
   if (idx >= per * H) return;
   const int h = (int)(idx / per);
   const int64_t r = idx % per;
-  if (r < nW) W[h * nW + r] = tab.w[h][r];
-  else if (r < nW + nA) a[(int64_t)h * nA + (r - nW)] = tab.a[h][r - nW];
-  else S[h * nS + (r - nW - nA)] = tab.s[h][r - nW - nA];
+  if (r < nWo) W[h * nWo + r] = r < nW ? tab.w[h][r] : 0.f;
+  else if (r < nWo + nA) a[(int64_t)h * nA + (r - nWo)] = tab.a[h][r - nWo];
+  else S[h * nSo + (r - nWo - nA)] = (r - nWo - nA) < nS ? tab.s[h][r - nWo - nA] : 0.f;
 }
 }  // namespace pygat
 
-extern "C" int pygat_stack_heads(int H, int64_t nW, int nA, int64_t nS, const float* const* W, const float* const* a,
-                                 const float* const* w_skip, float* W_out, float* a_out, float* skip_out, void* stream) {
-  if (!w_skip) nS = 0;
-  PYGAT_REQUIRE(H > 0 && H <= MAX_HEADS_TABLE && nW > 0 && nA > 0 && nS >= 0 && W && a && W_out && a_out && (!w_skip || (skip_out && nS > 0)),
+extern "C" int pygat_stack_heads_padded(int H, int64_t nW, int64_t nW_out, int nA, int64_t nS, int64_t nS_out, const float* const* W,
+                                        const float* const* a, const float* const* w_skip, float* W_out, float* a_out, float* skip_out,
+                                        void* stream) {
+  if (!w_skip) nS = nS_out = 0;
+  PYGAT_REQUIRE(H > 0 && H <= MAX_HEADS_TABLE && nW > 0 && nW_out >= nW && nA > 0 && nS >= 0 && nS_out >= nS && W && a && W_out &&
+                    a_out && (!w_skip || (skip_out && nS > 0)),
                 "stack_heads: bad arguments (1 <= H <= %d)", MAX_HEADS_TABLE);
   HeadPtrs tab = {};
   for (int h = 0; h < H; ++h) {
     PYGAT_REQUIRE(W[h] && a[h] && (!w_skip || w_skip[h]), "stack_heads: null parameter pointer of head %d", h);
     tab.w[h] = W[h]; tab.a[h] = a[h]; tab.s[h] = w_skip ? w_skip[h] : nullptr;
   }
-  const int64_t tot = (nW + nA + nS) * H;
-  hipLaunchKernelGGL(stack_heads_kernel, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, H, nW, nA, nS, tab,
-                     W_out, a_out, skip_out);
+  const int64_t tot = (nW_out + nA + nS_out) * H;
+  hipLaunchKernelGGL(stack_heads_kernel, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream, H, nW, nA, nS, nW_out,
+                     nS_out, tab, W_out, a_out, skip_out);
   PYGAT_CHECK_LAUNCH("stack_heads");
   return PYGAT_OK;
+}
+
+extern "C" int pygat_stack_heads(int H, int64_t nW, int nA, int64_t nS, const float* const* W, const float* const* a,
+                                 const float* const* w_skip, float* W_out, float* a_out, float* skip_out, void* stream) {
+  return pygat_stack_heads_padded(H, nW, nW, nA, nS, nS, W, a, w_skip, W_out, a_out, skip_out, stream);
 }
 
 extern "C" int pygat_pack_params_heads(int H, int Fin, int Fo, const float* const* W, const float* const* a,

@@ -76,3 +76,26 @@ def as_sparse_features(x: torch.Tensor, out_columns: int) -> Optional[SparseFeat
         _cache.clear()
     _cache[key] = (weakref.ref(x), xs)
     return xs
+
+
+_pad_cache = {}
+
+
+def padded_columns(x: torch.Tensor, multiple: int) -> torch.Tensor:
+    """x [N, Fin] with zero columns appended up to a multiple of `multiple`, float32 -- built once per feature tensor (same
+    cache discipline as the sparse pattern: keyed by storage, shape and version, dropped with the tensor).  For a first level
+    whose Fin is not a multiple of 16 (PPI: 50): ops.gat_level runs it on the padded copy with zero rows appended to W."""
+    fin = x.shape[1]
+    cols = -(-fin // multiple) * multiple
+    if cols == fin and x.dtype == torch.float32 and x.is_contiguous():
+        return x
+    key = (x.data_ptr(), tuple(x.shape), x._version, str(x.device), str(x.dtype), multiple)
+    hit = _pad_cache.get(key)
+    if hit is not None and hit[0]() is x:
+        return hit[1]
+    xp = torch.zeros(x.shape[0], cols, dtype=torch.float32, device=x.device)
+    xp[:, :fin] = x
+    if len(_pad_cache) > 16:
+        _pad_cache.clear()
+    _pad_cache[key] = (weakref.ref(x), xp)
+    return xp

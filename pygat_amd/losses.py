@@ -64,3 +64,44 @@ class EluLogSoftmaxNLL:
 
     def __call__(self, out: torch.Tensor) -> torch.Tensor:
         return _NLLFn.apply(out, self)
+
+
+class _BCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, crit):
+        if not logits.is_cuda:
+            raise RuntimeError("pygat_amd: BCEWithLogits needs GPU tensors; there is no CPU path")
+        x = logits.contiguous().float()
+        if x.shape != crit.target.shape:
+            raise ValueError(f"BCEWithLogits: logits {tuple(x.shape)} vs targets {tuple(crit.target.shape)}")
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            check(lib.pygat_bce_with_logits(x.numel(), x.data_ptr(), crit.target.data_ptr(), crit.ws.data_ptr(), loss.data_ptr(),
+                                            _stream()), "bce_with_logits")
+        ctx.save_for_backward(x)
+        ctx.crit, ctx.in_dtype = crit, logits.dtype
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = g.reshape(1).float().contiguous()
+        dx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            check(lib.pygat_bce_with_logits_backward(x.numel(), x.data_ptr(), ctx.crit.target.data_ptr(), g.data_ptr(),
+                                                     dx.data_ptr(), _stream()), "bce_with_logits_backward")
+        return (dx if ctx.in_dtype == torch.float32 else dx.to(ctx.in_dtype)), None
+
+
+class BCEWithLogits:
+    """loss(logits) == nn.BCEWithLogitsLoss(reduction='mean')(logits, targets)  (train_ppi.py:114,157), one launch forward and
+    one backward (csrc/k8_loss.hip) instead of ATen's dozen.  targets: float tensor of the logits' shape, on the GPU."""
+
+    def __init__(self, targets: torch.Tensor):
+        if not targets.is_cuda:
+            raise RuntimeError("pygat_amd: BCEWithLogits needs GPU tensors; there is no CPU path")
+        self.target = targets.contiguous().float()
+        self.ws = torch.zeros(lib.pygat_bce_workspace_bytes(self.target.numel()) // 4 + 1, dtype=torch.float32, device=targets.device)
+
+    def __call__(self, logits: torch.Tensor) -> torch.Tensor:
+        return _BCEFn.apply(logits, self)

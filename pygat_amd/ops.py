@@ -297,6 +297,7 @@ class GATLevelFn(torch.autograd.Function):
         return (cast(dx, 0), cast(dW, 1), cast(da, 2), cast(dWs, 3), None, None, None, None, None)
 
 
+PAD_K = os.environ.get("PYGAT_PAD_K", "1") != "0"     # development knob: 0 = run odd input widths as they are
 MAX_HEAD_TABLE = 16     # PYGAT_MAX_HEADS_TABLE: heads whose parameter pointers travel as kernel arguments
 
 
@@ -547,43 +548,51 @@ def _level_backward(ctx, G):
 
 class StackHeads(torch.autograd.Function):
     """(W [H,Fin,F'], a [H,2F'], Wskip [H,Fin,F'] | None) from the per-head parameter tensors in ONE launch (torch.stack: a
-    cat launch per parameter kind); backward: views of the stacked gradients.  forward(H, skip, *Ws, *As[, *Wskips])."""
+    cat launch per parameter kind); backward: views of the stacked gradients.  forward(H, skip, rows, *Ws, *As[, *Wskips]);
+    rows > Fin: W and Wskip come out as [H, rows, F'] with zero rows appended (gat_level on padded input columns)."""
 
     @staticmethod
-    def forward(ctx, H: int, skip: bool, *params):
+    def forward(ctx, H: int, skip: bool, rows: int, *params):
         Ws, As = params[:H], params[H:2 * H]
         Ss = params[2 * H:3 * H] if skip else ()
         dev, f32 = Ws[0].device, torch.float32
         ctx.shapes = [tuple(p.shape) for p in params]
         ctx.H, ctx.skip = H, skip
         ok = Ws[0].is_cuda and H <= MAX_HEAD_TABLE and all(p.dtype == f32 and p.is_contiguous() for p in params)
+        pad = rows > 0 and rows != Ws[0].shape[0]
         if not ok:
-            return (torch.stack(list(Ws), 0), torch.stack([q.reshape(-1) for q in As], 0),
-                    torch.stack(list(Ss), 0) if skip else None)
-        W = torch.empty(H, *Ws[0].shape, dtype=f32, device=dev)
+            grow = (lambda t: torch.nn.functional.pad(t, (0, 0, 0, rows - t.shape[0]))) if pad else (lambda t: t)   # noqa: E731
+            return (torch.stack([grow(w) for w in Ws], 0), torch.stack([q.reshape(-1) for q in As], 0),
+                    torch.stack([grow(w) for w in Ss], 0) if skip else None)
+        wshape = (rows, *Ws[0].shape[1:]) if pad else tuple(Ws[0].shape)
+        W = torch.empty(H, *wshape, dtype=f32, device=dev)
         a = torch.empty(H, As[0].numel(), dtype=f32, device=dev)
-        S = torch.empty(H, *Ss[0].shape, dtype=f32, device=dev) if skip else None     # (GATv2: W is [2 Fin, F'], the skip [Fin, F'])
+        S = None
+        if skip:                                                                        # (GATv2: W is [2 Fin, F'], the skip [Fin, F'])
+            S = torch.empty(H, *((rows, *Ss[0].shape[1:]) if pad else Ss[0].shape), dtype=f32, device=dev)
         PT = C.c_void_p * H
         with torch.cuda.device(dev):
-            check(lib.pygat_stack_heads(H, Ws[0].numel(), As[0].numel(), Ss[0].numel() if skip else 0,
-                                        PT(*[w.data_ptr() for w in Ws]), PT(*[v.data_ptr() for v in As]),
-                                        PT(*[w.data_ptr() for w in Ss]) if skip else None, W.data_ptr(), a.data_ptr(), _ptr(S),
-                                        _stream()), "stack_heads")
+            check(lib.pygat_stack_heads_padded(H, Ws[0].numel(), W[0].numel(), As[0].numel(), Ss[0].numel() if skip else 0,
+                                               S[0].numel() if skip else 0, PT(*[w.data_ptr() for w in Ws]),
+                                               PT(*[v.data_ptr() for v in As]), PT(*[w.data_ptr() for w in Ss]) if skip else None,
+                                               W.data_ptr(), a.data_ptr(), _ptr(S), _stream()), "stack_heads")
         return W, a, S
 
     @staticmethod
     def backward(ctx, dW, da, dS):
         H = ctx.H
-        outs = [None if dW is None else dW[k] for k in range(H)]
+        rows_w = ctx.shapes[0][0]
+        outs = [None if dW is None else dW[k][:rows_w] for k in range(H)]               # (a view: the first Fin rows are contiguous)
         outs += [None if da is None else da[k].reshape(ctx.shapes[H + k]) for k in range(H)]
         if ctx.skip:
-            outs += [None if dS is None else dS[k] for k in range(H)]
-        return (None, None) + tuple(outs)
+            rows_s = ctx.shapes[2 * H][0]
+            outs += [None if dS is None else dS[k][:rows_s] for k in range(H)]
+        return (None, None, None) + tuple(outs)
 
 
 def stack_heads(Ws, As, Wskips):
     """-> (W, a, Wskip) stacked; one launch."""
-    return StackHeads.apply(len(Ws), Wskips is not None, *Ws, *As, *(Wskips if Wskips is not None else ()))
+    return StackHeads.apply(len(Ws), Wskips is not None, 0, *Ws, *As, *(Wskips if Wskips is not None else ()))
 
 
 def gat_level(x: torch.Tensor, graph: CSRGraph, Ws: Sequence[torch.Tensor], As: Sequence[torch.Tensor],
@@ -593,6 +602,16 @@ def gat_level(x: torch.Tensor, graph: CSRGraph, Ws: Sequence[torch.Tensor], As: 
     layers.py:114); Wskips: H tensors [Fin,F'] or None.  pipeline: see GATLevelFn.  xs: features.SparseFeatures of x
     (a first level on sparse input features) or None."""
     H = len(Ws)
+    Fin = x.shape[1]
+    if (xs is None and PAD_K and Fin % 16 and 16 < Fin <= 1024 and x.is_cuda and not x.requires_grad and x.dim() == 2
+            and H <= MAX_HEAD_TABLE and Ws[0].dim() == 2 and Ws[0].is_cuda):
+        # input columns zero-padded to a multiple of 16 (cached with x, like the sparse pattern) and zero rows appended to the
+        # weights while they are stacked: the split-bf16 kernels take K in steps of 16; on PPI's 50 input features the fp32
+        # fallback ran the projection at 45 us and the two weight gradients at 60-67 us, against 12 / 10 us on 64
+        from .features import padded_columns
+        xp = padded_columns(x, 16)
+        W, a, Wskip = StackHeads.apply(H, Wskips is not None, xp.shape[1], *Ws, *As, *(Wskips if Wskips is not None else ()))
+        return GATLevelFn.apply(xp, W, a, Wskip, graph, alpha, concat, None, pipeline)
     if H <= MAX_HEAD_TABLE:        # parameters read in place through a pointer table: no torch.stack launches
         return GATLevelHeadsFn.apply(x, graph, alpha, concat, pipeline, H, Wskips is not None, xs, *Ws, *As,
                                      *(Wskips if Wskips is not None else ()))

@@ -76,7 +76,7 @@ QUERIES = {"pygat_abi_version", "pygat_last_error", "pygat_padded_width", "pygat
            "pygat_scan_workspace_bytes", "pygat_gemm_workspace_bytes", "pygat_partials_bytes", "pygat_head_group",
            "pygat_agrad_workspace_bytes", "pygat_gatv2_workspace_bytes", "pygat_wgrad_workspace_bytes",
            "pygat_headmask_supported", "pygat_project_dropout_workspace_bytes", "pygat_wgrad_dropout_workspace_bytes",
-           "pygat_default_gemm_mode", "pygat_nll_workspace_bytes", "pygat_wgrad_sparse_workspace_bytes", "pygat_dropout_narrow"}
+           "pygat_default_gemm_mode", "pygat_nll_workspace_bytes", "pygat_wgrad_sparse_workspace_bytes", "pygat_dropout_narrow", "pygat_bce_workspace_bytes"}
 
 
 def test_gemm_mode_is_a_call_argument(lib, monkeypatch):

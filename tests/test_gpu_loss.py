@@ -68,3 +68,30 @@ def test_fused_loss_in_a_training_step_matches_the_aten_sequence(topologies):
     assert abs(grads[0][0] - grads[1][0]) <= 1e-6
     for a_, b_ in zip(grads[0][1], grads[1][1]):
         assert np.abs(a_ - b_).max() <= 1e-6 * max(1.0, np.abs(a_).max())
+
+
+@pytest.mark.parametrize("n,C,scale", [(3144, 121, 1.0), (1612, 121, 20.0), (7, 3, 1.0), (5000, 50, 0.01)])
+def test_fused_bce_with_logits(n, C, scale):
+    """pygat_amd.BCEWithLogits against nn.BCEWithLogitsLoss(reduction='mean') (train_ppi.py:114,157) in fp64 (priced by the
+    fp32 CPU evaluation of the same formula), value and gradient, logits of both signs and large magnitude, replays."""
+    import pygat_amd as pg
+    g = torch.Generator().manual_seed(n + C)
+    x = torch.randn(n, C, generator=g, dtype=torch.float64) * scale
+    y = (torch.rand(n, C, generator=g) < 0.3).double()
+    gup = 1.3
+
+    def ref(dtype):
+        xx = x.to(dtype).clone().requires_grad_(True)
+        loss = torch.nn.BCEWithLogitsLoss(reduction="mean")(xx, y.to(dtype))
+        (loss * gup).backward()
+        return loss.detach().double(), xx.grad.double()
+    l64, d64 = ref(torch.float64)
+    l32, d32 = ref(torch.float32)
+    crit = pg.BCEWithLogits(y.float().cuda())
+    xd = x.float().cuda().requires_grad_(True)
+    for rep in range(3):                                        # the workspace counter is left ready for the next call
+        xd.grad = None
+        loss = crit(xd)
+        (loss * gup).backward()
+        close_fwd(loss.reshape(1), l64.reshape(1), f"bce loss rep {rep}", ref32=l32.reshape(1))
+        close_grad(xd.grad, d64, d32, f"bce gradient rep {rep}", floor=1e-9)

@@ -33,7 +33,7 @@ if args.name == "ppi":
     N = graph.n
     x = torch.randn(N, c["nfeats"][0], generator=g).to(dev)
     y = (torch.rand(N, c["nfeats"][-1], generator=g) < 0.3).float().to(dev)
-    loss_fn = lambda out: F.binary_cross_entropy_with_logits(out, y)   # noqa: E731
+    loss_fn = pg.BCEWithLogits(y)          # train_ppi.py:114,157
 else:
     z = np.load(os.path.join(ROOT, "tests", "golden", f"{args.name}_csr.npz"), allow_pickle=False)
     N = len(z["rowptr"]) - 1

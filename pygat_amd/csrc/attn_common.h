@@ -52,17 +52,34 @@ static inline int head_group_fwd(int H, int Fp) {
   const int g = 1024 / Fp;
   return g < 1 ? 1 : g;
 }
+// K2 on a cache-resident table (PPI: 3144 x 1024 floats): at VEC = 4 it holds 205 VGPRs = 2 waves per SIMD; two windows of
+// 512 floats run 4 and finish sooner despite the second launch (PPI epoch 2.43 -> 2.40 ms).  Large tables keep whole rows
+// (the gathered row is the HBM transaction; a window re-reads the edge structure).  PYGAT_FWD_WINDOW: floats per window, 0 off.
+static inline int head_group_fwd_n(int64_t n, int H, int Fp) {
+  static const int fwd_w = [] { const char* e = getenv("PYGAT_FWD_WINDOW"); return e ? atoi(e) : 512; }();
+  const int64_t R = (int64_t)H * Fp;
+  if (fwd_w > 0 && R > fwd_w && R <= 1024 && n * R * 4 < ((int64_t)256 << 20)) { const int g = fwd_w / Fp; return g < 1 ? 1 : g; }
+  return head_group_fwd(H, Fp);
+}
 // The two backward passes hold two gathered/row-local rows per edge: at VEC >= 3 they need 170-250
 // VGPRs, run 2 waves per SIMD and stop covering the HBM latency (same workload: K3b 11.0 -> 8.5 ms,
 // K4 11.6 -> 9.9 ms as windows of 256 floats = one chunk per lane).  Windows cost extra launches, so
-// they are used only where the gathered table is far beyond the caches (small graphs are launch-bound:
-// a PPI-sized epoch went 4.4 -> 5.9 ms with them) and rows are wider than 512 floats (neutral there).
-// PYGAT_BWD_WINDOW_BYTES overrides the table-size threshold (tests set 0 to window tiny graphs).
+// they are used where the gathered table is far beyond the caches and rows are wider than 512 floats (neutral there); a
+// cache-resident table wider than 512 floats takes windows of 512 (VEC = 2, 150 VGPRs) instead of whole rows -- K4 at
+// VEC = 4 holds 256 VGPRs + 16 AGPRs, ONE wave per SIMD (PPI epoch 2.55 -> 2.43 ms; windows of 256 there: 2.66).
+// PYGAT_BWD_WINDOW_BYTES overrides the table-size threshold (tests set 0 to window tiny graphs); PYGAT_BWD_SMALL_WINDOW the
+// floats per window of a cache-resident table (0: whole rows).
 static inline int head_group_bwd(int64_t n, int H, int Fp) {
   const int64_t R = (int64_t)H * Fp;
   int64_t min_bytes = (int64_t)256 << 20;
   if (const char* e = getenv("PYGAT_BWD_WINDOW_BYTES")) min_bytes = strtoll(e, nullptr, 10);
-  if (R <= 512 || n * R * 4 < min_bytes) return head_group_fwd(H, Fp);
+  if (R <= 512) return head_group_fwd(H, Fp);
+  if (n * R * 4 < min_bytes) {   // cache-resident table: development knob PYGAT_BWD_SMALL_WINDOW = floats per window (0: whole rows)
+    static const int small_w = [] { const char* e = getenv("PYGAT_BWD_SMALL_WINDOW"); return e ? atoi(e) : 512; }();
+    if (small_w <= 0 || small_w >= R) return head_group_fwd(H, Fp);
+    const int g = small_w / Fp;
+    return g < 1 ? 1 : g;
+  }
   const int g = 256 / Fp;
   return g < 1 ? 1 : g;
 }

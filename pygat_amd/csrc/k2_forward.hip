@@ -527,7 +527,7 @@ static int launch_forward(const pygat_graph* g, int H, int Fo, float alpha, int 
   hipStream_t st = (hipStream_t)stream;
   const int64_t nslots = a.g.kn;   // slots of this call (a row range, or all)
   // GATv2 gathers [Whi|Whj] rows and is not windowed
-  const int hg = v2 ? H : head_group_fwd(H, Fp);
+  const int hg = v2 ? H : head_group_fwd_n(a.g.n, H, Fp);
   for (int h0 = 0; h0 < H; h0 += hg) {
     const int hc = (H - h0 < hg) ? H - h0 : hg;
     PYGAT_REQUIRE(make_window_shape(H, Fo, hc, &a.rs),

@@ -198,7 +198,8 @@ WIDE = [s for s in SHAPES if s[0] * max(4, 1 << (s[2] - 1).bit_length()) > 512]
 @pytest.mark.parametrize("H,Fin,Fo,skip,concat", WIDE)
 def test_level_backward_head_windows(pg, monkeypatch, backward_mode, H, Fin, Fo, skip, concat):
     """Rows wider than 512 floats on a LARGE graph run the backward in head windows of <= 256 floats (GR laid
-    out window by window).  PYGAT_BWD_WINDOW_BYTES=0 forces that path on a small graph."""
+    out window by window).  PYGAT_BWD_WINDOW_BYTES=0 forces that path on a small graph (whose own default is windows
+    of <= 512 floats: every other wide-row test of this file runs those)."""
     monkeypatch.setenv("PYGAT_BWD_WINDOW_BYTES", "0")
     N = 80
     hg = pg._lib.lib.pygat_head_group(N, H, Fo)
@@ -211,7 +212,8 @@ def test_level_backward_head_windows(pg, monkeypatch, backward_mode, H, Fin, Fo,
     check(run_level(pg, x, rowptr, col, W, a, Sk, concat, G, slot=16), x, rowptr, col, W, a, Sk, concat, G,
           f"windows[{H},{Fin},{Fo},{skip},{concat},{backward_mode}]")
     monkeypatch.delenv("PYGAT_BWD_WINDOW_BYTES")
-    assert pg._lib.lib.pygat_head_group(N, H, Fo) == min(H, 1024 // pg.padded_width(Fo))
+    # (a cache-resident table wider than 512 floats: windows of <= 512 floats -- attn_common.h head_group_bwd)
+    assert pg._lib.lib.pygat_head_group(N, H, Fo) == min(H, max(1, 512 // pg.padded_width(Fo)))
 
 
 def test_eval_matches_both_oracle_formulations(pg):

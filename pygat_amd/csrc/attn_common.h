@@ -80,7 +80,8 @@ static inline int head_group_bwd(int64_t n, int H, int Fp) {
     const int g = small_w / Fp;
     return g < 1 ? 1 : g;
   }
-  const int g = 256 / Fp;
+  static const int large_w = [] { const char* e = getenv("PYGAT_BWD_LARGE_WINDOW"); return e ? atoi(e) : 256; }();   // development knob
+  const int g = large_w / Fp;
   return g < 1 ? 1 : g;
 }
 

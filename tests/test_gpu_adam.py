@@ -68,3 +68,23 @@ def test_adam_many_tensors_and_graph_replay():
     for step in range(3):
         feed(); graph.replay(); b.step(); same(f"replayed step {step}")
     assert a.steps_taken() == 5
+
+
+def test_adam_unaligned_and_tiny_tensors():
+    """Parameters that are views at odd offsets (no 16-byte alignment: the scalar path) and of 1-3 elements."""
+    import pygat_amd as pg
+    gen = torch.Generator().manual_seed(9)
+    base_a = torch.randn(10000, generator=gen).cuda()
+    base_b = base_a.clone()
+    cuts = [(1, 4098), (4099, 4102), (4103, 4104), (4105, 9999)]
+    ours = [base_a[i:j].detach().requires_grad_(True) for i, j in cuts]
+    theirs = [base_b[i:j].detach().requires_grad_(True) for i, j in cuts]
+    assert any(p.data_ptr() % 16 for p in ours)
+    a = pg.Adam(ours, lr=3e-3, weight_decay=1e-2)
+    b = torch.optim.Adam(theirs, lr=3e-3, weight_decay=1e-2)
+    for step in range(3):
+        for p, q in zip(ours, theirs):
+            g = torch.randn(p.shape, generator=gen).cuda()
+            p.grad = g.clone(); q.grad = g.clone()
+        a.step(); b.step()
+    assert torch.allclose(base_a, base_b, rtol=0, atol=1e-6)          # the views write through; untouched elements equal

@@ -169,7 +169,7 @@ def test_dropout_p_one_and_float64_inputs(pg):  # noqa: F811
 
 @pytest.mark.parametrize("N,Fin,H,Fo,skip", [(3000, 1433, 8, 8, False), (700, 50, 4, 16, True), (1300, 77, 3, 64, True),
                                             (900, 33, 1, 128, True), (5000, 64, 8, 3, False), (2708, 64, 1, 7, False),
-                                            (800, 100, 2, 20, True)])
+                                            (800, 100, 2, 20, True), (3, 5, 2, 1, True), (67, 128, 8, 8, False)])
 def test_headmask_projection_and_weight_gradient(pg, N, Fin, H, Fo, skip):  # noqa: F811
     """The mask-byte projection (pygat_project_dropout) and its weight gradient (pygat_wgrad_dropout, K slabs over the
     nodes) through the C ABI against fp64 torch on the same decisions; and the statistics of pygat_dropout_bits
@@ -190,7 +190,7 @@ def test_headmask_projection_and_weight_gradient(pg, N, Fin, H, Fo, skip):  # no
     n_el = N * Fin
     for h in range(H):
         assert abs(float(M[h].float().mean()) - keep) < 5 * (keep * (1 - keep) / n_el) ** 0.5
-    if H > 1:
+    if H > 1 and n_el >= 20000:          # (a 2 % band needs a sample)
         agree = float((M[0] == M[1]).float().mean())
         assert abs(agree - (keep * keep + (1 - keep) ** 2)) < 0.02
     gen = torch.Generator().manual_seed(3)

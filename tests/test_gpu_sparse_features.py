@@ -15,6 +15,7 @@ def _features(n, fin, density, seed):
     g = torch.Generator().manual_seed(seed)
     x = (torch.rand(n, fin, generator=g) < density).float() * (torch.rand(n, fin, generator=g) + 0.1)
     x[3] = 0                                         # an empty row
+    x[11] = torch.rand(fin, generator=g) + 0.1       # a full row: several 64-pair batches of the walk
     x[:, 5] = 0                                      # an empty column
     return x / x.sum(1, keepdim=True).clamp(min=1e-6)
 

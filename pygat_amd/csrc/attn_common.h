@@ -64,7 +64,8 @@ static inline int head_group_fwd_n(int64_t n, int H, int Fp) {
 // The two backward passes hold two gathered/row-local rows per edge: at VEC >= 3 they need 170-250
 // VGPRs, run 2 waves per SIMD and stop covering the HBM latency (same workload: K3b 11.0 -> 8.5 ms,
 // K4 11.6 -> 9.9 ms as windows of 256 floats = one chunk per lane).  Windows cost extra launches, so
-// they are used where the gathered table is far beyond the caches and rows are wider than 512 floats (neutral there); a
+// they are used where the gathered table is far beyond the caches and rows are wider than 256 floats (8 heads x 64 on the
+// config-5 graph: K4 5.14 -> 4.72 ms as two windows of 256, the step 13.6 -> 13.0; PYGAT_BWD_WINDOW_MIN_R); a
 // cache-resident table wider than 512 floats takes windows of 512 (VEC = 2, 150 VGPRs) instead of whole rows -- K4 at
 // VEC = 4 holds 256 VGPRs + 16 AGPRs, ONE wave per SIMD (PPI epoch 2.55 -> 2.43 ms; windows of 256 there: 2.66).
 // PYGAT_BWD_WINDOW_BYTES overrides the table-size threshold (tests set 0 to window tiny graphs); PYGAT_BWD_SMALL_WINDOW the
@@ -73,7 +74,8 @@ static inline int head_group_bwd(int64_t n, int H, int Fp) {
   const int64_t R = (int64_t)H * Fp;
   int64_t min_bytes = (int64_t)256 << 20;
   if (const char* e = getenv("PYGAT_BWD_WINDOW_BYTES")) min_bytes = strtoll(e, nullptr, 10);
-  if (R <= 512) return head_group_fwd(H, Fp);
+  static const int min_r = [] { const char* e = getenv("PYGAT_BWD_WINDOW_MIN_R"); return e ? atoi(e) : 256; }();   // development knob
+  if (R <= min_r) return head_group_fwd(H, Fp);
   if (n * R * 4 < min_bytes) {   // cache-resident table: development knob PYGAT_BWD_SMALL_WINDOW = floats per window (0: whole rows)
     static const int small_w = [] { const char* e = getenv("PYGAT_BWD_SMALL_WINDOW"); return e ? atoi(e) : 512; }();
     if (small_w <= 0 || small_w >= R) return head_group_fwd(H, Fp);

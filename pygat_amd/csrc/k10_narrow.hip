@@ -185,6 +185,18 @@ __global__ __launch_bounds__(256) void narrow_dx_kernel(NarrowArgs a, const floa
                                                         int64_t ld2, const float* __restrict__ Wcat, int64_t ldw,
                                                         float* __restrict__ dx, int64_t lddx, int accumulate) {
   constexpr int FP = 1 << FPS;
+  // the work-group's 64 rows of Wcat (its k chunk) staged in LDS with coalesced loads, row stride ntot + 1 (lane k then reads
+  // row k without bank conflicts): read straight from global memory, every lane walking its own row, the set-up was 2048
+  // cache lines per wave -- 24 us of Pubmed's 19717 x 64 level against 5 for the rows themselves
+  extern __shared__ float dx_sm[];
+  {
+    const int k0 = blockIdx.y * 64, nk = (a.Fin - k0 < 64) ? a.Fin - k0 : 64;
+    for (int e = threadIdx.x; e < 64 * a.ntot; e += 256) {
+      const int kk = e / a.ntot, c = e - kk * a.ntot;
+      dx_sm[kk * (a.ntot + 1) + c] = Wcat[(int64_t)(k0 + (kk < nk ? kk : nk - 1)) * ldw + c];
+    }
+  }
+  __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int r0 = wave * a.rpw;
   if (r0 >= a.n) return;
@@ -193,7 +205,9 @@ __global__ __launch_bounds__(256) void narrow_dx_kernel(NarrowArgs a, const floa
   const int nblk = a.ntot >> FPS;
   float w[NT];
 #pragma unroll
-  for (int c = 0; c < NT; ++c) w[c] = c < a.ntot ? Wcat[(int64_t)kv * ldw + c] : 0.f;
+  for (int c = 0; c < NT; ++c) w[c] = dx_sm[lane * (a.ntot + 1) + (c < a.ntot ? c : 0)];
+#pragma unroll
+  for (int c = 0; c < NT; ++c) w[c] = c < a.ntot ? w[c] : 0.f;
   int b = (int)a.bits[(int64_t)r0 * a.Fin + kv];
   for (int i = r0; i < r1; ++i) {
     const int bnx = (int)a.bits[(int64_t)((i + 1 < r1) ? i + 1 : i) * a.Fin + kv];
@@ -227,6 +241,11 @@ bool narrow_takes(int Fin, int H, int Fo, bool skip) {
 static int rows_per_wave(int n) {
   int r = n / 4096;
   return r < 4 ? 4 : (r > 32 ? 32 : r);
+}
+
+static int dx_rows(int n) {
+  static const int r = [] { const char* e = getenv("PYGAT_DX_ROWS"); return e ? atoi(e) : 0; }();   // development knob
+  return r > 0 ? r : rows_per_wave(n);
 }
 
 static NarrowArgs narrow_args(int n, int Fin, int H, int Fo, bool skip, const float* X, int64_t ldx, const unsigned char* bits, float p,
@@ -271,7 +290,7 @@ using namespace pygat;
 extern "C" int pygat_dropout_narrow(int Fin, int H, int Fo, int skip) { return narrow_takes(Fin, H, Fo, skip != 0) ? 1 : 0; }
 
 #define PYGAT_DX_CASE(NT, FPS)                                                                                          \
-  hipLaunchKernelGGL((narrow_dx_kernel<NT, FPS>), grid, dim3(256), 0, st, a, dWh, Gp, ldgp, Wcat, ldw, dx, lddx, accumulate)
+  hipLaunchKernelGGL((narrow_dx_kernel<NT, FPS>), grid, dim3(256), lds, st, a, dWh, Gp, ldgp, Wcat, ldw, dx, lddx, accumulate)
 
 extern "C" int pygat_dx_dropout(int n, int Fin, int H, int Fo, const float* dWh, const float* Gp, int64_t ldgp,
                                 const unsigned char* bits, float p, const float* Wcat, int64_t ldw, float* dx, int64_t lddx,
@@ -279,10 +298,11 @@ extern "C" int pygat_dx_dropout(int n, int Fin, int H, int Fo, const float* dWh,
   PYGAT_REQUIRE(n > 0 && dWh && bits && Wcat && dx && lddx >= Fin, "dx_dropout: bad arguments");
   PYGAT_REQUIRE(narrow_takes(Fin, H, Fo, Gp != nullptr), "dx_dropout: unsupported Fin=%d H=%d F'=%d (pygat_dropout_narrow)", Fin, H, Fo);
   PYGAT_REQUIRE(p >= 0.f && p <= 1.f, "dx_dropout: p=%g outside [0,1]", (double)p);
-  const NarrowArgs a = narrow_args(n, Fin, H, Fo, Gp != nullptr, nullptr, 0, bits, p, rows_per_wave(n));
+  const NarrowArgs a = narrow_args(n, Fin, H, Fo, Gp != nullptr, nullptr, 0, bits, p, dx_rows(n));
   PYGAT_REQUIRE(ldw >= a.ntot && (!Gp || ldgp >= a.R), "dx_dropout: bad leading dimensions");
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)cdiv(cdiv(n, a.rpw), 4), (unsigned)cdiv(Fin, 64));
+  const size_t lds = (size_t)64 * (a.ntot + 1) * sizeof(float);
   int fps = 0;
   while ((1 << fps) < a.Fp) ++fps;
   const int nt = a.ntot <= 32 ? 32 : (a.ntot <= 64 ? 64 : 128);

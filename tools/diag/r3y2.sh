@@ -1,4 +1,6 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3y; mkdir -p $O; cd $R
-for w in 512 256; do echo "bwd windows for R > $w"; PYGAT_BWD_WINDOW_MIN_R=$w timeout -k 10 300 python3 bench.py --fout 64 --no-cpu --no-epoch --no-v2 --steps 8 2>/dev/null > $O/f64_$w.json; python3 -c "
-import json; d=json.load(open('$O/f64_$w.json')); print(d['ms_per_step'], [(k['kernel'], round(k['avg_ms'],3)) for k in d['kernels']])"; done
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3y; mkdir -p $O; cd $R; export TMPDIR=/tmp
+for w in 2 4 8; do
+  (cd /tmp && PYGAT_DX_ROWS=$w timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_$w -- python3 $R/tools/epoch_profile.py pubmed --epochs 30 > $O/p_$w.log 2>&1)
+  python3 tools/rocprof_top.py $O/p_$w --per 35 --top 40 2>&1 | grep narrow_dx | sed "s/^/rows $w: /"; rm -rf $O/p_$w
+done

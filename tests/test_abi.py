@@ -35,15 +35,17 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_head_windows_host_logic(lib, monkeypatch):
-    """pygat_head_group is pure host code: one pass unless the graph is large AND rows exceed 512 floats."""
+    """pygat_head_group is pure host code (csrc/attn_common.h head_group_bwd): whole rows up to 256 floats; a table beyond the
+    caches (>= 256 MB) in windows of 256 floats; a cache-resident one whole up to 512 floats, in windows of 512 beyond."""
     hg = lib.lib.pygat_head_group
-    assert hg(1000, 8, 16) == 8 and hg(1 << 20, 8, 16) == 8 and hg(1 << 20, 8, 64) == 8      # R <= 512
-    assert hg(3000, 4, 256) == 4                       # PPI-sized: table 12 MB, launch-bound -> single pass
+    assert hg(1000, 8, 16) == 8 and hg(1 << 20, 8, 16) == 8 and hg(1 << 20, 8, 32) == 8      # R <= 256
+    assert hg(1000, 8, 64) == 8 and hg(1 << 20, 8, 64) == 4      # R = 512: whole on a small table, 2 x 256 on a large one
+    assert hg(3000, 4, 256) == 2                       # PPI-sized: table 12 MB, rows of 1024 floats -> two windows of 512
     assert hg(1 << 20, 8, 128) == 2 and hg(1 << 20, 4, 256) == 1 and hg(1 << 20, 6, 121) == 2
-    assert hg(1000, 12, 128) == 8                      # R = 1536 > 1024: passes of 1024 floats even when small
+    assert hg(1000, 12, 128) == 4                      # R = 1536 on a small table: windows of 512 floats
     assert hg(0, 8, 16) == 0 and hg(10, 0, 16) == 0 and hg(10, 8, 300) == 0
     monkeypatch.setenv("PYGAT_BWD_WINDOW_BYTES", "0")
-    assert hg(10, 6, 121) == 2 and hg(10, 8, 64) == 8
+    assert hg(10, 6, 121) == 2 and hg(10, 8, 64) == 4
 
 
 def test_abi_version_and_padding(lib):

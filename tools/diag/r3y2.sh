@@ -1,6 +1,5 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3y; mkdir -p $O; cd $R; export TMPDIR=/tmp
-for w in 2 4 8; do
-  (cd /tmp && PYGAT_DX_ROWS=$w timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_$w -- python3 $R/tools/epoch_profile.py pubmed --epochs 30 > $O/p_$w.log 2>&1)
-  python3 tools/rocprof_top.py $O/p_$w --per 35 --top 40 2>&1 | grep narrow_dx | sed "s/^/rows $w: /"; rm -rf $O/p_$w
-done
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3y; mkdir -p $O; cd $R
+timeout -k 10 400 python3 -m pytest tests/test_gpu_graphed.py tests/test_gpu_training.py -q -m gpu -x > $O/pytest_fork.log 2>&1; tail -2 $O/pytest_fork.log
+for f in 0 1; do echo "fork $f"; PYGAT_PROLOGUE_FORK=$f timeout -k 10 300 python3 bench.py --no-v2 --no-cpu --steps 5 2>/dev/null | python3 -c "
+import sys,json; d=json.loads(sys.stdin.read()); print({k: round(v['ms'],4) for k,v in d['epoch_ms'].items()})"; done

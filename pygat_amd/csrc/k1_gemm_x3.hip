@@ -886,7 +886,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // 1: took the call (slabs, if any, are in ws: the caller reduces them); 0: shape does not qualify; < 0: launch error
 int try_gemm_x3g(int transA, int transB, int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                  const pygat_out_segments* out, int accumulate, int splits, int64_t k_per_split, float* ws, hipStream_t st) {
-  if (M < 64 || N < 64 || K < 32) return 0;   // (a 64-row operand fills half a tile and still beats the fp32 kernel: PPI level-1 dW 38 -> 24 us)
+  if (M < 64 || N <= 64 || K < 32) return 0;   // (a 64-row operand fills half a tile and still beats the fp32 kernel: PPI level-1 dW 38 -> 24 us)
   if (!aligned16(A) || !aligned16(B) || (lda % 4) != 0 || (ldb % 4) != 0) return 0;
   const bool kca = !transA, kcb = transB != 0;
   if ((kca || kcb) && ((K % 4) != 0 || (k_per_split % 4) != 0)) return 0;

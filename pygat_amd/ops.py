@@ -139,7 +139,7 @@ def _x3g_takes(transA: bool, transB: bool, M: int, N: int, K: int) -> bool:
     """Shapes the general split-bf16 kernel takes (csrc/k1_gemm_x3.hip try_gemm_x3g; rows are assumed 16-byte aligned
     and, for a k-strided operand, padded to a multiple of 4 columns)."""
     kca, kcb = not transA, transB
-    return M >= 64 and N >= 64 and K >= 32 and ((K % 4) == 0 or not (kca or kcb))
+    return M >= 64 and N > 64 and K >= 32 and ((K % 4) == 0 or not (kca or kcb))
 
 
 def _split_k(M: int, N: int, K: int, streamed_k: bool = False, mode: Optional[str] = None, transB: bool = False) -> int:

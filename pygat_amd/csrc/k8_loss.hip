@@ -119,19 +119,24 @@ __global__ __launch_bounds__(256) void nll_bwd_kernel(int n, int C, const float*
 //   forward   loss = 1/n sum ( max(x, 0) - x y + log1p(exp(-|x|)) )        (ATen's own stable form)
 //   backward  dx   = g/n (sigmoid(x) - y)
 // BCE_PER_BLOCK elements per work-group, partial sums per block, the last block adds them in block order (as above).
-constexpr int BCE_PER_BLOCK = 256 * 8;
+constexpr int BCE_BWD_PER_BLOCK = 256 * 8;
+constexpr int BCE_PER_BLOCK = 256 * 8;   // (64 per thread, a ninth of the work-groups and their fences: 27 us instead of 11 -- the launch is latency-bound)
 
 __global__ __launch_bounds__(256) void bce_fwd_kernel(int64_t total, const float* __restrict__ x, const float* __restrict__ y,
                                                       float* __restrict__ ws, float* __restrict__ loss) {
   float v = 0.f;
   const int64_t base = (int64_t)blockIdx.x * BCE_PER_BLOCK + threadIdx.x;
+  for (int q0 = 0; q0 < BCE_PER_BLOCK / 256; q0 += 8) {      // eight loads of each operand in flight
+    float xs[8], ys[8];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int64_t i = base + q * 256;
-    if (i < total) {
-      const float xi = x[i];
-      v += fmaxf(xi, 0.f) - xi * y[i] + log1pf(expf(-fabsf(xi)));
+    for (int q = 0; q < 8; ++q) {
+      const int64_t i = base + (int64_t)(q0 + q) * 256;
+      xs[q] = i < total ? x[i] : 0.f;
+      ys[q] = i < total ? y[i] : 0.f;
     }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (base + (int64_t)(q0 + q) * 256 < total) v += fmaxf(xs[q], 0.f) - xs[q] * ys[q] + log1pf(expf(-fabsf(xs[q])));
   }
   v = group_sum<64>(v);
   __shared__ float sm[4];
@@ -163,9 +168,9 @@ __global__ __launch_bounds__(256) void bce_fwd_kernel(int64_t total, const float
 __global__ __launch_bounds__(256) void bce_bwd_kernel(int64_t total, const float* __restrict__ x, const float* __restrict__ y,
                                                       const float* __restrict__ gscale, float* __restrict__ dx) {
   const float g = gscale[0] / (float)total;
-  const int64_t base = (int64_t)blockIdx.x * BCE_PER_BLOCK + threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * BCE_BWD_PER_BLOCK + threadIdx.x;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
+  for (int q = 0; q < BCE_BWD_PER_BLOCK / 256; ++q) {
     const int64_t i = base + q * 256;
     if (i < total) dx[i] = g * (1.f / (1.f + expf(-x[i])) - y[i]);
   }
@@ -191,7 +196,7 @@ extern "C" int pygat_bce_with_logits(int64_t total, const float* logits, const f
 extern "C" int pygat_bce_with_logits_backward(int64_t total, const float* logits, const float* targets, const float* gscale,
                                               float* dlogits, void* stream) {
   PYGAT_REQUIRE(total > 0 && logits && targets && gscale && dlogits, "bce_with_logits_backward: bad arguments");
-  hipLaunchKernelGGL(bce_bwd_kernel, dim3((unsigned)cdiv(total, BCE_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, total, logits,
+  hipLaunchKernelGGL(bce_bwd_kernel, dim3((unsigned)cdiv(total, BCE_BWD_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, total, logits,
                      targets, gscale, dlogits);
   PYGAT_CHECK_LAUNCH("bce_with_logits_backward");
   return PYGAT_OK;

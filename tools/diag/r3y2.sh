@@ -1,5 +1,4 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3y; mkdir -p $O; cd $R; export TMPDIR=/tmp
-timeout -k 10 600 python3 -m pytest tests/test_gpu_loss.py -q -m gpu -x > $O/pytest_bce.log 2>&1; tail -2 $O/pytest_bce.log
-(cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ppi_prof -- python3 $R/tools/epoch_profile.py ppi --epochs 30 > $O/ppi_prof.log 2>&1)
-python3 tools/epoch_sequence.py $O/ppi_prof --epochs 35 2>&1 | grep bce; rm -rf $O/ppi_prof
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3y; mkdir -p $O; cd $R
+for w in 0 256; do for f in 64 128; do echo "fwd large window $w, F' $f"; PYGAT_FWD_WINDOW_LARGE=$w timeout -k 10 300 python3 bench.py --fout $f --no-cpu --no-epoch --no-v2 --steps 8 2>/dev/null | python3 -c "
+import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], [(k['kernel'], round(k['avg_ms'],3)) for k in d['kernels'][:2]])"; done; done

@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-epoch", action="store_true", help="skip the Cora / Pubmed epoch_ms leg")
     ap.add_argument("--no-v2", action="store_true", help="skip the GATv2 level leg")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--verify", action="store_true", help="check the gathered sharded output against the unsharded level")
     ap.add_argument("--forward-exchange", choices=["allgather", "replicate"], default="allgather",
                     help="N>1, how every rank gets the other ranks' head outputs: RCCL all-gather over xGMI (default, the "
@@ -84,21 +84,23 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(args, rowptr, col, X, W, a, G):
-    """oracle/gat_oracle.c (kind "port") on the host cores: the same level, same inputs."""
-    from oracle import c_oracle           # built for this host at start-up (main), before the GPU was initialised
-    lib = c_oracle.load()
-    tp = c_oracle.transpose_pattern(rowptr, col)
-    times = []
-    for _ in range(args.cpu_steps):
-        t0 = time.perf_counter()
-        c_oracle.level(X, rowptr, col, W, a, 0.2, True, G, want_dx=args.dx, lib=lib, tp=tp)
-        times.append(time.perf_counter() - t0)
-    best = min(times)
-    return {"value": len(col) / best, "unit": "edges/s", "cores": int(lib.gat_oracle_threads()), "kind": "port",
-            "cpu": cpu_model(),
-            "sample": f"full workload (N={len(rowptr)-1}, E={len(col)}), best of {args.cpu_steps} fwd+bwd steps, "
-                      f"{best:.2f} s/step, OpenMP C port oracle/gat_oracle.c"}
+def cpu_baseline_child(args):
+    """oracle/gat_oracle.c (kind "port") on the host's physical cores, in a process of its own (oracle/cpu_bench.py): started
+    from main() BEFORE this process touches the GPU or wakes torch's OpenMP pool; returns the child's JSON record."""
+    import subprocess
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD"):
+        # under rocprofv3 the profiler's library has initialised the GPU already: no child process from here
+        return {"value": None, "unit": "edges/s", "cores": os.cpu_count(), "kind": "port", "cpu": cpu_model(),
+                "sample": "skipped: running under rocprofv3 (no child process after the GPU is initialised)"}
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), "--scale", str(args.scale), "--draws", str(args.draws),
+           "--fin", str(args.fin), "--heads", str(args.heads), "--fout", str(args.fout), "--steps", str(max(5, args.cpu_steps))]
+    if args.dx:
+        cmd.append("--dx")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("OMP_") and k != "PYGAT_CPU_BENCH_CHILD"}
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    if r.returncode != 0:
+        raise RuntimeError(f"oracle/cpu_bench.py rc={r.returncode}: {r.stderr[-400:]}")
+    return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -239,12 +241,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    cpu_record = None
     if world == 1 and not args.no_cpu:
-        try:        # the cpu_baseline leg's library (-march=native) is rebuilt for this host NOW, before the GPU is touched
+        try:        # the cpu_baseline leg: library rebuilt for this host (-march=native) and the whole leg run in a child
+                    # process NOW, before this process touches the GPU (round 3 ran it in-process, after the GPU legs, on
+                    # every hardware thread beside torch's own OpenMP pool: 2.37 s/step one round, 4.63 the next)
             from oracle import c_oracle
             c_oracle.build_for_host()
-        except Exception as ex:
-            print(f"bench: oracle build failed ({ex!r}); cpu_baseline will report the failure", file=sys.stderr)
+            cpu_record = cpu_baseline_child(args)
+        except Exception as ex:  # the GPU number stays valid without the CPU leg
+            print(f"bench: cpu_baseline leg failed ({ex!r})", file=sys.stderr)
+            cpu_record = {"value": None, "unit": "edges/s", "cores": os.cpu_count(), "kind": "port", "cpu": cpu_model(),
+                          "sample": f"failed: {ex!r}"}
     if world != args.gpus:
         if rank == 0:
             print(f"bench: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
@@ -463,6 +471,9 @@ def main():
             "k4_backward_col": ("hbm", E * (8 + 4 * Rb + 8 * Hb) + N * (4 + 8 * Rb + 8 * Hb)),
             "k3c_rowsum": ("hbm", E * (12 + 4 * Hb) + N * 4 * Hb),
             "k5_agrad": ("hbm", N * (4 * Rb + 8 * Hb)),
+            # da taken along by the column pass (round 4): what is left is the fold of its per-work-group records [2 R] (one per
+            # 8 slots of ~64 edges) and of the rows its fix-up finished -- priced on the records' bytes
+            "k5_afold": ("hbm", -(-(-(-E // 64)) // 8) * 8 * Rb),
             "k5_wgrad": ("mfma", 2.0 * N * Fin * (Rb + Hb)),
             "k5_xgrad": ("mfma", 2.0 * N * Fin * Rb),
         }
@@ -536,13 +547,8 @@ def main():
             "traffic_source": traffic_source,
             "alt": alt,
         }
-        if world == 1 and not args.no_cpu:
-            try:
-                line["cpu_baseline"] = cpu_baseline(args, rowptr.cpu().numpy(), col.cpu().numpy(), X.detach().cpu().numpy(),
-                                                    W.cpu().numpy(), a.cpu().numpy(), G.cpu().numpy())
-            except Exception as ex:  # the GPU number stays valid without the CPU leg
-                line["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": os.cpu_count(), "kind": "port",
-                                        "cpu": cpu_model(), "sample": f"failed: {ex!r}"}
+        if cpu_record is not None:
+            line["cpu_baseline"] = cpu_record
         if world == 1 and model_world == 1 and not args.no_v2 and not args.dx:
             try:
                 line["gatv2"] = gatv2_level_record(pg, ops, graph, X, H, Fo)

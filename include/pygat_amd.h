@@ -23,6 +23,11 @@
  *     per head and R = H*Fp floats per node row ("head-interleaved row").
  *   - graph = CSR pattern of the adjacency: row i lists the j with adj[i][j] != 0
  *     (layers.py:129: edge[0] = i = softmax row, edge[1] = j = gathered node).
+ *   - no mutable library state besides the thread-local error string, and (since ABI 13) no environment variable is
+ *     read while the library runs: two process-level defaults are read ONCE when it is loaded -- PYGAT_GEMM_F32=1
+ *     (what PYGAT_GEMM_DEFAULT means, see the GEMM section) and PYGAT_NARROW=0 (pygat_dropout_narrow answers 0) --
+ *     and every layout choice a caller can see (head windows of the backward, slot length, GEMM product mode, split-K)
+ *     is an ARGUMENT.
  */
 #ifndef PYGAT_AMD_H
 #define PYGAT_AMD_H
@@ -34,7 +39,7 @@
 extern "C" {
 #endif
 
-#define PYGAT_ABI_VERSION 12
+#define PYGAT_ABI_VERSION 13
 
 enum {
   PYGAT_OK = 0,
@@ -222,7 +227,10 @@ size_t pygat_partials_bytes(int64_t nnz, int slot_edges, int H, int Fp);
  * the heads in windows of at most 256 floats (one 16-byte chunk per lane of a wave64): window w covers
  * heads [w*hg, min(H, (w+1)*hg)), hg = pygat_head_group(n, H, F').  Callers only need it to find Gp
  * inside GR (see K3a below).  Returns H when the backward takes the whole row in one pass, 0 on bad
- * arguments. */
+ * arguments.  It is a pure function of its arguments and only the DEFAULT: prepare / row / col take `head_group`
+ * (heads per window; 0 = this default; any value whose windows are at most 1024 floats wide) as an argument, and
+ * the caller passes the SAME value to all three and lays GR out accordingly.  (Until ABI 12 an environment
+ * variable read on every call moved the threshold: process state deciding a layout the caller allocates.) */
 int pygat_head_group(int n, int H, int Fo);
 
 /* Wh [n x R], s,t [n x H], sk [n x R] or NULL.
@@ -280,14 +288,30 @@ int pygat_gat_backward_prepare(int n, int H, int Fo, int flags, int mean_mode,
                                const float* G, const float* y, const float* sk,
                                const float* s, const float* m, const float* Z,
                                float* GR, const float* aneg, const float* qneg, float alpha, float* ds,
-                               int h_first, int h_count, void* stream);
+                               int h_first, int h_count, int head_group, void* stream);
 int pygat_gat_backward_row(const pygat_graph* g, int H, int Fo, float alpha,
                            const float* Wh, const float* a_pad, const float* GR,
-                           const float* att_mask, float* ds, void* part, int h_first, int h_count, void* stream);
+                           const float* att_mask, float* ds, void* part, int h_first, int h_count, int head_group,
+                           void* stream);
+/* da_part (or NULL): the column pass also takes the attention-vector gradient along (autograd of layers.py:60-61 /
+ * a.mm(edge_h) layers.py:144): where row j finishes -- dt_j just formed, ds_j loaded for the dWh term, Wh_j in L1 from the
+ * row's edges -- every lane adds ds_j Wh_j and dt_j Wh_j into two float4s of its own in LDS, and each work-group leaves ONE
+ * record [2 R] = (sum ds_j Wh_j | sum dt_j Wh_j) over the rows it finished, lane groups added in a fixed order.  Rows cut by a
+ * slot border are finished by the fix-up launch and are NOT in the records: pygat_a_grad_fold adds them from the cut-row
+ * list.  Needs ds (row sums known), all heads in one window of one-chunk rows (R <= 256) and a graph with a cut-row list:
+ * pygat_gat_backward_col_da_bytes returns the size of da_part, 0 when the pass cannot do it (then pygat_a_grad).
+ * What it replaces: a launch that streams Wh, ds and dt again (0.6 GB, 0.12 ms at config 5). */
+size_t pygat_gat_backward_col_da_bytes(const pygat_graph* gT, int H, int Fo, int head_group);
 int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm_t, int H, int Fo, float alpha,
                            const float* Wh, const float* a_pad, const float* GR,
                            const float* att_mask, const float* ds,
-                           float* dWh, float* dt, float* dz_t, void* part, int h_first, int h_count, void* stream);
+                           float* dWh, float* dt, float* dz_t, void* part, float* da_part, int h_first, int h_count,
+                           int head_group, void* stream);
+/* da [H x 2F'] from the records of a column pass that ran with da_part, plus the rows of gT's cut-row list (their ds, dt
+ * and Wh rows are read here).  Same gT / head_group as that pass; ws >= pygat_agrad_workspace_bytes(H, F').  Fixed
+ * summation order, no atomics: bitwise reproducible. */
+int pygat_a_grad_fold(const pygat_graph* gT, int H, int Fo, const float* Wh, const float* ds, const float* dt,
+                      const float* da_part, float* da, void* ws, int head_group, void* stream);
 /* Row sums without the row pass.  The column pass computes every dz_ij anyway (for dt_j): called with ds = NULL
  * and dz_t [nnz x H] it writes them out per TRANSPOSED edge and leaves the ds_j a_src term out of dWh_j; then
  *   pygat_gat_backward_rowsum   ds_i = sum over the forward edges k of row i of dz_t[perm_f[k]]

@@ -37,6 +37,9 @@ def load():
     lib.gat_oracle_level_f64.argtypes = [C.c_int64, C.c_int64, p, p, p, p, p, C.c_int, C.c_int, C.c_int, C.c_double,
                                          C.c_int, p, p, p, p, p, p, p, p]
     lib.gat_oracle_level_f64.restype = C.c_int
+    for fn, real in ((lib.gat_oracle_level_v2, C.c_float), (lib.gat_oracle_level_v2_f64, C.c_double)):
+        fn.argtypes = [C.c_int64, C.c_int64, p, p, p, p, p, C.c_int, C.c_int, C.c_int, real, C.c_int, p, p, p, p, p, p, p, p]
+        fn.restype = C.c_int
     lib.gat_oracle_threads.restype = C.c_int
     for fn in (lib.gat_oracle_capture_kinks, lib.gat_oracle_capture_kinks_f64):
         fn.argtypes = [C.c_double, C.c_int64, p, p, p, p, p]
@@ -89,3 +92,24 @@ def level(X, rowptr, col, W, a, alpha, concat, G, want_dx=True, lib=None, tp=Non
         order = np.lexsort((ke[:n], kh[:n]))          # thread timing decides the capture order: make it canonical
         res["kinks"] = dict(h=kh[:n][order], e=ke[:n][order], z=kz[:n][order], de=kde[:n][order])
     return res
+
+
+def level_v2(X, rowptr, col, W, a, alpha, concat, G, want_dx=True, lib=None, tp=None, dtype=np.float32):
+    """One SpGraphAttentionLayerV2 level (layers.py:258-313; gat_oracle.c gat_oracle_level_v2): W [H, 2 Fin, F], a [H, F];
+    -> dict(out, dW [H, 2 Fin, F], da [H, F], dX).  dtype as in level()."""
+    lib = lib or load()
+    X = np.ascontiguousarray(X, dtype=dtype); W = np.ascontiguousarray(W, dtype=dtype)
+    a = np.ascontiguousarray(a, dtype=dtype).reshape(W.shape[0], -1); G = np.ascontiguousarray(G, dtype=dtype)
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32); col = np.ascontiguousarray(col, dtype=np.int32)
+    rp_t, col_t, perm_t = tp if tp is not None else transpose_pattern(rowptr, col)
+    N, Fin = X.shape; H, twoFin, F = W.shape
+    assert twoFin == 2 * Fin and a.shape == (H, F)
+    out = np.empty_like(G); dW = np.empty_like(W); da = np.empty_like(a)
+    dX = np.empty_like(X) if want_dx else None
+    ptr = lambda v: None if v is None else v.ctypes.data
+    fn = lib.gat_oracle_level_v2_f64 if np.dtype(dtype) == np.float64 else lib.gat_oracle_level_v2
+    rc = fn(N, len(col), ptr(rowptr), ptr(col), ptr(rp_t), ptr(col_t), ptr(perm_t), Fin, H, F, alpha, int(concat),
+            ptr(X), ptr(W), ptr(a), ptr(G), ptr(out), ptr(dW), ptr(da), ptr(dX))
+    if rc != 0:
+        raise MemoryError("gat_oracle_level_v2: allocation failed")
+    return dict(out=out, dW=dW, da=da, dX=dX)

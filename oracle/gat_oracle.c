@@ -22,6 +22,13 @@
  *          (models.py:32) or averaged (models.py:34)
  *   backward = chain rule through the above, per edge (no N x N as in layers.py:85).
  *
+ * gat_oracle_level_v2 (round 4): the same for SpGraphAttentionLayerV2 (layers.py:234-316), per head
+ *   Whi = X W[:Fin], Whj = X W[Fin:]               layers.py:268-269
+ *   e_ij = a . LeakyReLU(Whi_i + Whj_j)            layers.py:280-283
+ *   softmax over row i as above                    layers.py:285-290
+ *   hp_i = sum_j p_ij Whi_j / Z_i                  layers.py:296-300 (Whi is what is aggregated)
+ * pinned against gat_oracle.py's sparse_head_forward_v2 + torch autograd (tests/test_oracle_c.py).
+ *
  * Built twice from this one source (oracle/Makefile): REAL = float -> gat_oracle_level (fp32 like the
  * reference; long sums already run in double), and -DORACLE_F64 -> gat_oracle_level_f64, the fp64 ground
  * truth the full-size GPU tests price BOTH fp32 implementations against (forward atol 1e-5,
@@ -236,5 +243,146 @@ int FN(gat_oracle_level)(int64_t N, int64_t E, const int32_t* rowptr, const int3
     }
   }
   free(Wh); free(s); free(t); free(hp); free(Gp); free(al); free(dz); free(ds); free(dt); free(dWh);
+  return 0;
+}
+
+
+/*
+ * One SpGraphAttentionLayerV2 level (layers.py:258-313), H heads, eval mode / dropout 0, no skip projection.
+ *   X [N x Fin], W [H x 2Fin x F] (rows 0..Fin-1: the Whi half, layers.py:268; rows Fin..: the Whj half, 269), a [H x F]
+ *   (layers.py:249), G as in gat_oracle_level.  outputs: out, dW [H x 2Fin x F], da [H x F], dX [N x Fin] (may be NULL).
+ * Gradients, with u_ijf = Whi_if + Whj_jf, L = LeakyReLU, alpha_ij = p_ij / Z_i, Gp = dL/dhp:
+ *   de_ij = alpha_ij (Gp_i . Whi_j - Gp_i . hp_i)                     (softmax Jacobian; the max shift cancels)
+ *   da_f  = sum_ij de_ij L(u_ijf),     q_ijf = de_ij a_f L'(u_ijf)
+ *   dWhi_i = sum_j q_ij (row sums) + sum_k alpha_ki Gp_k (column sums: Whi_i is aggregated by the rows k that see i)
+ *   dWhj_j = sum_i q_ij (column sums)
+ *   dW[:Fin] = X^T dWhi, dW[Fin:] = X^T dWhj, dX = dWhi W[:Fin]^T + dWhj W[Fin:]^T
+ */
+int FN(gat_oracle_level_v2)(int64_t N, int64_t E, const int32_t* rowptr, const int32_t* col,
+                        const int32_t* rowptr_t, const int32_t* col_t, const int32_t* perm_t,
+                        int Fin, int H, int F, REAL alpha, int concat,
+                        const REAL* X, const REAL* W, const REAL* a, const REAL* G,
+                        REAL* out, REAL* dW, REAL* da, REAL* dX) {
+  REAL* Whi = (REAL*)malloc((size_t)N * F * sizeof(REAL));
+  REAL* Whj = (REAL*)malloc((size_t)N * F * sizeof(REAL));
+  REAL* hp = (REAL*)malloc((size_t)N * F * sizeof(REAL));
+  REAL* Gp = (REAL*)malloc((size_t)N * F * sizeof(REAL));
+  REAL* al = (REAL*)malloc((size_t)E * sizeof(REAL));
+  REAL* de = (REAL*)malloc((size_t)E * sizeof(REAL));
+  REAL* dWhi = (REAL*)malloc((size_t)N * F * sizeof(REAL));
+  REAL* dWhj = (REAL*)malloc((size_t)N * F * sizeof(REAL));
+  const int nt = FN(gat_oracle_threads)();
+  double* dacc = (double*)malloc((size_t)nt * F * sizeof(double));
+  if (!Whi || !Whj || !hp || !Gp || !al || !de || !dWhi || !dWhj || !dacc) return -1;
+  const int OC = concat ? H * F : F;
+  if (!concat) memset(out, 0, (size_t)N * F * sizeof(REAL));
+  if (dX) memset(dX, 0, (size_t)N * Fin * sizeof(REAL));
+
+  for (int h = 0; h < H; ++h) {
+    const REAL* Wi = W + (size_t)h * 2 * Fin * F;
+    const REAL* Wj = Wi + (size_t)Fin * F;
+    const REAL* av = a + (size_t)h * F;
+    gemm_nn(N, F, Fin, X, Wi, Whi);
+    gemm_nn(N, F, Fin, X, Wj, Whj);
+    memset(dacc, 0, (size_t)nt * F * sizeof(double));
+    /* row pass: forward, de, the row sums of q and da */
+#pragma omp parallel
+    {
+#ifdef _OPENMP
+      double* dap = dacc + (size_t)omp_get_thread_num() * F;
+#else
+      double* dap = dacc;
+#endif
+#pragma omp for schedule(dynamic, 256)
+      for (int64_t i = 0; i < N; ++i) {
+        const int b = rowptr[i], e = rowptr[i + 1];
+        const REAL* wi = Whi + i * F;
+        REAL m = -INFINITY;
+        for (int k = b; k < e; ++k) {
+          const REAL* wj = Whj + (int64_t)col[k] * F;
+          REAL ev = (REAL)0;
+          for (int f = 0; f < F; ++f) {
+            const REAL u = wi[f] + wj[f];
+            ev += av[f] * (u > (REAL)0 ? u : alpha * u);
+          }
+          al[k] = ev;
+          if (ev > m) m = ev;
+        }
+        double Zd = 0.0;
+        for (int k = b; k < e; ++k) { al[k] = EXPR(al[k] - m); Zd += al[k]; }
+        const REAL Z = (REAL)Zd;
+        REAL* hr = hp + i * F;
+        for (int f = 0; f < F; ++f) {
+          double acc = 0.0;
+          for (int k = b; k < e; ++k) acc += (double)al[k] * Whi[(int64_t)col[k] * F + f];
+          hr[f] = (REAL)acc;
+        }
+        double D = 0.0;
+        for (int f = 0; f < F; ++f) {
+          hr[f] /= Z;
+          REAL g;
+          if (concat) {
+            out[i * OC + h * F + f] = hr[f] > (REAL)0 ? hr[f] : EXPM1R(hr[f]);
+            g = G[i * OC + h * F + f] * (hr[f] > (REAL)0 ? (REAL)1 : EXPR(hr[f]));
+          } else {
+            out[i * OC + f] += hr[f] / (REAL)H;
+            g = G[i * OC + f] / (REAL)H;
+          }
+          Gp[i * F + f] = g;
+          D += (double)g * hr[f];
+        }
+        REAL* dri = dWhi + i * F;
+        for (int f = 0; f < F; ++f) dri[f] = (REAL)0;
+        for (int k = b; k < e; ++k) {
+          const REAL* whi_j = Whi + (int64_t)col[k] * F;
+          const REAL* whj_j = Whj + (int64_t)col[k] * F;
+          REAL dp = (REAL)0;
+          for (int f = 0; f < F; ++f) dp += Gp[i * F + f] * whi_j[f];
+          al[k] /= Z;
+          const REAL d = al[k] * (dp - (REAL)D);
+          de[k] = d;
+          for (int f = 0; f < F; ++f) {
+            const REAL u = wi[f] + whj_j[f];
+            dap[f] += (double)d * (u > (REAL)0 ? u : alpha * u);
+            dri[f] += d * av[f] * (u > (REAL)0 ? (REAL)1 : alpha);
+          }
+        }
+      }
+    }
+    for (int f = 0; f < F; ++f) {
+      double x = 0;
+      for (int t = 0; t < nt; ++t) x += dacc[(size_t)t * F + f];
+      da[(size_t)h * F + f] = (REAL)x;
+    }
+    /* column pass over the transposed pattern: node j as the gathered node of the rows i = col_t[k] */
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t j = 0; j < N; ++j) {
+      const REAL* wj = Whj + j * F;
+      for (int f = 0; f < F; ++f) {
+        double qs = 0.0, ag = 0.0;
+        for (int k = rowptr_t[j]; k < rowptr_t[j + 1]; ++k) {
+          const int64_t i = col_t[k];
+          const int32_t fe = perm_t[k];
+          const REAL u = Whi[i * F + f] + wj[f];
+          qs += (double)de[fe] * av[f] * (u > (REAL)0 ? (REAL)1 : alpha);
+          ag += (double)al[fe] * Gp[i * F + f];
+        }
+        dWhj[j * F + f] = (REAL)qs;
+        dWhi[j * F + f] += (REAL)ag;
+      }
+    }
+    gemm_tn(N, F, Fin, X, dWhi, dW + (size_t)h * 2 * Fin * F);
+    gemm_tn(N, F, Fin, X, dWhj, dW + (size_t)h * 2 * Fin * F + (size_t)Fin * F);
+    if (dX) {
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < N; ++i)
+        for (int k = 0; k < Fin; ++k) {
+          REAL acc = (REAL)0;
+          for (int f = 0; f < F; ++f) acc += dWhi[i * F + f] * Wi[(size_t)k * F + f] + dWhj[i * F + f] * Wj[(size_t)k * F + f];
+          dX[i * Fin + k] += acc;
+        }
+    }
+  }
+  free(Whi); free(Whj); free(hp); free(Gp); free(al); free(de); free(dWhi); free(dWhj); free(dacc);
   return 0;
 }

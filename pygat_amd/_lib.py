@@ -17,8 +17,12 @@ import torch  # noqa: F401,E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpygat_amd.so")
+# development aid (tools/build_variant.sh, same-lease A/B runs): another build of the same library.  Still a HIP library or
+# nothing -- the symbol check below applies to it as well.
+if os.environ.get("PYGAT_AMD_LIB"):
+    LIB_PATH = os.path.abspath(os.environ["PYGAT_AMD_LIB"])
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 F_ELU = 1
 F_SKIP = 2
 
@@ -31,6 +35,7 @@ SYMBOLS = [
     "pygat_unpack_wgrad",
     "pygat_edge_pairs", "pygat_slot_bounds", "pygat_slot_meta", "pygat_partials_bytes", "pygat_head_group", "pygat_gat_forward", "pygat_head_mean",
     "pygat_gat_backward_prepare", "pygat_gat_backward_row", "pygat_gat_backward_col", "pygat_gat_backward_rowsum",
+    "pygat_gat_backward_col_da_bytes", "pygat_a_grad_fold",
     "pygat_agrad_workspace_bytes", "pygat_a_grad", "pygat_wgrad_workspace_bytes", "pygat_wgrad",
     "pygat_gatv2_forward", "pygat_gatv2_backward_prepare", "pygat_gatv2_workspace_bytes", "pygat_gatv2_backward",
     "pygat_dropout_mask", "pygat_dropout_mask2", "pygat_dropout_expand", "pygat_dropout_head_sum", "pygat_pack_blockdiag",
@@ -99,9 +104,12 @@ def _load():
     lib.pygat_head_group.restype = i
     lib.pygat_gat_forward.argtypes = [C.POINTER(Graph), i, i, f, i, p, p, p, p, p, p, p, p, p, p, p, p, p]
     lib.pygat_head_mean.argtypes = [i, i, i, p, p, p, p]
-    lib.pygat_gat_backward_prepare.argtypes = [i, i, i, i, i, p, p, p, p, p, p, p, p, p, f, p, i, i, p]
-    lib.pygat_gat_backward_row.argtypes = [C.POINTER(Graph), i, i, f, p, p, p, p, p, p, i, i, p]
-    lib.pygat_gat_backward_col.argtypes = [C.POINTER(Graph), p, i, i, f, p, p, p, p, p, p, p, p, p, i, i, p]
+    lib.pygat_gat_backward_prepare.argtypes = [i, i, i, i, i, p, p, p, p, p, p, p, p, p, f, p, i, i, i, p]
+    lib.pygat_gat_backward_row.argtypes = [C.POINTER(Graph), i, i, f, p, p, p, p, p, p, i, i, i, p]
+    lib.pygat_gat_backward_col.argtypes = [C.POINTER(Graph), p, i, i, f, p, p, p, p, p, p, p, p, p, p, i, i, i, p]
+    lib.pygat_gat_backward_col_da_bytes.argtypes = [C.POINTER(Graph), i, i, i]
+    lib.pygat_gat_backward_col_da_bytes.restype = sz
+    lib.pygat_a_grad_fold.argtypes = [C.POINTER(Graph), i, i, p, p, p, p, p, p, i, p]
     lib.pygat_gat_backward_rowsum.argtypes = [C.POINTER(Graph), p, i, i, p, p, p, i, i, p]
     lib.pygat_agrad_workspace_bytes.argtypes = [i, i]
     lib.pygat_agrad_workspace_bytes.restype = sz

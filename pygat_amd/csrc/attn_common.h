@@ -54,38 +54,45 @@ static inline int head_group_fwd(int H, int Fp) {
 }
 // K2 on a cache-resident table (PPI: 3144 x 1024 floats): at VEC = 4 it holds 205 VGPRs = 2 waves per SIMD; two windows of
 // 512 floats run 4 and finish sooner despite the second launch (PPI epoch 2.43 -> 2.40 ms).  Large tables keep whole rows
-// (the gathered row is the HBM transaction; a window re-reads the edge structure).  PYGAT_FWD_WINDOW: floats per window, 0 off.
+// (the gathered row is the HBM transaction; a window re-reads the edge structure: measured).
 static inline int head_group_fwd_n(int64_t n, int H, int Fp) {
-  static const int fwd_w = [] { const char* e = getenv("PYGAT_FWD_WINDOW"); return e ? atoi(e) : 512; }();
+  constexpr int fwd_w = 512;   // floats per window on a cache-resident table
   const int64_t R = (int64_t)H * Fp;
-  if (fwd_w > 0 && R > fwd_w && R <= 1024 && n * R * 4 < ((int64_t)256 << 20)) { const int g = fwd_w / Fp; return g < 1 ? 1 : g; }
+  if (R > fwd_w && R <= 1024 && n * R * 4 < ((int64_t)256 << 20)) { const int g = fwd_w / Fp; return g < 1 ? 1 : g; }
   return head_group_fwd(H, Fp);
 }
 // The two backward passes hold two gathered/row-local rows per edge: at VEC >= 3 they need 170-250
 // VGPRs, run 2 waves per SIMD and stop covering the HBM latency (same workload: K3b 11.0 -> 8.5 ms,
 // K4 11.6 -> 9.9 ms as windows of 256 floats = one chunk per lane).  Windows cost extra launches, so
 // they are used where the gathered table is far beyond the caches and rows are wider than 256 floats (8 heads x 64 on the
-// config-5 graph: K4 5.14 -> 4.72 ms as two windows of 256, the step 13.6 -> 13.0; PYGAT_BWD_WINDOW_MIN_R); a
-// cache-resident table wider than 512 floats takes windows of 512 (VEC = 2, 150 VGPRs) instead of whole rows -- K4 at
-// VEC = 4 holds 256 VGPRs + 16 AGPRs, ONE wave per SIMD (PPI epoch 2.55 -> 2.43 ms; windows of 256 there: 2.66).
-// PYGAT_BWD_WINDOW_BYTES overrides the table-size threshold (tests set 0 to window tiny graphs); PYGAT_BWD_SMALL_WINDOW the
-// floats per window of a cache-resident table (0: whole rows).
+// config-5 graph: K4 5.14 -> 4.72 ms as two windows of 256, the step 13.6 -> 13.0); a cache-resident table wider than 512
+// floats takes windows of 512 (VEC = 2, 150 VGPRs) instead of whole rows -- K4 at VEC = 4 holds 256 VGPRs + 16 AGPRs, ONE
+// wave per SIMD (PPI epoch 2.55 -> 2.43 ms; windows of 256 there: 2.66).
+// This is the DEFAULT (pygat_head_group): the backward entry points take the heads per window as an argument (0 = this
+// default), because it is also the layout of a GR row, which the caller allocates and reads -- no environment variable
+// decides it (rounds 1-3 read PYGAT_BWD_WINDOW_BYTES and three more on every call).
 static inline int head_group_bwd(int64_t n, int H, int Fp) {
   const int64_t R = (int64_t)H * Fp;
-  int64_t min_bytes = (int64_t)256 << 20;
-  if (const char* e = getenv("PYGAT_BWD_WINDOW_BYTES")) min_bytes = strtoll(e, nullptr, 10);
-  static const int min_r = [] { const char* e = getenv("PYGAT_BWD_WINDOW_MIN_R"); return e ? atoi(e) : 256; }();   // development knob
-  if (R <= min_r) return head_group_fwd(H, Fp);
-  if (n * R * 4 < min_bytes) {   // cache-resident table: development knob PYGAT_BWD_SMALL_WINDOW = floats per window (0: whole rows)
-    static const int small_w = [] { const char* e = getenv("PYGAT_BWD_SMALL_WINDOW"); return e ? atoi(e) : 512; }();
-    if (small_w <= 0 || small_w >= R) return head_group_fwd(H, Fp);
-    const int g = small_w / Fp;
+  constexpr int64_t min_bytes = (int64_t)256 << 20;   // gathered table beyond the Infinity Cache
+  if (R <= 256) return head_group_fwd(H, Fp);
+  if (n * R * 4 < min_bytes) {   // cache-resident table: windows of 512 floats
+    if (512 >= R) return head_group_fwd(H, Fp);
+    const int g = 512 / Fp;
     return g < 1 ? 1 : g;
   }
-  static const int large_w = [] { const char* e = getenv("PYGAT_BWD_LARGE_WINDOW"); return e ? atoi(e) : 256; }();   // development knob
-  const int g = large_w / Fp;
+  const int g = 256 / Fp;
   return g < 1 ? 1 : g;
 }
+// heads per window of a backward call: the caller's choice when it gave one (any window a kernel pass can take), else the default
+static inline int head_group_arg(int head_group, int64_t n, int H, int Fp) {
+  if (head_group <= 0) return head_group_bwd(n, H, Fp);
+  const int cap = head_group_fwd(H, Fp);
+  if (head_group > cap) return -1;                // rows of more than 1024 floats per pass
+  return head_group < H ? head_group : H;
+}
+// narrow rows (a wave carries 8-64 slots, the whole grid is a few ten waves per SIMD): one-wave work-groups, so that a SIMD
+// slot is refilled as soon as ITS wave ends instead of when the slowest of four does (measured against 128 / 256: DESIGN.md)
+static inline unsigned narrow_block() { return 64u; }
 
 // shape of the window [h0, h0+hc) of a level with Htot heads
 static inline bool make_window_shape(int Htot, int Fo, int hc, RowShape* rs) {
@@ -188,6 +195,21 @@ static inline int check_graph(const pygat_graph* g, GraphDev* d, bool allow_slot
 __host__ __device__
 #endif
 static inline int64_t num_slots(const GraphDev& g) { return (g.nnz + g.ts - 1) / g.ts; }
+
+// Work-groups of the column pass (pygat_gat_backward_col) over gT for a level of H heads = its da_part records, or 0 when the
+// pass cannot take the attention-vector gradient along: rows of more than one chunk per lane, head windows (hg < H), no
+// cut-row list (the rows its fix-up finishes are folded in by pygat_a_grad_fold from that list).
+static inline int64_t col_da_blocks(const GraphDev& g, int H, int Fp, int hg, int* lpr_out) {
+  RowShape rs;
+  if (!g.cut || !make_window_shape(H, Fp, H, &rs)) return 0;   // (Fp as F': padded_width(Fp) == Fp)
+  if (hg < H) return 0;
+  int lpr, vec;
+  pick_lanes(rs, &lpr, &vec);
+  if (vec != 1) return 0;
+  const unsigned bt = (lpr <= 8) ? narrow_block() : 256u;
+  if (lpr_out) *lpr_out = lpr;
+  return cdiv(cdiv(num_slots(g), 64 / lpr), bt / 64);
+}
 
 #ifdef __HIPCC__
 // edge range of slot k

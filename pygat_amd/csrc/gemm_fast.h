@@ -32,6 +32,9 @@ struct SmallKArgs {
   int sv_n;
   float* s_out;        // [M x s_ld]
   int64_t s_ld;
+  // (k1_gemm_x3.hip, set by try_gemm_smallk_x3) every output segment starts at a multiple of 32 columns with 16-byte aligned
+  // rows: a lane's four consecutive columns of a row go out as one 16-byte store; s_vec: the same for the lane's s values
+  int vec_out, s_vec;
 };
 
 struct TnArgs {

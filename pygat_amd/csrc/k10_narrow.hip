@@ -244,8 +244,7 @@ static int rows_per_wave(int n) {
 }
 
 static int dx_rows(int n) {
-  static const int r = [] { const char* e = getenv("PYGAT_DX_ROWS"); return e ? atoi(e) : 0; }();   // development knob
-  return r > 0 ? r : rows_per_wave(n);
+  return rows_per_wave(n);
 }
 
 static NarrowArgs narrow_args(int n, int Fin, int H, int Fo, bool skip, const float* X, int64_t ldx, const unsigned char* bits, float p,

@@ -575,11 +575,9 @@ static int launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
   const int nt_needed = (int)cdiv(g.N, 32);
   int NT = nt_needed <= 1 ? 1 : nt_needed <= 2 ? 2 : nt_needed <= 3 ? 3 : nt_needed <= 4 ? 4 : nt_needed <= 5 ? 5 : 4;
   dim3 grid((unsigned)cdiv(g.M, BM), (unsigned)cdiv(g.N, 32 * NT), (unsigned)splits);
-  // 32-deep k-tiles for the 128-column tile: PYGAT_GEMM_BK=32 (development knob; measured on the PPI level-2
-  // projection 3144 x 2056 x 1024: 189 us with 16-deep tiles, 219 us with 32-deep ones -- 66 KB of LDS leave two
-  // work-groups per CU where 34 KB leave three)
-  static const int bk_env = [] { const char* e = getenv("PYGAT_GEMM_BK"); return e ? atoi(e) : 0; }();
-  const bool deep = NT == 4 && bk_env == 32;
+  // (32-deep k-tiles for the 128-column tile were measured on the PPI level-2 projection 3144 x 2056 x 1024: 189 us with
+  // 16-deep tiles, 219 us with 32-deep ones -- 66 KB of LDS leave two work-groups per CU where 34 KB leave three)
+  constexpr bool deep = false;
   auto lds = [](int nt, int bk) { return (size_t)2 * bk * ((BM + PAD) + (32 * nt + PAD)) * sizeof(float); };
   switch (NT) {
     case 1: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 1, 16>), grid, dim3(256), lds(1, 16), st, g); break;
@@ -725,8 +723,7 @@ extern "C" int pygat_project(int n, int Fin, int H, int Fo, const float* X, int6
   }
   seg.col_start[0] = 0; seg.ptr[k] = Wh; seg.ld[k] = R; ++k;
   if (Sk) { seg.col_start[k] = R; seg.ptr[k] = Sk; seg.ld[k] = R; ++k; }
-  static const bool sv_off = getenv("PYGAT_K1_NO_SV") != nullptr;   // development knob: s as GEMM columns everywhere
-  if (H <= 8 && split_k <= 1 && !sv_off) {   // s on the VALU of the small-K kernel, no MFMA tile for it
+  if (H <= 8 && split_k <= 1) {   // s on the VALU of the small-K kernel, no MFMA tile for it
     seg.col_start[k] = nw; seg.nseg = k;
     const int r = try_gemm_smallk(0, n, nw, Fin, X, ldx, Wcat, ldw, &seg, 0, split, (hipStream_t)stream, Wcat + nw, ldw, H, s, H);
     if (r < 0) return r;

@@ -225,7 +225,7 @@ template <bool TB, bool SV>
 static hipError_t launch_smallk(const SmallKArgs& g, int NT, dim3 grid, size_t lds, hipStream_t st) {
   int dev = -1;
   (void)hipGetDevice(&dev);
-  static const int nbuf_wide = [] { const char* e = getenv("PYGAT_K1_NBUF"); return (e && atoi(e) == 3) ? 3 : 2; }();
+  constexpr int nbuf_wide = 2;   // (3 chunks in flight were measured: 0.434 -> 0.437 ms at 5 column tiles)
 #define PYGAT_SMALLK_LAUNCH(n, nb)                                                                        \
   {                                                                                                       \
     static bool attr_set[64] = {};   /* per device: the attribute belongs to the device's code object */ \
@@ -494,11 +494,10 @@ int try_gemm_tn_stream(int M, int N, int64_t K, const float* A, int64_t lda, con
   int splits = max_splits;
   // narrow outputs (one or two 32-column tiles: a head-parallel rank with 1-2 heads of 16) run one 4-wave work-group
   // per CU with few registers: 16 k-pairs per buffer instead of 8 keep twice the bytes in flight
-  const char* uke = getenv("PYGAT_TN_UK");   // development knob (tools/gemm_tn_sweep.py)
   // measured (1M x 128 operand, 256 slabs): 16 columns 0.162 / 0.127 / 0.121 ms at 8 / 16 / 32 k-pairs per buffer,
   // 64 columns 0.229 / 0.201 / 0.213, 128 columns 0.414 / 0.433 / 0.408 (MFMA-bound there): narrow outputs (a
   // head-parallel rank with 1-2 heads of 16) keep more bytes in flight
-  const int uk = uke ? atoi(uke) : (NT <= 2 ? 16 : 8);
+  const int uk = NT <= 2 ? 16 : 8;
   int64_t kps = cdiv(cdiv(K, splits), 2 * uk) * 2 * uk;
   splits = (int)cdiv(K, kps);
   TnArgs g;
@@ -513,7 +512,7 @@ int try_gemm_tn_stream(int M, int N, int64_t K, const float* A, int64_t lda, con
     const int r = try_gemm_tn_x3(gx, (int)cdiv(K, kps16), st);
     if (r != 0) return r;
   }
-  const bool wide = !B2 && getenv("PYGAT_TN_WIDE") && aligned16(A) && aligned16(B) && (lda % 4) == 0 && (ldb % 4) == 0 && (M % 4) == 0 && (N % 4) == 0 &&
+  const bool wide = false && !B2 && aligned16(A) && aligned16(B) && (lda % 4) == 0 && (ldb % 4) == 0 && (M % 4) == 0 && (N % 4) == 0 &&
                     M >= 4 && N >= 4;
   if (wide) {
     dim3 gridw((unsigned)splits, (unsigned)tiles_m, (unsigned)cdiv(N, 128));

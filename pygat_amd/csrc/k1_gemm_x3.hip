@@ -61,9 +61,18 @@ __device__ __forceinline__ f32x16 mfma_bf16(const TA_& a, const TB_& b, f32x16 c
 __device__ __forceinline__ void pair_of(const float4& a, const float4& b, int j, float& x0, float& x1) {
   if (j == 0) { x0 = a.x; x1 = a.y; } else if (j == 1) { x0 = a.z; x1 = a.w; } else if (j == 2) { x0 = b.x; x1 = b.y; } else { x0 = b.z; x1 = b.w; }
 }
+// PYGAT_DIAG_K1 (tools/build_variant.sh only; never set in the shipped library): bit 0 no output stores, bit 1 no s
+// reduction, bit 2 A rows folded onto 256 rows (cache-resident reads), bit 3 one piece product instead of nine --
+// decomposes the projection kernel's time into its store / reduction / HBM-read / MFMA shares.
+#ifndef PYGAT_DIAG_K1
+#define PYGAT_DIAG_K1 0
+#endif
 // all nine piece products of one 32 x 32 x 16 block, small terms first
 template <class TB_>
 __device__ __forceinline__ f32x16 mma9(const Frag3& a, const TB_& bh, const TB_& bm, const TB_& bl, f32x16 c) {
+#if (PYGAT_DIAG_K1 & 8)
+  return mfma_bf16(a.h, bh, c);
+#endif
   c = mfma_bf16(a.l, bl, c);
   c = mfma_bf16(a.l, bm, c);
   c = mfma_bf16(a.m, bl, c);
@@ -74,6 +83,35 @@ __device__ __forceinline__ f32x16 mma9(const Frag3& a, const TB_& bh, const TB_&
   c = mfma_bf16(a.h, bm, c);
   c = mfma_bf16(a.h, bh, c);
   return c;
+}
+
+// The same nine products with the operand ROLES swapped: the weight fragment is the MFMA's A operand, the streamed row
+// fragment its B operand (both are "lane (i, h) holds k = 8 h .. + 7 of row / column i": nothing is loaded differently), so
+// the 32 x 32 tile comes out TRANSPOSED -- register q of lane (r, h) is C[row r][column (q & 3) + 8 (q >> 2) + 4 h]: a lane
+// holds 16 columns of ONE row, four at a time consecutive.  What that buys the epilogue of gemm_smallk_x3_kernel (round 4):
+// 16-byte stores (16 per 32 x 128 tile and wave instead of 64 dword stores), and the per-head sums s = Wh . a_src as eight
+// in-lane FMAs + one half-wave swap per head instead of a four-step DPP reduction per accumulator register.
+template <class TB_>
+__device__ __forceinline__ f32x16 mma9t(const Frag3& x, const TB_& wh, const TB_& wm, const TB_& wl, f32x16 c) {
+#if (PYGAT_DIAG_K1 & 8)
+  return mfma_bf16(wh, x.h, c);
+#endif
+  c = mfma_bf16(wl, x.l, c);
+  c = mfma_bf16(wm, x.l, c);
+  c = mfma_bf16(wl, x.m, c);
+  c = mfma_bf16(wh, x.l, c);
+  c = mfma_bf16(wl, x.h, c);
+  c = mfma_bf16(wm, x.m, c);
+  c = mfma_bf16(wh, x.m, c);
+  c = mfma_bf16(wm, x.h, c);
+  c = mfma_bf16(wh, x.h, c);
+  return c;
+}
+// sum of a value over the two half-waves (lanes l and l ^ 32), in every lane: one v_permlane32_swap + one add
+__device__ __forceinline__ float half_wave_sum(float x) {
+  const uint32_t u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -99,7 +137,8 @@ __global__ __launch_bounds__(512) void gemm_smallk_x3_kernel(SmallKArgs g) {
   const int KP = g.K + 8;
   uint16_t* Bimg = reinterpret_cast<uint16_t*>(smem_x3);          // [3][BN][KP]
   const int IMG = BN * KP;
-  float* Us = reinterpret_cast<float*>(Bimg + 3 * IMG);            // [K][8]: svec, zero padded
+  float* Us = reinterpret_cast<float*>(Bimg + 3 * IMG);            // [K][8]: svec, zero padded (SV only)
+  float* Asr = Us + (SV ? g.K * 8 : 0);                            // [BN]: a_src of every output column of this block (SR only)
   const int n0 = blockIdx.y * BN;
   for (int idx = threadIdx.x; idx < g.K * BN; idx += 512) {
     int k, n;
@@ -119,6 +158,12 @@ __global__ __launch_bounds__(512) void gemm_smallk_x3_kernel(SmallKArgs g) {
     for (int idx = threadIdx.x; idx < g.K * 8; idx += 512) {
       const int k = idx >> 3, h = idx & 7;
       Us[idx] = (h < g.sv_n) ? g.svec[(int64_t)k * g.sv_ld + h] : 0.f;
+    }
+  }
+  if constexpr (SRF > 0) {
+    for (int n = threadIdx.x; n < BN; n += 512) {
+      const int col = n0 + n;
+      Asr[n] = (col < g.N) ? g.sr_a[(col / SRF) * 2 * SRF + (col % SRF)] : 0.f;
     }
   }
   __syncthreads();
@@ -147,27 +192,23 @@ __global__ __launch_bounds__(512) void gemm_smallk_x3_kernel(SmallKArgs g) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) sacc[i] = 0.f;
   const bool sv_on = SV && blockIdx.y == 0;
-  float avr[NT];   // SR: a_src of the lane's column in each column tile
-  if constexpr (SRF > 0) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int col = n0 + 32 * nt + fr;
-      avr[nt] = g.sr_a[(col / SRF) * 2 * SRF + (col % SRF)];
-    }
-  }
 
-  // FAST: the caller knows the wave's 32 rows lie inside M and accumulate is off -- no branch at all (a branch is a
-  // join, and behind a join hipcc waits for the stores: see SPC above)
+  // The accumulators hold the tile TRANSPOSED (mma9t): register 4 g + j of lane (fr, fh) is row row0 + fr, column
+  // colt + 8 g + 4 fh + j of the 32-column tile starting at colt -- four consecutive columns per register quad.
+  // FAST: the caller knows the wave's 32 rows lie inside M, N is a multiple of 32, accumulate is off and the output takes
+  // 16-byte stores (vec_out) -- no branch at all (a branch is a join, and behind a join hipcc waits for the stores: SPC above)
   auto store_tile = [&](int t, auto fast_tag) {
     constexpr bool FAST = decltype(fast_tag)::value;
     const int64_t row0 = ((int64_t)blockIdx.x + (int64_t)t * gridDim.x) * 256 + 32 * w;
+    const int64_t row = row0 + fr;
+    const bool row_ok = FAST || row < g.M;
     const bool full = FAST || row0 + 32 <= g.M;  // wave-uniform
     if constexpr (SV) {
       if (sv_on) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) sacc[i] += __shfl_xor(sacc[i], 32);
-        if (fh == 0 && (FAST || row0 + fr < g.M)) {
-          float* so = g.s_out + (row0 + fr) * g.s_ld;
+        if (fh == 0 && row_ok) {
+          float* so = g.s_out + row * g.s_ld;
           if (FAST && g.sv_n == 8) {   // (wave-uniform)
 #pragma unroll
             for (int i = 0; i < 8; ++i) so[i] = sacc[i];
@@ -181,47 +222,64 @@ __global__ __launch_bounds__(512) void gemm_smallk_x3_kernel(SmallKArgs g) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) sacc[i] = 0.f;
     }
+    // s[row, head] = sum over the head's SRF columns of C[row, col] a_src[col]: this lane holds 4 (SRF = 8) or 8 (SRF = 16)
+    // of them, lane ^ 32 the others.  Taken tile by tile, in front of the tile's stores (its registers are free after them);
+    // four finished heads go out as one 16-byte store of the half-wave (group index & 1).
+    constexpr int HPT = SRF > 0 ? 32 / SRF : 1, GPH = SRF > 0 ? SRF / 8 : 1;   // heads per 32-column tile, register quads per head
+    float hs[4] = {0.f, 0.f, 0.f, 0.f};
+    float* so = (SRF > 0) ? g.s_out + row * g.s_ld + n0 / (SRF > 0 ? SRF : 1) : nullptr;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const int col = n0 + 32 * nt + fr;
-      if constexpr (SRF > 0) {
-        // each of the 16 row registers summed over the head's SRF lanes; lane c of a head keeps rows c, c + SRF, ..
-        const int cl = fr & (SRF - 1);
-        float keep[16 / SRF];
+      if constexpr (SRF > 0 && !(PYGAT_DIAG_K1 & 2)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float tot = group_sum<SRF>(acc[nt][r] * avr[nt]);
-          if ((r % SRF) == 0) keep[r / SRF] = tot;
-          else keep[r / SRF] = (cl == (r % SRF)) ? tot : keep[r / SRF];
-        }
+        for (int hh = 0; hh < HPT; ++hh) {
+          float p = 0.f;
 #pragma unroll
-        for (int j = 0; j < 16 / SRF; ++j) {
-          const int q = cl + SRF * j;
-          const int64_t row = row0 + (q & 3) + 8 * (q >> 2) + 4 * fh;
-          if (FAST || row < g.M) g.s_out[row * g.s_ld + col / SRF] = keep[j];
-        }
-      }
-      int64_t ld;
-      float* base = out_segment(g.out, col, ld);
-      // (opaque to the optimiser: the 16 row offsets of every column tile are loop invariants, and hoisted out of the
-      // straight-line tile loop they cost more registers than the kernel has)
-      asm volatile("" : "+v"(ld));
-      base += (row0 + 4 * fh) * ld;
-      if (FAST || col < g.N) {
-        if (FAST || (full && !g.accumulate)) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float* p = base + 8 * q * ld;
-            p[0] = acc[nt][4 * q]; p[ld] = acc[nt][4 * q + 1]; p[2 * ld] = acc[nt][4 * q + 2]; p[3 * ld] = acc[nt][4 * q + 3];
+          for (int gg = 0; gg < GPH; ++gg) {
+            const int gq = hh * GPH + gg;
+            const float4 av = ld4(Asr + 32 * nt + 8 * gq + 4 * fh);   // (LDS broadcast: two addresses per wave)
+            p = fmaf(acc[nt][4 * gq], av.x, p); p = fmaf(acc[nt][4 * gq + 1], av.y, p);
+            p = fmaf(acc[nt][4 * gq + 2], av.z, p); p = fmaf(acc[nt][4 * gq + 3], av.w, p);
           }
-        } else {
+          const int hi = nt * HPT + hh;          // head index inside this block column
+          hs[hi & 3] = half_wave_sum(p);
+          if ((hi & 3) == 3) {                   // heads hi - 3 .. hi are complete
+            if (g.s_vec) {                       // (wave-uniform)
+              if (row_ok && fh == ((hi >> 2) & 1)) st4(so + (hi - 3), make_float4(hs[0], hs[1], hs[2], hs[3]));
+            } else if (row_ok && fh == 0) {
+              so[hi - 3] = hs[0]; so[hi - 2] = hs[1]; so[hi - 1] = hs[2]; so[hi] = hs[3];
+            }
+          } else if (hi == NT * HPT - 1) {        // a last group of fewer than four heads (NT * HPT not a multiple of 4)
+            if (row_ok && fh == 0) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int rr = (r & 3) + 8 * (r >> 2);
-            if (row0 + 4 * fh + rr < g.M) {
-              if (g.accumulate) base[rr * ld] += acc[nt][r]; else base[rr * ld] = acc[nt][r];
+              for (int q = 0; q <= (hi & 3); ++q) so[hi - (hi & 3) + q] = hs[q];
             }
           }
+        }
+      }
+      const int colt = n0 + 32 * nt;   // (wave-uniform)
+      const bool vec = FAST || (full && !g.accumulate && g.vec_out && colt + 32 <= g.N);
+      if ((PYGAT_DIAG_K1 & 1) ? (g.M == -12345) : vec) {
+        int64_t ld;
+        float* base = out_segment(g.out, colt, ld);   // vec_out: no segment border inside a 32-column tile
+        // (opaque to the optimiser: the row offsets of every column tile are loop invariants, and hoisted out of the
+        // straight-line tile loop they cost more registers than the kernel has)
+        asm volatile("" : "+v"(ld));
+        base += row * ld + 4 * fh;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+          st4(base + 8 * gq, make_float4(acc[nt][4 * gq], acc[nt][4 * gq + 1], acc[nt][4 * gq + 2], acc[nt][4 * gq + 3]));
+      } else if (!(PYGAT_DIAG_K1 & 1)) {   // (every segment starts at a multiple of 4 columns: try_gemm_smallk_x3)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int col4 = colt + 8 * gq + 4 * fh;
+          int64_t ld;
+          float* p = out_segment(g.out, col4, ld) + row * ld;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (row_ok && col4 + j < g.N) {
+              if (g.accumulate) p[j] += acc[nt][4 * gq + j]; else p[j] = acc[nt][4 * gq + j];
+            }
         }
       }
 #pragma unroll
@@ -272,7 +330,7 @@ __global__ __launch_bounds__(512) void gemm_smallk_x3_kernel(SmallKArgs g) {
       const int s__ = i__ / NT, nt__ = i__ % NT;                                              \
       if (i__ + 1 < (NSTEP) * NT) PYGAT_X3_BREAD(bf[(i__ + 1) & 1], (i__ + 1) / NT, (i__ + 1) % NT) \
       __builtin_amdgcn_sched_barrier(0);                                                      \
-      acc[nt__] = mma9(af[s__], bf[i__ & 1][0], bf[i__ & 1][1], bf[i__ & 1][2], acc[nt__]);   \
+      acc[nt__] = mma9t(af[s__], bf[i__ & 1][0], bf[i__ & 1][1], bf[i__ & 1][2], acc[nt__]);  \
       __builtin_amdgcn_sched_barrier(0);                                                      \
     }                                                                                         \
   }
@@ -311,6 +369,7 @@ __global__ __launch_bounds__(512) void gemm_smallk_x3_kernel(SmallKArgs g) {
       if (t > my_tiles - 1) t = my_tiles - 1;
       int64_t row = ((int64_t)blockIdx.x + (int64_t)t * gridDim.x) * 256 + 32 * w + fr;
       if (row > g.M - 1) row = g.M - 1;
+      if (PYGAT_DIAG_K1 & 4) row &= 255;
       return g.A + row * g.lda + (c & 3) * CW + 8 * fh;
     };
 #define PYGAT_X3_LOADC(R, P)                                                                  \
@@ -348,7 +407,7 @@ __global__ __launch_bounds__(512) void gemm_smallk_x3_kernel(SmallKArgs g) {
         PYGAT_X3_SACC(x0__, 0) PYGAT_X3_SACC(x1__, 1)                                         \
       }                                                                                       \
     }                                                                                         \
-    acc[i__] = mma9(AC, bfP[cur__][0], bfP[cur__][1], bfP[cur__][2], acc[i__]);               \
+    acc[i__] = mma9t(AC, bfP[cur__][0], bfP[cur__][1], bfP[cur__][2], acc[i__]);              \
     _Pragma("unroll") for (int m__ = 0; m__ < 9; ++m__) {                                     \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                      \
       __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);                                    \
@@ -400,7 +459,7 @@ __global__ __launch_bounds__(512) void gemm_smallk_x3_kernel(SmallKArgs g) {
     // only a wave's last tile can reach past M; accumulate calls use the any-K kernel (launch_smallk_x3)
     const int64_t last_row0 = ((int64_t)blockIdx.x + (int64_t)(my_tiles - 1) * gridDim.x) * 256 + 32 * w;
     // (N % 32 != 0: a column tile is cut by N, every tile takes the guarded epilogue)
-    const int n_fast = (g.N % 32) != 0 ? 0 : ((last_row0 + 32 <= g.M) ? my_tiles : my_tiles - 1);
+    const int n_fast = ((g.N % 32) != 0 || !g.vec_out) ? 0 : ((last_row0 + 32 <= g.M) ? my_tiles : my_tiles - 1);
     if (n_fast > 0) {
       PYGAT_X3_TILE(0, std::true_type{})
       for (int t = 1; t < n_fast; ++t) PYGAT_X3_TILE(t, std::true_type{})
@@ -444,10 +503,20 @@ static hipError_t launch_smallk_x3(const SmallKArgs& g, int NT, dim3 grid, size_
   return hipGetLastError();
 }
 
-int try_gemm_smallk_x3(const SmallKArgs& g, int NT, dim3 grid, hipStream_t st) {
-  const size_t lds = (size_t)3 * (32 * NT) * (g.K + 8) * sizeof(uint16_t) + (g.svec ? (size_t)g.K * 8 * sizeof(float) : 0);
+int try_gemm_smallk_x3(const SmallKArgs& g_in, int NT, dim3 grid, hipStream_t st) {
+  SmallKArgs g = g_in;
+  const size_t lds = (size_t)3 * (32 * NT) * (g.K + 8) * sizeof(uint16_t) + (g.svec ? (size_t)g.K * 8 * sizeof(float) : 0) +
+                     (g.sr_a ? (size_t)32 * NT * sizeof(float) : 0);
+  // 16-byte stores of four consecutive columns: every segment starts at a multiple of 32 columns (a 32-column tile lies in one
+  // segment) and has 16-byte aligned rows
+  g.vec_out = 1;
+  for (int q = 0; q < g.out.nseg; ++q) {
+    if ((g.out.col_start[q] % 4) != 0) return 0;   // a lane's four consecutive columns lie in one segment
+    if ((g.out.col_start[q] % 32) != 0 || (g.out.ld[q] % 4) != 0 || !aligned16(g.out.ptr[q])) g.vec_out = 0;
+  }
+  g.s_vec = (g.s_out && aligned16(g.s_out) && (g.s_ld % 4) == 0 && g.sr_fp > 0 && ((32 * NT / g.sr_fp) % 4) == 0) ? 1 : 0;
   if (lds > 150 * 1024 || (g.svec && NT == 5)) return 0;   // (5 tiles + the s accumulators do not fit 256 registers)
-  static const bool generic = getenv("PYGAT_X3_GENERIC") != nullptr;   // development knob: the any-K loop for K = 64 / 128 too
+  constexpr bool generic = false;
   // s on the VALU (svec) keeps the any-K loop: the pipelined one has no registers left for its accumulators
   // (five column tiles: the pipelined K = 128 loop spills)
   const int spc = (generic || g.accumulate || g.svec || (NT == 5 && g.K == 128)) ? 0 : (g.K == 128 ? 2 : (g.K == 64 ? 1 : 0));
@@ -532,7 +601,8 @@ __global__ __launch_bounds__(256) void gemm_tn_x3_kernel(TnArgs g) {
   {                                                                                           \
     const int st__ = (STEP) < nsteps ? (STEP) : nsteps - 1;                                   \
     const int64_t k__ = kbeg + 16 * (int64_t)st__ + 2 * kp;                                   \
-    const int64_t k0__ = k__ < kend ? k__ : kend - 1, k1__ = k__ + 1 < kend ? k__ + 1 : kend - 1; \
+    int64_t k0__ = k__ < kend ? k__ : kend - 1, k1__ = k__ + 1 < kend ? k__ + 1 : kend - 1;   \
+    if (PYGAT_DIAG_K1 & 4) { k0__ &= 255; k1__ &= 255; }   /* diagnostic builds only: cache-resident operand rows */ \
     R##a0 = ld4(la + k0__ * g.lda); R##a1 = ld4(la + k1__ * g.lda);                           \
     R##b0 = ld4(lb + k0__ * g.ldb); R##b1 = ld4(lb + k1__ * g.ldb);                           \
     R##z0 = k__ < kend ? 1.f : 0.f; R##z1 = k__ + 1 < kend ? 1.f : 0.f;                       \

@@ -230,11 +230,20 @@ __device__ __forceinline__ void fwd_flush(const FwdArgs& a, const LaneCols<VEC>&
 // 9-10 VGPRs less, which is what keeps the training forward (AUX) at 5 waves per SIMD.
 // LPH > 0: lanes per head known at compile time (0: read from the shape) -- the per-edge head sums are DPP chains whose
 // length otherwise costs a scalar branch per step, six per edge.
+#ifndef PYGAT_K2_PREFETCH_ALL
+#define PYGAT_K2_PREFETCH_ALL 0   // experiment (tools/build_variant.sh): edge-record prefetch on EVERY one-chunk instantiation
+#endif
+#ifndef PYGAT_K2_PREFETCH_TRAIN
+#define PYGAT_K2_PREFETCH_TRAIN 1 // edge-record prefetch on the training forward (AUX && FAST, one chunk per lane)
+#endif
+#ifndef PYGAT_K2_HEADLINE_WAVES
+#define PYGAT_K2_HEADLINE_WAVES 4 // (round 4: 5 waves at 96 VGPRs + 12 bytes of scratch without the prefetch, 1.04 ms; 4 waves at 104
+#endif                            //  VGPRs with it, 1.00 ms -- same box, gpurun_out r4a; the prefetch at 5 waves spills 24 bytes: 1.025)
 #ifndef PYGAT_K2_NARROW_U
 #define PYGAT_K2_NARROW_U 4   // (8 was measured: 0.32 -> 0.30 ms at one head of 16, 140 registers)
 #endif
 template <int LPR, int VEC, bool V2, bool AUX, bool FAST, int LPH = 0, int CR = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((AUX && FAST && VEC == 1 && LPR > 8) ? 5 : 1))) void gat_fwd_kernel(FwdArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((AUX && FAST && VEC == 1 && LPR > 8) ? PYGAT_K2_HEADLINE_WAVES : 1))) void gat_fwd_kernel(FwdArgs a) {
   constexpr int EPW = 64 / LPR;
   // Narrow rows (LPR <= 8: at most 32 floats -- one or two 16-float heads, the shard of an 8- or 4-GPU head-parallel run):
   // a gather is one or two sectors, a wave carries 8-16 slots and the whole grid is ~20 waves per SIMD, so the kernel is
@@ -242,6 +251,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((AUX && FAS
   // 60 % waiting, 3.4 waves per SIMD).  There: 8 edges per round instead of 4, and the edge records of the NEXT round
   // are fetched while this round's rows are in flight -- 1 serial round trip per 8 edges instead of 2 per 4.
   constexpr bool NARROW = (VEC == 1 && LPR <= 8);
+  constexpr bool PREF = NARROW || (PYGAT_K2_PREFETCH_ALL && VEC == 1) || (PYGAT_K2_PREFETCH_TRAIN && AUX && FAST && VEC == 1);   // edge records of the next round fetched a round ahead
   constexpr int U = (VEC == 1) ? (NARROW ? PYGAT_K2_NARROW_U : 4) : 2;
   const int lane = threadIdx.x & 63;
   const int64_t kl = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * EPW + lane / LPR;
@@ -277,8 +287,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((AUX && FAS
   RowState<VEC, AUX> st;
   st.reset();
 
-  int2 pn[NARROW ? U : 1];
-  if constexpr (NARROW) {
+  int2 pn[PREF ? U : 1];
+  if constexpr (PREF) {
 #pragma unroll
     for (int u = 0; u < U; ++u) pn[u] = rc[(e0 + u < e1) ? e0 + u : e1 - 1];
   }
@@ -286,9 +296,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((AUX && FAS
     int2 p[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if constexpr (NARROW) p[u] = pn[u];
+      if constexpr (PREF) p[u] = pn[u];
       else p[u] = rc[(e + u < e1) ? e + u : e1 - 1];
     }
+    // All U edge records are ISSUED before the first one is used.  Round 3's build of the headline instantiation had lost
+    // this: hipcc sank record 0's first use above the loads of records 1..3 and waited vmcnt(0) for it -- one more dependent
+    // memory round trip per 4 edges, K2 1.04 -> 1.11 ms on the same box (same-lease A/B, profiles/r4ab_*).
+    if constexpr (!PREF) __builtin_amdgcn_sched_barrier(0);
     float sv[U][VEC], tv[U][VEC], mk[U][VEC];
     float4 wv[U][VEC];
 #pragma unroll
@@ -314,7 +328,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((AUX && FAS
           sv[u][v] = a.s[(int64_t)p[u].x * ldh + lc.head[v]];
         }
       }
-    if constexpr (NARROW) {   // next round's edge records: in flight together with this round's rows
+    if constexpr (PREF) {   // next round's edge records: in flight together with this round's rows
 #pragma unroll
       for (int u = 0; u < U; ++u) pn[u] = rc[(e + U + u < e1) ? e + U + u : e1 - 1];
     }
@@ -547,8 +561,7 @@ static int launch_forward(const pygat_graph* g, int H, int Fo, float alpha, int 
     pick_lanes(a.rs, &lpr, &vec);
     // narrow rows (a wave carries 8-64 slots, the whole grid is a few ten waves per SIMD): one-wave work-groups, so that a
     // SIMD slot is refilled as soon as ITS wave ends instead of when the slowest of four does
-    static const int narrow_bt = [] { const char* e = getenv("PYGAT_NARROW_BLOCK"); return e ? atoi(e) : 64; }();   // development knob
-    const unsigned bt = (vec == 1 && lpr <= 8) ? (unsigned)narrow_bt : 256u;
+    const unsigned bt = (vec == 1 && lpr <= 8) ? narrow_block() : 256u;
     const unsigned blocks = (unsigned)cdiv(cdiv(nslots, 64 / lpr), bt / 64);
     const bool aux = aneg != nullptr;
     // 32-bit element offsets: the gathered table and s below 2^32 bytes
@@ -559,7 +572,7 @@ static int launch_forward(const pygat_graph* g, int H, int Fo, float alpha, int 
     PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_fwd_kernel<LPR, VEC, V2V, AUXV, FASTV>), dim3(blocks),    \
                                                       dim3(bt), 0, st, a))
     if (v2) PYGAT_FWD(true, false, false);
-    else if (aux && fast && lpr == 32 && vec == 1 && a.rs.lph == 4 && !getenv("PYGAT_K2_NO_LPH"))   // 8 heads x 16: the headline shape
+    else if (aux && fast && lpr == 32 && vec == 1 && a.rs.lph == 4)   // 8 heads x 16: the headline shape
       if (a.rs.R == 128 && a.rs.ldr == 128 && a.rs.ldh == 8 && a.rs.ldo == 128 && a.rs.Fo == 16 && a.ldwh == 128 && !(flags & PYGAT_F_SKIP))
         hipLaunchKernelGGL((gat_fwd_kernel<32, 1, false, true, true, 4, 128>), dim3(blocks), dim3(bt), 0, st, a);
       else

@@ -412,14 +412,14 @@ using namespace pygat;
 static int launch_prepare(int n, int H, int Fo, int flags, int mean_mode, const float* G, const float* y,
                           const float* sk, const float* s, const float* m, const float* Z, float* GR,
                           const float* whi, int64_t ld_whi, const float* aneg, const float* qneg, float slope, float* ds,
-                          int h_first, int h_count, void* stream);
+                          int h_first, int h_count, int head_group, void* stream);
 
 extern "C" int pygat_gat_backward_prepare(int n, int H, int Fo, int flags, int mean_mode, const float* G,
                                           const float* y, const float* sk, const float* s, const float* m,
                                           const float* Z, float* GR, const float* aneg, const float* qneg, float alpha,
-                                          float* ds, int h_first, int h_count, void* stream) {
+                                          float* ds, int h_first, int h_count, int head_group, void* stream) {
   return launch_prepare(n, H, Fo, flags, mean_mode, G, y, sk, s, m, Z, GR, nullptr, 0, aneg, qneg, alpha, ds, h_first,
-                        h_count, stream);
+                        h_count, head_group, stream);
 }
 
 /* GATv2: GRW [n x (2R + 4H)] = [Gp | (., m, 1/Z, D) | Whi], Whi copied from WW [n x 2R] */
@@ -429,13 +429,13 @@ extern "C" int pygat_gatv2_backward_prepare(int n, int H, int Fo, int flags, int
   if (!WW) { pygat::set_error("gatv2_backward_prepare: null WW"); return PYGAT_EINVAL; }
   int Fp = pygat::padded_width(Fo);
   return launch_prepare(n, H, Fo, flags, mean_mode, G, y, sk, m /* s slot unused in V2 */, m, Z, GRW, WW,
-                        2 * (int64_t)H * Fp, nullptr, nullptr, 0.f, nullptr, 0, 0, stream);
+                        2 * (int64_t)H * Fp, nullptr, nullptr, 0.f, nullptr, 0, 0, 0, stream);
 }
 
 static int launch_prepare(int n, int H, int Fo, int flags, int mean_mode, const float* G, const float* y,
                           const float* sk, const float* s, const float* m, const float* Z, float* GR,
                           const float* whi, int64_t ld_whi, const float* aneg, const float* qneg, float slope, float* ds,
-                          int h_first, int h_count, void* stream) {
+                          int h_first, int h_count, int head_group, void* stream) {
   PrepArgs a;
   const int Fp = padded_width(Fo);
   HeadRange rg;
@@ -452,6 +452,8 @@ static int launch_prepare(int n, int H, int Fo, int flags, int mean_mode, const 
                 "gat_backward_prepare: row tables must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int hg = whi ? H : head_group_fwd(rg.hr, Fp);   // kernel passes (GATv2 is not windowed)
+  const int gr_hg = head_group_arg(head_group, n, rg.hr, Fp);   // heads per window of the GR layout
+  PYGAT_REQUIRE(gr_hg > 0, "gat_backward_prepare: head_group=%d gives rows of more than 1024 floats per pass", head_group);
   for (int h0 = 0; h0 < rg.hr; h0 += hg) {
     const int hc = (rg.hr - h0 < hg) ? rg.hr - h0 : hg;
     const int gh = rg.hb + h0;                             // first head of the pass inside the level
@@ -463,7 +465,7 @@ static int launch_prepare(int n, int H, int Fo, int flags, int mean_mode, const 
     a.sk = sk ? sk + (int64_t)gh * Fp : nullptr;
     a.s = s + gh; a.m = m + gh; a.Z = Z + gh;
     a.ldgr = (int64_t)rg.hr * Fp * (whi ? 2 : 1) + 4 * rg.hr;
-    a.GR = GR; a.h0p = h0; a.gr_hg = whi ? H : head_group_bwd(n, rg.hr, Fp); a.gr_heads = rg.hr;
+    a.GR = GR; a.h0p = h0; a.gr_hg = whi ? H : gr_hg; a.gr_heads = rg.hr;
     a.whi = whi; a.ld_whi = ld_whi;
     a.aneg = aneg ? aneg + (int64_t)gh * Fp : nullptr; a.qneg = qneg ? qneg + gh : nullptr;
     a.ds = ds ? ds + gh : nullptr; a.slope = slope;
@@ -495,7 +497,7 @@ static int launch_prepare(int n, int H, int Fo, int flags, int mean_mode, const 
 
 extern "C" int pygat_gat_backward_row(const pygat_graph* g, int H, int Fo, float alpha, const float* Wh,
                                       const float* a_pad, const float* GR, const float* att_mask, float* ds,
-                                      void* part, int h_first, int h_count, void* stream) {
+                                      void* part, int h_first, int h_count, int head_group, void* stream) {
   RowArgs a;
   int rc = check_graph(g, &a.g);
   if (rc) return rc;
@@ -507,7 +509,8 @@ extern "C" int pygat_gat_backward_row(const pygat_graph* g, int H, int Fo, float
   PYGAT_REQUIRE(aligned16(Wh) && aligned16(GR) && aligned16(a_pad), "gat_backward_row: row tables must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int64_t nslots = num_slots(a.g);
-  const int hg = head_group_bwd(a.g.n, rg.hr, Fp);
+  const int hg = head_group_arg(head_group, a.g.n, rg.hr, Fp);
+  PYGAT_REQUIRE(hg > 0, "gat_backward_row: head_group=%d gives rows of more than 1024 floats per pass", head_group);
   for (int h0 = 0; h0 < rg.hr; h0 += hg) {
     const int hc = (rg.hr - h0 < hg) ? rg.hr - h0 : hg;
     const int gh = rg.hb + h0;

@@ -29,12 +29,26 @@ struct ColArgs {
   float* dWh;
   float* dt;
   float* part;  // [2 * nslots][R + 2H]: acc[R], dt[H]
+  float* da_part;  // DA instantiations: [work-groups][2 R] = (sum ds_j Wh_j | sum dt_j Wh_j) over the rows the work-group finished
 };
 
+#ifndef PYGAT_K4_DA_ATOMIC
+#define PYGAT_K4_DA_ATOMIC 0
+#endif
+__device__ __forceinline__ void lds_add(float* p, float v) {   // ds_add_f32 without a return value
+  (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // CR > 0 (with LPH > 0, VEC == 1): dense row tables of CR floats, heads of 4 LPH columns -- constant strides
-template <int VEC, int LPH = 0, int CR = 0>
+// DA (round 4): the attention-vector gradient da_src = sum_j ds_j Wh_j, da_dst = sum_j dt_j Wh_j (autograd of layers.py:60-61,
+// a.mm(edge_h) layers.py:144) taken HERE, where row j finishes with dt_j just formed, ds_j loaded for the dWh term and Wh_j in
+// L1 from the row's edges -- instead of by a pass of its own that streams Wh, ds and dt again (pygat_a_grad: 0.6 GB, 0.12 ms
+// at config 5).  The 8 running sums of a lane live in LDS (da_lds[0], da_lds[da_stride]: its own two float4s, no other lane
+// touches them), not in registers: the kernel sits at 122 of the 128 VGPRs that keep four waves per SIMD.
+template <int VEC, int LPH = 0, int CR = 0, bool DA = false>
 __device__ __forceinline__ void col_finish(const ColArgs& a, const LaneCols<VEC>& lc, int j,
-                                           const float4 (&acc)[VEC], const float (&dt)[VEC]) {
+                                           const float4 (&acc)[VEC], const float (&dt)[VEC], float4* da_lds = nullptr,
+                                           int da_stride = 0) {
   const int Fp = CR ? 4 * LPH : a.rs.Fp;
   const int64_t ldr = CR ? CR : a.rs.ldr, ldh = CR ? CR / (4 * (LPH ? LPH : 1)) : a.rs.ldh;
 #pragma unroll
@@ -44,20 +58,50 @@ __device__ __forceinline__ void col_finish(const ColArgs& a, const LaneCols<VEC>
     const float dsj = a.ds ? a.ds[(int64_t)j * ldh + h] : 0.f;
     const float4 as = ld4(a.a_pad + (int64_t)h * 2 * Fp + f0);
     const float4 ad = ld4(a.a_pad + (int64_t)h * 2 * Fp + Fp + f0);
+    // DA: Wh_j is fetched HERE, with the other loads of the flush and before its stores.  vmcnt counts loads and stores
+    // together in issue order: issued behind the dWh / dt stores, the wait for this load was a wait for their acknowledgement
+    // from HBM -- K4 1.21 -> 2.12 ms in the first build of this path (gpurun_out r4b).
+    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (DA) w = ld4(a.Wh + (int64_t)j * ldr + co);
     float4 o;
     o.x = acc[v].x + dsj * as.x + dt[v] * ad.x;
     o.y = acc[v].y + dsj * as.y + dt[v] * ad.y;
     o.z = acc[v].z + dsj * as.z + dt[v] * ad.z;
     o.w = acc[v].w + dsj * as.w + dt[v] * ad.w;
+    if constexpr (DA) {
+      static_assert(VEC == 1, "da accumulation: one chunk per lane");
+      // Read-modify-write of the lane's own two float4s, ONE AFTER THE OTHER (the fence keeps hipcc from fetching both up
+      // front: with both in flight the kernel's peak is 130 VGPRs = three waves per SIMD instead of four).  Only this lane
+      // touches these eight words, in program order: the sums are as reproducible as register accumulators.
+      // (ds_add_f32 instead -- one product register at a time, 128 VGPRs -- was measured: LDS float atomics retire about
+      // one lane per clock, K4 1.20 -> 2.14 ms; gpurun_out r4b / r4c.)
+#if PYGAT_K4_DA_ATOMIC
+      float* xs = reinterpret_cast<float*>(da_lds);
+      float* ys = reinterpret_cast<float*>(da_lds + da_stride);
+      lds_add(xs + 0, dsj * w.x); lds_add(xs + 1, dsj * w.y); lds_add(xs + 2, dsj * w.z); lds_add(xs + 3, dsj * w.w);
+      lds_add(ys + 0, dt[v] * w.x); lds_add(ys + 1, dt[v] * w.y); lds_add(ys + 2, dt[v] * w.z); lds_add(ys + 3, dt[v] * w.w);
+#else
+      {
+        float4 x = da_lds[0];
+        x.x = fmaf(dsj, w.x, x.x); x.y = fmaf(dsj, w.y, x.y); x.z = fmaf(dsj, w.z, x.z); x.w = fmaf(dsj, w.w, x.w);
+        da_lds[0] = x;
+      }
+      {
+        float4 y = da_lds[da_stride];
+        y.x = fmaf(dt[v], w.x, y.x); y.y = fmaf(dt[v], w.y, y.y); y.z = fmaf(dt[v], w.z, y.z); y.w = fmaf(dt[v], w.w, y.w);
+        da_lds[da_stride] = y;
+      }
+#endif
+    }
     st4(a.dWh + (int64_t)j * ldr + co, o);
     if (((co >> 2) & (a.rs.lph - 1)) == 0) a.dt[(int64_t)j * ldh + h] = dt[v];
   }
 }
 
-template <int VEC, int LPH = 0, int CR = 0>
+template <int VEC, int LPH = 0, int CR = 0, bool DA = false>
 __device__ __forceinline__ void col_flush(const ColArgs& a, const LaneCols<VEC>& lc, int64_t k, int j,
                                           bool is_head, bool is_tail, const float4 (&acc)[VEC],
-                                          const float (&dt)[VEC]) {
+                                          const float (&dt)[VEC], float4* da_lds = nullptr, int da_stride = 0) {
   if (is_head || is_tail) {
     float* p = a.part + (2 * k + (is_head ? 0 : 1)) * (int64_t)(a.rs.R + 2 * a.rs.H);
 #pragma unroll
@@ -67,7 +111,7 @@ __device__ __forceinline__ void col_flush(const ColArgs& a, const LaneCols<VEC>&
       if (((lc.cofs[v] >> 2) & (a.rs.lph - 1)) == 0) p[a.rs.R + lc.head[v]] = dt[v];
     }
   } else {
-    col_finish<VEC, LPH, CR>(a, lc, j, acc, dt);
+    col_finish<VEC, LPH, CR, DA>(a, lc, j, acc, dt, da_lds, da_stride);
   }
 }
 
@@ -89,16 +133,21 @@ __device__ __forceinline__ T pick(const T (&x)[U], int u) {
 // The lanes of a head all hold dz for the U edges of a round: lane (u mod S) of the head stores edge u.
 // LPH > 0: lanes per head known at compile time (0: read from the shape): the two head sums per edge are DPP chains
 // whose length otherwise costs a scalar branch per step.
-template <int LPR, int VEC, bool WRITE_DZ, int LPH = 0, int CR = 0>
-__global__ __launch_bounds__(256) void gat_bwd_col_kernel(ColArgs a) {
-  constexpr int EPW = 64 / LPR;
+#ifndef PYGAT_K4_DA_WAVES
+#define PYGAT_K4_DA_WAVES 4         // minimum waves per SIMD asked of the dense 8 x 16 instantiation that takes da along
+#endif
+#ifndef PYGAT_K4_HEADLINE_WAVES
+#define PYGAT_K4_HEADLINE_WAVES 1   // (experiment: minimum waves per SIMD asked of the CR > 0 instantiation)
+#endif
+template <int LPR, int VEC, bool WRITE_DZ, int LPH, int CR, bool DA>
+__device__ __forceinline__ void col_walk(const ColArgs& a, const int64_t k, float4* da_lds, int da_stride) {
   // narrow rows: next round's edge records prefetched (see gat_fwd_kernel; 8 edges per round were measured too: two rows
   // per edge in registers leave 2 waves per SIMD at U = 8, 0.30 -> 0.35 ms at one head of 16)
-  constexpr bool NARROW = (VEC == 1 && LPR <= 8);
+#ifndef PYGAT_K4_PREFETCH_ALL
+#define PYGAT_K4_PREFETCH_ALL 0   // experiment (tools/build_variant.sh): edge-record prefetch on one-chunk rows of any width
+#endif
+  constexpr bool NARROW = (VEC == 1 && LPR <= 8) || (PYGAT_K4_PREFETCH_ALL && VEC == 1);
   constexpr int U = (VEC == 1) ? 4 : 2;
-  const int lane = threadIdx.x & 63;
-  const int64_t k = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * EPW + lane / LPR;
-  if (k >= num_slots(a.g)) return;
   int64_t e0, e1;
   int r_first;
   bool head_partial, tail_known = false, tail_flag = false;
@@ -192,7 +241,7 @@ __global__ __launch_bounds__(256) void gat_bwd_col_kernel(ColArgs a) {
     for (int u = 0; u < U; ++u) {
       if (e + u < e1) {
         if (p[u].x != cur) {
-          col_flush<VEC, LPH, CR>(a, lc, k, cur, cur == r_first && head_partial, false, acc, dt);
+          col_flush<VEC, LPH, CR, DA>(a, lc, k, cur, cur == r_first && head_partial, false, acc, dt, da_lds, da_stride);
           cur = p[u].x;
 #pragma unroll
           for (int v = 0; v < VEC; ++v) { acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); dt[v] = 0.f; }
@@ -207,7 +256,36 @@ __global__ __launch_bounds__(256) void gat_bwd_col_kernel(ColArgs a) {
     }
   }
   const bool tail_partial = tail_known ? tail_flag : a.g.rowptr[cur + 1] > e1;
-  col_flush<VEC, LPH, CR>(a, lc, k, cur, cur == r_first && head_partial, tail_partial, acc, dt);
+  col_flush<VEC, LPH, CR, DA>(a, lc, k, cur, cur == r_first && head_partial, tail_partial, acc, dt, da_lds, da_stride);
+}
+
+template <int LPR, int VEC, bool WRITE_DZ, int LPH = 0, int CR = 0, bool DA = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CR > 0 ? (DA ? PYGAT_K4_DA_WAVES : PYGAT_K4_HEADLINE_WAVES) : 1))) void gat_bwd_col_kernel(ColArgs a) {
+  constexpr int EPW = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int64_t k = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * EPW + lane / LPR;
+  if constexpr (!DA) {
+    if (k >= num_slots(a.g)) return;
+    col_walk<LPR, VEC, WRITE_DZ, LPH, CR, false>(a, k, nullptr, 0);
+  } else {
+    extern __shared__ __attribute__((aligned(16))) float4 da_sm[];   // [2][blockDim.x]: (src | dst) running sums, one pair per lane
+    const int nt = (int)blockDim.x;
+    float4* mine = da_sm + threadIdx.x;
+    mine[0] = make_float4(0.f, 0.f, 0.f, 0.f); mine[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < num_slots(a.g)) col_walk<LPR, VEC, WRITE_DZ, LPH, CR, true>(a, k, mine, nt);
+    __syncthreads();
+    // the work-group's lane groups added in a fixed order: thread (which, c) owns float4 c of the (src | dst) half
+    if ((int)threadIdx.x < 2 * LPR) {
+      const int which = (int)threadIdx.x / LPR, c = (int)threadIdx.x % LPR;
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int g = 0; g < nt / LPR; ++g) {
+        const float4 x = da_sm[which * nt + g * LPR + c];
+        t.x += x.x; t.y += x.y; t.z += x.z; t.w += x.w;
+      }
+      const int R = CR ? CR : a.rs.R;
+      if (4 * c < R) st4(a.da_part + (int64_t)blockIdx.x * 2 * R + which * R + 4 * c, t);
+    }
+  }
 }
 
 // Fix-up of cut rows (same scheme as gat_fwd_fixup_kernel): a work-group screens FIX_SCREEN slots, the
@@ -393,10 +471,18 @@ __global__ __launch_bounds__(64 * FIX_LIST_WAVES) void gat_bwd_col_fixup_list_ke
 
 using namespace pygat;
 
+extern "C" size_t pygat_gat_backward_col_da_bytes(const pygat_graph* gT, int H, int Fo, int head_group) {
+  GraphDev g;
+  if (!gT || check_graph(gT, &g) != PYGAT_OK) return 0;
+  const int Fp = padded_width(Fo);
+  if (H <= 0 || Fp <= 0) return 0;
+  return (size_t)col_da_blocks(g, H, Fp, head_group_arg(head_group, g.n, H, Fp), nullptr) * 2 * (size_t)H * Fp * sizeof(float);
+}
+
 extern "C" int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm_t, int H, int Fo, float alpha,
                                       const float* Wh, const float* a_pad, const float* GR,
                                       const float* att_mask, const float* ds, float* dWh, float* dt, float* dz_t,
-                                      void* part, int h_first, int h_count, void* stream) {
+                                      void* part, float* da_part, int h_first, int h_count, int head_group, void* stream) {
 
   ColArgs a;
   int rc = check_graph(gT, &a.g);
@@ -411,9 +497,16 @@ extern "C" int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm
   PYGAT_REQUIRE(!att_mask || perm_t, "gat_backward_col: an attention mask needs perm_t (mask is in forward edge order)");
   PYGAT_REQUIRE(aligned16(Wh) && aligned16(GR) && aligned16(dWh) && aligned16(a_pad) && aligned16(part),
                 "gat_backward_col: row tables must be 16-byte aligned");
+  const int hg = head_group_arg(head_group, a.g.n, rg.hr, Fp);
+  PYGAT_REQUIRE(hg > 0, "gat_backward_col: head_group=%d gives rows of more than 1024 floats per pass", head_group);
+  if (da_part) {
+    PYGAT_REQUIRE(ds && rg.hr == H && aligned16(da_part) && col_da_blocks(a.g, H, Fp, hg, nullptr) > 0,
+                  "gat_backward_col: da_part needs ds, all heads in one pass of one-chunk rows and a cut-row list "
+                  "(pygat_gat_backward_col_da_bytes() == 0 otherwise)");
+  }
+  a.da_part = da_part;
   hipStream_t st = (hipStream_t)stream;
   const int64_t nslots = num_slots(a.g);
-  const int hg = head_group_bwd(a.g.n, rg.hr, Fp);
   for (int h0 = 0; h0 < rg.hr; h0 += hg) {
     const int hc = (rg.hr - h0 < hg) ? rg.hr - h0 : hg;
     const int gh = rg.hb + h0;
@@ -426,18 +519,30 @@ extern "C" int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm
     pick_lanes(a.rs, &lpr, &vec);
     // narrow rows (a wave carries 8-64 slots, the whole grid is a few ten waves per SIMD): one-wave work-groups, so that a
     // SIMD slot is refilled as soon as ITS wave ends instead of when the slowest of four does
-    static const int narrow_bt = [] { const char* e = getenv("PYGAT_NARROW_BLOCK"); return e ? atoi(e) : 64; }();   // development knob
-    const unsigned bt = (vec == 1 && lpr <= 8) ? (unsigned)narrow_bt : 256u;
+    const unsigned bt = (vec == 1 && lpr <= 8) ? (unsigned)narrow_block() : 256u;
     const unsigned blocks = (unsigned)cdiv(cdiv(nslots, 64 / lpr), bt / 64);
+    const size_t da_lds = da_part ? 2 * (size_t)bt * sizeof(float4) : 0;
     if (dz_t) {
       PYGAT_DISPATCH_LANES(lpr, vec,
                            hipLaunchKernelGGL((gat_bwd_col_kernel<LPR, VEC, true>), dim3(blocks), dim3(bt), 0, st, a));
     } else if (lpr == 32 && vec == 1 && a.rs.lph == 4) {   // 8 heads x 16: the headline shape
-      if (a.rs.R == 128 && a.rs.ldr == 128 && a.rs.ldh == 8 && a.ldgr == 160 && a.rs.H == 8 && !att_mask &&
-          (int64_t)a.g.n * 160 * 4 < ((int64_t)1 << 32) && !getenv("PYGAT_K4_NO_CONST"))   // (development knob)
+      const bool dense = a.rs.R == 128 && a.rs.ldr == 128 && a.rs.ldh == 8 && a.ldgr == 160 && a.rs.H == 8 && !att_mask &&
+                         (int64_t)a.g.n * 160 * 4 < ((int64_t)1 << 32);
+      if (dense && da_part)
+        hipLaunchKernelGGL((gat_bwd_col_kernel<32, 1, false, 4, 128, true>), dim3(blocks), dim3(bt), da_lds, st, a);
+      else if (dense)
         hipLaunchKernelGGL((gat_bwd_col_kernel<32, 1, false, 4, 128>), dim3(blocks), dim3(bt), 0, st, a);
+      else if (da_part)
+        hipLaunchKernelGGL((gat_bwd_col_kernel<32, 1, false, 4, 0, true>), dim3(blocks), dim3(bt), da_lds, st, a);
       else
         hipLaunchKernelGGL((gat_bwd_col_kernel<32, 1, false, 4>), dim3(blocks), dim3(bt), 0, st, a);
+    } else if (da_part) {   // (vec == 1: checked above)
+      switch (lpr) {
+#define PYGAT_COL_DA(L) case L: hipLaunchKernelGGL((gat_bwd_col_kernel<L, 1, false, 0, 0, true>), dim3(blocks), dim3(bt), da_lds, st, a); break;
+        PYGAT_COL_DA(1) PYGAT_COL_DA(2) PYGAT_COL_DA(4) PYGAT_COL_DA(8) PYGAT_COL_DA(16) PYGAT_COL_DA(32)
+        default: hipLaunchKernelGGL((gat_bwd_col_kernel<64, 1, false, 0, 0, true>), dim3(blocks), dim3(bt), da_lds, st, a); break;
+#undef PYGAT_COL_DA
+      }
     } else {
       PYGAT_DISPATCH_LANES(lpr, vec,
                            hipLaunchKernelGGL((gat_bwd_col_kernel<LPR, VEC, false>), dim3(blocks), dim3(bt), 0, st, a));

@@ -120,6 +120,54 @@ __global__ __launch_bounds__(256) void a_grad_final_kernel(RowShape rs, int nblo
   if (ok && q == 0) da[idx] = acc;
 }
 
+// da when the column pass took the sums along (pygat_gat_backward_col with da_part): its per-work-group records [2 R] and the
+// rows it left to its fix-up launch (the cut-row list: their ds / dt / Wh rows are read here, a few ten thousand rows) are
+// folded into gridDim.x slabs in a fixed order; a_grad_final_kernel adds the slabs.  TPR threads (power of two >= R / 2)
+// own the R / 2 float4s of a record, 256 / TPR records or rows are in flight per round.
+__global__ __launch_bounds__(256) void a_grad_fold_kernel(RowShape rs, int64_t nrec, const float* __restrict__ da_part, int n_cut,
+                                                          const int32_t* __restrict__ cut, const float* __restrict__ Wh,
+                                                          const float* __restrict__ ds, const float* __restrict__ dt,
+                                                          float* __restrict__ ws) {
+  const int q4n = rs.R / 2;   // float4s per record
+  int tpr = 1;
+  while (tpr < q4n) tpr <<= 1;
+  const int nsub = 256 / tpr, q4 = threadIdx.x % tpr, sub = threadIdx.x / tpr;
+  const bool valid = q4 < q4n;
+  const int qq = valid ? q4 : 0;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int64_t stride = (int64_t)gridDim.x * nsub;
+  int64_t r = (int64_t)blockIdx.x * nsub + sub;
+  for (; r + 3 * stride < nrec; r += 4 * stride) {
+    float4 x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x[u] = ld4(da_part + (r + u * stride) * 2 * rs.R + 4 * qq);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
+  }
+  for (; r < nrec; r += stride) {
+    const float4 x = ld4(da_part + r * 2 * rs.R + 4 * qq);
+    acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+  }
+  const int which = qq >= rs.R / 4, col = 4 * (qq - which * (rs.R / 4)), h = col >> rs.fp_shift;
+  const float* sc = which ? dt : ds;
+  for (int64_t c = (int64_t)blockIdx.x * nsub + sub; c < n_cut; c += stride) {
+    const int64_t row = cut[3 * c + 1];
+    const float4 w = ld4(Wh + row * rs.ldr + col);
+    const float v = sc[row * rs.ldh + h];
+    acc.x = fmaf(v, w.x, acc.x); acc.y = fmaf(v, w.y, acc.y); acc.z = fmaf(v, w.z, acc.z); acc.w = fmaf(v, w.w, acc.w);
+  }
+  __shared__ float4 sm[256];
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  if (sub == 0 && valid) {
+    for (int g = 1; g < nsub; ++g) {   // fixed order: deterministic
+      const float4 x = sm[g * tpr + q4];
+      acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+    }
+    st4(ws + (int64_t)blockIdx.x * 2 * rs.R + 4 * q4, acc);
+  }
+}
+
 // s, t from a (masked) Wh table: one thread per (node, head).  wh_mask != nullptr: the Wh dropout (layers.py:37,136) is applied
 // here, in place, instead of by a launch of its own
 __global__ __launch_bounds__(256) void attn_scores_kernel(int n, int H, int Fp, float* __restrict__ Wh,
@@ -267,6 +315,32 @@ extern "C" int pygat_a_grad(int n, int H, int Fo, const float* Wh, const float* 
                        (const float*)ws, da + (int64_t)gh * 2 * Fo);
     PYGAT_CHECK_LAUNCH("a_grad");
   }
+  return PYGAT_OK;
+}
+
+extern "C" int pygat_a_grad_fold(const pygat_graph* gT, int H, int Fo, const float* Wh, const float* ds, const float* dt,
+                                 const float* da_part, float* da, void* ws, int head_group, void* stream) {
+  GraphDev g;
+  int rc = check_graph(gT, &g);
+  if (rc) return rc;
+  const int Fp = padded_width(Fo);
+  PYGAT_REQUIRE(H > 0 && Fp > 0, "a_grad_fold: unsupported H=%d F'=%d", H, Fo);
+  const int hg = head_group_arg(head_group, g.n, H, Fp);
+  const int64_t nrec = hg > 0 ? col_da_blocks(g, H, Fp, hg, nullptr) : 0;
+  PYGAT_REQUIRE(nrec > 0, "a_grad_fold: the column pass leaves no da records for this level (pygat_gat_backward_col_da_bytes() == 0)");
+  PYGAT_REQUIRE(Wh && ds && dt && da_part && da && ws && aligned16(Wh) && aligned16(da_part) && aligned16(ws), "a_grad_fold: bad arguments");
+  RowShape rs;
+  PYGAT_REQUIRE(make_window_shape(H, Fo, H, &rs), "a_grad_fold: unsupported H=%d F'=%d", H, Fo);
+  hipStream_t st = (hipStream_t)stream;
+  int tpr = 1;
+  while (tpr < rs.R / 2) tpr <<= 1;
+  const int nsub = 256 / tpr;
+  int64_t nb = cdiv(nrec + g.n_cut, (int64_t)nsub * 8);
+  const int nblocks = nb > AG_BLOCKS ? AG_BLOCKS : (nb < 1 ? 1 : (int)nb);
+  hipLaunchKernelGGL(a_grad_fold_kernel, dim3(nblocks), dim3(256), 0, st, rs, nrec, da_part, g.n_cut, g.cut, Wh, ds, dt, (float*)ws);
+  hipLaunchKernelGGL(a_grad_final_kernel, dim3((unsigned)cdiv(rs.H * 2 * rs.Fo * 8, 256)), dim3(256), 0, st, rs, nblocks,
+                     (const float*)ws, da);
+  PYGAT_CHECK_LAUNCH("a_grad_fold");
   return PYGAT_OK;
 }
 

@@ -199,27 +199,27 @@ class GATLevelDropoutFn(torch.autograd.Function):
             rowlocal = ctx.flavour == "rowlocal"
             check(lib.pygat_gat_backward_prepare(L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(), y.data_ptr(),
                                                  _ptr(Sk), s.data_ptr(), m.data_ptr(), Z.data_ptr(), GR.data_ptr(),
-                                                 _ptr(aneg), _ptr(qneg), ctx.alpha, ds.data_ptr() if rowlocal else None, 0, 0, st),
+                                                 _ptr(aneg), _ptr(qneg), ctx.alpha, ds.data_ptr() if rowlocal else None, 0, 0, L.hg, st),
                   "gat_backward_prepare")
             two_gather = ctx.flavour != "rowsum"       # below: does a_grad still have to finish dWh += ds a_src ?
             if rowlocal:       # ds known from the forward's alpha-branch shares (ops.BACKWARD_FLAVOUR)
                 check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), graph.perm_t.data_ptr(), H, Fo, ctx.alpha,
                                                  Wh.data_ptr(), a_pad.data_ptr(), GR.data_ptr(), matt.data_ptr(),
-                                                 ds.data_ptr(), dWh.data_ptr(), dt.data_ptr(), None, part.data_ptr(), 0, 0, st),
+                                                 ds.data_ptr(), dWh.data_ptr(), dt.data_ptr(), None, part.data_ptr(), None, 0, 0, L.hg, st),
                       "gat_backward_col")
             elif two_gather:
                 check(lib.pygat_gat_backward_row(graph.fwd.ref(L.ts), H, Fo, ctx.alpha, Wh.data_ptr(), a_pad.data_ptr(),
-                                                 GR.data_ptr(), matt.data_ptr(), ds.data_ptr(), part.data_ptr(), 0, 0, st),
+                                                 GR.data_ptr(), matt.data_ptr(), ds.data_ptr(), part.data_ptr(), 0, 0, L.hg, st),
                       "gat_backward_row")
                 check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), graph.perm_t.data_ptr(), H, Fo, ctx.alpha,
                                                  Wh.data_ptr(), a_pad.data_ptr(), GR.data_ptr(), matt.data_ptr(),
-                                                 ds.data_ptr(), dWh.data_ptr(), dt.data_ptr(), None, part.data_ptr(), 0, 0, st),
+                                                 ds.data_ptr(), dWh.data_ptr(), dt.data_ptr(), None, part.data_ptr(), None, 0, 0, L.hg, st),
                       "gat_backward_col")
             else:      # K4 writes dz per transposed edge, the row sums come from those records (ops.GATLevelFn)
                 dz_t = torch.empty(graph.nnz, H, dtype=f32, device=dev)
                 check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), graph.perm_t.data_ptr(), H, Fo, ctx.alpha,
                                                  Wh.data_ptr(), a_pad.data_ptr(), GR.data_ptr(), matt.data_ptr(),
-                                                 None, dWh.data_ptr(), dt.data_ptr(), dz_t.data_ptr(), part.data_ptr(), 0, 0, st),
+                                                 None, dWh.data_ptr(), dt.data_ptr(), dz_t.data_ptr(), part.data_ptr(), None, 0, 0, L.hg, st),
                       "gat_backward_col")
                 check(lib.pygat_gat_backward_rowsum(graph.fwd.ref(L.ts), graph.perm_f.data_ptr(), H, Fo, dz_t.data_ptr(),
                                                     ds.data_ptr(), part.data_ptr(), 0, 0, st), "gat_backward_rowsum")

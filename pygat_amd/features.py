@@ -10,6 +10,7 @@ and hidden levels keep the dense GEMMs.  PYGAT_SPARSE_X=0 switches the whole pat
 """
 from __future__ import annotations
 
+import collections
 import os
 import weakref
 from typing import Optional
@@ -58,27 +59,63 @@ class SparseFeatures:
         self.density = self.nnz / max(1, n * fin)
 
 
-_cache: "dict" = {}
+CACHE_ENTRIES = 64          # per cache; least recently used entries leave first (a dead tensor's entry when its key is reused)
+MIN_PROBE_COLUMNS = 128     # narrower inputs are never probed: they are dense features (PPI: 50), not bags of words
 
 
-def as_sparse_features(x: torch.Tensor, out_columns: int) -> Optional[SparseFeatures]:
-    """The cached SparseFeatures of `x` if the sparse kernels should take its projection, else None."""
-    if not ENABLED or not isinstance(x, torch.Tensor) or not x.is_cuda or x.requires_grad or x.dim() != 2 \
-            or x.dtype != torch.float32 or out_columns > MAX_COLUMNS:
-        return None
+class _LRU(collections.OrderedDict):
+    """key -> (weakref of the tensor, value); a hit moves the entry to the young end, an insert beyond CACHE_ENTRIES drops the
+    OLDEST one only (rounds 2-3 cleared the whole cache at 17 entries: a loop over 17 feature tensors missed every time)."""
+
+    def lookup(self, key, x):
+        hit = self.get(key)
+        if hit is not None and hit[0]() is x:
+            self.move_to_end(key)
+            return True, hit[1]
+        return False, None
+
+    def insert(self, key, x, value):
+        self[key] = (weakref.ref(x), value)
+        self.move_to_end(key)
+        while len(self) > CACHE_ENTRIES:
+            self.popitem(last=False)
+
+
+_cache = _LRU()
+
+
+def prepare_features(x: torch.Tensor) -> Optional[SparseFeatures]:
+    """The EXPLICIT form of what as_sparse_features does on a model's first forward: extract (and cache) the sparse pattern
+    of an input feature tensor, outside any timed region or stream capture.  Returns the SparseFeatures, or None when the
+    tensor is too dense for the sparse kernels.  Costs one host sync (the density probe) and a few sort / scan launches."""
     key = (x.data_ptr(), tuple(x.shape), x._version, str(x.device))
-    hit = _cache.get(key)
-    if hit is not None and hit[0]() is x:
-        return hit[1]
-    density = float(torch.count_nonzero(x)) / max(1, x.numel())      # one device sync per feature tensor, then cached
+    ok, val = _cache.lookup(key, x)
+    if ok:
+        return val
+    density = float(torch.count_nonzero(x)) / max(1, x.numel())      # the one device sync per feature tensor
     xs = SparseFeatures(x) if 0.0 < density <= MAX_DENSITY else None
-    if len(_cache) > 16:
-        _cache.clear()
-    _cache[key] = (weakref.ref(x), xs)
+    _cache.insert(key, x, xs)
     return xs
 
 
-_pad_cache = {}
+def as_sparse_features(x: torch.Tensor, out_columns: int) -> Optional[SparseFeatures]:
+    """The cached SparseFeatures of `x` if the sparse kernels should take its projection, else None.
+    A tensor seen for the first time is probed (prepare_features: one host sync) -- unless it is too narrow to be a bag of
+    words (a per-batch loop over fresh dense feature tensors, train_ppi.py:118, is never synchronised), or a stream capture
+    is in progress (a sync would abort it: the level then runs dense; call prepare_features(x) before capturing)."""
+    if not ENABLED or not isinstance(x, torch.Tensor) or not x.is_cuda or x.requires_grad or x.dim() != 2 \
+            or x.dtype != torch.float32 or out_columns > MAX_COLUMNS or x.shape[1] < MIN_PROBE_COLUMNS:
+        return None
+    key = (x.data_ptr(), tuple(x.shape), x._version, str(x.device))
+    ok, val = _cache.lookup(key, x)
+    if ok:
+        return val
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    return prepare_features(x)
+
+
+_pad_cache = _LRU()
 
 
 def padded_columns(x: torch.Tensor, multiple: int) -> torch.Tensor:
@@ -90,12 +127,10 @@ def padded_columns(x: torch.Tensor, multiple: int) -> torch.Tensor:
     if cols == fin and x.dtype == torch.float32 and x.is_contiguous():
         return x
     key = (x.data_ptr(), tuple(x.shape), x._version, str(x.device), str(x.dtype), multiple)
-    hit = _pad_cache.get(key)
-    if hit is not None and hit[0]() is x:
-        return hit[1]
+    ok, val = _pad_cache.lookup(key, x)
+    if ok:
+        return val
     xp = torch.zeros(x.shape[0], cols, dtype=torch.float32, device=x.device)
     xp[:, :fin] = x
-    if len(_pad_cache) > 16:
-        _pad_cache.clear()
-    _pad_cache[key] = (weakref.ref(x), xp)
+    _pad_cache.insert(key, x, xp)
     return xp

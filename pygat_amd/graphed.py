@@ -128,11 +128,16 @@ class FusedEpoch:
     """The reference's epoch (train.py:151-179: training step = forward, loss on the training subset, backward,
     optimiser step; then an eval-mode forward + loss) captured into ONE HIP graph.
 
-    model: pygat_amd.GAT (or any module over the HIP levels); optimizer: a torch optimiser built with
-    `capturable=True` (Adam / AdamW) so that its step counters live on the device; `loss_fn(out) -> scalar`
-    closes over labels and index sets; `eval_fn(out) -> tensor` (default: loss_fn) is evaluated on the eval-mode
+    model: pygat_amd.GAT (or any module over the HIP levels); optimizer: pygat_amd.Adam (its step counter is a device
+    integer the kernel advances itself) or a torch optimiser built with `capturable=True` (Adam / AdamW); `loss_fn(out) ->
+    scalar` closes over labels and index sets; `eval_fn(out) -> tensor` (default: loss_fn) is evaluated on the eval-mode
     output, `evaluate=False` drops that half (train.py's --fastmode).  Dropout masks differ on every replay.
-    The `warmup` epochs run before the capture are real epochs: they train the model."""
+    The `warmup` epochs run before the capture are real epochs: they train the model.
+
+    What the capture FREEZES (run() raises instead of silently replaying stale values): the input features `x` -- a first
+    level on sparse features bakes x's non-zero pattern and values into the graph, so x must not be modified in place
+    afterwards (x._version is checked) -- and the optimiser's hyper-parameters, which reach the kernels as launch arguments
+    (a changed lr / weight_decay / betas / eps, e.g. by an LR scheduler, needs a new FusedEpoch)."""
 
     def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, x: torch.Tensor, graph,
                  loss_fn: Callable[[torch.Tensor], torch.Tensor], eval_fn: Optional[Callable] = None,
@@ -153,6 +158,11 @@ class FusedEpoch:
                 with torch.cuda.graph(self.g):
                     self.static = self._eager_epoch()
         self.epochs = 0
+        self._x_version = x._version
+        self._hyper = self._hyper_now()
+
+    def _hyper_now(self):
+        return [tuple((k, grp[k]) for k in ("lr", "weight_decay", "betas", "eps") if k in grp) for grp in self.opt.param_groups]
 
     def _eager_epoch(self):
         self.model.train()
@@ -174,6 +184,12 @@ class FusedEpoch:
         read them (`.item()`, `.clone()`) before the next call if they are to be kept."""
         if self.g is None:
             return self._eager_epoch()
+        if self.x._version != self._x_version:
+            raise RuntimeError("FusedEpoch: x was modified in place after the capture; the captured graph holds the old "
+                               "features (and, for a sparse first level, their non-zero pattern).  Build a new FusedEpoch.")
+        if self._hyper_now() != self._hyper:
+            raise RuntimeError("FusedEpoch: the optimiser's hyper-parameters changed after the capture; they are launch "
+                               "arguments of the captured kernels and would not take effect.  Build a new FusedEpoch.")
         self.g.replay()
         self.epochs += 1
         return self.static

@@ -58,11 +58,25 @@ class EluLogSoftmaxNLL:
             raise RuntimeError("pygat_amd: EluLogSoftmaxNLL needs GPU tensors; there is no CPU path")
         self.n = int(n)
         idx = idx.long()
+        # one-time host-side checks (F.nll_loss raises on these; the kernels would read out of bounds or drop rows silently)
+        if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= self.n):
+            raise IndexError(f"EluLogSoftmaxNLL: idx outside [0, {self.n})")
+        if labels.numel() < self.n:
+            raise ValueError(f"EluLogSoftmaxNLL: {labels.numel()} labels for {self.n} rows")
         self.weight = (torch.bincount(idx, minlength=self.n).float() / max(1, idx.numel())).contiguous()
         self.label = labels.to(torch.int32).contiguous()
+        self._label_range = ((int(labels[idx].min()), int(labels[idx].max())) if idx.numel() else (0, 0))   # of the weighted rows
+        self._checked_C = None
         self.ws = torch.zeros(lib.pygat_nll_workspace_bytes(self.n) // 4, dtype=torch.float32, device=idx.device)
 
     def __call__(self, out: torch.Tensor) -> torch.Tensor:
+        C_ = out.shape[1]
+        if self._checked_C != C_:        # the class count is only known from the output: checked once per width, no sync
+            if out.shape[0] != self.n:
+                raise ValueError(f"EluLogSoftmaxNLL: output has {out.shape[0]} rows, the criterion was built for {self.n}")
+            if self._label_range[0] < 0 or self._label_range[1] >= C_:
+                raise IndexError(f"EluLogSoftmaxNLL: labels of the weighted rows span {self._label_range}, outside [0, {C_})")
+            self._checked_C = C_
         return _NLLFn.apply(out, self)
 
 

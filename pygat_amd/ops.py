@@ -84,6 +84,27 @@ def backward_flavour(row_floats: int) -> str:
     return "rowlocal" if row_floats <= 256 else "rowsum"
 
 
+# Heads per window of the backward passes = layout of a GR row (include/pygat_amd.h, pygat_head_group): None = the library's
+# default for the level's (N, H, F'); a number of FLOATS = windows of at most that many floats on rows wider than it,
+# whatever the table size (tests walk tiny graphs in windows of 256 this way; until ABI 12 an environment variable of the
+# C library did that).  The choice is fixed per level in its forward and handed to every backward entry point.
+BWD_WINDOW_FLOATS: Optional[int] = None
+
+# da inside the column pass (pygat_gat_backward_col with da_part + pygat_a_grad_fold) instead of a pass of its own over Wh,
+# ds and dt: on tables of DA_MIN_BYTES and more (the a-gradient stream is HBM time there: 0.12 ms at config 5); a small
+# graph's epoch is launch-bound and gains nothing from it (two launches either way).  PYGAT_DA_IN_K4=0 switches it off.
+DA_IN_K4 = os.environ.get("PYGAT_DA_IN_K4", "1") != "0"
+DA_MIN_BYTES = 32 << 20
+
+
+def head_group(N: int, H: int, Fo: int) -> int:
+    """Heads per backward window for a level of H heads (see BWD_WINDOW_FLOATS)."""
+    if BWD_WINDOW_FLOATS is None:
+        return lib.pygat_head_group(N, H, Fo)
+    Fp = padded_width(Fo)
+    return H if H * Fp <= BWD_WINDOW_FLOATS else max(1, min(H, BWD_WINDOW_FLOATS // Fp))
+
+
 class _span:
     def __init__(self, name):
         self.name = name
@@ -240,7 +261,7 @@ class _Level:
         self.H, self.Fo, self.skip = H, Fo, skip
         self.Fp = padded_width(Fo)
         self.R = H * self.Fp
-        self.hg = lib.pygat_head_group(self.N, H, Fo)   # heads per backward pass = layout of a GR row
+        self.hg = head_group(self.N, H, Fo)   # heads per backward pass = layout of a GR row
         self.ldw = -(-(self.R * (2 if skip else 1) + 2 * H) // 4) * 4
         self.ts = 0        # slot length of the nnz-split kernels (rows cut by a slot border cost a partial record)
 
@@ -451,34 +472,42 @@ def _level_backward(ctx, G):
         part = torch.empty(lib.pygat_partials_bytes(graph.nnz, L.ts, H, L.Fp) // 4, dtype=f32,
                            device=dev)
         rowlocal = ctx.flavour == "rowlocal"
+        # heads per window: the level's choice for all its heads, or the library default for the range a ranged backward covers
+        hgw = lib.pygat_head_group(L.N, Hb, Fo) if (ranged and BWD_WINDOW_FLOATS is None) else (min(L.hg, Hb) if not ranged else head_group(L.N, Hb, Fo))
+        # da along with the column pass (no separate stream over Wh, ds, dt), when the pass can and the table is large
+        da_part = None
+        if DA_IN_K4 and not ranged and ctx.flavour != "rowsum" and ctx.need[2] and L.N * L.R * 4 >= DA_MIN_BYTES:
+            nb = lib.pygat_gat_backward_col_da_bytes(graph.bwd.ref(L.ts), H, Fo, hgw)
+            if nb:
+                da_part = torch.empty(nb // 4, dtype=f32, device=dev)
         with _span("k3a_prepare"):
             check(lib.pygat_gat_backward_prepare(L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(),
                                                  y.data_ptr(), _ptr(Sk), s.data_ptr(), m.data_ptr(), Z.data_ptr(),
                                                  GR.data_ptr(), _ptr(aneg), _ptr(qneg), ctx.alpha,
-                                                 ds.data_ptr() if rowlocal else None, hb, hr, st), "gat_backward_prepare")
+                                                 ds.data_ptr() if rowlocal else None, hb, hr, hgw, st), "gat_backward_prepare")
         two_gather = ctx.flavour == "two-gather"
         if rowlocal:        # ds is known: the column pass finishes dWh on its own
             with _span("k4_backward_col"):
                 check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), None, H, Fo, ctx.alpha, Wh.data_ptr(),
                                                  a_pad.data_ptr(), GR.data_ptr(), None, ds.data_ptr(),
-                                                 dWh.data_ptr(), dt.data_ptr(), None, part.data_ptr(), hb, hr, st),
+                                                 dWh.data_ptr(), dt.data_ptr(), None, part.data_ptr(), _ptr(da_part), hb, hr, hgw, st),
                       "gat_backward_col")
         elif two_gather:
             with _span("k3b_row"):
                 check(lib.pygat_gat_backward_row(graph.fwd.ref(L.ts), H, Fo, ctx.alpha, Wh.data_ptr(),
                                                  a_pad.data_ptr(), GR.data_ptr(), None, ds.data_ptr(),
-                                                 part.data_ptr(), hb, hr, st), "gat_backward_row")
+                                                 part.data_ptr(), hb, hr, hgw, st), "gat_backward_row")
             with _span("k4_backward_col"):
                 check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), None, H, Fo, ctx.alpha, Wh.data_ptr(),
                                                  a_pad.data_ptr(), GR.data_ptr(), None, ds.data_ptr(),
-                                                 dWh.data_ptr(), dt.data_ptr(), None, part.data_ptr(), hb, hr, st),
+                                                 dWh.data_ptr(), dt.data_ptr(), None, part.data_ptr(), _ptr(da_part), hb, hr, hgw, st),
                       "gat_backward_col")
         else:
             dz_t = torch.empty(graph.nnz, H, dtype=f32, device=dev)
             with _span("k4_backward_col"):
                 check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), None, H, Fo, ctx.alpha, Wh.data_ptr(),
                                                  a_pad.data_ptr(), GR.data_ptr(), None, None,
-                                                 dWh.data_ptr(), dt.data_ptr(), dz_t.data_ptr(), part.data_ptr(), hb, hr, st),
+                                                 dWh.data_ptr(), dt.data_ptr(), dz_t.data_ptr(), part.data_ptr(), None, hb, hr, hgw, st),
                       "gat_backward_col")
             with _span("k3c_rowsum"):
                 check(lib.pygat_gat_backward_rowsum(graph.fwd.ref(L.ts), graph.perm_f.data_ptr(), H, Fo,
@@ -501,11 +530,17 @@ def _level_backward(ctx, G):
         if fork:
             main, side = torch.cuda.current_stream(), _side_stream(dev)
             side.wait_stream(main)      # the tensors it touches stay referenced until the join below
-        with _span("k5_agrad"):
-            check(lib.pygat_a_grad(L.N, H, Fo, Wh.data_ptr(), ds.data_ptr(), dt.data_ptr(), da.data_ptr(),
-                                   ws.data_ptr(), a_pad.data_ptr() if finish else None,
-                                   dWh.data_ptr() if finish else None, None, hb, hr,
-                                   side.cuda_stream if fork else st), "a_grad")
+        if da_part is not None:      # the column pass left one record per work-group: fold them (and the cut rows) in a fixed order
+            with _span("k5_afold"):
+                check(lib.pygat_a_grad_fold(graph.bwd.ref(L.ts), H, Fo, Wh.data_ptr(), ds.data_ptr(), dt.data_ptr(),
+                                            da_part.data_ptr(), da.data_ptr(), ws.data_ptr(), hgw,
+                                            side.cuda_stream if fork else st), "a_grad_fold")
+        else:
+            with _span("k5_agrad"):
+                check(lib.pygat_a_grad(L.N, H, Fo, Wh.data_ptr(), ds.data_ptr(), dt.data_ptr(), da.data_ptr(),
+                                       ws.data_ptr(), a_pad.data_ptr() if finish else None,
+                                       dWh.data_ptr() if finish else None, None, hb, hr,
+                                       side.cuda_stream if fork else st), "a_grad")
         # dW = x^T dWh (split-K over the nodes), dWskip = x^T Gp
         dW = dWs = dx = None
         if sparse_w and (ctx.need[1] or (L.skip and ctx.need[3])):

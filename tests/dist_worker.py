@@ -53,12 +53,13 @@ def model_step_and_sync(rank, world):
 
 def main():
     rank, world, port, H2 = (int(v) for v in sys.argv[1:5])
+    H1_arg = int(sys.argv[5]) if len(sys.argv) > 5 else 3
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pygat_amd.dist import gat_level_head_parallel, partition_heads
     torch.manual_seed(0)                      # identical replicas of every parameter
-    N, Fin, F1, H1, C = 40, 6, 4, 3, 5
+    N, Fin, F1, H1, C = 40, 6, 4, H1_arg, 5
     rowptr, col = O.random_symmetric_csr(N, 4, 1)
     graph = (rowptr, col)
     x = torch.randn(N, Fin, dtype=torch.float64)

@@ -232,6 +232,21 @@ def close_fullsize_grads(got, r64, r32, X, W, a, rowptr, col, alpha, what="level
         report[side + "_flips"] = [cand[q] for q in range(len(cand)) if sig[q]]
         report[side + "_flip_idx"] = [q for q in range(len(cand)) if sig[q]]
     report["flips"] = _flip_leash(report, rel, tau, what)
+    if got.get("dX") is not None and r64.get("dX") is not None:
+        # dX [N, Fin] at full size: a candidate's effect on it is two rows (dX_i += D W_h a_src, dX_j += D W_h a_dst), kept
+        # sparse; the flips are the ones the parameter gradients chose above -- the SAME flip vector has to explain dX
+        Fo_ = W.shape[2]
+        for side, v in (("hip", _np64(got["dX"])), ("fp32", np.asarray(r32["dX"], np.float64))):
+            res = v.reshape(r64["dX"].shape) - r64["dX"]
+            report[side + "_raw"]["dX"] = float(np.abs(res).max())
+            for q in report[side + "_flip_idx"]:
+                h, e = cand[q]
+                i, j = int(np.searchsorted(rp64, e, side="right") - 1), int(col[e])
+                D = float(k["de"][q]) * ((alpha - 1.0) if float(k["z"][q]) > 0 else (1.0 - alpha))
+                res[i] -= D * (W[h] @ a[h, :Fo_]); res[j] -= D * (W[h] @ a[h, Fo_:])
+            report[side]["dX"] = float(np.abs(res).max())
+            del res
+        names = tuple(names) + ("dX",)
     for n in names:
         assert np.isfinite(_np64(got[n])).all(), f"{what} {n}: non-finite values"
         tol = max(floor, factor * report["fp32"][n])

@@ -44,8 +44,9 @@ def test_head_windows_host_logic(lib, monkeypatch):
     assert hg(1 << 20, 8, 128) == 2 and hg(1 << 20, 4, 256) == 1 and hg(1 << 20, 6, 121) == 2
     assert hg(1000, 12, 128) == 4                      # R = 1536 on a small table: windows of 512 floats
     assert hg(0, 8, 16) == 0 and hg(10, 0, 16) == 0 and hg(10, 8, 300) == 0
+    # a pure function of its arguments: no environment variable moves it (ABI 13; PYGAT_BWD_WINDOW_BYTES used to)
     monkeypatch.setenv("PYGAT_BWD_WINDOW_BYTES", "0")
-    assert hg(10, 6, 121) == 2 and hg(10, 8, 64) == 4
+    assert hg(10, 6, 121) == 4 and hg(10, 8, 64) == 8
 
 
 def test_abi_version_and_padding(lib):
@@ -78,7 +79,8 @@ QUERIES = {"pygat_abi_version", "pygat_last_error", "pygat_padded_width", "pygat
            "pygat_scan_workspace_bytes", "pygat_gemm_workspace_bytes", "pygat_partials_bytes", "pygat_head_group",
            "pygat_agrad_workspace_bytes", "pygat_gatv2_workspace_bytes", "pygat_wgrad_workspace_bytes",
            "pygat_headmask_supported", "pygat_project_dropout_workspace_bytes", "pygat_wgrad_dropout_workspace_bytes",
-           "pygat_default_gemm_mode", "pygat_nll_workspace_bytes", "pygat_wgrad_sparse_workspace_bytes", "pygat_dropout_narrow", "pygat_bce_workspace_bytes"}
+           "pygat_default_gemm_mode", "pygat_nll_workspace_bytes", "pygat_wgrad_sparse_workspace_bytes", "pygat_dropout_narrow", "pygat_bce_workspace_bytes",
+           "pygat_gat_backward_col_da_bytes"}
 
 
 def test_gemm_mode_is_a_call_argument(lib, monkeypatch):

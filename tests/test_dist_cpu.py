@@ -16,12 +16,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("H2", [2, 1])        # H2 = 1: rank 1 owns no head of the last level
-def test_head_parallel_world2_gloo(H2):
+def _run_world(world, H2, H1):
     port = _free_port()
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_worker.py")
-    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), str(H2)],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")       # world processes on the container's 8 cores
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(H2), str(H1)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     for p in procs:
         try:
@@ -33,6 +33,19 @@ def test_head_parallel_world2_gloo(H2):
         outs.append(out)
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"rank {r} ok" in out, out[-2000:]
+
+
+@pytest.mark.parametrize("H2", [2, 1])        # H2 = 1: rank 1 owns no head of the last level
+def test_head_parallel_world2_gloo(H2):
+    _run_world(2, H2, 3)
+
+
+def test_head_parallel_world8_gloo():
+    """The shape of the driver's 8-GPU run (bench.py --gpus 8: 8 heads, ONE per rank) plus an uneven last level (6 heads on
+    8 ranks: two ranks own none and still take part in every collective): all-gather / reduce-scatter / all-reduce algebra
+    and sync_head_parameters over 8 gloo ranks against the unsharded oracle (the N = 8 path had only ever
+    been rehearsed at 2 and 4 ranks)."""
+    _run_world(8, 6, 8)
 
 
 def test_partition_heads():

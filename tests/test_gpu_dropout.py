@@ -26,7 +26,7 @@ def test_dropout_explicit_masks(pg, monkeypatch, two_gather, H, Fin, Fo, skip, c
         monkeypatch.setattr(D, "FORCE_WIDE", True)
         two_gather = None
     monkeypatch.setattr(pg.ops, "TWO_GATHER_BACKWARD", two_gather)   # all backward flavours carry the attention mask (None: the default, row-local one)
-    monkeypatch.setenv("PYGAT_BWD_WINDOW_BYTES", "0")   # rows > 512 floats: backward in head windows
+    monkeypatch.setattr(pg.ops, "BWD_WINDOW_FLOATS", 256)   # rows > 256 floats: backward in head windows
     N, p = 70, 0.6
     rowptr, col = O.random_symmetric_csr(N, 5, 3, hub=(2, 50))
     E = len(col)

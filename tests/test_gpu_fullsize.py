@@ -33,33 +33,38 @@ def world():
     return dict(pg=pg, graph=graph, rowptr=rowptr, col=col, X=X, W=W, a=a, G=G, H=H, Fo=Fo, Fin=Fin)
 
 
-def run(w, X, W, a, G):
+def run(w, X, W, a, G, want_dx=False):
     Wd = W.clone().requires_grad_(True); ad = a.clone().requires_grad_(True)
-    out = w["pg"].GATLevelFn.apply(X, Wd, ad, None, w["graph"], 0.2, True)
+    Xd = X.clone().requires_grad_(True) if want_dx else X
+    out = w["pg"].GATLevelFn.apply(Xd, Wd, ad, None, w["graph"], 0.2, True)
     out.backward(G)
     torch.cuda.synchronize()
-    return out.detach(), Wd.grad, ad.grad
+    return (out.detach(), Wd.grad, ad.grad) + ((Xd.grad,) if want_dx else ())
 
 
 KINK_TAU = float(os.environ.get('PYGAT_TEST_KINK_TAU', 4e-6))     # near-kink band of the full-size runs: ~60 ulp of |s| + |t| (a few hundred of 86 M logits)
 
 
-def c_refs(X, rowptr, col, W, a, G):
+def c_refs(X, rowptr, col, W, a, G, want_dx=False):
     """(fp64 ground truth incl. its near-kink edges, fp32 port) of the level from the two builds of oracle/gat_oracle.c."""
     from oracle import c_oracle          # built for this host by tests/conftest.py before anything touched the GPU
     args = (X.cpu().numpy(), rowptr.cpu().numpy(), col.cpu().numpy(), W.detach().cpu().numpy(), a.detach().cpu().numpy(), 0.2,
             True, G.cpu().numpy())
     tp = c_oracle.transpose_pattern(args[1], args[2])
-    return (c_oracle.level(*args, want_dx=False, tp=tp, dtype=np.float64, kink_tau=KINK_TAU, kink_cap=1 << 16),
-            c_oracle.level(*args, want_dx=False, tp=tp))
+    return (c_oracle.level(*args, want_dx=want_dx, tp=tp, dtype=np.float64, kink_tau=KINK_TAU, kink_cap=1 << 16),
+            c_oracle.level(*args, want_dx=want_dx, tp=tp))
 
 
-def check_grads(got_dW, got_da, r64, r32, X, rowptr, col, W, a, what):
-    rep = close_fullsize_grads({"dW": got_dW, "da": got_da}, r64, r32, X.cpu().numpy(), W.detach().cpu().numpy(),
+def check_grads(got_dW, got_da, r64, r32, X, rowptr, col, W, a, what, got_dX=None):
+    got = {"dW": got_dW, "da": got_da}
+    if got_dX is not None:
+        got["dX"] = got_dX
+    rep = close_fullsize_grads(got, r64, r32, X.cpu().numpy(), W.detach().cpu().numpy(),
                                a.detach().cpu().numpy(), rowptr.cpu().numpy(), col.cpu().numpy(), 0.2, what=what, tau=KINK_TAU * 1.0001)
     return (rep["flips"] + "; "
             + "; ".join(f"{n} err {rep['hip'][n]:.2e} (raw {rep['hip_raw'][n]:.2e}; fp32 oracle {rep['fp32'][n]:.2e}, raw "
-                        f"{rep['fp32_raw'][n]:.2e}; max |{n}| {np.abs(r64[n]).max():.3g})" for n in ("dW", "da")))
+                        f"{rep['fp32_raw'][n]:.2e}; max |{n}| {np.abs(r64[n]).max():.3g})"
+                        for n in ("dW", "da") + (("dX",) if got_dX is not None else ())))
 
 
 @pytest.mark.parametrize("flavour", ["rowlocal", "rowsum", "two-gather"])
@@ -80,6 +85,47 @@ def test_fullsize_against_c_oracle(world, monkeypatch, flavour):
     e, e32 = close_grad(out, r64["out"], r32["out"], "out")
     print(f"fullsize[{flavour}]: out err {e:.2e} (fp32 oracle {e32:.2e}, max |out| {np.abs(r64['out']).max():.3g}); "
           + check_grads(dW, da, r64, r32, w["X"], w["rowptr"], w["col"], w["W"], w["a"], f"fullsize[{flavour}]"))
+
+
+def test_fullsize_input_gradient_against_c_oracle(world, monkeypatch):
+    """dX at the size it is timed (bench.py --dx; what every level but the first pays) against the C
+    oracle, under the same flip-aware rule: the flips the parameter gradients choose must explain dX too (a flip touches
+    two of its rows).  Default backward flavour, da taken along by the column pass (the table is 512 MB)."""
+    w = world
+    monkeypatch.setattr(w["pg"].ops, "BACKWARD_FLAVOUR", None)
+    out, dW, da, dX = run(w, w["X"], w["W"], w["a"], w["G"], want_dx=True)
+    r64, r32 = c_refs(w["X"], w["rowptr"], w["col"], w["W"], w["a"], w["G"], want_dx=True)
+    w["refs"] = (r64, r32)                       # (the parameter-gradient tests reuse them)
+    e, e32 = close_grad(out, r64["out"], r32["out"], "out")
+    print(f"fullsize[dX]: out err {e:.2e} (fp32 oracle {e32:.2e}); "
+          + check_grads(dW, da, r64, r32, w["X"], w["rowptr"], w["col"], w["W"], w["a"], "fullsize[dX]", got_dX=dX))
+
+
+def test_fullsize_gatv2_level_against_c_oracle(world):
+    """the SpGraphAttentionLayerV2 level (layers.py:234-316) at the size bench.py times it (the `gatv2`
+    record: config-5 graph, 8 heads x 16) against gat_oracle_level_v2 in fp64, priced by the 8(c) rule against the fp32
+    build of the same C source.  (Per-feature LeakyReLU kinks: 86 M edges x 16 features; a flip moves a gradient by
+    de_ij a_f (1 - alpha), in both fp32 sides alike -- no flip fit here, the rule's 4 x the fp32 oracle's own error is the bar.)"""
+    from oracle import c_oracle
+    from pygat_amd.gatv2 import GATv2LevelFn
+    w = world
+    H, Fo, Fin, dev = w["H"], w["Fo"], w["Fin"], w["X"].device
+    g = torch.Generator(device=dev).manual_seed(12)
+    W2 = (torch.randn(H, 2 * Fin, Fo, generator=g, device=dev) * (1.414 * (2.0 / (2 * Fin + Fo)) ** 0.5)).requires_grad_(True)
+    a2 = (torch.randn(H, Fo, generator=g, device=dev) * (1.414 * (2.0 / (1 + Fo)) ** 0.5)).requires_grad_(True)
+    out = GATv2LevelFn.apply(w["X"], W2, a2, None, w["graph"], 0.2, True)
+    out.backward(w["G"])
+    torch.cuda.synchronize()
+    args = (w["X"].cpu().numpy(), w["rowptr"].cpu().numpy(), w["col"].cpu().numpy(), W2.detach().cpu().numpy(),
+            a2.detach().cpu().numpy(), 0.2, True, w["G"].cpu().numpy())
+    tp = c_oracle.transpose_pattern(args[1], args[2])
+    r64 = c_oracle.level_v2(*args, want_dx=False, tp=tp, dtype=np.float64)
+    r32 = c_oracle.level_v2(*args, want_dx=False, tp=tp)
+    msgs = []
+    for n, got in (("out", out.detach()), ("dW", W2.grad), ("da", a2.grad)):
+        e, e32 = close_grad(got, r64[n], r32[n], f"gatv2 fullsize {n}")
+        msgs.append(f"{n} err {e:.2e} (fp32 oracle {e32:.2e}, max |{n}| {np.abs(r64[n]).max():.3g})")
+    print("fullsize[gatv2]: " + "; ".join(msgs))
 
 
 def test_fullsize_properties(world, monkeypatch):

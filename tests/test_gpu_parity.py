@@ -171,11 +171,14 @@ SHAPES = [  # (H, Fin, Fo, skip, concat)
 ]
 
 
-@pytest.fixture(params=["rowlocal", "rowsum", "two-gather"])
+@pytest.fixture(params=["rowlocal", "rowsum", "two-gather", "rowlocal+da"])
 def backward_mode(request, pg, monkeypatch):
     """The three backward flavours of pygat_amd.ops: row sums of dz from the forward's alpha-branch shares (default) /
-    K4 + row sums of its per-edge dz records / K3b (second gather) + K4."""
-    monkeypatch.setattr(pg.ops, "BACKWARD_FLAVOUR", request.param)
+    K4 + row sums of its per-edge dz records / K3b (second gather) + K4.  "+da": the attention-vector gradient taken along by
+    the column pass (pygat_gat_backward_col with da_part + pygat_a_grad_fold: the default on tables of 32 MB and more)
+    instead of by pygat_a_grad -- wherever the pass can (one-chunk rows, one head window), else the level falls back itself."""
+    monkeypatch.setattr(pg.ops, "BACKWARD_FLAVOUR", request.param.split("+")[0])
+    monkeypatch.setattr(pg.ops, "DA_MIN_BYTES", 0 if request.param.endswith("+da") else 1 << 60)
     return request.param
 
 
@@ -198,11 +201,12 @@ WIDE = [s for s in SHAPES if s[0] * max(4, 1 << (s[2] - 1).bit_length()) > 512]
 @pytest.mark.parametrize("H,Fin,Fo,skip,concat", WIDE)
 def test_level_backward_head_windows(pg, monkeypatch, backward_mode, H, Fin, Fo, skip, concat):
     """Rows wider than 512 floats on a LARGE graph run the backward in head windows of <= 256 floats (GR laid
-    out window by window).  PYGAT_BWD_WINDOW_BYTES=0 forces that path on a small graph (whose own default is windows
-    of <= 512 floats: every other wide-row test of this file runs those)."""
-    monkeypatch.setenv("PYGAT_BWD_WINDOW_BYTES", "0")
+    out window by window).  ops.BWD_WINDOW_FLOATS = 256 asks for that on a small graph (whose own default is windows
+    of <= 512 floats: every other wide-row test of this file runs those): the heads per window are an ARGUMENT of the
+    backward entry points since ABI 13, no environment variable of the library."""
+    monkeypatch.setattr(pg.ops, "BWD_WINDOW_FLOATS", 256)
     N = 80
-    hg = pg._lib.lib.pygat_head_group(N, H, Fo)
+    hg = pg.ops.head_group(N, H, Fo)
     assert 1 <= hg < H and hg * pg.padded_width(Fo) <= 256
     rowptr, col = O.random_symmetric_csr(N, 6, 21 + H, hub=(5, 60))
     W, a, Sk = params(H, Fin, Fo, skip, 22 + Fo)
@@ -211,9 +215,30 @@ def test_level_backward_head_windows(pg, monkeypatch, backward_mode, H, Fin, Fo,
     G = torch.randn(N, H * Fo if concat else Fo, dtype=torch.float64, generator=gen)
     check(run_level(pg, x, rowptr, col, W, a, Sk, concat, G, slot=16), x, rowptr, col, W, a, Sk, concat, G,
           f"windows[{H},{Fin},{Fo},{skip},{concat},{backward_mode}]")
-    monkeypatch.delenv("PYGAT_BWD_WINDOW_BYTES")
+    monkeypatch.setattr(pg.ops, "BWD_WINDOW_FLOATS", None)
     # (a cache-resident table wider than 512 floats: windows of <= 512 floats -- attn_common.h head_group_bwd)
-    assert pg._lib.lib.pygat_head_group(N, H, Fo) == min(H, max(1, 512 // pg.padded_width(Fo)))
+    assert pg.ops.head_group(N, H, Fo) == pg._lib.lib.pygat_head_group(N, H, Fo) == min(H, max(1, 512 // pg.padded_width(Fo)))
+
+
+def test_da_of_the_column_pass_is_the_a_grad_pass(pg, monkeypatch):
+    """da from the column pass's per-work-group records + the cut-row list (pygat_a_grad_fold) against da from the pass
+    of its own (pygat_a_grad): same sums in another order, and bit-identical between two runs (no atomics across lanes:
+    the LDS adds of a lane go to words only that lane touches)."""
+    N, Fin, Fo, H = 3000, 32, 16, 8
+    rowptr, col = O.random_symmetric_csr(N, 9, 31, hub=(7, 2500))      # a hub row: cut by every slot border
+    W, a, _ = params(H, Fin, Fo, False, 32)
+    gen = torch.Generator().manual_seed(33)
+    x = torch.randn(N, Fin, dtype=torch.float64, generator=gen)
+    G = torch.randn(N, H * Fo, dtype=torch.float64, generator=gen)
+    res = {}
+    for tag, minb in (("fold", 0), ("fold2", 0), ("pass", 1 << 60)):
+        monkeypatch.setattr(pg.ops, "DA_MIN_BYTES", minb)
+        res[tag] = run_level(pg, x, rowptr, col, W, a, None, True, G, slot=16)
+    assert torch.equal(res["fold"][3], res["fold2"][3])
+    assert torch.equal(res["fold"][2], res["pass"][2])                 # dW does not depend on where da is taken
+    d = (res["fold"][3] - res["pass"][3]).abs().max().item()
+    assert d <= 2e-5 * res["pass"][3].abs().max().item(), d
+    check(res["fold"], x, rowptr, col, W, a, None, True, G, "da in the column pass")
 
 
 def test_eval_matches_both_oracle_formulations(pg):

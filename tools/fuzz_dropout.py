@@ -28,7 +28,7 @@ for seed in range(150):
         rowptr = np.concatenate([[0], np.cumsum(dense.sum(1))]).astype(np.int32); col = np.nonzero(dense)[1].astype(np.int32)
     E = len(col)
     pg.ops.TWO_GATHER_BACKWARD = [None, True, False][seed % 3]
-    os.environ["PYGAT_BWD_WINDOW_BYTES"] = "0" if seed % 2 else str(256 << 20)
+    pg.ops.BWD_WINDOW_FLOATS = 256 if seed % 2 else None     # odd seeds: backward in head windows of <= 256 floats
     W, a, Sk = params(H, Fin, Fo, skip, seed)
     gen = torch.Generator().manual_seed(seed)
     x = torch.randn(N, Fin, dtype=torch.float64, generator=gen)

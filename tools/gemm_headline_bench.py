@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""The two streamed GEMMs of the headline step (config 5: projection [Wh | s] = X Wcat, weight gradient dW = X^T dWh) timed
+through the C ABI, HIP events, median of --iters.  With PYGAT_AMD_LIB=<variant .so> (tools/build_variant.sh) it times a
+diagnostic build.   python3 tools/gemm_headline_bench.py [--heads 8] [--fout 16] [--fin 128] [--iters 30]"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import pygat_amd as pg  # noqa: E402
+from pygat_amd._lib import lib, check  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=1 << 20)
+ap.add_argument("--fin", type=int, default=128)
+ap.add_argument("--heads", type=int, default=8)
+ap.add_argument("--fout", type=int, default=16)
+ap.add_argument("--iters", type=int, default=30)
+ap.add_argument("--mode", default="split-bf16")
+ap.add_argument("--tag", default=os.path.basename(os.environ.get("PYGAT_AMD_LIB", "default")))
+a_ = ap.parse_args()
+n, Fin, H, Fo = a_.n, a_.fin, a_.heads, a_.fout
+torch.manual_seed(0)
+x = torch.randn(n, Fin, device="cuda")
+W = torch.randn(H, Fin, Fo, device="cuda") * 0.2
+a = torch.randn(H, 2 * Fo, device="cuda")
+Fp = pg.padded_width(Fo); R = H * Fp
+ldw = -(-(R + 2 * H) // 4) * 4
+Wcat = torch.empty(Fin, ldw, device="cuda"); a_pad = torch.empty(H, 2, Fp, device="cuda")
+check(lib.pygat_pack_params(H, Fin, Fo, W.data_ptr(), a.data_ptr(), None, Wcat.data_ptr(), ldw, a_pad.data_ptr(), None), "pack")
+Wh = torch.empty(n, R, device="cuda"); s = torch.empty(n, H, device="cuda")
+dWh = torch.randn(n, R, device="cuda")
+mode = pg.ops.GEMM_MODES[a_.mode]
+split_k = pg.ops._split_k(Fin, R, n, streamed_k=True, mode=a_.mode)
+wsw = torch.empty(lib.pygat_wgrad_workspace_bytes(Fin, H, Fo, split_k) // 4, device="cuda")
+dW = torch.empty(H, Fin, Fo, device="cuda")
+
+
+def timed(fn):
+    ts = []
+    for _ in range(a_.iters):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts[5:]))
+
+
+def project():
+    check(lib.pygat_project(n, Fin, H, Fo, x.data_ptr(), Fin, Wcat.data_ptr(), ldw, a_pad.data_ptr(), Wh.data_ptr(), None,
+                            s.data_ptr(), 1, None, mode, None), "project")
+
+
+def wgrad():
+    check(lib.pygat_wgrad(n, Fin, H, Fo, x.data_ptr(), Fin, dWh.data_ptr(), None, a_pad.data_ptr(), dW.data_ptr(), split_k,
+                          wsw.data_ptr(), 0, 0, mode, None), "wgrad")
+
+
+tp, tw = timed(project), timed(wgrad)
+gbp, gbw = 4.0 * n * (Fin + R + H) / 1e9, 4.0 * n * (Fin + R) / 1e9
+# a checksum so that a diagnostic build that computes something else shows it
+print(f"{a_.tag:28s} project {tp*1e3:7.1f} us ({gbp/tp:5.2f} TB/s)  wgrad {tw*1e3:7.1f} us ({gbw/tw:5.2f} TB/s, split_k {split_k})  "
+      f"|Wh| {float(Wh.abs().sum()):.6e} |dW| {float(dW.abs().sum()):.6e}", flush=True)

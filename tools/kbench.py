@@ -70,24 +70,24 @@ def main():
 
     def k3a():
         check(lib.pygat_gat_backward_prepare(N, H, Fo, _lib.F_ELU, 0, P(G), P(out), None, P(s), P(m), P(Z), P(GR), None, None,
-                                             0.2, None, 0, 0, None))
+                                             0.2, None, 0, 0, 0, None))
 
     def k3a_ds():
         check(lib.pygat_gat_backward_prepare(N, H, Fo, _lib.F_ELU, 0, P(G), P(out), None, P(s), P(m), P(Z), P(GR), P(aneg),
-                                             P(qneg), 0.2, P(ds), 0, 0, None))
+                                             P(qneg), 0.2, P(ds), 0, 0, 0, None))
 
     def k3b():
-        check(lib.pygat_gat_backward_row(graph.fwd.ref(), H, Fo, 0.2, P(Wh), P(a_pad), P(GR), None, P(ds), P(part), 0, 0, None))
+        check(lib.pygat_gat_backward_row(graph.fwd.ref(), H, Fo, 0.2, P(Wh), P(a_pad), P(GR), None, P(ds), P(part), 0, 0, 0, None))
 
     def k4():
         check(lib.pygat_gat_backward_col(graph.bwd.ref(), None, H, Fo, 0.2, P(Wh), P(a_pad), P(GR), None, P(ds),
-                                         P(dWh), P(dt), None, P(part), 0, 0, None))
+                                         P(dWh), P(dt), None, P(part), None, 0, 0, 0, None))
 
     dz_t = torch.empty(E, H, device=dev)
 
     def k4dz():   # default backward: K4 writes its dz per transposed edge ...
         check(lib.pygat_gat_backward_col(graph.bwd.ref(), None, H, Fo, 0.2, P(Wh), P(a_pad), P(GR), None, None,
-                                         P(dWh), P(dt), P(dz_t), P(part), 0, 0, None))
+                                         P(dWh), P(dt), P(dz_t), P(part), None, 0, 0, 0, None))
 
     def k3c():    # ... and the row sums are taken from those records
         check(lib.pygat_gat_backward_rowsum(graph.fwd.ref(), graph.perm_f.data_ptr(), H, Fo, P(dz_t), P(ds), P(part), 0, 0, None))

@@ -40,13 +40,23 @@ def short(name):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("dirs", nargs="+")
-    ap.add_argument("--out", required=True)
+    ap.add_argument("dirs", nargs="*")
+    ap.add_argument("--out")
+    ap.add_argument("--promote", help="an existing summary (profiles/rNN_pmc_bench.json): rewrite profiles/pmc_latest.json from it")
     ap.add_argument("--note", default="")
     ap.add_argument("--latest", action="store_true")
     ap.add_argument("--edges", type=int, default=10758702)
     ap.add_argument("--heads", type=int, default=8)
     a = ap.parse_args()
+    if a.promote:   # the GPU box cannot write profiles/: summaries come back under gpurun_out/, are copied, then promoted here
+        doc = json.load(open(a.promote))
+        here = os.path.dirname(os.path.abspath(__file__))
+        doc["source"] = os.path.relpath(os.path.abspath(a.promote), os.path.join(here, ".."))
+        with open(os.path.join(here, "..", "profiles", "pmc_latest.json"), "w") as fh:
+            json.dump({k: doc[k] for k in ("note", "source", "workload_edges", "heads_per_gpu", "traffic_bytes")}, fh, indent=1)
+        print("pmc_latest.json <-", doc["source"], {k: round(v / 1e9, 3) for k, v in doc["traffic_bytes"].items()})
+        return
+    assert a.dirs and a.out, "counter directories and --out, or --promote"
     merged = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in a.dirs:
         for k, ctrs in fold(d).items():
@@ -67,32 +77,36 @@ def main():
         if e.get("TCC_HIT_sum", 0) + e.get("TCC_MISS_sum", 0) > 0:
             e["l2_hit_rate"] = e["TCC_HIT_sum"] / (e["TCC_HIT_sum"] + e["TCC_MISS_sum"])
         out[k] = e
+    spans = {   # bench.py span -> kernel name prefixes (pygat_amd/ops.py)
+        # (bench.py also runs its `alt` pass -- the fp32-MFMA kernels -- under the profiler: the default mode's kernels only)
+        "k1_project": ("pygat::gemm_smallk_x3_kernel", "pygat::gemm_rowtile_x3_kernel"),
+        "k2_forward": ("pygat::gat_fwd_",),
+        "k3a_prepare": ("pygat::gat_bwd_prepare",),
+        "k3b_row": ("pygat::gat_bwd_row_kernel",),
+        "k4_backward_col": ("pygat::gat_bwd_col_",),
+        "k3c_rowsum": ("pygat::gat_bwd_rowsum_kernel",),
+        "k5_agrad": ("pygat::a_grad_partial", "pygat::a_grad_final"),
+        "k5_afold": ("pygat::a_grad_fold", "pygat::a_grad_final"),
+        "k5_wgrad": ("pygat::gemm_tn_x3_kernel", "pygat::gemm_splitk_reduce_kernel", "pygat::unpack_wgrad"),
+    }
+    traffic = {}
+    for span, prefixes in spans.items():
+        t = sum(v.get("hbm_traffic_bytes", 0.0) for k, v in out.items() if k.startswith(prefixes))
+        if t > 0:
+            traffic[span] = t
+    here = os.path.dirname(os.path.abspath(__file__))
+    # ONE schema for every summary (round 3 lost `roofline.traffic` to a pmc_latest.json written without these keys):
+    # bench.py reads workload_edges / heads_per_gpu / traffic_bytes / source from profiles/pmc_latest.json
     doc = {"note": a.note or "rocprofv3 --pmc, separate passes (FETCH_SIZE; WRITE_SIZE+TCC); per-launch means; "
-           "FETCH_SIZE/WRITE_SIZE are KiB, FETCH_SIZE doubled per MI355X_MICROARCH.md", "kernels": out}
+           "FETCH_SIZE/WRITE_SIZE are KiB, FETCH_SIZE doubled per MI355X_MICROARCH.md",
+           "source": os.path.relpath(os.path.abspath(a.out), os.path.join(here, "..")),
+           "workload_edges": a.edges, "heads_per_gpu": a.heads, "traffic_bytes": traffic, "kernels": out}
     with open(a.out, "w") as fh:
         json.dump(doc, fh, indent=1)
     if a.latest:
-        spans = {   # bench.py span -> kernel name prefixes (pygat_amd/ops.py)
-            # (bench.py also runs its `alt` pass -- the fp32-MFMA kernels -- under the profiler: the default mode's kernels only)
-            "k1_project": ("pygat::gemm_smallk_x3_kernel",),
-            "k2_forward": ("pygat::gat_fwd_",),
-            "k3a_prepare": ("pygat::gat_bwd_prepare",),
-            "k3b_row": ("pygat::gat_bwd_row_kernel",),
-            "k4_backward_col": ("pygat::gat_bwd_col_",),
-            "k3c_rowsum": ("pygat::gat_bwd_rowsum_kernel",),
-            "k5_agrad": ("pygat::a_grad_",),
-            "k5_wgrad": ("pygat::gemm_tn_x3_kernel", "pygat::gemm_splitk_reduce_kernel", "pygat::unpack_wgrad"),
-        }
-        traffic = {}
-        for span, prefixes in spans.items():
-            t = sum(v.get("hbm_traffic_bytes", 0.0) for k, v in out.items() if k.startswith(prefixes))
-            if t > 0:
-                traffic[span] = t
-        here = os.path.dirname(os.path.abspath(__file__))
         with open(os.path.join(here, "..", "profiles", "pmc_latest.json"), "w") as fh:
-            json.dump({"source": os.path.relpath(a.out, os.path.join(here, "..")), "workload_edges": a.edges,
-                       "heads_per_gpu": a.heads, "traffic_bytes": traffic}, fh, indent=1)
-        print("traffic GB:", {k: round(v / 1e9, 3) for k, v in traffic.items()})
+            json.dump({k: doc[k] for k in ("note", "source", "workload_edges", "heads_per_gpu", "traffic_bytes")}, fh, indent=1)
+    print("traffic GB:", {k: round(v / 1e9, 3) for k, v in traffic.items()})
     for k, v in sorted(out.items()):
         print(f"{k:48s} {v.get('hbm_traffic_bytes', float('nan')) / 1e6:10.1f} MB  L2 hit {v.get('l2_hit_rate', float('nan')):.2f}")
 

@@ -518,6 +518,17 @@ def main():
                 kernels.append({"kernel": name, "bound": "mfma", "avg_ms": t, "achieved": ach, "peak": MFMA_F32_PEAK_TF,
                                 "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "flops": work,
                                 "traffic": traffic.get(name)})
+        for r in kernels:
+            if r["kernel"] == "k4_backward_col" and "k5_afold" in kt:
+                # since round 4 the column pass also takes the attention-vector gradient along (pygat_gat_backward_col with
+                # da_part): `frac` above prices the FUSED kernel on K4's own SURVEY 8(d) bytes (every byte the da sums need
+                # -- Wh_j, ds_j, dt_j -- is already in them); beside it, the pair (K4 + fold) on the bytes of the two passes
+                # it replaces (K4 + the a-gradient stream), comparable with earlier rounds' K4 + k5_agrad
+                pair_bytes = model["k4_backward_col"][1] + model["k5_agrad"][1]
+                pair_ms = r["avg_ms"] + kt["k5_afold"]
+                r["fused"] = {"with": "k5_agrad (da = sum_j [ds_j | dt_j] (x) Wh_j), folded by k5_afold",
+                              "pair_algorithmic_bytes": int(pair_bytes), "pair_ms": pair_ms,
+                              "pair_frac": pair_bytes / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
         dominant = max(kernels, key=lambda r: r["avg_ms"])
         roof = dict(dominant)
         roof["timing"] = "HIP events around each launch, instrumented eager pass of the same steps after the timed region"

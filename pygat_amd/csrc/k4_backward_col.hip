@@ -35,6 +35,14 @@ struct ColArgs {
 #ifndef PYGAT_K4_DA_ATOMIC
 #define PYGAT_K4_DA_ATOMIC 0
 #endif
+#ifndef PYGAT_K4_DA_WROW
+#define PYGAT_K4_DA_WROW 0   // 1: the finished row's Wh from the registers of the round's previous edge where there is one --
+                             // measured: the longer-lived rows cost 36 bytes of scratch at four waves (K4 1.26 -> 1.39 ms) or
+                             // the fourth wave at 144 VGPRs (1.38 ms); the fetch in the flush stays (gpurun_out r4g)
+#endif
+#ifndef PYGAT_DIAG_K4
+#define PYGAT_DIAG_K4 0   // tools/build_variant.sh only: bit 0 no LDS sums, bit 1 no Wh_j load either (then da is wrong, the time is the point)
+#endif
 __device__ __forceinline__ void lds_add(float* p, float v) {   // ds_add_f32 without a return value
   (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -48,7 +56,7 @@ __device__ __forceinline__ void lds_add(float* p, float v) {   // ds_add_f32 wit
 template <int VEC, int LPH = 0, int CR = 0, bool DA = false>
 __device__ __forceinline__ void col_finish(const ColArgs& a, const LaneCols<VEC>& lc, int j,
                                            const float4 (&acc)[VEC], const float (&dt)[VEC], float4* da_lds = nullptr,
-                                           int da_stride = 0) {
+                                           int da_stride = 0, const float4* wrow = nullptr) {
   const int Fp = CR ? 4 * LPH : a.rs.Fp;
   const int64_t ldr = CR ? CR : a.rs.ldr, ldh = CR ? CR / (4 * (LPH ? LPH : 1)) : a.rs.ldh;
 #pragma unroll
@@ -58,11 +66,14 @@ __device__ __forceinline__ void col_finish(const ColArgs& a, const LaneCols<VEC>
     const float dsj = a.ds ? a.ds[(int64_t)j * ldh + h] : 0.f;
     const float4 as = ld4(a.a_pad + (int64_t)h * 2 * Fp + f0);
     const float4 ad = ld4(a.a_pad + (int64_t)h * 2 * Fp + Fp + f0);
-    // DA: Wh_j is fetched HERE, with the other loads of the flush and before its stores.  vmcnt counts loads and stores
-    // together in issue order: issued behind the dWh / dt stores, the wait for this load was a wait for their acknowledgement
-    // from HBM -- K4 1.21 -> 2.12 ms in the first build of this path (gpurun_out r4b).
+    // DA: Wh_j.  wrow: the caller still holds it in registers (the row's last edge was gathered in this round of U edges:
+    // three flushes of four); else it is fetched HERE, with the other loads of the flush and before its stores -- vmcnt
+    // counts loads and stores together in issue order (issued behind the dWh / dt stores, the wait for this load was a wait
+    // for their acknowledgement from HBM: K4 1.21 -> 2.12 ms in the first build of this path, gpurun_out r4b).  The fetch is
+    // not free even so: the row comes from L2, not L1 (16 waves of 640-byte gathers turn the 32 KB L1 over every round), and
+    // one more 512-byte read per finished row cost K4 0.05 ms (diagnostic builds, gpurun_out r4f).
     float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-    if constexpr (DA) w = ld4(a.Wh + (int64_t)j * ldr + co);
+    if constexpr (DA && !(PYGAT_DIAG_K4 & 2)) w = wrow ? wrow[v] : ld4(a.Wh + (int64_t)j * ldr + co);
     float4 o;
     o.x = acc[v].x + dsj * as.x + dt[v] * ad.x;
     o.y = acc[v].y + dsj * as.y + dt[v] * ad.y;
@@ -75,7 +86,9 @@ __device__ __forceinline__ void col_finish(const ColArgs& a, const LaneCols<VEC>
       // touches these eight words, in program order: the sums are as reproducible as register accumulators.
       // (ds_add_f32 instead -- one product register at a time, 128 VGPRs -- was measured: LDS float atomics retire about
       // one lane per clock, K4 1.20 -> 2.14 ms; gpurun_out r4b / r4c.)
-#if PYGAT_K4_DA_ATOMIC
+#if PYGAT_DIAG_K4 & 1     /* diagnostic builds only: the Wh_j load without the LDS sums */
+      asm volatile("" :: "v"(w.x), "v"(w.y), "v"(w.z), "v"(w.w));
+#elif PYGAT_K4_DA_ATOMIC
       float* xs = reinterpret_cast<float*>(da_lds);
       float* ys = reinterpret_cast<float*>(da_lds + da_stride);
       lds_add(xs + 0, dsj * w.x); lds_add(xs + 1, dsj * w.y); lds_add(xs + 2, dsj * w.z); lds_add(xs + 3, dsj * w.w);
@@ -101,7 +114,8 @@ __device__ __forceinline__ void col_finish(const ColArgs& a, const LaneCols<VEC>
 template <int VEC, int LPH = 0, int CR = 0, bool DA = false>
 __device__ __forceinline__ void col_flush(const ColArgs& a, const LaneCols<VEC>& lc, int64_t k, int j,
                                           bool is_head, bool is_tail, const float4 (&acc)[VEC],
-                                          const float (&dt)[VEC], float4* da_lds = nullptr, int da_stride = 0) {
+                                          const float (&dt)[VEC], float4* da_lds = nullptr, int da_stride = 0,
+                                          const float4* wrow = nullptr) {
   if (is_head || is_tail) {
     float* p = a.part + (2 * k + (is_head ? 0 : 1)) * (int64_t)(a.rs.R + 2 * a.rs.H);
 #pragma unroll
@@ -111,7 +125,7 @@ __device__ __forceinline__ void col_flush(const ColArgs& a, const LaneCols<VEC>&
       if (((lc.cofs[v] >> 2) & (a.rs.lph - 1)) == 0) p[a.rs.R + lc.head[v]] = dt[v];
     }
   } else {
-    col_finish<VEC, LPH, CR, DA>(a, lc, j, acc, dt, da_lds, da_stride);
+    col_finish<VEC, LPH, CR, DA>(a, lc, j, acc, dt, da_lds, da_stride, wrow);
   }
 }
 
@@ -241,7 +255,9 @@ __device__ __forceinline__ void col_walk(const ColArgs& a, const int64_t k, floa
     for (int u = 0; u < U; ++u) {
       if (e + u < e1) {
         if (p[u].x != cur) {
-          col_flush<VEC, LPH, CR, DA>(a, lc, k, cur, cur == r_first && head_partial, false, acc, dt, da_lds, da_stride);
+          // (u > 0: the finished row's last edge is edge u - 1 of this round, its Wh row is still in wv[u - 1])
+          col_flush<VEC, LPH, CR, DA>(a, lc, k, cur, cur == r_first && head_partial, false, acc, dt, da_lds, da_stride,
+                                      (DA && PYGAT_K4_DA_WROW && u > 0) ? wv[u > 0 ? u - 1 : 0] : nullptr);
           cur = p[u].x;
 #pragma unroll
           for (int v = 0; v < VEC; ++v) { acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); dt[v] = 0.f; }
@@ -269,21 +285,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CR > 0 ? (D
     col_walk<LPR, VEC, WRITE_DZ, LPH, CR, false>(a, k, nullptr, 0);
   } else {
     extern __shared__ __attribute__((aligned(16))) float4 da_sm[];   // [2][blockDim.x]: (src | dst) running sums, one pair per lane
+    __shared__ int da_arrived;
     const int nt = (int)blockDim.x;
     float4* mine = da_sm + threadIdx.x;
     mine[0] = make_float4(0.f, 0.f, 0.f, 0.f); mine[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (threadIdx.x == 0) da_arrived = 0;
+    __syncthreads();   // (at the START, where the waves stand together anyway: the counter below must be zero before its first add)
     if (k < num_slots(a.g)) col_walk<LPR, VEC, WRITE_DZ, LPH, CR, true>(a, k, mine, nt);
-    __syncthreads();
-    // the work-group's lane groups added in a fixed order: thread (which, c) owns float4 c of the (src | dst) half
-    if ((int)threadIdx.x < 2 * LPR) {
-      const int which = (int)threadIdx.x / LPR, c = (int)threadIdx.x % LPR;
-      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int g = 0; g < nt / LPR; ++g) {
-        const float4 x = da_sm[which * nt + g * LPR + c];
-        t.x += x.x; t.y += x.y; t.z += x.z; t.w += x.w;
-      }
+    // No barrier at the end: a wave that is done leaves its SIMD slot; the LAST wave of the work-group to arrive adds the lane
+    // groups, always in the same order (so the record does not depend on which wave that is).  Its workgroup-scope
+    // acquire-release add comes after every other wave's LDS sums (theirs precede their own add in program order).
+    int old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(&da_arrived, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old == (nt >> 6) - 1) {
       const int R = CR ? CR : a.rs.R;
-      if (4 * c < R) st4(a.da_part + (int64_t)blockIdx.x * 2 * R + which * R + 4 * c, t);
+      for (int idx = lane; idx < 2 * LPR; idx += 64) {     // (which, c): float4 c of the (src | dst) half
+        const int which = idx / LPR, c = idx % LPR;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int g = 0; g < nt / LPR; ++g) {
+          const float4 x = da_sm[which * nt + g * LPR + c];
+          t.x += x.x; t.y += x.y; t.z += x.z; t.w += x.w;
+        }
+        if (4 * c < R) st4(a.da_part + (int64_t)blockIdx.x * 2 * R + which * R + 4 * c, t);
+      }
     }
   }
 }

@@ -40,6 +40,18 @@ def _world():
     return 0, 1
 
 
+# Test hook: with a process group of ONE rank the collectives below are still issued (a 1-GPU box can host one RCCL rank:
+# tests/test_gpu_dist.py drives all_gather_into_tensor(async_op=True), reduce_scatter_tensor and all_reduce through the
+# "nccl" backend this way).  Off: a world of one takes the short cuts.
+FORCE_COLLECTIVES = False
+
+
+def _single():
+    """True when the collectives may be skipped (no process group, or one rank and no FORCE_COLLECTIVES)."""
+    _, world = _world()
+    return world == 1 and not (FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized())
+
+
 def gather_columns_layout(buf: torch.Tensor) -> torch.Tensor:
     """[world, N, w] (what an all-gather delivers: rank-major column blocks) -> [N, world*w] (torch.cat(dim=1),
     models.py:32).  One strided copy."""
@@ -50,7 +62,7 @@ def gather_columns_layout(buf: torch.Tensor) -> torch.Tensor:
 def all_gather_columns_raw(local: torch.Tensor, widths: Sequence[int]) -> torch.Tensor:
     """[N, widths[rank]] on every rank -> [N, sum(widths)] on every rank (no autograd)."""
     rank, world = _world()
-    if world == 1:
+    if _single():
         return local
     N, wmax = local.shape[0], max(widths)
     if all(w == wmax for w in widths):
@@ -77,7 +89,7 @@ class AllGatherColumns(torch.autograd.Function):
     def backward(ctx, G):
         rank, world = _world()
         widths = ctx.widths
-        if world == 1:
+        if _single():
             return G, None
         N, wmax = G.shape[0], max(widths)
         offs = [0]
@@ -147,8 +159,7 @@ class AllReduceSum(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, t):
-        _, world = _world()
-        if world == 1:
+        if _single():
             return t
         t = t.contiguous().clone()
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -179,7 +190,7 @@ def gat_level_head_parallel(x, graph, Ws, As, Wskips, alpha: float, concat: bool
     sk = None if Wskips is None else list(Wskips[s:e])
     widths = [(b - a) * Fo for a, b in parts]
     nchunks = PIPELINE_CHUNKS
-    if (concat and hip_level and dropout == 0.0 and world > 1 and nchunks > 1 and x.shape[0] >= PIPELINE_MIN_ROWS
+    if (concat and hip_level and dropout == 0.0 and not _single() and nchunks > 1 and x.shape[0] >= PIPELINE_MIN_ROWS
             and len(set(widths)) == 1 and e > s):
         return _pipelined_concat_level(x, graph, list(Ws[s:e]), list(As[s:e]), sk, alpha, widths, nchunks)
     if concat:

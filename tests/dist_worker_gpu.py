@@ -96,11 +96,66 @@ def pipeline(rank, world, pg, dev):
                 assert float((ps[key].grad - pr[key].grad).abs().max()) < 5e-5 * scale, key
 
 
+def rccl_world1(pg, dev):
+    """ONE rank on the "nccl" backend (= RCCL; a 1-GPU box hosts exactly one) with dist.FORCE_COLLECTIVES: the pipelined
+    hidden level issues all_gather_into_tensor(async_op=True) per row chunk on RCCL's stream, its backward
+    reduce_scatter_tensor, the output level all_reduce -- the calls the driver's N-GPU run makes, never executed through
+    RCCL before round 4.  With one rank every collective is the identity, so the model must equal the unsharded one."""
+    import pygat_amd.dist as D
+    assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    D.FORCE_COLLECTIVES = True
+    N = 1 << 16                                   # >= dist.PIPELINE_MIN_ROWS: the row-chunk pipeline runs
+    assert N >= D.PIPELINE_MIN_ROWS and D.PIPELINE_CHUNKS > 1
+    from pygat_amd.rmat import rmat_csr
+    rowptr, col = rmat_csr(16, 300_000, seed=4, device=dev)
+    g = pg.CSRGraph(rowptr, col)
+    torch.manual_seed(2)
+    kw = dict(nfeat=[32, 16, 16, 5], nheads=[4, 4, 3], nlayers=3, dropout=0.0, alpha=0.2, layer_type=pg.SpGraphAttentionLayer)
+    sharded = pg.GAT(head_parallel=True, **kw).to(dev)
+    plain = pg.GAT(**kw).to(dev)
+    plain.load_state_dict(sharded.state_dict())
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(N, 32, generator=gen).to(dev); G = torch.randn(N, 5, generator=gen).to(dev)
+    calls = {"ag": 0, "rs": 0, "ar": 0}
+    real = (dist.all_gather_into_tensor, dist.reduce_scatter_tensor, dist.all_reduce)
+
+    def counted(name, fn):
+        def f(*a, **k):
+            calls[name] += 1
+            return fn(*a, **k)
+        return f
+    dist.all_gather_into_tensor = counted("ag", real[0]); dist.reduce_scatter_tensor = counted("rs", real[1])
+    dist.all_reduce = counted("ar", real[2])
+    try:
+        y = sharded(x, g); y.backward(G)
+    finally:
+        dist.all_gather_into_tensor, dist.reduce_scatter_tensor, dist.all_reduce = real
+    torch.cuda.synchronize()
+    yr = plain(x, g); yr.backward(G)
+    torch.cuda.synchronize()
+    assert calls["ag"] == 2 * D.PIPELINE_CHUNKS and calls["rs"] == 2 and calls["ar"] >= 1, calls    # two hidden levels, one output level
+    assert float((y - yr).abs().max()) <= 1e-6 * max(1.0, float(yr.abs().max())), float((y - yr).abs().max())
+    for (k, p), (_, q) in zip(sharded.named_parameters(), plain.named_parameters()):
+        assert p.grad is not None and float((p.grad - q.grad).abs().max()) <= 1e-5 * max(1.0, float(q.grad.abs().max())), k
+    D.FORCE_COLLECTIVES = False
+    print("rccl world-1: collectives", calls)
+
+
 def main():
     rank, world, port = (int(v) for v in sys.argv[1:4])
     mode = sys.argv[4] if len(sys.argv) > 4 else "small"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if mode == "rccl1":
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        import pygat_amd as pg
+        rccl_world1(pg, dev)
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+        print("rank 0 ok")
+        return
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import pygat_amd as pg
     from pygat_amd.dist import partition_heads

@@ -50,3 +50,23 @@ def test_pipelined_hidden_levels_world2_on_one_card():
         outs.append(o.decode())
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"rank {r} ok" in o, o[-3000:]
+
+
+def test_rccl_backend_world1_drives_the_collectives():
+    """SURVEY.md 7.3 "world_size 1 RCCL smoke on the single GPU": a fresh child initialises the "nccl" backend (RCCL) with
+    one rank and runs a 3-level head-parallel model whose collectives are forced on (dist.FORCE_COLLECTIVES): the row-chunk
+    pipeline's all_gather_into_tensor(async_op=True), the reduce_scatter_tensor of its backward and the output level's
+    all_reduce all execute through RCCL, and the result equals the unsharded model."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker_gpu.py"), "0", "1", str(port), "rccl1"],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
+    try:
+        o, _ = p.communicate(timeout=300)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        raise
+    o = o.decode()
+    assert p.returncode == 0 and "rank 0 ok" in o and "rccl world-1: collectives" in o, o[-3000:]

@@ -18,6 +18,10 @@ if [ "$PART" = all ] || [ "$PART" = a ]; then
   prof --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/sq2 -- python3 $R/bench.py --no-cpu --no-epoch --no-v2 --steps 4 --warmup 2 > $O/sq2.log 2>&1
   python3 tools/sq_summary.py $O/sq1 $O/sq2 --out $P/${TAG}_sq_counters.json > $O/sq_summary.log 2>&1; rm -rf $O/sq1 $O/sq2
   for n in 8 4 2; do python3 bench.py --as-rank-of $n --no-cpu --no-epoch --no-v2 --steps 20 2> $O/rank$n.err; done > $P/${TAG}_as_rank_of.jsonl
+  # the shard of an 8-GPU run at wider heads: rank-0 work against the 1-GPU step of the same F'
+  for f in 64 128; do
+    python3 bench.py --fout $f --as-rank-of 8 --no-cpu --no-epoch --no-v2 --steps 10 2> $O/rank8_f$f.err
+  done > $P/${TAG}_as_rank_of_8_wide_heads.jsonl
   python3 bench.py --dx --no-cpu --no-epoch --steps 20 > $P/${TAG}_bench_dx.json 2> $O/dx.err
 fi
 if [ "$PART" = all ] || [ "$PART" = b ]; then
@@ -31,5 +35,14 @@ if [ "$PART" = all ] || [ "$PART" = b ]; then
   prof --kernel-trace --stats --output-format csv -d $O/v2 -- python3 $R/tools/v2_bench.py > $O/v2.log 2>&1
   python3 tools/rocprof_top.py $O/v2 --per 25 --top 10 --csv $P/${TAG}_gatv2_kernel_stats.csv > $P/${TAG}_gatv2_top_kernels.txt 2>&1; rm -rf $O/v2; grep ms_per_step $O/v2.log >> $P/${TAG}_gatv2_top_kernels.txt
   BENCH_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29621 bench.py --gpus 2 --steps 5 --warmup 2 --verify > $O/gloo2.json 2> $P/${TAG}_gloo_rehearsal_2ranks.log
+  # the per-rank shapes of the driver's 8-GPU default (ONE 16-float head per rank: 32-edge slots, narrow-row kernels) at the most
+  # ranks one card may host (the pool's process guard admits 6 GPU processes, not 8): 6 heads on 6 ranks, and 4 on 4
+  for n in 6 4; do
+    BENCH_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 2963$n bench.py --gpus $n --heads $n --steps 3 --warmup 1 --verify > $O/gloo_1head_$n.json 2> $P/${TAG}_gloo_rehearsal_${n}ranks_one_head_each.log
+  done
+  # config 4: PMC traffic of the PPI epoch's kernels (separate passes, as for configs 3 and 5)
+  prof --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/ppi_fetch -- python3 $R/tools/epoch_profile.py ppi --epochs 12 > $O/ppi_fetch.log 2>&1
+  prof --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/ppi_write -- python3 $R/tools/epoch_profile.py ppi --epochs 12 > $O/ppi_write.log 2>&1
+  python3 tools/pmc_summary.py $O/ppi_fetch $O/ppi_write --out $P/${TAG}_ppi_epoch_pmc.json --edges 0 --heads 4 --note "PPI-shaped epoch (BASELINE config 4), tools/epoch_profile.py ppi: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE+TCC in separate passes, per-launch means, FETCH_SIZE doubled" > $O/ppi_pmc.log 2>&1; rm -rf $O/ppi_fetch $O/ppi_write
 fi
 echo "profile_round $TAG $PART done"

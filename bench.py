@@ -350,9 +350,19 @@ def main():
             chunk_rows[c] = (r0, r1)
         assert chunk_rows[c] == (r0, r1), f"chunk {c}: rows {(r0, r1)} now, {chunk_rows[c]} before"
         works.append(dist.all_gather_into_tensor(buf.view(world * (r1 - r0), h_loc * Fo), out[r0:r1], async_op=True))
+        if c >= 1:
+            land(c - 1)          # the previous chunk's exchange has had a chunk of compute to finish (as pygat_amd.dist does)
 
     chunk_rows = {}
     full_out = None
+    side = torch.cuda.Stream(device=dev) if use_pg else None
+
+    def land(c):
+        """gathered chunk c -> its column slices of the [N, H F'] activation (models.py:32 torch.cat), on the side stream."""
+        r0, r1 = chunk_rows[c]
+        with torch.cuda.stream(side):
+            works[c].wait()
+            full_out[r0:r1].view(r1 - r0, world, h_loc * Fo).copy_(gbufs[c].permute(1, 0, 2))
 
     def step():
         if use_pg:
@@ -360,17 +370,17 @@ def main():
             W_loc.grad = a_loc.grad = None
             if args.dx:
                 Xb.grad = None
-            out = pg.GATLevelFn.apply(Xb, W_loc, a_loc, None, graph, 0.2, True, None, (nchunks, on_chunk))
-            out.backward(G_loc)
-            # join the exchange and lay the gathered blocks out as the next level reads them ([N, H F'], models.py:32 torch.cat):
-            # what pygat_amd.dist._pipelined_concat_level does -- one strided copy per chunk, part of the step
             nonlocal full_out
             if full_out is None:
                 full_out = torch.empty(N, world * h_loc * Fo, device=dev)
-            for c, wk in enumerate(works):
-                wk.wait()
-                r0, r1 = chunk_rows[c]
-                full_out[r0:r1].view(r1 - r0, world, h_loc * Fo).copy_(gbufs[c].permute(1, 0, 2))
+            side.wait_stream(torch.cuda.current_stream(dev))
+            out = pg.GATLevelFn.apply(Xb, W_loc, a_loc, None, graph, 0.2, True, None, (nchunks, on_chunk))
+            land(len(works) - 1)
+            out.backward(G_loc)
+            # the gathered blocks are laid out as the next level reads them ([N, H F'], models.py:32 torch.cat) -- what
+            # pygat_amd.dist._pipelined_concat_level does: one strided copy per chunk on a side stream, beside the later chunks
+            # and this level's backward; the step ends when the last of them has landed
+            torch.cuda.current_stream(dev).wait_stream(side)
             return full_out
         out = level_fwd()
         level_bwd(out)

@@ -298,8 +298,9 @@ int pygat_gat_backward_row(const pygat_graph* g, int H, int Fo, float alpha,
  * row's edges -- every lane adds ds_j Wh_j and dt_j Wh_j into two float4s of its own in LDS, and each work-group leaves ONE
  * record [2 R] = (sum ds_j Wh_j | sum dt_j Wh_j) over the rows it finished, lane groups added in a fixed order.  Rows cut by a
  * slot border are finished by the fix-up launch and are NOT in the records: pygat_a_grad_fold adds them from the cut-row
- * list.  Needs ds (row sums known), all heads in one window of one-chunk rows (R <= 256) and a graph with a cut-row list:
- * pygat_gat_backward_col_da_bytes returns the size of da_part, 0 when the pass cannot do it (then pygat_a_grad).
+ * list.  Needs ds (row sums known), a level of 8 heads x 16 in one window (the instantiation that keeps four waves per
+ * SIMD with the sums; the others lose a wave to them and more time than the a-gradient pass costs) and a graph with a cut-row
+ * list: pygat_gat_backward_col_da_bytes returns the size of da_part, 0 when the pass does not do it (then pygat_a_grad).
  * What it replaces: a launch that streams Wh, ds and dt again (0.6 GB, 0.12 ms at config 5). */
 size_t pygat_gat_backward_col_da_bytes(const pygat_graph* gT, int H, int Fo, int head_group);
 int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm_t, int H, int Fo, float alpha,

@@ -197,15 +197,18 @@ __host__ __device__
 static inline int64_t num_slots(const GraphDev& g) { return (g.nnz + g.ts - 1) / g.ts; }
 
 // Work-groups of the column pass (pygat_gat_backward_col) over gT for a level of H heads = its da_part records, or 0 when the
-// pass cannot take the attention-vector gradient along: rows of more than one chunk per lane, head windows (hg < H), no
-// cut-row list (the rows its fix-up finishes are folded in by pygat_a_grad_fold from that list).
+// pass does not take the attention-vector gradient along: no cut-row list (the rows its fix-up finishes are folded in by
+// pygat_a_grad_fold from that list), head windows (hg < H), or a row shape other than 8 heads x 16 -- the one
+// instantiation that keeps its four waves per SIMD with the sums (128 VGPRs).  The others hold 130-138 VGPRs with them,
+// three waves, and lose more than the a-gradient pass costs: measured at 1 / 2 / 4 heads of 16 on the config-5 graph, K4
+// 0.275 -> 0.291, 0.413 -> 0.444, 0.71 -> 0.83 ms (profiles/r4m_as_rank_of.jsonl of the first build), so they are not built.
 static inline int64_t col_da_blocks(const GraphDev& g, int H, int Fp, int hg, int* lpr_out) {
   RowShape rs;
   if (!g.cut || !make_window_shape(H, Fp, H, &rs)) return 0;   // (Fp as F': padded_width(Fp) == Fp)
   if (hg < H) return 0;
   int lpr, vec;
   pick_lanes(rs, &lpr, &vec);
-  if (vec != 1) return 0;
+  if (vec != 1 || H != 8 || Fp != 16) return 0;
   const unsigned bt = (lpr <= 8) ? narrow_block() : 256u;
   if (lpr_out) *lpr_out = lpr;
   return cdiv(cdiv(num_slots(g), 64 / lpr), bt / 64);

@@ -190,8 +190,8 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_fast_kernel(PrepArgs a) {
         st4(a.GR + i * RW + gp_off, g);
         if (a.whi) st4(a.GR + i * RW + R + 4 * H + co, ld4(a.whi + i * a.ld_whi + co));
       }
+      if (lead) st4(a.GR + i * RW + rt_off, make_float4(sv[r], mv[r], 1.0f / zv[r], D));
       if (lead) {
-        st4(a.GR + i * RW + rt_off, make_float4(sv[r], mv[r], 1.0f / zv[r], D));
         if (a.aneg) a.ds[i * ldh + h] = (qv[r] != 0.f) ? (a.slope - 1.f) * (gn - D * qv[r]) : 0.f;
       }
     }

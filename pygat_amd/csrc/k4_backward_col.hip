@@ -211,10 +211,13 @@ __device__ __forceinline__ void col_walk(const ColArgs& a, const int64_t k, floa
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         if constexpr (CR > 0) {   // both tables below 4 GiB (checked at launch): 32-bit element offsets from a scalar base
+          // (measured and dropped, gpurun_out r4h / r4i: without the record read -- 128 of the row's 640 bytes, its fifth line --
+          // K4 runs 1.24 -> 1.07 ms; from a table of its own (128 MB, Infinity-Cache sized) the records cost the same 0.17 ms:
+          // the price is the gathered line, wherever it lies)
           const uint32_t go = (uint32_t)p[u].y * (uint32_t)RW;
           gv[u][v] = ld4(a.GR + (go + (uint32_t)lc.cofs[v]));
-          rt[u][v] = ld4(a.GR + (go + (uint32_t)(R + 4 * lc.head[v])));
-          wv[u][v] = ld4(a.Wh + ((uint32_t)p[u].x * (uint32_t)ldr + (uint32_t)lc.cofs[v]));
+          rt[u][v] = (PYGAT_DIAG_K4 & 8) ? gv[u][v] : ld4(a.GR + (go + (uint32_t)(R + 4 * lc.head[v])));   // (bit 3: diagnostic, no scalar-record read)
+          wv[u][v] = ld4(a.Wh + ((uint32_t)((PYGAT_DIAG_K4 & 4) ? (p[u].x & 63) : p[u].x) * (uint32_t)ldr + (uint32_t)lc.cofs[v]));   // (bit 2: diagnostic, row-local reads from 64 cached rows)
         } else {
         const float* gr = a.GR + (int64_t)p[u].y * RW;           // gathered: one contiguous row
         gv[u][v] = ld4(gr + lc.cofs[v]);
@@ -526,7 +529,7 @@ extern "C" int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm
   PYGAT_REQUIRE(hg > 0, "gat_backward_col: head_group=%d gives rows of more than 1024 floats per pass", head_group);
   if (da_part) {
     PYGAT_REQUIRE(ds && rg.hr == H && aligned16(da_part) && col_da_blocks(a.g, H, Fp, hg, nullptr) > 0,
-                  "gat_backward_col: da_part needs ds, all heads in one pass of one-chunk rows and a cut-row list "
+                  "gat_backward_col: da_part needs ds, 8 heads x 16 in one pass and a cut-row list "
                   "(pygat_gat_backward_col_da_bytes() == 0 otherwise)");
   }
   a.da_part = da_part;
@@ -557,17 +560,10 @@ extern "C" int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm
         hipLaunchKernelGGL((gat_bwd_col_kernel<32, 1, false, 4, 128, true>), dim3(blocks), dim3(bt), da_lds, st, a);
       else if (dense)
         hipLaunchKernelGGL((gat_bwd_col_kernel<32, 1, false, 4, 128>), dim3(blocks), dim3(bt), 0, st, a);
-      else if (da_part)
+      else if (da_part)   // (8 x 16 with an attention mask or a table of 4 GiB and more: run-time strides, 130 VGPRs)
         hipLaunchKernelGGL((gat_bwd_col_kernel<32, 1, false, 4, 0, true>), dim3(blocks), dim3(bt), da_lds, st, a);
       else
         hipLaunchKernelGGL((gat_bwd_col_kernel<32, 1, false, 4>), dim3(blocks), dim3(bt), 0, st, a);
-    } else if (da_part) {   // (vec == 1: checked above)
-      switch (lpr) {
-#define PYGAT_COL_DA(L) case L: hipLaunchKernelGGL((gat_bwd_col_kernel<L, 1, false, 0, 0, true>), dim3(blocks), dim3(bt), da_lds, st, a); break;
-        PYGAT_COL_DA(1) PYGAT_COL_DA(2) PYGAT_COL_DA(4) PYGAT_COL_DA(8) PYGAT_COL_DA(16) PYGAT_COL_DA(32)
-        default: hipLaunchKernelGGL((gat_bwd_col_kernel<64, 1, false, 0, 0, true>), dim3(blocks), dim3(bt), da_lds, st, a); break;
-#undef PYGAT_COL_DA
-      }
     } else {
       PYGAT_DISPATCH_LANES(lpr, vec,
                            hipLaunchKernelGGL((gat_bwd_col_kernel<LPR, VEC, false>), dim3(blocks), dim3(bt), 0, st, a));

@@ -95,9 +95,15 @@ class AllGatherColumns(torch.autograd.Function):
         offs = [0]
         for w in widths:
             offs.append(offs[-1] + w)
-        stacked = torch.zeros(world, N, wmax, dtype=G.dtype, device=G.device)
-        for r in range(world):
-            stacked[r, :, :widths[r]] = G[:, offs[r]:offs[r + 1]]
+        if all(w == wmax for w in widths):
+            # [N, world w] -> [world, N, w], the layout the reduce-scatter sends: ONE strided copy (rounds 1-3: a zero fill and
+            # a Python loop of `world` slice copies).  Writing the input gradient in this layout to begin with needs a
+            # column-blocked C in the dX GEMM of the next level: DESIGN.md section 5, not built.
+            stacked = G.reshape(N, world, wmax).permute(1, 0, 2).contiguous()
+        else:
+            stacked = torch.zeros(world, N, wmax, dtype=G.dtype, device=G.device)
+            for r in range(world):
+                stacked[r, :, :widths[r]] = G[:, offs[r]:offs[r + 1]]
         out = torch.empty(N, wmax, dtype=G.dtype, device=G.device)
         if dist.get_backend() == "nccl":
             dist.reduce_scatter_tensor(out, stacked.view(world * N, wmax), op=dist.ReduceOp.SUM)
@@ -114,6 +120,17 @@ import os as _os
 # could disagree and hang); set the environment identically on all ranks, or assign dist.PIPELINE_CHUNKS on all of them.
 PIPELINE_CHUNKS = int(_os.environ.get("PYGAT_DIST_CHUNKS", 4))
 PIPELINE_MIN_ROWS = 1 << 15  # below this a level is launch-bound and one blocking all-gather is cheaper
+
+
+_layout = {}
+
+
+def _layout_stream(dev) -> "torch.cuda.Stream":
+    """One side stream per device for the layout copies of gathered chunks."""
+    key = torch.device(dev).index
+    if key not in _layout:
+        _layout[key] = torch.cuda.Stream(device=dev)
+    return _layout[key]
 
 
 class _GatheredColumns(torch.autograd.Function):
@@ -142,15 +159,29 @@ def _pipelined_concat_level(x, graph, Ws, As, sk, alpha, widths, nchunks):
     N, w = x.shape[0], widths[rank]
     full = torch.empty(N, sum(widths), dtype=torch.float32, device=x.device)
     works = []
+    main = torch.cuda.current_stream(x.device)
+    side = _layout_stream(x.device)
+    side.wait_stream(main)                                  # `full` was allocated on the compute stream
+
+    def land(item):
+        """chunk `item` into its column slices of `full`, on the SIDE stream: it waits for the chunk's all-gather there and
+        the strided copy runs beside the computation of the later chunks (round 4; rounds 2-3 made all these copies on the
+        compute stream after the level, ~0.17 ms per level at config 5)."""
+        work, buf, r0, r1 = item
+        with torch.cuda.stream(side):
+            work.wait()
+            full[r0:r1].view(r1 - r0, world, w).copy_(buf.permute(1, 0, 2))
+        buf.record_stream(side)
 
     def on_chunk(c, r0, r1, out):
         buf = torch.empty(world, r1 - r0, w, dtype=out.dtype, device=out.device)
         works.append((dist.all_gather_into_tensor(buf.view(world * (r1 - r0), w), out[r0:r1], async_op=True), buf, r0, r1))
+        if c >= 1:
+            land(works[c - 1])                              # the previous chunk's exchange has had a chunk of compute to finish
 
     local = gat_level(x, graph, Ws, As, sk, alpha, True, pipeline=(nchunks, on_chunk))
-    for work, buf, r0, r1 in works:
-        work.wait()                                         # the compute stream waits for this chunk only
-        full[r0:r1].view(r1 - r0, world, w).copy_(buf.permute(1, 0, 2))
+    land(works[-1])
+    main.wait_stream(side)                                  # the next level reads `full` on the compute stream
     return _GatheredColumns.apply(local, full, widths)
 
 

@@ -225,9 +225,10 @@ __global__ __launch_bounds__(512) void gemm_smallk_x3_kernel(SmallKArgs g) {
     // s[row, head] = sum over the head's SRF columns of C[row, col] a_src[col]: this lane holds 4 (SRF = 8) or 8 (SRF = 16)
     // of them, lane ^ 32 the others.  Taken tile by tile, in front of the tile's stores (its registers are free after them);
     // four finished heads go out as one 16-byte store of the half-wave (group index & 1).
-    constexpr int HPT = SRF > 0 ? 32 / SRF : 1, GPH = SRF > 0 ? SRF / 8 : 1;   // heads per 32-column tile, register quads per head
+    constexpr int SRD = SRF > 0 ? SRF : 32;                 // (no division by a zero template argument in the SRF = 0 instantiations)
+    constexpr int HPT = 32 / SRD, GPH = SRF > 0 ? SRF / 8 : 1;   // heads per 32-column tile, register quads per head
     float hs[4] = {0.f, 0.f, 0.f, 0.f};
-    float* so = (SRF > 0) ? g.s_out + row * g.s_ld + n0 / (SRF > 0 ? SRF : 1) : nullptr;
+    float* so = (SRF > 0) ? g.s_out + row * g.s_ld + n0 / SRD : nullptr;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       if constexpr (SRF > 0 && !(PYGAT_DIAG_K1 & 2)) {

@@ -577,27 +577,12 @@ static int launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
   dim3 grid((unsigned)cdiv(g.M, BM), (unsigned)cdiv(g.N, 32 * NT), (unsigned)splits);
   // (32-deep k-tiles for the 128-column tile were measured on the PPI level-2 projection 3144 x 2056 x 1024: 189 us with
   // 16-deep tiles, 219 us with 32-deep ones -- 66 KB of LDS leave two work-groups per CU where 34 KB leave three)
-  constexpr bool deep = false;
   auto lds = [](int nt, int bk) { return (size_t)2 * bk * ((BM + PAD) + (32 * nt + PAD)) * sizeof(float); };
   switch (NT) {
     case 1: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 1, 16>), grid, dim3(256), lds(1, 16), st, g); break;
     case 2: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 2, 16>), grid, dim3(256), lds(2, 16), st, g); break;
     case 3: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 3, 16>), grid, dim3(256), lds(3, 16), st, g); break;
-    case 4:
-      if (deep) {
-        int dev = -1;
-        (void)hipGetDevice(&dev);
-        static bool attr_set[64] = {};   // 66 KB of LDS: above the 64 KB a kernel gets without asking
-        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<TA, TB, 4, 32>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-          if (dev >= 0 && dev < 64) attr_set[dev] = true;
-        }
-        hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 4, 32>), grid, dim3(256), lds(4, 32), st, g);
-      } else {
-        hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 4, 16>), grid, dim3(256), lds(4, 16), st, g);
-      }
-      break;
+    case 4: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 4, 16>), grid, dim3(256), lds(4, 16), st, g); break;
     default: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, 5, 16>), grid, dim3(256), lds(5, 16), st, g); break;
   }
   return 0;

@@ -225,7 +225,7 @@ template <bool TB, bool SV>
 static hipError_t launch_smallk(const SmallKArgs& g, int NT, dim3 grid, size_t lds, hipStream_t st) {
   int dev = -1;
   (void)hipGetDevice(&dev);
-  constexpr int nbuf_wide = 2;   // (3 chunks in flight were measured: 0.434 -> 0.437 ms at 5 column tiles)
+  // (three A chunks in flight at 3-5 column tiles were measured: 0.434 -> 0.437 ms at 5 tiles, DESIGN.md section 8: two)
 #define PYGAT_SMALLK_LAUNCH(n, nb)                                                                        \
   {                                                                                                       \
     static bool attr_set[64] = {};   /* per device: the attribute belongs to the device's code object */ \
@@ -238,7 +238,7 @@ static hipError_t launch_smallk(const SmallKArgs& g, int NT, dim3 grid, size_t l
   }
 #define PYGAT_SMALLK_CASE(n)                                                                              \
   case n:                                                                                                 \
-    if (nbuf_wide == 3) PYGAT_SMALLK_LAUNCH(n, 3) else PYGAT_SMALLK_LAUNCH(n, 2)                          \
+    PYGAT_SMALLK_LAUNCH(n, 2)                                                                             \
     break;
   switch (NT) {
     case 1: PYGAT_SMALLK_LAUNCH(1, 4) break;
@@ -398,87 +398,8 @@ __global__ __launch_bounds__(256) void gemm_tn_stream_kernel(TnArgs g) {
   }
 }
 
-// Wide-load variant (A and B rows 16-byte aligned, M % 4 == 0, N % 4 == 0): every lane fetches FOUR
-// consecutive columns of a k row with one 16-byte load -- lanes 0-31 sweep 512 contiguous bytes of row
-// k, lanes 32-63 of row k+1 -- and the 128 x 128 tile is dealt out by column RESIDUE instead of by
-// block: MFMA (q, c) computes rows {4i+q} x columns {4j+c}, so component q of the A vector and
-// component c of the B vector are exactly its operands.  Wave w takes q = w and all four c: 2 wide
-// loads feed 4 MFMAs (the dword version needs 5 narrow ones).
-__global__ __launch_bounds__(256) void gemm_tn_wide_kernel(TnArgs g) {
-  constexpr int UK = 8;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int fr = lane & 31, fh = lane >> 5;
-  const int m0 = blockIdx.y * 128, n0 = blockIdx.z * 128;
-  const int64_t kbeg = (int64_t)blockIdx.x * g.k_per_split;
-  const int64_t kend = (kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K;
-  // clamp out-of-range column groups to a valid one: their products only reach rows / columns of C
-  // that are never stored
-  const float* ap = g.A + ((m0 + 4 * fr + 3 < g.M) ? m0 + 4 * fr : 0);
-  const float* bp = g.B + ((n0 + 4 * fr + 3 < g.N) ? n0 + 4 * fr : 0);
-  f32x16 acc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  auto pick = [&](const float4& v) { return w == 0 ? v.x : (w == 1 ? v.y : (w == 2 ? v.z : v.w)); };
-#define PYGAT_TNW_LOAD(AX, BX, KBASE)                                                         \
-  _Pragma("unroll") for (int u = 0; u < UK; ++u) {                                            \
-    const int64_t k = (KBASE) + 2 * u + fh;                                                   \
-    AX[u] = ld4(ap + k * g.lda);                                                              \
-    BX[u] = ld4(bp + k * g.ldb);                                                              \
-  }
-#define PYGAT_TNW_MMA(AX, BX)                                                                 \
-  _Pragma("unroll") for (int u = 0; u < UK; ++u) {                                            \
-    const float av = pick(AX[u]);                                                             \
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, BX[u].x, acc[0], 0, 0, 0);              \
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, BX[u].y, acc[1], 0, 0, 0);              \
-    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, BX[u].z, acc[2], 0, 0, 0);              \
-    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, BX[u].w, acc[3], 0, 0, 0);              \
-  }
-  int64_t k0 = kbeg;
-  const int64_t nfull = (kend - kbeg) / (2 * UK);
-  if (nfull > 0) {
-    float4 a0[UK], b0[UK], a1[UK], b1[UK];
-    PYGAT_TNW_LOAD(a0, b0, k0)
-    for (int64_t i = 0; i < nfull; i += 2) {
-      const int64_t kn1 = kbeg + ((i + 1 < nfull) ? i + 1 : nfull - 1) * 2 * UK;
-      PYGAT_TNW_LOAD(a1, b1, kn1)
-      __builtin_amdgcn_sched_barrier(0);
-      PYGAT_TNW_MMA(a0, b0)
-      __builtin_amdgcn_sched_barrier(0);
-      const int64_t kn2 = kbeg + ((i + 2 < nfull) ? i + 2 : nfull - 1) * 2 * UK;
-      PYGAT_TNW_LOAD(a0, b0, kn2)
-      __builtin_amdgcn_sched_barrier(0);
-      if (i + 1 < nfull) PYGAT_TNW_MMA(a1, b1)
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    k0 = kbeg + nfull * 2 * UK;
-  }
-#undef PYGAT_TNW_LOAD
-#undef PYGAT_TNW_MMA
-  for (; k0 < kend; k0 += 2) {  // K tail: rows past kend contribute a zero A operand
-    const int64_t k = k0 + fh;
-    const float keep = k < kend ? 1.f : 0.f;
-    const int64_t kk = k < kend ? k : kend - 1;
-    const float av = pick(ld4(ap + kk * g.lda)) * keep;
-    const float4 bv = ld4(bp + kk * g.ldb);
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.x, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.y, acc[1], 0, 0, 0);
-    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.z, acc[2], 0, 0, 0);
-    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.w, acc[3], 0, 0, 0);
-  }
-  // MFMA (q = w, c): tile element (i', j') is C[m0 + 4 i' + w][n0 + 4 j' + c]
-  float* base = g.ws + (int64_t)blockIdx.x * g.M * g.N;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int col = n0 + 4 * fr + c;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + 4 * ((r & 3) + 8 * (r >> 2) + 4 * fh) + w;
-      if (row < g.M && col < g.N) base[(int64_t)row * g.N + col] = acc[c][r];
-    }
-  }
-}
+// (A wide-load variant -- every lane fetching four consecutive columns of a k row, the tile dealt out by column residue -- was
+// built in round 1 and measured slower: it re-fetches A once per wave, 3.5 GB of HBM reads for a 1 GB problem.  Removed in round 4.)
 
 // picks the slab count, launches; returns the number of slabs written to ws (>= 1), 0 if the shape
 // does not qualify, < 0 on error.  ws must hold max_splits * M * N floats.
@@ -503,8 +424,6 @@ int try_gemm_tn_stream(int M, int N, int64_t K, const float* A, int64_t lda, con
   TnArgs g;
   g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.k_per_split = kps; g.ws = ws;
   g.N1 = N1; g.B2 = B2; g.ldb2 = ldb2;
-  // the wide-load variant re-fetches A four times (once per wave) and measured slower (3.5 GB of HBM
-  // reads for a 1 GB problem); it stays selectable for experiments
   if (split) {
     const int64_t kps16 = cdiv(cdiv(K, max_splits), 48) * 48;
     TnArgs gx = g;
@@ -512,24 +431,10 @@ int try_gemm_tn_stream(int M, int N, int64_t K, const float* A, int64_t lda, con
     const int r = try_gemm_tn_x3(gx, (int)cdiv(K, kps16), st);
     if (r != 0) return r;
   }
-  const bool wide = false && !B2 && aligned16(A) && aligned16(B) && (lda % 4) == 0 && (ldb % 4) == 0 && (M % 4) == 0 && (N % 4) == 0 &&
-                    M >= 4 && N >= 4;
-  if (wide) {
-    dim3 gridw((unsigned)splits, (unsigned)tiles_m, (unsigned)cdiv(N, 128));
-    hipLaunchKernelGGL(gemm_tn_wide_kernel, gridw, dim3(256), 0, st, g);
-    hipError_t ew = hipGetLastError();
-    if (ew != hipSuccess) {
-      set_error("gemm_tn_wide: %s", hipGetErrorString(ew));
-      return PYGAT_EHIP;
-    }
-    return splits;
-  }
   dim3 grid((unsigned)splits, (unsigned)tiles_m, (unsigned)tiles_n);
 #define PYGAT_TN_CASE(NTV)                                                                                      \
   case NTV:                                                                                                     \
-    if (uk == 32) hipLaunchKernelGGL((gemm_tn_stream_kernel<NTV, 32>), grid, dim3(256), 0, st, g);              \
-    else if (uk == 16) hipLaunchKernelGGL((gemm_tn_stream_kernel<NTV, 16>), grid, dim3(256), 0, st, g);         \
-    else if (uk == 4) hipLaunchKernelGGL((gemm_tn_stream_kernel<NTV, 4>), grid, dim3(256), 0, st, g);           \
+    if (uk == 16) hipLaunchKernelGGL((gemm_tn_stream_kernel<NTV, 16>), grid, dim3(256), 0, st, g);              \
     else hipLaunchKernelGGL((gemm_tn_stream_kernel<NTV, 8>), grid, dim3(256), 0, st, g);                        \
     break;
   switch (NT) {

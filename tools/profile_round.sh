@@ -35,9 +35,12 @@ if [ "$PART" = all ] || [ "$PART" = b ]; then
   prof --kernel-trace --stats --output-format csv -d $O/v2 -- python3 $R/tools/v2_bench.py > $O/v2.log 2>&1
   python3 tools/rocprof_top.py $O/v2 --per 25 --top 10 --csv $P/${TAG}_gatv2_kernel_stats.csv > $P/${TAG}_gatv2_top_kernels.txt 2>&1; rm -rf $O/v2; grep ms_per_step $O/v2.log >> $P/${TAG}_gatv2_top_kernels.txt
   BENCH_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29621 bench.py --gpus 2 --steps 5 --warmup 2 --verify > $O/gloo2.json 2> $P/${TAG}_gloo_rehearsal_2ranks.log
+fi
+if [ "$PART" = all ] || [ "$PART" = c ]; then
   # the per-rank shapes of the driver's 8-GPU default (ONE 16-float head per rank: 32-edge slots, narrow-row kernels) at the most
-  # ranks one card may host (the pool's process guard admits 6 GPU processes, not 8): 6 heads on 6 ranks, and 4 on 4
-  for n in 6 4; do
+  # ranks one card may host (the pool's process guard admits 6 processes with the GPU open, the launcher included -- a 6-rank
+  # run was killed by it): 5 heads on 5 ranks, and 4 on 4
+  for n in 5 4; do
     BENCH_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 2963$n bench.py --gpus $n --heads $n --steps 3 --warmup 1 --verify > $O/gloo_1head_$n.json 2> $P/${TAG}_gloo_rehearsal_${n}ranks_one_head_each.log
   done
   # config 4: PMC traffic of the PPI epoch's kernels (separate passes, as for configs 3 and 5)

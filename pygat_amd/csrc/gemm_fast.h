@@ -35,6 +35,7 @@ struct SmallKArgs {
   // (k1_gemm_x3.hip, set by try_gemm_smallk_x3) every output segment starts at a multiple of 32 columns with 16-byte aligned
   // rows: a lane's four consecutive columns of a row go out as one 16-byte store; s_vec: the same for the lane's s values
   int vec_out, s_vec;
+  int lds_rows;   // 1: the epilogue turns every 32 x 32 tile through the wave's own LDS patch and stores WHOLE 128-byte lines
 };
 
 struct TnArgs {

@@ -67,6 +67,9 @@ __device__ __forceinline__ void pair_of(const float4& a, const float4& b, int j,
 #ifndef PYGAT_DIAG_K1
 #define PYGAT_DIAG_K1 0
 #endif
+#ifndef PYGAT_K1_LDS_ROWS
+#define PYGAT_K1_LDS_ROWS 1   // the projection's epilogue stores whole lines through LDS patches (0: 16-byte stores of 32 rows each)
+#endif
 // all nine piece products of one 32 x 32 x 16 block, small terms first
 template <class TB_>
 __device__ __forceinline__ f32x16 mma9(const Frag3& a, const TB_& bh, const TB_& bm, const TB_& bl, f32x16 c) {
@@ -139,20 +142,39 @@ __global__ __launch_bounds__(512) void gemm_smallk_x3_kernel(SmallKArgs g) {
   const int IMG = BN * KP;
   float* Us = reinterpret_cast<float*>(Bimg + 3 * IMG);            // [K][8]: svec, zero padded (SV only)
   float* Asr = Us + (SV ? g.K * 8 : 0);                            // [BN]: a_src of every output column of this block (SR only)
+  float* Stg = Asr + (SRF > 0 ? BN : 0) + 4;                       // [8 waves][32][36]: the epilogue's row patches (lds_rows), behind the 4 turn words
   const int n0 = blockIdx.y * BN;
-  for (int idx = threadIdx.x; idx < g.K * BN; idx += 512) {
-    int k, n;
-    float v;
+  unsigned long long st_entry = 0; (void)st_entry;
+  if ((PYGAT_DIAG_K1 & 16)) st_entry = __builtin_amdgcn_s_memrealtime();
+  // op(B) into its three bf16 images: a thread takes 8 consecutive k of one column -- eight loads in flight (coalesced over the
+  // columns of the lanes when B is [k][n]), one ds_write_b128 per image.  (Rounds 2-3: one element per thread and turn, 32
+  // dependent load -> split -> three 2-byte LDS writes per thread: stamps showed a wave's tile loop spanning 236 of the
+  // kernel's 293 us.)
+  for (int item = threadIdx.x; item < (g.K >> 3) * BN; item += 512) {
+    const int n = item % BN, k8 = item / BN;
+    const bool ok = n0 + n < g.N;
+    float v[8];
     if constexpr (!TB) {
-      k = idx / BN; n = idx % BN;
-      v = (n0 + n < g.N) ? g.B[(int64_t)k * g.ldb + n0 + n] : 0.f;
+      const float* bp = g.B + (int64_t)(8 * k8) * g.ldb + (ok ? n0 + n : 0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = bp[(int64_t)j * g.ldb];
     } else {
-      n = idx / g.K; k = idx % g.K;
-      v = (n0 + n < g.N) ? g.B[(int64_t)(n0 + n) * g.ldb + k] : 0.f;
+      const float* bp = g.B + (int64_t)(ok ? n0 + n : 0) * g.ldb + 8 * k8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = bp[j];
     }
-    uint16_t h, m, l;
-    split_one(v, h, m, l);
-    Bimg[n * KP + k] = h; Bimg[IMG + n * KP + k] = m; Bimg[2 * IMG + n * KP + k] = l;
+    uint32_t ph[4], pm[4], pl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint16_t h0, m0, l0, h1, m1, l1;
+      split_one(ok ? v[2 * j] : 0.f, h0, m0, l0);
+      split_one(ok ? v[2 * j + 1] : 0.f, h1, m1, l1);
+      ph[j] = (uint32_t)h0 | ((uint32_t)h1 << 16); pm[j] = (uint32_t)m0 | ((uint32_t)m1 << 16); pl[j] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+    }
+    uint16_t* d = Bimg + n * KP + 8 * k8;
+    *reinterpret_cast<uint4*>(d) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+    *reinterpret_cast<uint4*>(d + IMG) = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+    *reinterpret_cast<uint4*>(d + 2 * IMG) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
   }
   if constexpr (SV) {
     for (int idx = threadIdx.x; idx < g.K * 8; idx += 512) {
@@ -166,6 +188,7 @@ __global__ __launch_bounds__(512) void gemm_smallk_x3_kernel(SmallKArgs g) {
       Asr[n] = (col < g.N) ? g.sr_a[(col / SRF) * 2 * SRF + (col % SRF)] : 0.f;
     }
   }
+  if (threadIdx.x < 4) reinterpret_cast<int*>(Asr + (SRF > 0 ? BN : 0))[threadIdx.x] = 0;   // word 0: the wave-tile counter
   __syncthreads();
 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -195,11 +218,11 @@ __global__ __launch_bounds__(512) void gemm_smallk_x3_kernel(SmallKArgs g) {
 
   // The accumulators hold the tile TRANSPOSED (mma9t): register 4 g + j of lane (fr, fh) is row row0 + fr, column
   // colt + 8 g + 4 fh + j of the 32-column tile starting at colt -- four consecutive columns per register quad.
-  // FAST: the caller knows the wave's 32 rows lie inside M, N is a multiple of 32, accumulate is off and the output takes
-  // 16-byte stores (vec_out) -- no branch at all (a branch is a join, and behind a join hipcc waits for the stores: SPC above)
-  auto store_tile = [&](int t, auto fast_tag) {
+  // FAST: the caller knows the wave's 32 rows lie inside M, N is a multiple of 32, accumulate is off, the output takes
+  // 16-byte stores (vec_out), s too (s_vec) and the LDS holds the row patches (lds_rows) -- no branch at all (a branch is a
+  // join, and behind a join hipcc waits for the stores: SPC above)
+  auto store_tile = [&](int64_t row0, auto fast_tag) {   // row0: the first of the wave's 32 rows
     constexpr bool FAST = decltype(fast_tag)::value;
-    const int64_t row0 = ((int64_t)blockIdx.x + (int64_t)t * gridDim.x) * 256 + 32 * w;
     const int64_t row = row0 + fr;
     const bool row_ok = FAST || row < g.M;
     const bool full = FAST || row0 + 32 <= g.M;  // wave-uniform
@@ -228,6 +251,8 @@ __global__ __launch_bounds__(512) void gemm_smallk_x3_kernel(SmallKArgs g) {
     constexpr int SRD = SRF > 0 ? SRF : 32;                 // (no division by a zero template argument in the SRF = 0 instantiations)
     constexpr int HPT = 32 / SRD, GPH = SRF > 0 ? SRF / 8 : 1;   // heads per 32-column tile, register quads per head
     float hs[4] = {0.f, 0.f, 0.f, 0.f};
+    float keep[4] = {0.f, 0.f, 0.f, 0.f};   // FAST: the even four-head group of a pair, held back for one store of the pair
+    (void)keep;
     float* so = (SRF > 0) ? g.s_out + row * g.s_ld + n0 / SRD : nullptr;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -244,7 +269,23 @@ __global__ __launch_bounds__(512) void gemm_smallk_x3_kernel(SmallKArgs g) {
           }
           const int hi = nt * HPT + hh;          // head index inside this block column
           hs[hi & 3] = half_wave_sum(p);
-          if ((hi & 3) == 3) {                   // heads hi - 3 .. hi are complete
+          if constexpr (FAST) {
+            // (FAST implies s_vec and NT HPT % 4 == 0.)  No store under a lane mask -- that is a branch around the store, and
+            // a join for the wait counts: half-wave 0 keeps the even group of a pair, half-wave 1 the odd one, and every lane
+            // stores 16 bytes once per pair (a last group without a partner: both half-waves store it, same bytes).
+            if ((hi & 3) == 3) {
+              const int grp = hi >> 2;
+              if ((grp & 1) == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) keep[q] = hs[q];
+                if (hi == NT * HPT - 1) st4(so + 4 * grp, make_float4(keep[0], keep[1], keep[2], keep[3]));
+              } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) keep[q] = fh ? hs[q] : keep[q];
+                st4(so + 4 * (grp - 1) + 4 * fh, make_float4(keep[0], keep[1], keep[2], keep[3]));
+              }
+            }
+          } else if ((hi & 3) == 3) {                   // heads hi - 3 .. hi are complete
             if (g.s_vec) {                       // (wave-uniform)
               if (row_ok && fh == ((hi >> 2) & 1)) st4(so + (hi - 3), make_float4(hs[0], hs[1], hs[2], hs[3]));
             } else if (row_ok && fh == 0) {
@@ -259,14 +300,30 @@ __global__ __launch_bounds__(512) void gemm_smallk_x3_kernel(SmallKArgs g) {
         }
       }
       const int colt = n0 + 32 * nt;   // (wave-uniform)
-      const bool vec = FAST || (full && !g.accumulate && g.vec_out && colt + 32 <= g.N);
+      if constexpr (FAST) {
+        if (!(PYGAT_DIAG_K1 & 1)) {
+          int64_t ld;
+          float* base = out_segment(g.out, colt, ld);   // vec_out: no segment border inside a 32-column tile
+          // (opaque to the optimiser: the row offsets of every column tile are loop invariants, and hoisted out of the
+          // straight-line tile loop they cost more registers than the kernel has)
+          asm volatile("" : "+v"(ld));
+          // The tile through the wave's own LDS patch [32 rows][36 floats] (LDS operations of one wave execute in order: no
+          // barrier), read back so that 8 lanes hold one row's 128 bytes: a store instruction then writes 8 WHOLE lines
+          // instead of 32 bytes of each of 32 rows (same-lease A/B, gpurun_out r4u: projection 0.301-0.311 -> 0.274-0.277 ms).
+          float* patch = Stg + w * (32 * 36);
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq)
+            st4(patch + fr * 36 + 8 * gq + 4 * fh, make_float4(acc[nt][4 * gq], acc[nt][4 * gq + 1], acc[nt][4 * gq + 2], acc[nt][4 * gq + 3]));
+          float* bq = base + (row0 + (lane >> 3)) * ld + 4 * (lane & 7);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            st4(bq + (int64_t)8 * q * ld, ld4(patch + ((lane >> 3) + 8 * q) * 36 + 4 * (lane & 7)));
+        }
+      } else {
+      const bool vec = full && !g.accumulate && g.vec_out && colt + 32 <= g.N;
       if ((PYGAT_DIAG_K1 & 1) ? (g.M == -12345) : vec) {
         int64_t ld;
-        float* base = out_segment(g.out, colt, ld);   // vec_out: no segment border inside a 32-column tile
-        // (opaque to the optimiser: the row offsets of every column tile are loop invariants, and hoisted out of the
-        // straight-line tile loop they cost more registers than the kernel has)
-        asm volatile("" : "+v"(ld));
-        base += row * ld + 4 * fh;
+        float* base = out_segment(g.out, colt, ld) + row * ld + 4 * fh;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq)
           st4(base + 8 * gq, make_float4(acc[nt][4 * gq], acc[nt][4 * gq + 1], acc[nt][4 * gq + 2], acc[nt][4 * gq + 3]));
@@ -282,6 +339,7 @@ __global__ __launch_bounds__(512) void gemm_smallk_x3_kernel(SmallKArgs g) {
               if (g.accumulate) p[j] += acc[nt][4 * gq + j]; else p[j] = acc[nt][4 * gq + j];
             }
         }
+      }
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
@@ -340,7 +398,7 @@ __global__ __launch_bounds__(512) void gemm_smallk_x3_kernel(SmallKArgs g) {
     const int c__ = (CIDX);                                                                   \
     const int t__ = c__ / nchunks, kc__ = c__ - t__ * nchunks;                                \
     PYGAT_X3_BODY(R, kc__ * 32, 2)                                                            \
-    if (kc__ == nchunks - 1) store_tile(t__, std::false_type{});                                              \
+    if (kc__ == nchunks - 1) store_tile(((int64_t)blockIdx.x + (int64_t)t__ * gridDim.x) * 256 + 32 * w, std::false_type{}); \
   }
 
   float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, rc0, rc1, rc2, rc3, rd0, rd1, rd2, rd3;
@@ -365,13 +423,28 @@ __global__ __launch_bounds__(512) void gemm_smallk_x3_kernel(SmallKArgs g) {
     }
   } else {
     constexpr int CW = 16 * SPC;   // k per chunk; K == 4 * CW
-    auto tile_ptr = [&](int c) -> const float* {   // chunk c & 3 of the wave's tile c >> 2, clamped to its last tile
-      int t = c >> 2;
-      if (t > my_tiles - 1) t = my_tiles - 1;
-      int64_t row = ((int64_t)blockIdx.x + (int64_t)t * gridDim.x) * 256 + 32 * w + fr;
+    // Wave tiles (32 rows) are handed out DYNAMICALLY inside the work-group: wave tile q = row tile q >> 3 of this work-group,
+    // rows 32 (q & 7) .. + 31 of it, taken from an LDS counter one tile ahead.  With a fixed 16 tiles per wave the ends of the
+    // 8 waves of a work-group lay 177 .. 248 us after the kernel's start (100 MHz stamps, kernel 261 us): of the two waves that
+    // share a SIMD one is served first and runs ahead, and once it has finished the other issues its MFMAs alone, at ~70 %.
+    const int total_q = 8 * my_tiles;
+    auto q_row0 = [&](int q) -> int64_t {
+      return ((int64_t)blockIdx.x + (int64_t)(q >> 3) * gridDim.x) * 256 + 32 * (q & 7);
+    };
+    auto tile_ptr = [&](int q, int chunk) -> const float* {   // chunk 0..3 of wave tile q, clamped to the work-group's last
+      if (q > total_q - 1) q = total_q - 1;
+      int64_t row = q_row0(q) + fr;
       if (row > g.M - 1) row = g.M - 1;
       if (PYGAT_DIAG_K1 & 4) row &= 255;
-      return g.A + row * g.lda + (c & 3) * CW + 8 * fh;
+      return g.A + row * g.lda + chunk * CW + 8 * fh;
+    };
+    int* q_next = reinterpret_cast<int*>(Asr + (SRF > 0 ? BN : 0));   // (zeroed above)
+    const uint32_t q_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int*)q_next;
+    auto grab = [&]() -> int {   // lane 0 adds one, the others nothing: lane 0's return value is this wave's alone
+      // (as one instruction: the compiler's atomic optimiser turns the builtin with a per-lane value into a loop over the lanes)
+      int r;
+      asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(q_addr), "v"(lane == 0 ? 1 : 0) : "memory");
+      return r;
     };
 #define PYGAT_X3_LOADC(R, P)                                                                  \
   {                                                                                           \
@@ -416,38 +489,54 @@ __global__ __launch_bounds__(512) void gemm_smallk_x3_kernel(SmallKArgs g) {
     }                                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                        \
   }
-#define PYGAT_X3_TILE(T, FAST)                                                                \
+#if (PYGAT_DIAG_K1 & 16)   /* diagnostic builds only: shader-clock stamps around a tile's MFMA phase and its epilogue */
+#define PYGAT_X3_STAMP(V) { __builtin_amdgcn_sched_barrier(0); V = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define PYGAT_X3_STAMP(V)
+#endif
+    unsigned long long st_a = 0, st_b = 0, st_c = 0, st_mfma = 0, st_epi = 0, st_first = 0, st_real = 0, st_n = 0;
+    (void)st_n; (void)st_a; (void)st_b; (void)st_c; (void)st_mfma; (void)st_epi; (void)st_first; (void)st_real;
+    if ((PYGAT_DIAG_K1 & 16)) st_real = __builtin_amdgcn_s_memrealtime();   // the constant 100 MHz counter beside the shader clock
+#define PYGAT_X3_TILE(FAST)                                                                   \
   {                                                                                           \
-    const int t4__ = 4 * (T);                                                                 \
-    PYGAT_X3_LOADC(rd, tile_ptr(t4__ + 3))                                                    \
+    PYGAT_X3_STAMP(st_a)                                                                      \
+    PYGAT_X3_LOADC(rd, tile_ptr(qc, 3))                                                       \
+    const int qn = __builtin_amdgcn_readfirstlane(qn_v);                                      \
     if constexpr (SPC == 2) {                                                                 \
       PYGAT_X3_PSTEP(0, afA, afB, ra2, ra3, ra0, ra1, 0, 16)                                  \
       PYGAT_X3_PSTEP(1, afB, afA, rb0, rb1, ra2, ra3, 16, 32)                                 \
-      PYGAT_X3_LOADC(ra, tile_ptr(t4__ + 4))                                                  \
+      PYGAT_X3_LOADC(ra, tile_ptr(qn, 0))                                                     \
       PYGAT_X3_PSTEP(2, afA, afB, rb2, rb3, rb0, rb1, 32, 48)                                 \
       PYGAT_X3_PSTEP(3, afB, afA, rc0, rc1, rb2, rb3, 48, 64)                                 \
-      PYGAT_X3_LOADC(rb, tile_ptr(t4__ + 5))                                                  \
+      PYGAT_X3_LOADC(rb, tile_ptr(qn, 1))                                                     \
       PYGAT_X3_PSTEP(4, afA, afB, rc2, rc3, rc0, rc1, 64, 80)                                 \
       PYGAT_X3_PSTEP(5, afB, afA, rd0, rd1, rc2, rc3, 80, 96)                                 \
-      PYGAT_X3_LOADC(rc, tile_ptr(t4__ + 6))                                                  \
+      PYGAT_X3_LOADC(rc, tile_ptr(qn, 2))                                                     \
       PYGAT_X3_PSTEP(6, afA, afB, rd2, rd3, rd0, rd1, 96, 112)                                \
       PYGAT_X3_PSTEP(7, afB, afA, ra0, ra1, rd2, rd3, 112, 0)                                 \
     } else {                                                                                  \
       PYGAT_X3_PSTEP(0, afA, afB, rb0, rb1, ra0, ra1, 0, 16)                                  \
-      PYGAT_X3_LOADC(ra, tile_ptr(t4__ + 4))                                                  \
+      PYGAT_X3_LOADC(ra, tile_ptr(qn, 0))                                                     \
       PYGAT_X3_PSTEP(1, afB, afA, rc0, rc1, rb0, rb1, 16, 32)                                 \
-      PYGAT_X3_LOADC(rb, tile_ptr(t4__ + 5))                                                  \
+      PYGAT_X3_LOADC(rb, tile_ptr(qn, 1))                                                     \
       PYGAT_X3_PSTEP(2, afA, afB, rd0, rd1, rc0, rc1, 32, 48)                                 \
-      PYGAT_X3_LOADC(rc, tile_ptr(t4__ + 6))                                                  \
+      PYGAT_X3_LOADC(rc, tile_ptr(qn, 2))                                                     \
       PYGAT_X3_PSTEP(3, afB, afA, ra0, ra1, rd0, rd1, 48, 0)                                  \
     }                                                                                         \
-    store_tile(T, FAST);                                                                      \
+    PYGAT_X3_STAMP(st_b)                                                                      \
+    store_tile(q_row0(qc), FAST);                                                             \
+    qc = qn;                                                                                  \
+    qn_v = grab();                                                                            \
+    PYGAT_X3_STAMP(st_c)                                                                      \
+    if ((PYGAT_DIAG_K1 & 16)) { if (!st_first) st_first = st_a; st_mfma += st_b - st_a; st_epi += st_c - st_b; ++st_n; }   \
   }
-    PYGAT_X3_LOADC(ra, tile_ptr(0))
+    int qc = __builtin_amdgcn_readfirstlane(grab());
+    int qn_v = grab();
+    PYGAT_X3_LOADC(ra, tile_ptr(qc, 0))
     __builtin_amdgcn_sched_barrier(0);
-    PYGAT_X3_LOADC(rb, tile_ptr(1))
+    PYGAT_X3_LOADC(rb, tile_ptr(qc, 1))
     __builtin_amdgcn_sched_barrier(0);
-    PYGAT_X3_LOADC(rc, tile_ptr(2))
+    PYGAT_X3_LOADC(rc, tile_ptr(qc, 2))
     __builtin_amdgcn_sched_barrier(0);
     Frag3 afA = split8v(ra0, ra1), afB;
     uint4 bfP[2][3];
@@ -457,15 +546,27 @@ __global__ __launch_bounds__(512) void gemm_smallk_x3_kernel(SmallKArgs g) {
       bfP[0][1] = *reinterpret_cast<const uint4*>(q__ + IMG);
       bfP[0][2] = *reinterpret_cast<const uint4*>(q__ + 2 * IMG);
     }
-    // only a wave's last tile can reach past M; accumulate calls use the any-K kernel (launch_smallk_x3)
-    const int64_t last_row0 = ((int64_t)blockIdx.x + (int64_t)(my_tiles - 1) * gridDim.x) * 256 + 32 * w;
+    // only the work-group's last row tile can reach past M: its wave tiles with all 32 rows inside M, and every wave tile of
+    // the row tiles before it, take the branch-free epilogue (accumulate calls use the any-K kernel: launch_smallk_x3).
     // (N % 32 != 0: a column tile is cut by N, every tile takes the guarded epilogue)
-    const int n_fast = ((g.N % 32) != 0 || !g.vec_out) ? 0 : ((last_row0 + 32 <= g.M) ? my_tiles : my_tiles - 1);
-    if (n_fast > 0) {
-      PYGAT_X3_TILE(0, std::true_type{})
-      for (int t = 1; t < n_fast; ++t) PYGAT_X3_TILE(t, std::true_type{})
+    const int64_t last_base = ((int64_t)blockIdx.x + (int64_t)(my_tiles - 1) * gridDim.x) * 256;
+    int full_last = (int)((g.M - last_base) / 32);
+    full_last = full_last < 0 ? 0 : (full_last > 8 ? 8 : full_last);
+    constexpr bool FASTABLE = SRF == 0 || ((NT * 32 / (SRF > 0 ? SRF : 32)) % 4) == 0;   // whole four-head groups of s
+    const int fast_q = (!FASTABLE || (g.N % 32) != 0 || !g.vec_out || !g.lds_rows || (SRF > 0 && !g.s_vec)) ? 0 : 8 * (my_tiles - 1) + full_last;
+    if (qc < fast_q) {   // (peeled: the first tile's operands come from the loads above)
+      PYGAT_X3_TILE(std::true_type{})
+      while (qc < fast_q) PYGAT_X3_TILE(std::true_type{})
     }
-    for (int t = n_fast; t < my_tiles; ++t) PYGAT_X3_TILE(t, std::false_type{})
+    while (qc < total_q) PYGAT_X3_TILE(std::false_type{})
+#if (PYGAT_DIAG_K1 & 16)
+    if (lane == 0 && g.s_out) {   // behind the s table proper (tools/gemm_headline_bench.py --stamps allocates the room)
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(g.s_out + (int64_t)g.M * g.s_ld) + ((int64_t)blockIdx.x * 8 + w) * 8;
+      o[0] = st_c - st_first; o[1] = st_mfma; o[2] = st_epi; o[3] = st_n;
+      o[4] = st_entry; o[5] = st_real; o[6] = __builtin_amdgcn_s_memrealtime(); o[7] = 0;   // 100 MHz stamps: entry, first tile, end
+    }
+#endif
+#undef PYGAT_X3_STAMP
 #undef PYGAT_X3_LOADC
 #undef PYGAT_X3_TILE
 #undef PYGAT_X3_PSTEP
@@ -507,7 +608,8 @@ static hipError_t launch_smallk_x3(const SmallKArgs& g, int NT, dim3 grid, size_
 int try_gemm_smallk_x3(const SmallKArgs& g_in, int NT, dim3 grid, hipStream_t st) {
   SmallKArgs g = g_in;
   const size_t lds = (size_t)3 * (32 * NT) * (g.K + 8) * sizeof(uint16_t) + (g.svec ? (size_t)g.K * 8 * sizeof(float) : 0) +
-                     (g.sr_a ? (size_t)32 * NT * sizeof(float) : 0);
+                     (g.sr_a ? (size_t)32 * NT * sizeof(float) : 0) + 16;   // (+ the four turn words of the MFMA token)
+  const size_t lds_patches = (size_t)8 * 32 * 36 * sizeof(float);
   // 16-byte stores of four consecutive columns: every segment starts at a multiple of 32 columns (a 32-column tile lies in one
   // segment) and has 16-byte aligned rows
   g.vec_out = 1;
@@ -515,8 +617,11 @@ int try_gemm_smallk_x3(const SmallKArgs& g_in, int NT, dim3 grid, hipStream_t st
     if ((g.out.col_start[q] % 4) != 0) return 0;   // a lane's four consecutive columns lie in one segment
     if ((g.out.col_start[q] % 32) != 0 || (g.out.ld[q] % 4) != 0 || !aligned16(g.out.ptr[q])) g.vec_out = 0;
   }
+  // whole-line stores through LDS patches where the patches fit beside the B images
+  g.lds_rows = (PYGAT_K1_LDS_ROWS && g.vec_out && lds + lds_patches <= 150 * 1024) ? 1 : 0;
   g.s_vec = (g.s_out && aligned16(g.s_out) && (g.s_ld % 4) == 0 && g.sr_fp > 0 && ((32 * NT / g.sr_fp) % 4) == 0) ? 1 : 0;
-  if (lds > 150 * 1024 || (g.svec && NT == 5)) return 0;   // (5 tiles + the s accumulators do not fit 256 registers)
+  if (lds > 150 * 1024 || (g.svec && NT == 5)) return 0;
+  const size_t ldsz = lds + (g.lds_rows ? lds_patches : 0);   // (5 tiles + the s accumulators do not fit 256 registers)
   constexpr bool generic = false;
   // s on the VALU (svec) keeps the any-K loop: the pipelined one has no registers left for its accumulators
   // (five column tiles: the pipelined K = 128 loop spills)
@@ -524,16 +629,16 @@ int try_gemm_smallk_x3(const SmallKArgs& g_in, int NT, dim3 grid, hipStream_t st
   hipError_t e;
   if (g.sr_a) {
     if (spc == 0 || g.transB || g.svec || (g.sr_fp != 8 && g.sr_fp != 16) || (g.N % (32 * NT)) != 0) return 0;
-    if (spc == 2) e = g.sr_fp == 16 ? launch_smallk_x3<false, 16, 2>(g, NT, grid, lds, st) : launch_smallk_x3<false, 8, 2>(g, NT, grid, lds, st);
-    else e = g.sr_fp == 16 ? launch_smallk_x3<false, 16, 1>(g, NT, grid, lds, st) : launch_smallk_x3<false, 8, 1>(g, NT, grid, lds, st);
+    if (spc == 2) e = g.sr_fp == 16 ? launch_smallk_x3<false, 16, 2>(g, NT, grid, ldsz, st) : launch_smallk_x3<false, 8, 2>(g, NT, grid, ldsz, st);
+    else e = g.sr_fp == 16 ? launch_smallk_x3<false, 16, 1>(g, NT, grid, ldsz, st) : launch_smallk_x3<false, 8, 1>(g, NT, grid, ldsz, st);
   } else if (g.svec) {
-    e = launch_smallk_x3<false, 1, 0>(g, NT, grid, lds, st);
+    e = launch_smallk_x3<false, 1, 0>(g, NT, grid, ldsz, st);
   } else if (g.transB) {
-    e = spc == 2 ? launch_smallk_x3<true, 0, 2>(g, NT, grid, lds, st)
-                 : (spc == 1 ? launch_smallk_x3<true, 0, 1>(g, NT, grid, lds, st) : launch_smallk_x3<true, 0, 0>(g, NT, grid, lds, st));
+    e = spc == 2 ? launch_smallk_x3<true, 0, 2>(g, NT, grid, ldsz, st)
+                 : (spc == 1 ? launch_smallk_x3<true, 0, 1>(g, NT, grid, ldsz, st) : launch_smallk_x3<true, 0, 0>(g, NT, grid, ldsz, st));
   } else {
-    e = spc == 2 ? launch_smallk_x3<false, 0, 2>(g, NT, grid, lds, st)
-                 : (spc == 1 ? launch_smallk_x3<false, 0, 1>(g, NT, grid, lds, st) : launch_smallk_x3<false, 0, 0>(g, NT, grid, lds, st));
+    e = spc == 2 ? launch_smallk_x3<false, 0, 2>(g, NT, grid, ldsz, st)
+                 : (spc == 1 ? launch_smallk_x3<false, 0, 1>(g, NT, grid, ldsz, st) : launch_smallk_x3<false, 0, 0>(g, NT, grid, ldsz, st));
   }
   if (e != hipSuccess) {
     set_error("gemm_smallk_x3: %s", hipGetErrorString(e));

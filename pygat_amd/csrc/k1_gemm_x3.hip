@@ -131,6 +131,10 @@ __device__ __forceinline__ float half_wave_sum(float x) {
 //     CONDITIONAL epilogue (SPC = 0, any K % 32 == 0) the first chunk of the next tile -- loaded long before -- waits
 //     for the tile's 64 stores to be acknowledged, 22 % of the kernel.
 //   * SM = 0: no s columns; 1: SV; 8 / 16: SR, s from the accumulators for heads of 8 / 16 columns (SmallKArgs).
+#if (PYGAT_DIAG_K1 & 16)
+// diagnostic builds only (tools/build_variant.sh): the stamps of the last launch, 8 words per wave of at most 2048 work-groups x 8
+__device__ unsigned long long k1_stamps[2048 * 8 * 8];
+#endif
 template <bool TB, int NT, int SM, int SPC>
 __global__ __launch_bounds__(512) void gemm_smallk_x3_kernel(SmallKArgs g) {
   constexpr bool SV = (SM == 1);
@@ -560,8 +564,8 @@ __global__ __launch_bounds__(512) void gemm_smallk_x3_kernel(SmallKArgs g) {
     }
     while (qc < total_q) PYGAT_X3_TILE(std::false_type{})
 #if (PYGAT_DIAG_K1 & 16)
-    if (lane == 0 && g.s_out) {   // behind the s table proper (tools/gemm_headline_bench.py --stamps allocates the room)
-      unsigned long long* o = reinterpret_cast<unsigned long long*>(g.s_out + (int64_t)g.M * g.s_ld) + ((int64_t)blockIdx.x * 8 + w) * 8;
+    if (lane == 0 && blockIdx.x < 2048) {
+      unsigned long long* o = k1_stamps + ((int64_t)blockIdx.x * 8 + w) * 8;
       o[0] = st_c - st_first; o[1] = st_mfma; o[2] = st_epi; o[3] = st_n;
       o[4] = st_entry; o[5] = st_real; o[6] = __builtin_amdgcn_s_memrealtime(); o[7] = 0;   // 100 MHz stamps: entry, first tile, end
     }
@@ -1103,3 +1107,13 @@ int try_gemm_x3g(int transA, int transB, int M, int N, int64_t K, const float* A
 }
 
 }  // namespace pygat
+
+#if (PYGAT_DIAG_K1 & 16)
+// diagnostic builds only: copies the stamps the last streamed-A GEMM launch left (device-synchronising); tools/k1_stamps.py
+extern "C" __attribute__((visibility("default"))) int pygat_diag_k1_stamps(unsigned long long* host, int words) {
+  const int all = 2048 * 8 * 8;
+  if (!host || words < all) return -1;
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(pygat::k1_stamps), sizeof(unsigned long long) * all) == hipSuccess ? all : -3;
+}
+#endif

@@ -1,8 +1,6 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4z; mkdir -p $O; cd $R
-timeout -k 10 600 python3 -m pytest tests/test_gpu_gemm_split.py tests/test_gpu_project_narrow_shapes.py tests/test_gpu_parity.py -x -q -m gpu > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest.log
-PYGAT_AMD_LIB=$R/pygat_amd/libpygat_amd_k1rowsst.so timeout -k 10 120 python3 tools/gemm_headline_bench.py --stamps --gap-ms 20 > $O/stamps20.log 2>> $O/stamps.err && cat $O/stamps20.log
-for v in default k1norows k1head; do
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4ab; mkdir -p $O; cd $R
+for v in default k1stg20 k1stg44; do
   if [ $v = default ]; then unset PYGAT_AMD_LIB; else export PYGAT_AMD_LIB=$R/pygat_amd/libpygat_amd_$v.so; fi
   timeout -k 10 120 python3 tools/gemm_headline_bench.py --gap-ms 20 --tag $v >> $O/gemm.log 2>> $O/gemm.err
 done; cat $O/gemm.log; unset PYGAT_AMD_LIB
-bash tools/ab_variants.sh r4z default k1norows k1head
+bash tools/ab_variants.sh r4ab default k1stg20 k1stg44

@@ -21,7 +21,7 @@ ap.add_argument("--heads", type=int, default=8)
 ap.add_argument("--fout", type=int, default=16)
 ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--mode", default="split-bf16")
-ap.add_argument("--stamps", action="store_true", help="read the shader-clock stamps a PYGAT_DIAG_K1 & 16 build leaves behind s")
+ap.add_argument("--stamps", action="store_true", help="read the stamps of a PYGAT_DIAG_K1 & 16 build (pygat_diag_k1_stamps)")
 ap.add_argument("--tag", default=os.path.basename(os.environ.get("PYGAT_AMD_LIB", "default")))
 ap.add_argument("--gap-ms", type=float, default=0.0, help="idle time between timed launches (lets the clocks recover)")
 a_ = ap.parse_args()
@@ -34,7 +34,7 @@ Fp = pg.padded_width(Fo); R = H * Fp
 ldw = -(-(R + 2 * H) // 4) * 4
 Wcat = torch.empty(Fin, ldw, device="cuda"); a_pad = torch.empty(H, 2, Fp, device="cuda")
 check(lib.pygat_pack_params(H, Fin, Fo, W.data_ptr(), a.data_ptr(), None, Wcat.data_ptr(), ldw, a_pad.data_ptr(), None), "pack")
-Wh = torch.empty(n, R, device="cuda"); s = torch.zeros(n + 8192, H, device="cuda")[:n + 8192]   # (room for the diagnostic stamps behind row n)
+Wh = torch.empty(n, R, device="cuda"); s = torch.zeros(n, H, device="cuda")
 dWh = torch.randn(n, R, device="cuda")
 mode = pg.ops.GEMM_MODES[a_.mode]
 split_k = pg.ops._split_k(Fin, R, n, streamed_k=True, mode=a_.mode)
@@ -64,7 +64,12 @@ def wgrad():
 
 tp, tw = timed(project), timed(wgrad)
 if a_.stamps:
-    raw = s[n:].contiguous().view(torch.int64).cpu().numpy().reshape(-1, 8)
+    import ctypes
+    lib.pygat_diag_k1_stamps.restype = ctypes.c_int
+    lib.pygat_diag_k1_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    buf = np.zeros(2048 * 64, dtype=np.uint64)
+    assert lib.pygat_diag_k1_stamps(buf.ctypes.data, buf.size) == buf.size
+    raw = buf.reshape(-1, 8).astype(np.int64)
     raw = raw[raw[:, 3] > 0]
     tot, mf, ep, nt = raw[:, 0], raw[:, 1], raw[:, 2], raw[:, 3]
     t0 = raw[:, 4].min()

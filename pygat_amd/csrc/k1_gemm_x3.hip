@@ -709,8 +709,7 @@ __global__ __launch_bounds__(256) void gemm_tn_x3_kernel(TnArgs g) {
   // rows past kend (the last step of the last slab) read row kend - 1, and A's copy is zeroed
 #define PYGAT_TNL_LOAD(R, STEP)                                                               \
   {                                                                                           \
-    const int st__ = (STEP) < nsteps ? (STEP) : nsteps - 1;                                   \
-    const int64_t k__ = kbeg + 16 * (int64_t)st__ + 2 * kp;                                   \
+    const int64_t k__ = kbeg + 16 * (int64_t)(STEP) + 2 * kp;   /* (steps past the slab: row kend - 1, zeroed) */ \
     int64_t k0__ = k__ < kend ? k__ : kend - 1, k1__ = k__ + 1 < kend ? k__ + 1 : kend - 1;   \
     if (PYGAT_DIAG_K1 & 4) { k0__ &= 255; k1__ &= 255; }   /* diagnostic builds only: cache-resident operand rows */ \
     R##a0 = ld4(la + k0__ * g.lda); R##a1 = ld4(la + k1__ * g.lda);                           \
@@ -798,10 +797,13 @@ __global__ __launch_bounds__(256) void gemm_tn_x3_kernel(TnArgs g) {
   __syncthreads();
   // step i: MFMAs on stage i & 1; ring slot (i + 1) % 3 is split into stage (i + 1) & 1; slot i % 3 (split during
   // step i - 1) takes the loads of step i + 3
+  // (three steps per turn, unconditionally: the one or two steps past the slab multiply zeroed rows of A -- with the two steps
+  // under `if (i + k < nsteps)` the loop had joins, and behind them hipcc gave a load the registers of an address still in
+  // use: `s_waitcnt vmcnt(0)` at the top of every turn, the loads issued three steps ahead waited for after one)
   for (int i = 0; i < nsteps; i += 3) {
     PYGAT_TNL_STEP(r1, r0, i)
-    if (i + 1 < nsteps) PYGAT_TNL_STEP(r2, r1, i + 1)
-    if (i + 2 < nsteps) PYGAT_TNL_STEP(r0, r2, i + 2)
+    PYGAT_TNL_STEP(r2, r1, i + 1)
+    PYGAT_TNL_STEP(r0, r2, i + 2)
   }
 #undef PYGAT_TNL_LOAD
 #undef PYGAT_TNL_PUT

@@ -23,6 +23,7 @@ ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--mode", default="split-bf16")
 ap.add_argument("--stamps", action="store_true", help="read the stamps of a PYGAT_DIAG_K1 & 16 build (pygat_diag_k1_stamps)")
 ap.add_argument("--tag", default=os.path.basename(os.environ.get("PYGAT_AMD_LIB", "default")))
+ap.add_argument("--split-k", type=int, default=0, help="slabs of the weight gradient (0: the package's choice)")
 ap.add_argument("--gap-ms", type=float, default=0.0, help="idle time between timed launches (lets the clocks recover)")
 a_ = ap.parse_args()
 n, Fin, H, Fo = a_.n, a_.fin, a_.heads, a_.fout
@@ -37,7 +38,7 @@ check(lib.pygat_pack_params(H, Fin, Fo, W.data_ptr(), a.data_ptr(), None, Wcat.d
 Wh = torch.empty(n, R, device="cuda"); s = torch.zeros(n, H, device="cuda")
 dWh = torch.randn(n, R, device="cuda")
 mode = pg.ops.GEMM_MODES[a_.mode]
-split_k = pg.ops._split_k(Fin, R, n, streamed_k=True, mode=a_.mode)
+split_k = a_.split_k or pg.ops._split_k(Fin, R, n, streamed_k=True, mode=a_.mode)
 wsw = torch.empty(lib.pygat_wgrad_workspace_bytes(Fin, H, Fo, split_k) // 4, device="cuda")
 dW = torch.empty(H, Fin, Fo, device="cuda")
 

@@ -17,6 +17,11 @@
 namespace pygat {
 
 constexpr int FIX_LIST_WAVES = 16;  // waves per work-group of the list-driven fix-up kernels
+// Cut rows one wave of a list-driven fix-up merges side by side (the entries behind the wide ones): a wave of 64 / LPR lane
+// groups per row piece had most of them idle -- the config-5 graph has 21.7 k cut rows of 5 pieces on average at 64-edge slots,
+// 57.9 k of 4.8 at 32 -- and the launch is latency per wave, not bytes.  The list is sorted by piece count, so the rows of a
+// wave are alike.
+__host__ __device__ constexpr int fix_rows_per_wave(int lpr) { return 64 / lpr >= 8 ? 4 : (64 / lpr >= 2 ? 2 : 1); }
 constexpr int FIX_WIDE = 32;   // cut rows with more pieces are merged by a whole work-group
 constexpr int FIX_SCREEN = 8;  // slots screened per wave by the fix-up kernels (owned rows are merged serially)
 constexpr float NEG_BIG = -1.0e30f;  // running-max seed: exp(NEG_BIG - x) == 0, exp(NEG_BIG - NEG_BIG) == 1
@@ -269,16 +274,16 @@ __device__ __forceinline__ bool row_any(bool p) {
   }
 }
 
-template <int LPR>
+template <int LPR, int SPAN = 64>   // sum over the lane groups of every aligned SPAN-lane block
 __device__ __forceinline__ float slot_sum(float x) {
 #pragma unroll
-  for (int off = LPR; off < 64; off <<= 1) x += __shfl_xor(x, off);
+  for (int off = LPR; off < SPAN; off <<= 1) x += __shfl_xor(x, off);
   return x;
 }
-template <int LPR>
+template <int LPR, int SPAN = 64>
 __device__ __forceinline__ float4 slot_sum4(float4 v) {
 #pragma unroll
-  for (int off = LPR; off < 64; off <<= 1) {
+  for (int off = LPR; off < SPAN; off <<= 1) {
     v.x += __shfl_xor(v.x, off); v.y += __shfl_xor(v.y, off);
     v.z += __shfl_xor(v.z, off); v.w += __shfl_xor(v.w, off);
   }

@@ -365,31 +365,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((AUX && FAS
 // Merge of one cut row: its pieces tail(k), head(k+1), ..., head(k + npieces - 1) are dealt round-robin to
 // nw (1, or the NW waves of the work-group) waves x EPW lane groups (PF pieces in flight each -- the chain of a 26k-edge row has 400+ pieces), combined
 // inside a wave with shuffles and across waves through LDS, always in the same order (reproducible).
-template <int LPR, int VEC, bool AUX, int NW>
+// G: lane groups that share one row (64 / LPR = the whole wave: one row per wave; fewer: 64 / LPR / G rows side by side, each
+// lane group with its own k, r, npieces -- the packed entries of the list-driven kernel, never `wide`).
+template <int LPR, int VEC, bool AUX, int NW, int G = 64 / LPR>
 __device__ __forceinline__ void fwd_merge_row(const FwdArgs& a, const LaneCols<VEC>& lc, float* fix_sm, int64_t k, int r,
                                               int npieces, bool wide, int w) {
-  constexpr int EPW = 64 / LPR;
   constexpr int PF = (VEC == 1) ? 4 : 2;
-  const int lane = threadIdx.x & 63, slot = lane / LPR;
+  const int lane = threadIdx.x & 63, slot = lane / LPR, g = slot % G;
   const int64_t PS = part_stride<AUX>(a.rs);
   RowState<VEC, AUX> st;
   st.reset();
   if (wide || w == 0) {
     const int nw = wide ? NW : 1;
-    for (int q = (wide ? w : 0) * EPW * PF + slot; q < npieces; q += nw * EPW * PF) {
+    for (int q = (wide ? w : 0) * G * PF + g; q < npieces; q += nw * G * PF) {
       PartRec<VEC, AUX> rec[PF];
 #pragma unroll
       for (int f = 0; f < PF; ++f) {
-        const int qq = q + f * EPW;
+        const int qq = q + f * G;
         const int qc = qq < npieces ? qq : q;   // clamped: the loads stay unconditional
         part_load<VEC, AUX>(a, lc, a.part + (qc == 0 ? 2 * k + 1 : 2 * (k + qc)) * PS, rec[f]);
       }
 #pragma unroll
       for (int f = 0; f < PF; ++f)
-        if (q + f * EPW < npieces) part_merge<VEC, AUX>(st, rec[f]);
+        if (q + f * G < npieces) part_merge<VEC, AUX>(st, rec[f]);
     }
 #pragma unroll
-    for (int off = LPR; off < 64; off <<= 1) {
+    for (int off = LPR; off < LPR * G; off <<= 1) {
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         const float mo = __shfl_xor(st.m[v], off), zo = __shfl_xor(st.z[v], off);
@@ -419,7 +420,7 @@ __device__ __forceinline__ void fwd_merge_row(const FwdArgs& a, const LaneCols<V
     }
     __syncthreads();
   }
-  if (w == 0 && slot == 0) fwd_finish<LPR, VEC, AUX>(a, lc, r, st);
+  if (w == 0 && g == 0 && npieces > 0) fwd_finish<LPR, VEC, AUX>(a, lc, r, st);
 }
 
 // Fix-up of the rows cut by a slot border.  A work-group screens FIX_SCREEN consecutive slots: slot k
@@ -462,14 +463,21 @@ __global__ __launch_bounds__(256) void gat_fwd_fixup_kernel(FwdArgs a) {
 template <int LPR, int VEC, bool AUX>
 __global__ __launch_bounds__(64 * FIX_LIST_WAVES) void gat_fwd_fixup_list_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float fix_sm[];  // [FIX_LIST_WAVES][PS]
+  constexpr int RPW = fix_rows_per_wave(LPR), G = 64 / LPR / RPW;
   const int w = threadIdx.x >> 6;
   const bool wide = (int)blockIdx.x < a.g.n_cut_wide;
-  const int q0 = wide ? (int)blockIdx.x : a.g.n_cut_wide + ((int)blockIdx.x - a.g.n_cut_wide) * FIX_LIST_WAVES + w;
-  if (q0 >= a.g.n_cut) return;   // never in a wide block: the __syncthreads of the merge are reached by all 4 waves
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
-  // a lone wave plays wave 0 of the merge
-  fwd_merge_row<LPR, VEC, AUX, FIX_LIST_WAVES>(a, lc, fix_sm, a.g.cut[3 * q0], a.g.cut[3 * q0 + 1], a.g.cut[3 * q0 + 2], wide,
-                                               wide ? w : 0);
+  if (wide) {
+    const int q0 = (int)blockIdx.x;
+    fwd_merge_row<LPR, VEC, AUX, FIX_LIST_WAVES>(a, lc, fix_sm, a.g.cut[3 * q0], a.g.cut[3 * q0 + 1], a.g.cut[3 * q0 + 2], true, w);
+    return;
+  }
+  // RPW rows per wave, G lane groups each; a lone wave plays wave 0 of the merge
+  const int q0 = a.g.n_cut_wide + (((int)blockIdx.x - a.g.n_cut_wide) * FIX_LIST_WAVES + w) * RPW + ((threadIdx.x & 63) / LPR) / G;
+  const bool have = q0 < a.g.n_cut;
+  const int qc = have ? q0 : a.g.n_cut - 1;
+  fwd_merge_row<LPR, VEC, AUX, FIX_LIST_WAVES, G>(a, lc, fix_sm, a.g.cut[3 * qc], a.g.cut[3 * qc + 1], have ? a.g.cut[3 * qc + 2] : 0,
+                                                  false, 0);
 }
 
 
@@ -585,7 +593,7 @@ static int launch_forward(const pygat_graph* g, int H, int Fo, float alpha, int 
     const bool listed = a.g.cut != nullptr;   // the caller listed the cut rows: go straight to them
     const int fix_waves = listed ? FIX_LIST_WAVES : 4;
     const size_t fix_lds = fix_waves * (size_t)(aux ? part_stride<true>(a.rs) : part_stride<false>(a.rs)) * sizeof(float);
-    const unsigned fb = listed ? (unsigned)(a.g.n_cut_wide + cdiv(a.g.n_cut - a.g.n_cut_wide, FIX_LIST_WAVES))
+    const unsigned fb = listed ? (unsigned)(a.g.n_cut_wide + cdiv(a.g.n_cut - a.g.n_cut_wide, FIX_LIST_WAVES * fix_rows_per_wave(lpr)))
                                : (unsigned)cdiv(nslots, FIX_SCREEN);
     if (listed && a.g.n_cut == 0) continue;
 #define PYGAT_FIX(AUXV)                                                                                               \

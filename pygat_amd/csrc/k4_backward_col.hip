@@ -419,16 +419,20 @@ template <int LPR, int VEC>
 __global__ __launch_bounds__(64 * FIX_LIST_WAVES) void gat_bwd_col_fixup_list_kernel(ColArgs a) {
   constexpr int EPW = 64 / LPR;
   constexpr int PF = (VEC == 1) ? 4 : 2;
+  constexpr int RPW = fix_rows_per_wave(LPR), GP = EPW / RPW;   // packed entries: RPW rows per wave, GP lane groups each
   extern __shared__ __attribute__((aligned(16))) float fix_sm[];  // [FIX_LIST_WAVES][R + 2H]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const bool wide = (int)blockIdx.x < a.g.n_cut_wide;
-  const int q0 = wide ? (int)blockIdx.x : a.g.n_cut_wide + ((int)blockIdx.x - a.g.n_cut_wide) * FIX_LIST_WAVES + w;
-  if (q0 >= a.g.n_cut) return;
-  const int64_t k = a.g.cut[3 * q0];
-  const int r = a.g.cut[3 * q0 + 1];
-  const int npieces = a.g.cut[3 * q0 + 2];
-  const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
+  const bool wide = (int)blockIdx.x < a.g.n_cut_wide;   // (block-uniform)
   const int slot = lane / LPR;
+  const int G = wide ? EPW : GP, g = slot % G;
+  const int q0 = wide ? (int)blockIdx.x
+                      : a.g.n_cut_wide + (((int)blockIdx.x - a.g.n_cut_wide) * FIX_LIST_WAVES + w) * RPW + slot / GP;
+  const bool have = q0 < a.g.n_cut;
+  const int qe = have ? q0 : a.g.n_cut - 1;
+  const int64_t k = a.g.cut[3 * qe];
+  const int r = a.g.cut[3 * qe + 1];
+  const int npieces = have ? a.g.cut[3 * qe + 2] : 0;
+  const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
   const int64_t PS = a.rs.R + 2 * a.rs.H;
   const int wsel = wide ? w : 0;   // wave index inside the merge; a lone wave plays wave 0
   float4 acc[VEC];
@@ -437,12 +441,12 @@ __global__ __launch_bounds__(64 * FIX_LIST_WAVES) void gat_bwd_col_fixup_list_ke
   for (int v = 0; v < VEC; ++v) { acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); dt[v] = 0.f; }
   {
     const int nw = wide ? FIX_LIST_WAVES : 1;
-    for (int q = (wide ? w : 0) * EPW * PF + slot; q < npieces; q += nw * EPW * PF) {
+    for (int q = (wide ? w : 0) * G * PF + g; q < npieces; q += nw * G * PF) {
       float4 xp[PF][VEC];
       float tp[PF][VEC];
 #pragma unroll
       for (int f = 0; f < PF; ++f) {
-        const int qq = q + f * EPW;
+        const int qq = q + f * G;
         const int qc = qq < npieces ? qq : q;
         const float* p = a.part + (qc == 0 ? 2 * k + 1 : 2 * (k + qc)) * PS;
 #pragma unroll
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(64 * FIX_LIST_WAVES) void gat_bwd_col_fixup_list_ke
       }
 #pragma unroll
       for (int f = 0; f < PF; ++f)
-        if (q + f * EPW < npieces) {
+        if (q + f * G < npieces) {
 #pragma unroll
           for (int v = 0; v < VEC; ++v) {
             acc[v].x += xp[f][v].x; acc[v].y += xp[f][v].y; acc[v].z += xp[f][v].z; acc[v].w += xp[f][v].w;
@@ -460,10 +464,18 @@ __global__ __launch_bounds__(64 * FIX_LIST_WAVES) void gat_bwd_col_fixup_list_ke
           }
         }
     }
+    if (wide) {
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      acc[v] = slot_sum4<LPR>(acc[v]);
-      dt[v] = slot_sum<LPR>(dt[v]);
+      for (int v = 0; v < VEC; ++v) {
+        acc[v] = slot_sum4<LPR>(acc[v]);
+        dt[v] = slot_sum<LPR>(dt[v]);
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        acc[v] = slot_sum4<LPR, LPR * GP>(acc[v]);
+        dt[v] = slot_sum<LPR, LPR * GP>(dt[v]);
+      }
     }
   }
   if (wide) {
@@ -477,7 +489,7 @@ __global__ __launch_bounds__(64 * FIX_LIST_WAVES) void gat_bwd_col_fixup_list_ke
         }
     }
     __syncthreads();
-    if (wsel == 0 && slot == 0) {
+    if (w == 0 && slot == 0) {
 #pragma unroll
       for (int ww = 1; ww < FIX_LIST_WAVES; ++ww) {
         const float* p = fix_sm + ww * PS;
@@ -491,7 +503,7 @@ __global__ __launch_bounds__(64 * FIX_LIST_WAVES) void gat_bwd_col_fixup_list_ke
     }
     __syncthreads();
   }
-  if (wsel == 0 && slot == 0) col_finish<VEC>(a, lc, r, acc, dt);
+  if (wsel == 0 && g == 0 && npieces > 0) col_finish<VEC>(a, lc, r, acc, dt);
 }
 
 
@@ -572,7 +584,7 @@ extern "C" int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm
     const size_t fix_lds = (a.g.cut ? FIX_LIST_WAVES : 4) * (size_t)(a.rs.R + 2 * a.rs.H) * sizeof(float);
     if (a.g.cut) {
       if (a.g.n_cut > 0) {
-        const unsigned fb = (unsigned)(a.g.n_cut_wide + cdiv(a.g.n_cut - a.g.n_cut_wide, FIX_LIST_WAVES));
+        const unsigned fb = (unsigned)(a.g.n_cut_wide + cdiv(a.g.n_cut - a.g.n_cut_wide, FIX_LIST_WAVES * fix_rows_per_wave(lpr)));
         PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_bwd_col_fixup_list_kernel<LPR, VEC>), dim3(fb),
                                                           dim3(64 * FIX_LIST_WAVES), fix_lds, st, a));
       }

@@ -609,6 +609,26 @@ static hipError_t launch_smallk_x3(const SmallKArgs& g, int NT, dim3 grid, size_
   return hipGetLastError();
 }
 
+// s on the VALU (SV) in the pipelined loop: one or two column tiles only (with more the s accumulators spill)
+template <int SPC>
+static hipError_t launch_smallk_x3_sv(const SmallKArgs& g, int NT, dim3 grid, size_t lds, hipStream_t st) {
+  int dev = -1;
+  (void)hipGetDevice(&dev);
+#define PYGAT_X3_LAUNCH(n)                                                                                \
+  {                                                                                                       \
+    static bool attr_set[64] = {};                                                                        \
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_smallk_x3_kernel<false, n, 1, SPC>),  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
+      if (dev >= 0 && dev < 64) attr_set[dev] = true;                                                     \
+    }                                                                                                     \
+    hipLaunchKernelGGL((gemm_smallk_x3_kernel<false, n, 1, SPC>), grid, dim3(512), lds, st, g);           \
+  }
+  if (NT == 1) PYGAT_X3_LAUNCH(1) else PYGAT_X3_LAUNCH(2)
+#undef PYGAT_X3_LAUNCH
+  return hipGetLastError();
+}
+
 int try_gemm_smallk_x3(const SmallKArgs& g_in, int NT, dim3 grid, hipStream_t st) {
   SmallKArgs g = g_in;
   const size_t lds = (size_t)3 * (32 * NT) * (g.K + 8) * sizeof(uint16_t) + (g.svec ? (size_t)g.K * 8 * sizeof(float) : 0) +
@@ -636,7 +656,11 @@ int try_gemm_smallk_x3(const SmallKArgs& g_in, int NT, dim3 grid, hipStream_t st
     if (spc == 2) e = g.sr_fp == 16 ? launch_smallk_x3<false, 16, 2>(g, NT, grid, ldsz, st) : launch_smallk_x3<false, 8, 2>(g, NT, grid, ldsz, st);
     else e = g.sr_fp == 16 ? launch_smallk_x3<false, 16, 1>(g, NT, grid, ldsz, st) : launch_smallk_x3<false, 8, 1>(g, NT, grid, ldsz, st);
   } else if (g.svec) {
-    e = launch_smallk_x3<false, 1, 0>(g, NT, grid, ldsz, st);
+    // (one or two column tiles -- the one- and two-head shards of a head-parallel level, 16-wide hidden levels: the straight-line
+    // pipelined loop has the registers for the s accumulators there, and the any-K loop's joins cost it its prefetch)
+    const int spc_sv = (NT <= 2 && !g.accumulate) ? (g.K == 128 ? 2 : (g.K == 64 ? 1 : 0)) : 0;
+    e = spc_sv == 2 ? launch_smallk_x3_sv<2>(g, NT, grid, ldsz, st)
+                    : (spc_sv == 1 ? launch_smallk_x3_sv<1>(g, NT, grid, ldsz, st) : launch_smallk_x3<false, 1, 0>(g, NT, grid, ldsz, st));
   } else if (g.transB) {
     e = spc == 2 ? launch_smallk_x3<true, 0, 2>(g, NT, grid, ldsz, st)
                  : (spc == 1 ? launch_smallk_x3<true, 0, 1>(g, NT, grid, ldsz, st) : launch_smallk_x3<true, 0, 0>(g, NT, grid, ldsz, st));

@@ -1,11 +1,10 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4z2; P=$O/out; mkdir -p $P; cd $R
-for n in 8 4 2; do python3 bench.py --as-rank-of $n --no-cpu --no-epoch --no-v2 --steps 20 2> $O/rank$n.err; done > $P/r4z_as_rank_of.jsonl
-for f in 64 128; do python3 bench.py --fout $f --as-rank-of 8 --no-cpu --no-epoch --no-v2 --steps 10 2> $O/rank8_f$f.err; done > $P/r4z_as_rank_of_8_wide_heads.jsonl
-python3 bench.py > $P/r4z_bench.json 2> $O/bench.err
-python3 - <<PY
-import json
-for f in ("r4z_as_rank_of.jsonl","r4z_as_rank_of_8_wide_heads.jsonl"):
-    for ln in open("$P/"+f):
-        j=json.loads(ln); print(f, j["config"].get("f_out"), round(j["ms_per_step"],3), {k["kernel"]:round(k["avg_ms"],3) for k in j["kernels"]})
-j=json.load(open("$P/r4z_bench.json")); print(j["ms_per_step"], {k["kernel"]:round(k["avg_ms"],4) for k in j["kernels"]}, j["epoch_ms"]["ppi"]["ms"], j["epoch_ms"]["cora"]["ms"])
-PY
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4aj; mkdir -p $O; cd $R
+timeout -k 10 900 python3 -m pytest tests/test_gpu_gemm_split.py tests/test_gpu_project_narrow_shapes.py tests/test_gpu_parity.py -x -q -m gpu > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest.log
+for v in default svold default svold; do
+  if [ $v = default ]; then unset PYGAT_AMD_LIB; else export PYGAT_AMD_LIB=$R/pygat_amd/libpygat_amd_$v.so; fi
+  for n in 8 4; do
+  python3 bench.py --as-rank-of $n --no-cpu --no-epoch --no-v2 --steps 20 --warmup 3 2>> $O/err.log | python3 -c "
+import json,sys
+j=json.loads(sys.stdin.read()); print('$v rank-of-$n', round(j['ms_per_step'],4), {k['kernel']:round(k['avg_ms'],4) for k in j['kernels']})"
+  done
+done; unset PYGAT_AMD_LIB

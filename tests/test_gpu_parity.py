@@ -571,3 +571,37 @@ def test_pubmed_full_model_logits_and_output_level(pg, topologies):
                             what="pubmed level 2")
     print(f"pubmed: logits err {e:.2e} (fp32 oracle {own:.2e}); level-2 grads after {len(rep['hip_flips'])} flips: "
           + ", ".join(f"{n} {rep['hip'][n]:.2e} (fp32 oracle {rep['fp32'][n]:.2e})" for n in ("dX", "dW", "da")))
+
+
+# ------------------------------------------------------------------- cut rows of every length, all row widths
+def _ladder_graph(N=360, seed=5):
+    """Symmetric pattern + self loops whose degrees run from 3 to ~180: with 4-edge slots the cut-row list holds chains of 2 ...
+    40+ pieces -- packed entries (several rows per wave of the list-driven fix-ups), every remainder of the last wave, and
+    `wide` entries (more than 32 pieces: a whole work-group each)."""
+    rng = np.random.default_rng(seed)
+    r, c = [], []
+    for i in range(N):
+        d = 170 if i % 45 == 0 else (40 if i % 45 == 7 else 1 + (i * 7) % 6)   # forward neighbours, symmetrised below
+        nb = (i + 1 + rng.choice(N - 1, size=d, replace=False)) % N
+        r.append(np.full(d, i)); c.append(nb)
+    r = np.concatenate(r); c = np.concatenate(c)
+    rr = np.concatenate([r, c, np.arange(N)]); cc = np.concatenate([c, r, np.arange(N)])
+    key = np.unique(rr.astype(np.int64) * N + cc)
+    rr = (key // N).astype(np.int32); cc = (key % N).astype(np.int32)
+    rowptr = np.zeros(N + 1, dtype=np.int64); np.add.at(rowptr, rr + 1, 1)
+    return np.cumsum(rowptr).astype(np.int32), cc
+
+
+@pytest.mark.parametrize("H,Fo", [(1, 16), (2, 16), (4, 16), (8, 16), (8, 64)])   # 4 / 8 / 16 / 32 / 64 lanes per row
+def test_cut_rows_of_every_length(pg, H, Fo):
+    rowptr, col = _ladder_graph()
+    deg = np.diff(rowptr)
+    assert deg.max() > 32 * 4 + 8 and (deg > 8).sum() > 100 and (deg <= 8).sum() > 20   # wide chains, a long list of packed ones, uncut rows
+    N, Fin = len(rowptr) - 1, 32
+    W, a, _ = params(H, Fin, Fo, False, 11)
+    gen = torch.Generator().manual_seed(12)
+    x = torch.randn(N, Fin, dtype=torch.float64, generator=gen)
+    G = torch.randn(N, H * Fo, dtype=torch.float64, generator=gen)
+    for slot in (4, 8):
+        check(run_level(pg, x, rowptr, col, W, a, None, True, G, slot=slot), x, rowptr, col, W, a, None, True, G,
+              f"cut rows, {H}x{Fo}, {slot}-edge slots")

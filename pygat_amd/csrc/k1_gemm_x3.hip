@@ -130,7 +130,13 @@ __device__ __forceinline__ float half_wave_sum(float x) {
 //     loads and stores together in issue order, and hipcc merges wait counts conservatively at every join: behind a
 //     CONDITIONAL epilogue (SPC = 0, any K % 32 == 0) the first chunk of the next tile -- loaded long before -- waits
 //     for the tile's 64 stores to be acknowledged, 22 % of the kernel.
+//     In that loop (round 4) a wave takes its 32-row tiles from an LDS counter of the work-group, one tile ahead (with a fixed
+//     16 tiles per wave the 8 waves ended 177 .. 248 us into a 261 us launch), and a full tile leaves through a per-wave LDS
+//     patch as whole 128-byte lines; the products are formed with the weight fragment as the MFMA's A operand, so a lane holds
+//     16 columns of one row (mma9t).
 //   * SM = 0: no s columns; 1: SV; 8 / 16: SR, s from the accumulators for heads of 8 / 16 columns (SmallKArgs).
+//   * PYGAT_DIAG_K1 (tools/build_variant.sh only): 1 no stores, 2 no s, 4 cache-resident rows, 8 one product of nine,
+//     16 s_memtime / s_memrealtime stamps per wave (read back with pygat_diag_k1_stamps: tools/k1_stamps.py).
 #if (PYGAT_DIAG_K1 & 16)
 // diagnostic builds only (tools/build_variant.sh): the stamps of the last launch, 8 words per wave of at most 2048 work-groups x 8
 __device__ unsigned long long k1_stamps[2048 * 8 * 8];

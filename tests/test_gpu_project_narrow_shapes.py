@@ -11,7 +11,11 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("N,Fin,H,Fo,skip", [(2708, 64, 1, 7, False), (3000, 128, 8, 8, True), (501, 20, 3, 5, True),
-                                            (1000, 64, 8, 3, False), (40000, 64, 8, 8, False)])
+                                            (1000, 64, 8, 3, False), (40000, 64, 8, 8, False),
+                                            # the streamed kernel with s on the VALU, one / two column tiles, up to four and more s columns,
+                                            # ragged row counts (the shards of a head-parallel level)
+                                            (20000, 128, 1, 16, False), (20011, 64, 2, 7, False), (9001, 128, 3, 5, False),
+                                            (30000, 128, 1, 7, True), (12345, 128, 6, 5, False), (8200, 64, 5, 3, True)])
 def test_plain_projection(N, Fin, H, Fo, skip):
     import pygat_amd as pg
     from pygat_amd._lib import lib, check

@@ -15,9 +15,11 @@ drop-in model calls).  --hip-graph replays the level from two captured HIP graph
 (pygat_amd.GraphedLevel): that wins on the reference's small graphs, where launches dominate (epoch_ms
 below is measured that way), and measured 5 % SLOWER here, where each kernel runs for ~1 ms.
 
-N GPUs: heads sharded head-per-GPU (pygat_amd/dist.py): each rank projects and attends its H/N
-heads, an RCCL all-gather over xGMI concatenates the head outputs (models.py:32) while the rank's
-backward runs; parameter gradients stay local.  Total work is fixed -> "scaling": "strong".
+N GPUs (`python bench.py --gpus N` starts the N ranks itself; under torch.distributed.run it is one of them): heads
+sharded head-per-GPU (pygat_amd/dist.py): each rank projects and attends its H/N heads, the head outputs are
+exchanged over xGMI (RCCL, copy-free: straight into the column-blocked activation the next level reads,
+models.py:32) while the rank's later row chunks and its backward run; parameter gradients stay local.  Total work
+is fixed -> "scaling": "strong".
 (--forward-exchange replicate is a labelled experiment: no collective, every rank recomputes all
 heads' forward.)
 
@@ -231,8 +233,60 @@ def gatv2_level_record(pg, ops, graph, X, H, Fo, steps=10):
                     "profiles/ rocprof summary of tools/v2_bench.py"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` typed without a launcher: start the N ranks as CHILD processes of this one (which never
+    touches the GPU: no HIP call before or after), one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as
+    torch.distributed.run would; rank 0's stdout (the one JSON line) is relayed, every rank's stderr is this process's
+    stderr; any rank failing ends the others and the exit code is non-zero.  Under torch.distributed.run (WORLD_SIZE set)
+    this function is never reached."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(args.gpus):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    chunks0 = []
+    reader = threading.Thread(target=lambda: chunks0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:          # a rank that died takes the job with it: the others would wait in a collective for ever
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    reader.join(timeout=10)
+    lines = [ln for ln in b"".join(chunks0).decode().splitlines() if ln.startswith("{")]
+    if rc == 0 and not lines:
+        print("bench: rank 0 printed no JSON line", file=sys.stderr)
+        rc = 1
+    if lines:
+        print(lines[-1], flush=True)
+    sys.exit(rc)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     # stdout carries exactly ONE line, the JSON record: native libraries (RCCL prints a version banner on its
     # first collective) get stderr instead
     sys.stdout.flush()
@@ -332,37 +386,26 @@ def main():
         def level_bwd(out):
             lvl.backward(G_loc)
 
-    # N > 1: the level runs row chunk by row chunk (GATLevelFn pipeline): chunk c's head outputs (models.py:32
-    # torch.cat) are all-gathered on RCCL's own stream while chunk c+1 is computed; the rest of the exchange hides
-    # behind this level's backward, which does not depend on it, and is joined at the end of the step, where the gathered
-    # rank-major chunks [world, rows, w] are copied into their column slices of the [N, H F'] activation (as pygat_amd.dist does).
-    # The chunk borders are the level's own (GATLevelFn cuts with the slot length of ITS row width: 32-edge slots for a
-    # one-head 64-byte row, graph.slot_edges otherwise), so the receive buffers are sized from the (r0, r1) the callback
-    # gets: allocated on the first step, reused -- and checked -- on every later one.
+    # N > 1: the level runs row chunk by row chunk (GATLevelFn pipeline): K2 writes the rank's head columns straight into ITS block
+    # of the column-blocked activation full_out [world, N, w] (models.py:32 torch.cat, as the next level's GEMMs read it:
+    # pygat_amd/dist.py "copy-free exchange"), and as soon as chunk c's launches are enqueued its rows go out to the peers and
+    # the peers' rows come in -- one grouped RCCL send/recv launch per chunk, straight between the contiguous views
+    # full_out[r, r0:r1]: no staging buffer, no landing copy (rounds 2-4: all-gather into [world, rows, w] chunks + a strided
+    # copy of every chunk).  The exchange of chunk c overlaps chunk c + 1; the rest hides behind this level's backward, which
+    # does not depend on it, and is joined at the end of the step.
     nchunks = max(1, args.chunks) if use_pg else 0
-    gbufs = {}
     works = []
+    full_out = None
+    if use_pg:
+        from pygat_amd import dist as pgdist
+        w_loc = h_loc * Fo
+        if any(b - a != h_loc for a, b in parts) or not pgdist.blocked_width_ok(w_loc):
+            raise SystemExit(f"bench: {H} heads x {Fo} over {world} ranks: the exchange needs equal shards of a power-of-two width >= 16 "
+                             f"floats (got {[(b - a) * Fo for a, b in parts]})")
+        full_out = torch.empty(world, N, w_loc, device=dev)
 
     def on_chunk(c, r0, r1, out):
-        buf = gbufs.get(c)
-        if buf is None:
-            buf = gbufs[c] = torch.empty(world, r1 - r0, h_loc * Fo, device=dev)
-            chunk_rows[c] = (r0, r1)
-        assert chunk_rows[c] == (r0, r1), f"chunk {c}: rows {(r0, r1)} now, {chunk_rows[c]} before"
-        works.append(dist.all_gather_into_tensor(buf.view(world * (r1 - r0), h_loc * Fo), out[r0:r1], async_op=True))
-        if c >= 1:
-            land(c - 1)          # the previous chunk's exchange has had a chunk of compute to finish (as pygat_amd.dist does)
-
-    chunk_rows = {}
-    full_out = None
-    side = torch.cuda.Stream(device=dev) if use_pg else None
-
-    def land(c):
-        """gathered chunk c -> its column slices of the [N, H F'] activation (models.py:32 torch.cat), on the side stream."""
-        r0, r1 = chunk_rows[c]
-        with torch.cuda.stream(side):
-            works[c].wait()
-            full_out[r0:r1].view(r1 - r0, world, h_loc * Fo).copy_(gbufs[c].permute(1, 0, 2))
+        works.extend(pgdist.exchange_blocks(full_out, r0, r1))
 
     def step():
         if use_pg:
@@ -370,17 +413,10 @@ def main():
             W_loc.grad = a_loc.grad = None
             if args.dx:
                 Xb.grad = None
-            nonlocal full_out
-            if full_out is None:
-                full_out = torch.empty(N, world * h_loc * Fo, device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            out = pg.GATLevelFn.apply(Xb, W_loc, a_loc, None, graph, 0.2, True, None, (nchunks, on_chunk))
-            land(len(works) - 1)
+            out = pg.GATLevelFn.apply(Xb, W_loc, a_loc, None, graph, 0.2, True, None, (nchunks, on_chunk, full_out[rank]))
             out.backward(G_loc)
-            # the gathered blocks are laid out as the next level reads them ([N, H F'], models.py:32 torch.cat) -- what
-            # pygat_amd.dist._pipelined_concat_level does: one strided copy per chunk on a side stream, beside the later chunks
-            # and this level's backward; the step ends when the last of them has landed
-            torch.cuda.current_stream(dev).wait_stream(side)
+            for wk in works:            # the step ends when every peer's rows have arrived
+                wk.wait()
             return full_out
         out = level_fwd()
         level_bwd(out)
@@ -462,6 +498,8 @@ def main():
             # the gathered concat output of the sharded run against the unsharded level on this rank
             ref = pg.GATLevelFn.apply(X, W, a, None, graph, 0.2, True)
             got = full if (use_pg or replicate or model_world == 1) else None
+            if got is not None and got.dim() == 3:          # column-blocked [world, N, w] -> [N, H F'] for the comparison only
+                got = got.permute(1, 0, 2).reshape(N, -1)
             if got is not None:
                 err = float((got - ref).abs().max())
                 print(f"bench --verify: max |sharded - unsharded| = {err:.3e} over {tuple(ref.shape)}", file=sys.stderr)
@@ -555,7 +593,8 @@ def main():
                        "nodes": N, "edges": E, "fin": Fin, "heads": H, "f_out": Fo,
                        "parallelism": (f"head-parallel x{model_world}, "
                                        + ("forward replicated (no collective; experiment)" if replicate
-                                          else "RCCL all-gather of the head outputs overlapped with the backward")
+                                          else "copy-free exchange of the head outputs (grouped RCCL send/recv per row chunk into the "
+                                               "column-blocked activation) overlapped with the forward's later chunks and the backward")
                                        + (" (rank-0 work only, modelled)" if model_world != world else ""))
                        if model_world > 1 else "single GPU",
                        "heads_per_gpu": h_loc,

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define PYGAT_ABI_VERSION 13
+#define PYGAT_ABI_VERSION 14
 
 enum {
   PYGAT_OK = 0,
@@ -51,7 +51,13 @@ enum {
 /* flags for pygat_gat_forward / pygat_gat_backward */
 enum {
   PYGAT_F_ELU = 1,      /* apply ELU to (attention + skip): concat=True, layers.py:50-51,168-170 */
-  PYGAT_F_SKIP = 2      /* add the skip projection rows `sk` (layers.py:47-48,165-166) */
+  PYGAT_F_SKIP = 2,     /* add the skip projection rows `sk` (layers.py:47-48,165-166) */
+  /* pygat_gat_forward only (ABI 14): run ONE phase of the pass over the graph's slot range -- the main launch (rows that lie
+   * inside a slot are final after it) or the fix-up launch (finishes the rows a slot border cuts, from the main launch's
+   * partial records).  A row-chunk pipeline puts chunk c's fix-up on a second stream beside chunk c + 1's main launch.
+   * Needs the level in one head window: pygat_gat_forward_phases_ok(n, H, F') == 1. */
+  PYGAT_F_MAIN_ONLY = 4,
+  PYGAT_F_FIXUP_ONLY = 8
 };
 
 int pygat_abi_version(void);
@@ -125,6 +131,26 @@ int pygat_gemm_f32(int transA, int transB, int M, int N, int64_t K,
                    const pygat_out_segments* out, int accumulate,
                    int split_k, void* ws, int gemm_mode, void* stream);
 
+/* Column-blocked matrices (ABI 14): the activation of a head-parallel hidden level as the exchange over xGMI delivers it
+ * (pygat_amd/dist.py; replaces torch.cat([...], dim=1), models.py:32, WITHOUT the concatenating copy).  A logical
+ * [rows x cols] row-major matrix is stored as cols / w BLOCKS of [rows x w], block b (= rank b's heads, all rows) at
+ * base + b * stride floats, row stride ld inside a block:
+ *      element (r, c)  at  base + (c / w) * stride + r * ld + (c % w)
+ * w: a power of two >= 16 dividing cols (w = 0, or a NULL descriptor: an ordinary matrix); stride, ld, base: multiples
+ * of 4 floats / 16-byte aligned.  `a_blk` describes the STORED matrix of operand A along its contiguous dimension (the
+ * K columns of a plain A, the M columns of a transA one: in both cases X [nodes x features] blocked by features);
+ * `c_blk` the output C along its N columns (then `out` has ONE segment: ptr[0] = base, ld[0] = row stride, and
+ * split_k must be 1) -- an input gradient written straight into the layout the reduce-scatter sends.
+ * Blocked operands run on the general kernels of either product mode (no streamed fast path takes them). */
+typedef struct {
+  int w;             /* columns per block; 0 = not blocked */
+  int64_t stride;    /* floats between block b and block b + 1 */
+} pygat_col_blocks;
+int pygat_gemm_f32_blocked(int transA, int transB, int M, int N, int64_t K,
+                           const float* A, int64_t lda, const pygat_col_blocks* a_blk, const float* B, int64_t ldb,
+                           const pygat_out_segments* out, const pygat_col_blocks* c_blk, int accumulate,
+                           int split_k, void* ws, int gemm_mode, void* stream);
+
 /* Pack the per-head parameters of one level into the projection operand
  *   Wcat [Fin x ldw], columns: [0,R) W heads (padded to Fp), [R,2R) skip heads if
  *   w_skip != NULL, then H columns W_h a_src_h and H columns W_h a_dst_h (so the
@@ -158,6 +184,10 @@ int pygat_stack_heads_padded(int H, int64_t nW, int64_t nW_out, int nA, int64_t 
  * Sk may be NULL (no skip).  split_k / ws as pygat_gemm_f32. */
 int pygat_project(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const float* Wcat, int64_t ldw, const float* a_pad,
                   float* Wh, float* Sk, float* s, int split_k, void* ws, int gemm_mode, void* stream);
+/* The same with X column-blocked (x_blk as in pygat_gemm_f32_blocked; NULL / w = 0: pygat_project). */
+int pygat_project_blocked(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const pygat_col_blocks* x_blk,
+                          const float* Wcat, int64_t ldw, const float* a_pad, float* Wh, float* Sk, float* s, int split_k,
+                          void* ws, int gemm_mode, void* stream);
 /* s[n x H], t[n x H] (t may be NULL) from the masked Wh table: s_ih = Wh_ih . a_src_h, t_ih = Wh_ih . a_dst_h
  * (layers.py:60-61 after the Wh dropout of layers.py:37,136).  wh_mask [n x R] (pre-scaled) non-NULL: that dropout is
  * applied HERE, in place (Wh *= wh_mask), instead of by a launch of its own; NULL: Wh is taken as it is.
@@ -241,6 +271,7 @@ int pygat_head_group(int n, int H, int Fo);
  *     aneg_i = sum_{j: s_i+t_j <= 0} alpha_ij mask_ij Wh_j,     qneg_i = sum_{j: s_i+t_j <= 0} alpha_ij,
  * from which pygat_gat_backward_prepare takes the row sums ds_i = sum_j dz_ij without touching an edge again
  * (sum_j de_ij = 0, so ds_i = -(1 - alpha)(Gp_i . aneg_i - D_i qneg_i)). */
+int pygat_gat_forward_phases_ok(int n, int H, int Fo);   /* 1: PYGAT_F_MAIN_ONLY / PYGAT_F_FIXUP_ONLY may be used */
 int pygat_gat_forward(const pygat_graph* g, int H, int Fo, float alpha, int flags,
                       const float* Wh, const float* s, const float* a_pad, const float* sk,
                       const float* att_mask,
@@ -341,6 +372,11 @@ int pygat_a_grad(int n, int H, int Fo, const float* Wh, const float* ds, const f
 size_t pygat_wgrad_workspace_bytes(int Fin, int H, int Fo, int split_k);
 int pygat_wgrad(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const float* dWh, const float* ds,
                 const float* a_pad, float* dW, int split_k, void* ws, int h_first, int h_count, int gemm_mode, void* stream);
+
+/* The same with X column-blocked (pygat_col_blocks; NULL / w = 0: pygat_wgrad). */
+int pygat_wgrad_blocked(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const pygat_col_blocks* x_blk,
+                        const float* dWh, const float* ds, const float* a_pad, float* dW, int split_k, void* ws,
+                        int h_first, int h_count, int gemm_mode, void* stream);
 
 /* ------------------------------------------------ GATv2 (next row of the scope table)
  * The reference's SpGraphAttentionLayerV2 (layers.py:258-313): per head

@@ -22,18 +22,20 @@ LIB_PATH = os.path.join(_HERE, "libpygat_amd.so")
 if os.environ.get("PYGAT_AMD_LIB"):
     LIB_PATH = os.path.abspath(os.environ["PYGAT_AMD_LIB"])
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 F_ELU = 1
 F_SKIP = 2
+F_MAIN_ONLY = 4
+F_FIXUP_ONLY = 8
 
 # every entry point declared in include/pygat_amd.h
 SYMBOLS = [
     "pygat_abi_version", "pygat_last_error", "pygat_padded_width", "pygat_device_count",
     "pygat_device_name", "pygat_default_gemm_mode", "pygat_dense_row_counts", "pygat_scan_workspace_bytes",
     "pygat_exclusive_scan_i32", "pygat_dense_fill_cols", "pygat_csr_symmetric_perm",
-    "pygat_gemm_workspace_bytes", "pygat_gemm_f32", "pygat_pack_params", "pygat_pack_params_heads", "pygat_stack_heads", "pygat_stack_heads_padded", "pygat_project", "pygat_attn_scores",
+    "pygat_gemm_workspace_bytes", "pygat_gemm_f32", "pygat_gemm_f32_blocked", "pygat_project_blocked", "pygat_wgrad_blocked", "pygat_pack_params", "pygat_pack_params_heads", "pygat_stack_heads", "pygat_stack_heads_padded", "pygat_project", "pygat_attn_scores",
     "pygat_unpack_wgrad",
-    "pygat_edge_pairs", "pygat_slot_bounds", "pygat_slot_meta", "pygat_partials_bytes", "pygat_head_group", "pygat_gat_forward", "pygat_head_mean",
+    "pygat_edge_pairs", "pygat_slot_bounds", "pygat_slot_meta", "pygat_partials_bytes", "pygat_head_group", "pygat_gat_forward", "pygat_gat_forward_phases_ok", "pygat_head_mean",
     "pygat_gat_backward_prepare", "pygat_gat_backward_row", "pygat_gat_backward_col", "pygat_gat_backward_rowsum",
     "pygat_gat_backward_col_da_bytes", "pygat_a_grad_fold",
     "pygat_agrad_workspace_bytes", "pygat_a_grad", "pygat_wgrad_workspace_bytes", "pygat_wgrad",
@@ -55,6 +57,11 @@ MAX_SEGMENTS = 4    # PYGAT_MAX_SEGMENTS
 class OutSegments(C.Structure):
     _fields_ = [("nseg", C.c_int), ("col_start", C.c_int32 * (MAX_SEGMENTS + 1)), ("ptr", C.c_void_p * MAX_SEGMENTS),
                 ("ld", C.c_int64 * MAX_SEGMENTS)]
+
+
+class ColBlocks(C.Structure):
+    """pygat_col_blocks: a [rows x cols] matrix stored as cols / w blocks of [rows x w], `stride` floats apart."""
+    _fields_ = [("w", C.c_int), ("stride", C.c_int64)]
 
 
 class Graph(C.Structure):
@@ -88,6 +95,10 @@ def _load():
     lib.pygat_gemm_workspace_bytes.argtypes = [i, i, i]
     lib.pygat_gemm_workspace_bytes.restype = sz
     lib.pygat_gemm_f32.argtypes = [i, i, i, i, i64, p, i64, p, i64, C.POINTER(OutSegments), i, i, p, i, p]
+    CB = C.POINTER(ColBlocks)
+    lib.pygat_gemm_f32_blocked.argtypes = [i, i, i, i, i64, p, i64, CB, p, i64, C.POINTER(OutSegments), CB, i, i, p, i, p]
+    lib.pygat_project_blocked.argtypes = [i, i, i, i, p, i64, CB, p, i64, p, p, p, p, i, p, i, p]
+    lib.pygat_wgrad_blocked.argtypes = [i, i, i, i, p, i64, CB, p, p, p, p, i, p, i, i, i, p]
     lib.pygat_pack_params.argtypes = [i, i, i, p, p, p, p, i64, p, p]
     lib.pygat_pack_params_heads.argtypes = [i, i, i, p, p, p, p, i64, p, p]
     lib.pygat_stack_heads.argtypes = [i, i64, i, i64, p, p, p, p, p, p, p]
@@ -103,6 +114,7 @@ def _load():
     lib.pygat_head_group.argtypes = [i, i, i]
     lib.pygat_head_group.restype = i
     lib.pygat_gat_forward.argtypes = [C.POINTER(Graph), i, i, f, i, p, p, p, p, p, p, p, p, p, p, p, p, p]
+    lib.pygat_gat_forward_phases_ok.argtypes = [i, i, i]
     lib.pygat_head_mean.argtypes = [i, i, i, p, p, p, p]
     lib.pygat_gat_backward_prepare.argtypes = [i, i, i, i, i, p, p, p, p, p, p, p, p, p, f, p, i, i, i, p]
     lib.pygat_gat_backward_row.argtypes = [C.POINTER(Graph), i, i, f, p, p, p, p, p, p, i, i, i, p]

@@ -36,6 +36,31 @@ __host__ __device__
 #endif
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Column-block addressing of a pygat_col_blocks matrix inside the kernels: lw = log2(w), bs = block stride in floats; an
+// ordinary matrix is the one-block case (lw = 62, bs = 0), so kernels carry no second code path for it.
+struct ColBlocks {
+  int lw;
+  int64_t bs;
+};
+static inline ColBlocks col_blocks_of(const pygat_col_blocks* b) {
+  ColBlocks c;
+  c.lw = 62; c.bs = 0;
+  if (b && b->w > 0) { c.lw = 0; while ((1 << c.lw) < b->w) ++c.lw; c.bs = b->stride; }
+  return c;
+}
+static inline bool col_blocks_on(const pygat_col_blocks* b) { return b && b->w > 0; }
+// w a power of two >= 16 that divides `cols`; stride and row stride 16-byte multiples
+static inline bool col_blocks_ok(const pygat_col_blocks* b, int64_t cols, int64_t ld) {
+  if (!col_blocks_on(b)) return true;
+  return b->w >= 16 && (b->w & (b->w - 1)) == 0 && cols % b->w == 0 && (b->stride % 4) == 0 && ld >= b->w && (ld % 4) == 0;
+}
+#ifdef __HIPCC__
+// float offset of column c of row 0 (c and c + 3 lie in one block when c % 4 == 0)
+__host__ __device__ __forceinline__ int64_t blk_off(int64_t c, const ColBlocks& b) {
+  return (c >> b.lw) * b.bs + (c & ((int64_t(1) << b.lw) - 1));
+}
+#endif
+
 // width of one head inside a padded row: power of two in [4, 256]
 static inline int padded_width(int f) {
   if (f <= 0 || f > 256) return 0;

@@ -35,12 +35,15 @@ struct GemmArgs {
   int64_t k_per_split;
   float* ws;        // != nullptr: partial tile results go to ws[z][M][N]
   int a_vec, b_vec; // 16-B vector loads allowed (base and ld aligned)
+  ColBlocks ab, cb; // column blocks of the stored A / of C (common.h); one block = an ordinary matrix
 };
+
+constexpr ColBlocks kOneBlock = {62, 0};
 
 // operand stored [rows x K] (K contiguous): tile ROWS x 16, staged transposed into S[k][row]
 template <int ROWS, int NV, int BKT = BK>
 __device__ __forceinline__ void load_kcontig(const float* __restrict__ P, int64_t ld, int vec, int row0,
-                                             int nrows, int64_t k0, int64_t kend, float4 (&r)[NV]) {
+                                             int nrows, int64_t k0, int64_t kend, float4 (&r)[NV], const ColBlocks& cbk = kOneBlock) {
   constexpr int QK = BKT / 4;   // float4 units per row of the tile
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -50,7 +53,7 @@ __device__ __forceinline__ void load_kcontig(const float* __restrict__ P, int64_
       int row = row0 + (idx / QK);
       int64_t k = k0 + (idx % QK) * 4;
       if (row < nrows && k < kend) {
-        const float* p = P + (int64_t)row * ld + k;
+        const float* p = P + (int64_t)row * ld + blk_off(k, cbk);
         if (vec && k + 3 < kend) {
           v = ld4(p);
         } else {
@@ -83,7 +86,7 @@ __device__ __forceinline__ void store_kcontig(float* S, const float4 (&r)[NV]) {
 // operand stored [K x cols] (K strided): tile 16 x COLS, staged as is into S[k][col]
 template <int COLS, int NV, int BKT = BK>
 __device__ __forceinline__ void load_kstrided(const float* __restrict__ P, int64_t ld, int vec, int col0,
-                                              int ncols, int64_t k0, int64_t kend, float4 (&r)[NV]) {
+                                              int ncols, int64_t k0, int64_t kend, float4 (&r)[NV], const ColBlocks& cbk = kOneBlock) {
   constexpr int Q = COLS / 4;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -93,7 +96,7 @@ __device__ __forceinline__ void load_kstrided(const float* __restrict__ P, int64
       int64_t k = k0 + idx / Q;
       int c = col0 + (idx % Q) * 4;
       if (k < kend && c < ncols) {
-        const float* p = P + k * ld + c;
+        const float* p = P + k * ld + blk_off(c, cbk);
         if (vec && c + 3 < ncols) {
           v = ld4(p);
         } else {
@@ -125,7 +128,7 @@ __device__ __forceinline__ void store_kstrided(float* S, const float4 (&r)[NV]) 
 // vmcnt(0) for it BEFORE the MFMA phase of the current k-tile -- the prefetch of the next tile then overlaps nothing.
 template <int ROWS, int NV, int BKT>
 __device__ __forceinline__ void load_kcontig_fast(const float* __restrict__ P, int64_t ld, int row0, int nrows, int64_t k0,
-                                                  int64_t kend, float4 (&r)[NV]) {
+                                                  int64_t kend, float4 (&r)[NV], const ColBlocks& cbk = kOneBlock) {
   constexpr int QK = BKT / 4;
   static_assert(ROWS * QK == NV * 256, "exact cover");
 #pragma unroll
@@ -135,13 +138,13 @@ __device__ __forceinline__ void load_kcontig_fast(const float* __restrict__ P, i
     row = row < nrows ? row : nrows - 1;
     const int64_t k = k0 + (idx % QK) * 4;
     const float keep = k < kend ? 1.f : 0.f;
-    const float4 v = ld4(P + (int64_t)row * ld + (k < kend ? k : kend - 4));
+    const float4 v = ld4(P + (int64_t)row * ld + blk_off(k < kend ? k : kend - 4, cbk));
     r[i] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
   }
 }
 template <int COLS, int NV, int BKT>
 __device__ __forceinline__ void load_kstrided_fast(const float* __restrict__ P, int64_t ld, int col0, int ncols, int64_t k0,
-                                                   int64_t kend, float4 (&r)[NV]) {
+                                                   int64_t kend, float4 (&r)[NV], const ColBlocks& cbk = kOneBlock) {
   constexpr int Q = COLS / 4;
   static_assert(BKT * Q == NV * 256, "exact cover");
 #pragma unroll
@@ -151,7 +154,7 @@ __device__ __forceinline__ void load_kstrided_fast(const float* __restrict__ P, 
     const float keep = k < kend ? 1.f : 0.f;
     int c = col0 + (idx % Q) * 4;
     c = c < ncols ? c : ncols - 4;
-    const float4 v = ld4(P + (k < kend ? k : kend - 1) * ld + c);
+    const float4 v = ld4(P + (k < kend ? k : kend - 1) * ld + blk_off(c, cbk));
     r[i] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
   }
 }
@@ -206,13 +209,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     float4 ra[NVA], rb[NVB];
     auto gload = [&](int64_t k0) {
       if constexpr (FAST && EXACT) {
-        if constexpr (TA) load_kstrided_fast<BM, NVA, BK>(g.A, g.lda, m0, g.M, k0, kend, ra);
-        else load_kcontig_fast<BM, NVA, BK>(g.A, g.lda, m0, g.M, k0, kend, ra);
+        if constexpr (TA) load_kstrided_fast<BM, NVA, BK>(g.A, g.lda, m0, g.M, k0, kend, ra, g.ab);
+        else load_kcontig_fast<BM, NVA, BK>(g.A, g.lda, m0, g.M, k0, kend, ra, g.ab);
         if constexpr (TB) load_kcontig_fast<BN, NVB, BK>(g.B, g.ldb, n0, g.N, k0, kend, rb);
         else load_kstrided_fast<BN, NVB, BK>(g.B, g.ldb, n0, g.N, k0, kend, rb);
       } else {
-        if constexpr (TA) load_kstrided<BM, NVA, BK>(g.A, g.lda, g.a_vec, m0, g.M, k0, kend, ra);
-        else load_kcontig<BM, NVA, BK>(g.A, g.lda, g.a_vec, m0, g.M, k0, kend, ra);
+        if constexpr (TA) load_kstrided<BM, NVA, BK>(g.A, g.lda, g.a_vec, m0, g.M, k0, kend, ra, g.ab);
+        else load_kcontig<BM, NVA, BK>(g.A, g.lda, g.a_vec, m0, g.M, k0, kend, ra, g.ab);
         if constexpr (TB) load_kcontig<BN, NVB, BK>(g.B, g.ldb, g.b_vec, n0, g.N, k0, kend, rb);
         else load_kstrided<BN, NVB, BK>(g.B, g.ldb, g.b_vec, n0, g.N, k0, kend, rb);
       }
@@ -252,8 +255,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
       // an HBM / L2 round trip under load, and the grid of a PPI-sized projection leaves 1-2 work-groups per CU
       float4 ra2[NVA], rb2[NVB];
       auto gload2 = [&](int64_t k0) {
-        if constexpr (TA) load_kstrided_fast<BM, NVA, BK>(g.A, g.lda, m0, g.M, k0, kend, ra2);
-        else load_kcontig_fast<BM, NVA, BK>(g.A, g.lda, m0, g.M, k0, kend, ra2);
+        if constexpr (TA) load_kstrided_fast<BM, NVA, BK>(g.A, g.lda, m0, g.M, k0, kend, ra2, g.ab);
+        else load_kcontig_fast<BM, NVA, BK>(g.A, g.lda, m0, g.M, k0, kend, ra2, g.ab);
         if constexpr (TB) load_kcontig_fast<BN, NVB, BK>(g.B, g.ldb, n0, g.N, k0, kend, rb2);
         else load_kstrided_fast<BN, NVB, BK>(g.B, g.ldb, n0, g.N, k0, kend, rb2);
       };
@@ -315,6 +318,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     if (g.ws) {
       base = g.ws + ((int64_t)blockIdx.z * g.M) * g.N + col;
       ld = g.N;
+    } else if (g.cb.lw < 62) {      // column-blocked C (one segment)
+      base = g.out.ptr[0] + blk_off(col, g.cb);
+      ld = g.out.ld[0];
     } else {
       int s = 0;
 #pragma unroll
@@ -596,7 +602,8 @@ int try_gemm_tn_stream(int M, int N, int64_t K, const float* A, int64_t lda, con
 int try_project_x3(int n, int Fin, int H, int Fp, const float* X, int64_t ldx, const float* Wcat, int64_t ldw, float* Wh,
                    float* s, const float* a_pad, bool split, hipStream_t st);
 int try_gemm_x3g(int transA, int transB, int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
-                 const pygat_out_segments* out, int accumulate, int splits, int64_t k_per_split, float* ws, hipStream_t st);
+                 const pygat_out_segments* out, int accumulate, int splits, int64_t k_per_split, float* ws, hipStream_t st,
+                 ColBlocks ab, ColBlocks cb);
 bool gemm_split(int mode);
 
 }  // namespace pygat
@@ -611,26 +618,43 @@ extern "C" size_t pygat_gemm_workspace_bytes(int M, int N, int split_k) {
 extern "C" int pygat_gemm_f32(int transA, int transB, int M, int N, int64_t K, const float* A, int64_t lda,
                               const float* B, int64_t ldb, const pygat_out_segments* out, int accumulate,
                               int split_k, void* ws, int gemm_mode, void* stream) {
+  return pygat_gemm_f32_blocked(transA, transB, M, N, K, A, lda, nullptr, B, ldb, out, nullptr, accumulate, split_k, ws, gemm_mode,
+                                stream);
+}
+
+extern "C" int pygat_gemm_f32_blocked(int transA, int transB, int M, int N, int64_t K, const float* A, int64_t lda,
+                                      const pygat_col_blocks* a_blk, const float* B, int64_t ldb, const pygat_out_segments* out,
+                                      const pygat_col_blocks* c_blk, int accumulate, int split_k, void* ws, int gemm_mode,
+                                      void* stream) {
   PYGAT_REQUIRE(A && B && out, "gemm: null pointer");
   PYGAT_REQUIRE(gemm_mode >= PYGAT_GEMM_DEFAULT && gemm_mode <= PYGAT_GEMM_FP32_MFMA, "gemm: unknown product mode %d", gemm_mode);
   const bool split = gemm_split(gemm_mode);
   PYGAT_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad sizes M=%d N=%d K=%lld", M, N, (long long)K);
   PYGAT_REQUIRE(out->nseg >= 1 && out->nseg <= PYGAT_MAX_SEGMENTS && out->col_start[0] == 0 && out->col_start[out->nseg] == N,
                 "gemm: output segments must cover [0,N) (nseg=%d)", out->nseg);
+  const bool a_blocked = col_blocks_on(a_blk), c_blocked = col_blocks_on(c_blk);
   for (int s = 0; s < out->nseg; ++s)
     PYGAT_REQUIRE(out->ptr[s] && out->col_start[s + 1] > out->col_start[s] &&
-                      out->ld[s] >= out->col_start[s + 1] - out->col_start[s],
+                      (c_blocked || out->ld[s] >= out->col_start[s + 1] - out->col_start[s]),
                   "gemm: bad output segment %d", s);
-  PYGAT_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N), "gemm: leading dimension too small");
+  PYGAT_REQUIRE((a_blocked ? lda >= a_blk->w : lda >= (transA ? M : K)) && ldb >= (transB ? K : N), "gemm: leading dimension too small");
+  PYGAT_REQUIRE(col_blocks_ok(a_blk, transA ? M : K, lda) && (!a_blocked || aligned16(A)),
+                "gemm: bad column blocks of A (w a power of two >= 16 dividing the blocked extent; 16-byte aligned base, rows, blocks)");
+  PYGAT_REQUIRE(!c_blocked || (col_blocks_ok(c_blk, N, out->ld[0]) && out->nseg == 1 && aligned16(out->ptr[0])),
+                "gemm: bad column blocks of C (one segment; w a power of two >= 16 dividing N)");
   if (split_k < 1) split_k = 1;
   PYGAT_REQUIRE(split_k == 1 || ws, "gemm: split_k > 1 needs a workspace");
+  PYGAT_REQUIRE(!c_blocked || split_k == 1, "gemm: a column-blocked C takes no split-K");
+  const ColBlocks ab = col_blocks_of(a_blk), cb = col_blocks_of(c_blk);
   hipStream_t st = (hipStream_t)stream;
-  if (!transA && split_k == 1) {  // tall-skinny, small K: B resident in LDS, A streamed through registers
+  if (a_blocked || c_blocked) {
+    // blocked operands: the general kernels only (the streamed fast paths below address A / C as ordinary matrices)
+  } else if (!transA && split_k == 1) {  // tall-skinny, small K: B resident in LDS, A streamed through registers
     int r = try_gemm_smallk(transB, M, N, K, A, lda, B, ldb, out, accumulate, split, st);
     if (r < 0) return r;
     if (r == 1) return PYGAT_OK;
   }
-  if (transA && !transB && split_k > 1) {  // weight gradient: huge K, small M x N, no LDS
+  if (!a_blocked && transA && !transB && split_k > 1) {  // weight gradient: huge K, small M x N, no LDS
     int r = try_gemm_tn_stream(M, N, K, A, lda, B, ldb, split_k, (float*)ws, split, st, N, nullptr, 0);
     if (r < 0) return r;
     if (r >= 1) {
@@ -644,7 +668,7 @@ extern "C" int pygat_gemm_f32(int transA, int transB, int M, int N, int64_t K, c
   if (split) {   // any layout on the bf16 pipe from exactly split operands (gemm_x3g_kernel); odd shapes fall through
     const int64_t kps16 = cdiv(cdiv(K, split_k), 16) * 16;
     const int sp = (int)cdiv(K, kps16);
-    const int r = try_gemm_x3g(transA, transB, M, N, K, A, lda, B, ldb, out, accumulate, sp, kps16, (float*)ws, st);
+    const int r = try_gemm_x3g(transA, transB, M, N, K, A, lda, B, ldb, out, accumulate, sp, kps16, (float*)ws, st, ab, cb);
     if (r < 0) return r;
     if (r == 1) {
       if (sp > 1) {
@@ -658,6 +682,7 @@ extern "C" int pygat_gemm_f32(int transA, int transB, int M, int N, int64_t K, c
   GemmArgs g;
   g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.out = *out;
   g.accumulate = accumulate;
+  g.ab = ab; g.cb = cb;
   int64_t kps = cdiv(cdiv(K, split_k), BK) * BK;
   int splits = (int)cdiv(K, kps);
   g.k_per_split = kps;
@@ -689,15 +714,24 @@ extern "C" int pygat_gemm_f32(int transA, int transB, int M, int N, int64_t K, c
 extern "C" int pygat_project(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const float* Wcat, int64_t ldw,
                              const float* a_pad, float* Wh, float* Sk, float* s, int split_k, void* ws, int gemm_mode,
                              void* stream) {
+  return pygat_project_blocked(n, Fin, H, Fo, X, ldx, nullptr, Wcat, ldw, a_pad, Wh, Sk, s, split_k, ws, gemm_mode, stream);
+}
+
+// x_blk: X as the head exchange of the previous level left it (column blocks = ranks, include/pygat_amd.h): the general
+// kernels read it in place, all output columns [Wh | Sk | s] from one GEMM
+extern "C" int pygat_project_blocked(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const pygat_col_blocks* x_blk,
+                                     const float* Wcat, int64_t ldw, const float* a_pad, float* Wh, float* Sk, float* s,
+                                     int split_k, void* ws, int gemm_mode, void* stream) {
+  const bool blocked = col_blocks_on(x_blk);
   const int Fp = padded_width(Fo);
   PYGAT_REQUIRE(n > 0 && Fin > 0 && H > 0 && Fp > 0 && X && Wcat && Wh && s, "project: bad arguments");
   PYGAT_REQUIRE(gemm_mode >= PYGAT_GEMM_DEFAULT && gemm_mode <= PYGAT_GEMM_FP32_MFMA, "project: unknown product mode %d", gemm_mode);
   const bool split = gemm_split(gemm_mode);
   const int R = H * Fp, nw = R * (Sk ? 2 : 1), ncols = nw + H;
-  PYGAT_REQUIRE(ldw >= nw + 2 * H && ldx >= Fin, "project: leading dimension too small");
+  PYGAT_REQUIRE(ldw >= nw + 2 * H && (blocked ? ldx >= x_blk->w : ldx >= Fin), "project: leading dimension too small");
   pygat_out_segments seg;
   int k = 0;
-  if (a_pad && split_k <= 1) {   // heads of 8 / 16 columns, Fin 64 / 128: s = Wh . a_src from the accumulators (k1_gemm_x3.hip)
+  if (!blocked && a_pad && split_k <= 1) {   // heads of 8 / 16 columns, Fin 64 / 128: s = Wh . a_src from the accumulators (k1_gemm_x3.hip)
     const int r = try_project_x3(n, Fin, H, Fp, X, ldx, Wcat, ldw, Wh, s, a_pad, split, (hipStream_t)stream);
     if (r < 0) return r;
     if (r == 1) {
@@ -708,7 +742,7 @@ extern "C" int pygat_project(int n, int Fin, int H, int Fo, const float* X, int6
   }
   seg.col_start[0] = 0; seg.ptr[k] = Wh; seg.ld[k] = R; ++k;
   if (Sk) { seg.col_start[k] = R; seg.ptr[k] = Sk; seg.ld[k] = R; ++k; }
-  if (H <= 8 && split_k <= 1) {   // s on the VALU of the small-K kernel, no MFMA tile for it
+  if (!blocked && H <= 8 && split_k <= 1) {   // s on the VALU of the small-K kernel, no MFMA tile for it
     seg.col_start[k] = nw; seg.nseg = k;
     const int r = try_gemm_smallk(0, n, nw, Fin, X, ldx, Wcat, ldw, &seg, 0, split, (hipStream_t)stream, Wcat + nw, ldw, H, s, H);
     if (r < 0) return r;
@@ -717,7 +751,7 @@ extern "C" int pygat_project(int n, int Fin, int H, int Fo, const float* X, int6
   seg.col_start[k] = nw; seg.ptr[k] = s; seg.ld[k] = H; ++k;
   seg.col_start[k] = ncols;
   seg.nseg = k;
-  return pygat_gemm_f32(0, 0, n, ncols, Fin, X, ldx, Wcat, ldw, &seg, 0, split_k, ws, gemm_mode, stream);
+  return pygat_gemm_f32_blocked(0, 0, n, ncols, Fin, X, ldx, x_blk, Wcat, ldw, &seg, nullptr, 0, split_k, ws, gemm_mode, stream);
 }
 
 // Weight gradient of one level (autograd of layers.py:35,134):  dW_h = X^T dWh_h, all heads in one GEMM.
@@ -751,10 +785,18 @@ extern "C" size_t pygat_wgrad_workspace_bytes(int Fin, int H, int Fo, int split_
 extern "C" int pygat_wgrad(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const float* dWh, const float* ds,
                            const float* a_pad, float* dW, int split_k, void* ws, int h_first, int h_count, int gemm_mode,
                            void* stream) {
+  return pygat_wgrad_blocked(n, Fin, H, Fo, X, ldx, nullptr, dWh, ds, a_pad, dW, split_k, ws, h_first, h_count, gemm_mode, stream);
+}
+
+extern "C" int pygat_wgrad_blocked(int n, int Fin, int H, int Fo, const float* X, int64_t ldx, const pygat_col_blocks* x_blk,
+                                   const float* dWh, const float* ds, const float* a_pad, float* dW, int split_k, void* ws,
+                                   int h_first, int h_count, int gemm_mode, void* stream) {
+  const bool blocked = col_blocks_on(x_blk);
   const int Fp = padded_width(Fo);
   PYGAT_REQUIRE(gemm_mode >= PYGAT_GEMM_DEFAULT && gemm_mode <= PYGAT_GEMM_FP32_MFMA, "wgrad: unknown product mode %d", gemm_mode);
   const bool split = gemm_split(gemm_mode);
-  PYGAT_REQUIRE(n > 0 && Fin > 0 && H > 0 && Fp > 0 && X && dWh && dW && ws && ldx >= Fin, "wgrad: bad arguments");
+  PYGAT_REQUIRE(n > 0 && Fin > 0 && H > 0 && Fp > 0 && X && dWh && dW && ws && (blocked ? ldx >= x_blk->w : ldx >= Fin),
+                "wgrad: bad arguments");
   PYGAT_REQUIRE(!ds || a_pad, "wgrad: ds needs a_pad");
   if (h_count == 0 && h_first == 0) h_count = H;
   PYGAT_REQUIRE(h_first >= 0 && h_count > 0 && h_first + h_count <= H, "wgrad: bad head range [%d, +%d) of %d", h_first, h_count, H);
@@ -774,7 +816,7 @@ extern "C" int pygat_wgrad(int n, int Fin, int H, int Fo, const float* X, int64_
   pygat_out_segments seg;
   seg.nseg = 1; seg.col_start[0] = 0; seg.ptr[0] = dWc; seg.ld[0] = ldc;
   bool done = false;
-  if (ds && split_k > 1 && split && R > 64 && Fin > 64) {
+  if (!blocked && ds && split_k > 1 && split && R > 64 && Fin > 64) {
     // split-bf16 mode: the wide part on the split kernel (it takes one B operand), the H columns of ds in a second,
     // narrow streamed-K pass over X -- 0.1 ms of extra reading against 45 % fewer MFMA cycles on the R columns
     seg.col_start[1] = R;
@@ -801,7 +843,7 @@ extern "C" int pygat_wgrad(int n, int Fin, int H, int Fo, const float* X, int64_
       done = true;
     }
   }
-  if (!done && ds && split_k > 1) {                 // one streamed-K GEMM over [dWh | ds]
+  if (!blocked && !done && ds && split_k > 1) {     // one streamed-K GEMM over [dWh | ds]
     seg.col_start[1] = R + H;
     int r = try_gemm_tn_stream(Fin, R + H, n, X, ldx, dWh, ldd, split_k, slabs, split, st, R, ds, lds);
     if (r < 0) return r;
@@ -815,11 +857,11 @@ extern "C" int pygat_wgrad(int n, int Fin, int H, int Fo, const float* X, int64_
   }
   if (!done) {                                      // any shape: the general path, once per operand
     seg.col_start[1] = R;
-    int rc = pygat_gemm_f32(1, 0, Fin, R, n, X, ldx, dWh, ldd, &seg, 0, split_k, slabs, gemm_mode, stream);
+    int rc = pygat_gemm_f32_blocked(1, 0, Fin, R, n, X, ldx, x_blk, dWh, ldd, &seg, nullptr, 0, split_k, slabs, gemm_mode, stream);
     if (rc) return rc;
     if (ds) {
       seg.col_start[1] = H; seg.ptr[0] = dWc + R;
-      rc = pygat_gemm_f32(1, 0, Fin, H, n, X, ldx, ds, lds, &seg, 0, split_k, slabs, gemm_mode, stream);
+      rc = pygat_gemm_f32_blocked(1, 0, Fin, H, n, X, ldx, x_blk, ds, lds, &seg, nullptr, 0, split_k, slabs, gemm_mode, stream);
       if (rc) return rc;
     }
   }

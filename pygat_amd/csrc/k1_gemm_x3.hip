@@ -912,6 +912,7 @@ struct X3gArgs {
   float* ws;
   pygat_out_segments out;
   int accumulate;
+  ColBlocks ab, cb;   // column blocks of the stored A / of C (common.h; one block = an ordinary matrix)
 };
 
 struct X3gSlot {      // one step of both operands, in flight
@@ -933,7 +934,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const float* la;
   const float* lb;
   if constexpr (KCA) la = g.A + (int64_t)((m0 + lrow < g.M) ? m0 + lrow : g.M - 1) * g.lda;   // rows past M: the last row
-  else la = g.A + ((m0 + 4 * c4 < g.M) ? m0 + 4 * c4 : 0);   // columns past M: column 0 (a float4 may run up to 3 columns into the row's padding)
+  else la = g.A + blk_off((m0 + 4 * c4 < g.M) ? m0 + 4 * c4 : 0, g.ab);   // columns past M: column 0 (a float4 may run up to 3 columns into the row's padding)
   if constexpr (KCB) lb = g.B + (int64_t)((n0 + lrow < g.N) ? n0 + lrow : g.N - 1) * g.ldb;
   else lb = g.B + ((n0 + 4 * c4 < g.N) ? n0 + 4 * c4 : 0);
   // (their products only reach rows / columns of C that are never stored)
@@ -950,7 +951,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     {   // k-contiguous addressing (floats 8 lh .. + 7 of the step)
       const int64_t k = ks + 8 * lh;
       const int64_t k0 = k < kend ? k : kend - 4, k1 = k + 4 < kend ? k + 4 : kend - 4;
-      if constexpr (KCA) { r.a0 = ld4(la + k0); r.a1 = ld4(la + k1); }
+      // (a column-blocked A: the step's 16 k -- and kend - 4 >= ks -- lie in ONE block, blocks being >= 16 wide and slabs
+      // starting at multiples of 16: the block offset is a scalar of the step)
+      if constexpr (KCA) { const float* las = la + (blk_off(ks, g.ab) - ks); r.a0 = ld4(las + k0); r.a1 = ld4(las + k1); }
       if constexpr (KCB) { r.b0 = ld4(lb + k0); r.b1 = ld4(lb + k1); }
     }
   };
@@ -1081,6 +1084,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       float* base;
       int64_t ld;
       if (g.ws) { base = g.ws + (int64_t)blockIdx.x * g.M * g.N + col; ld = g.N; }
+      else if (g.cb.lw < 62) { base = g.out.ptr[0] + blk_off(col, g.cb); ld = g.out.ld[0]; }
       else base = out_segment(g.out, col, ld);
       const bool add = !g.ws && g.accumulate;
 #pragma unroll
@@ -1097,7 +1101,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // 1: took the call (slabs, if any, are in ws: the caller reduces them); 0: shape does not qualify; < 0: launch error
 int try_gemm_x3g(int transA, int transB, int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
-                 const pygat_out_segments* out, int accumulate, int splits, int64_t k_per_split, float* ws, hipStream_t st) {
+                 const pygat_out_segments* out, int accumulate, int splits, int64_t k_per_split, float* ws, hipStream_t st,
+                 ColBlocks ab, ColBlocks cb) {
   if (M < 64 || N <= 64 || K < 32) return 0;   // (a 64-row operand fills half a tile and still beats the fp32 kernel: PPI level-1 dW 38 -> 24 us)
   if (!aligned16(A) || !aligned16(B) || (lda % 4) != 0 || (ldb % 4) != 0) return 0;
   const bool kca = !transA, kcb = transB != 0;
@@ -1111,6 +1116,8 @@ int try_gemm_x3g(int transA, int transB, int M, int N, int64_t K, const float* A
   g.k_per_split = splits > 1 ? k_per_split : K;
   g.ws = splits > 1 ? ws : nullptr;
   g.out = *out; g.accumulate = accumulate;
+  g.ab = ab; g.cb = cb;
+  if (cb.lw < 62 && splits > 1) return 0;
   dim3 grid((unsigned)splits, (unsigned)cdiv(M, 128), (unsigned)cdiv(N, 128));
   constexpr size_t lds = 2 * TNX_STAGE * sizeof(uint32_t);
 #define PYGAT_X3G_LAUNCH(KA, KB)                                                                                          \

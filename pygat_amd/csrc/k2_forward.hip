@@ -550,6 +550,13 @@ static int launch_forward(const pygat_graph* g, int H, int Fo, float alpha, int 
   const int64_t nslots = a.g.kn;   // slots of this call (a row range, or all)
   // GATv2 gathers [Whi|Whj] rows and is not windowed
   const int hg = v2 ? H : head_group_fwd_n(a.g.n, H, Fp);
+  // one phase of the pass only (PYGAT_F_MAIN_ONLY / PYGAT_F_FIXUP_ONLY: a row-chunk pipeline runs chunk c's fix-up on a second
+  // stream beside chunk c + 1's main launch): the partial records are indexed by slot, so chunks never share one -- head
+  // WINDOWS do (the launches of a window reuse `part` in stream order), hence one window only
+  const bool do_main = !(flags & PYGAT_F_FIXUP_ONLY), do_fix = !(flags & PYGAT_F_MAIN_ONLY);
+  PYGAT_REQUIRE(do_main || do_fix, "gat_forward: PYGAT_F_MAIN_ONLY and PYGAT_F_FIXUP_ONLY exclude each other");
+  PYGAT_REQUIRE((do_main && do_fix) || hg >= H, "gat_forward: a single phase needs the level in one head window (pygat_gat_forward_phases_ok)");
+  flags &= ~(PYGAT_F_MAIN_ONLY | PYGAT_F_FIXUP_ONLY);
   for (int h0 = 0; h0 < H; h0 += hg) {
     const int hc = (H - h0 < hg) ? H - h0 : hg;
     PYGAT_REQUIRE(make_window_shape(H, Fo, hc, &a.rs),
@@ -579,7 +586,8 @@ static int launch_forward(const pygat_graph* g, int H, int Fo, float alpha, int 
 #define PYGAT_FWD(V2V, AUXV, FASTV)                                                                                   \
     PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat_fwd_kernel<LPR, VEC, V2V, AUXV, FASTV>), dim3(blocks),    \
                                                       dim3(bt), 0, st, a))
-    if (v2) PYGAT_FWD(true, false, false);
+    if (!do_main) {}
+    else if (v2) PYGAT_FWD(true, false, false);
     else if (aux && fast && lpr == 32 && vec == 1 && a.rs.lph == 4)   // 8 heads x 16: the headline shape
       if (a.rs.R == 128 && a.rs.ldr == 128 && a.rs.ldh == 8 && a.rs.ldo == 128 && a.rs.Fo == 16 && a.ldwh == 128 && !(flags & PYGAT_F_SKIP))
         hipLaunchKernelGGL((gat_fwd_kernel<32, 1, false, true, true, 4, 128>), dim3(blocks), dim3(bt), 0, st, a);
@@ -595,7 +603,7 @@ static int launch_forward(const pygat_graph* g, int H, int Fo, float alpha, int 
     const size_t fix_lds = fix_waves * (size_t)(aux ? part_stride<true>(a.rs) : part_stride<false>(a.rs)) * sizeof(float);
     const unsigned fb = listed ? (unsigned)(a.g.n_cut_wide + cdiv(a.g.n_cut - a.g.n_cut_wide, FIX_LIST_WAVES * fix_rows_per_wave(lpr)))
                                : (unsigned)cdiv(nslots, FIX_SCREEN);
-    if (listed && a.g.n_cut == 0) continue;
+    if ((listed && a.g.n_cut == 0) || !do_fix) continue;
 #define PYGAT_FIX(AUXV)                                                                                               \
     do {                                                                                                              \
       if (listed) {                                                                                                   \
@@ -617,6 +625,12 @@ extern "C" int pygat_head_group(int n, int H, int Fo) {
   const int Fp = padded_width(Fo);
   if (n <= 0 || H <= 0 || Fp <= 0) return 0;
   return head_group_bwd(n, H, Fp);
+}
+
+extern "C" int pygat_gat_forward_phases_ok(int n, int H, int Fo) {
+  const int Fp = padded_width(Fo);
+  if (n <= 0 || H <= 0 || Fp <= 0) return 0;
+  return head_group_fwd_n(n, H, Fp) >= H ? 1 : 0;
 }
 
 extern "C" int pygat_gat_forward(const pygat_graph* g, int H, int Fo, float alpha, int flags, const float* Wh,

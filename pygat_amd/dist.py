@@ -119,70 +119,96 @@ import os as _os
 # the same number and shapes of collectives, so the count may not change under a running job (a per-call read on each rank
 # could disagree and hang); set the environment identically on all ranks, or assign dist.PIPELINE_CHUNKS on all of them.
 PIPELINE_CHUNKS = int(_os.environ.get("PYGAT_DIST_CHUNKS", 4))
-PIPELINE_MIN_ROWS = 1 << 15  # below this a level is launch-bound and one blocking all-gather is cheaper
+PIPELINE_MIN_ROWS = 1 << 15  # below this a level is launch-bound and one exchange after the whole level is cheaper
 
 
-_layout = {}
+# ---------------------------------------------------------------------------------------------------------------------
+# The copy-free exchange (round 5).  The activation of a sharded hidden level lives COLUMN-BLOCKED: `full [world, N, w]`,
+# block r = rank r's head columns of EVERY node (w = heads per rank x F').  Rank r's K2 writes its rows straight into
+# full[r] (the level's output buffer); per row chunk [r0, r1) the exchange sends the contiguous view full[r, r0:r1] to
+# every peer and receives the peers' views full[r', r0:r1] in place -- no staging buffer, no permute, no self copy (rounds
+# 2-4 gathered into [world, rows, w] chunks and copied every chunk into [N, world w]: at config 5 a 512 MB permute
+# beside HBM-bound kernels, 0.7 ms of a 3.1 ms step at RCCL world 1).  The next level reads the blocks in place: the
+# projection / weight-gradient GEMMs take a column-blocked operand (include/pygat_amd.h, pygat_col_blocks: with whole-N
+# blocks the block base is uniform per k-step), and the input gradient is written in the same blocks, which is the layout
+# reduce_scatter_tensor sends (models.py:32 torch.cat and its autograd, without either copy).
+# ---------------------------------------------------------------------------------------------------------------------
+def blocked_width_ok(w: int) -> bool:
+    """Block widths the GEMMs read in place: a power of two >= 16 floats (one 64-byte sector and up)."""
+    return w >= 16 and (w & (w - 1)) == 0
 
 
-def _layout_stream(dev) -> "torch.cuda.Stream":
-    """One side stream per device for the layout copies of gathered chunks."""
-    key = torch.device(dev).index
-    if key not in _layout:
-        _layout[key] = torch.cuda.Stream(device=dev)
-    return _layout[key]
+def exchange_blocks(full: torch.Tensor, r0: int, r1: int):
+    """Rows [r0, r1) of this rank's block full[rank] are enqueued on the current stream: deliver them into every peer's
+    full[rank, r0:r1] and receive the peers' rows into full[peer, r0:r1].  Returns the pending works (wait() on each
+    before `full` is read).  RCCL: ONE grouped send/recv launch (ncclGroupStart ... End: every pair's transfer runs
+    concurrently over its own xGMI link -- the direct all-gather of SURVEY.md 8(e)); gloo (CPU tests, 1-card rehearsals):
+    one broadcast per owner."""
+    rank, world = _world()
+    if dist.get_backend() == "nccl":
+        if world == 1:      # FORCE_COLLECTIVES on one rank: the in-place all-gather of the (contiguous) view -- drives RCCL
+            v = full[0, r0:r1]
+            return [dist.all_gather_into_tensor(v, v, async_op=True)]
+        ops = []
+        for d in range(1, world):       # rank -> rank + d, rank - d -> rank: every step of the loop is a perfect matching
+            ops.append(dist.P2POp(dist.isend, full[rank, r0:r1], (rank + d) % world))
+            ops.append(dist.P2POp(dist.irecv, full[(rank - d) % world, r0:r1], (rank - d) % world))
+        return list(dist.batch_isend_irecv(ops))
+    return [dist.broadcast(full[o, r0:r1], src=o, async_op=True) for o in range(world)]
 
 
-class _GatheredColumns(torch.autograd.Function):
-    """Ties the gathered activation `full` (assembled chunk by chunk from the ranks' column blocks while the
-    level was still running) to the local block it was gathered from: forward returns `full`, backward is the
-    reduce-scatter(sum) of AllGatherColumns."""
+def reduce_scatter_blocks(G: torch.Tensor) -> torch.Tensor:
+    """[world, N, w] partial gradients on every rank -> this rank's block [N, w], summed over the ranks: the layout is
+    already the one reduce_scatter_tensor sends."""
+    rank, world = _world()
+    G = G.contiguous()
+    _, N, w = G.shape
+    if dist.get_backend() == "nccl":
+        out = torch.empty(N, w, dtype=G.dtype, device=G.device)
+        dist.reduce_scatter_tensor(out, G.view(world * N, w), op=dist.ReduceOp.SUM)
+        return out
+    G = G.clone()           # gloo has no reduce_scatter: all-reduce, then the own block (CPU tests, 1-card rehearsals)
+    dist.all_reduce(G, op=dist.ReduceOp.SUM)
+    return G[rank].contiguous()
+
+
+def unblock(xb: torch.Tensor) -> torch.Tensor:
+    """[world, N, w] -> [N, world w] (torch.cat(dim=1), models.py:32): ONE strided copy, differentiable.  Only for
+    consumers that cannot read blocks (a level function injected by a test, dropout levels)."""
+    world, N, w = xb.shape
+    return xb.permute(1, 0, 2).reshape(N, world * w)
+
+
+class _GatheredBlocks(torch.autograd.Function):
+    """Ties the exchanged activation `full [world, N, w]` to the local block it was assembled around: forward returns
+    `full`, backward is the reduce-scatter(sum) of the gradient blocks."""
 
     @staticmethod
-    def forward(ctx, local, full, widths):
-        ctx.widths = tuple(widths)
+    def forward(ctx, local, full):
         return full
 
     @staticmethod
     def backward(ctx, G):
-        return AllGatherColumns.backward(ctx, G)[0], None, None
+        return reduce_scatter_blocks(G), None
 
 
-def _pipelined_concat_level(x, graph, Ws, As, sk, alpha, widths, nchunks):
-    """Hidden level with its heads sharded over the ranks, row-chunk pipelined: K2 runs chunk by
-    chunk; as soon as chunk c's launches are enqueued its rows are all-gathered on RCCL's stream (which first waits
-    for them), so the exchange of chunk c overlaps the computation of chunk c+1, and so on.  The gathered chunks
-    arrive as [world, rows, w] blocks and are copied into their column slices of the [N, sum(widths)] activation
-    as they land."""
+def _blocked_concat_level(x, graph, Ws, As, sk, alpha, w, nchunks):
+    """Hidden level with its heads sharded over the ranks, copy-free (see above), row-chunk pipelined: K2
+    runs chunk by chunk into full[rank]; as soon as chunk c's launches are enqueued its rows go out to the peers (RCCL's
+    stream waits for them first), so the exchange of chunk c overlaps the computation of chunk c + 1."""
     from .ops import gat_level
     rank, world = _world()
-    N, w = x.shape[0], widths[rank]
-    full = torch.empty(N, sum(widths), dtype=torch.float32, device=x.device)
+    N = x.shape[0] if x.dim() == 2 else x.shape[1]
+    full = torch.empty(world, N, w, dtype=torch.float32, device=x.device)
     works = []
-    main = torch.cuda.current_stream(x.device)
-    side = _layout_stream(x.device)
-    side.wait_stream(main)                                  # `full` was allocated on the compute stream
-
-    def land(item):
-        """chunk `item` into its column slices of `full`, on the SIDE stream: it waits for the chunk's all-gather there and
-        the strided copy runs beside the computation of the later chunks (round 4; rounds 2-3 made all these copies on the
-        compute stream after the level, ~0.17 ms per level at config 5)."""
-        work, buf, r0, r1 = item
-        with torch.cuda.stream(side):
-            work.wait()
-            full[r0:r1].view(r1 - r0, world, w).copy_(buf.permute(1, 0, 2))
-        buf.record_stream(side)
 
     def on_chunk(c, r0, r1, out):
-        buf = torch.empty(world, r1 - r0, w, dtype=out.dtype, device=out.device)
-        works.append((dist.all_gather_into_tensor(buf.view(world * (r1 - r0), w), out[r0:r1], async_op=True), buf, r0, r1))
-        if c >= 1:
-            land(works[c - 1])                              # the previous chunk's exchange has had a chunk of compute to finish
+        works.extend(exchange_blocks(full, r0, r1))
 
-    local = gat_level(x, graph, Ws, As, sk, alpha, True, pipeline=(nchunks, on_chunk))
-    land(works[-1])
-    main.wait_stream(side)                                  # the next level reads `full` on the compute stream
-    return _GatheredColumns.apply(local, full, widths)
+    local = gat_level(x, graph, Ws, As, sk, alpha, True, pipeline=(nchunks, on_chunk, full[rank]))
+    for wk in works:
+        wk.wait()                                           # the next level reads `full` on the compute stream
+    return _GatheredBlocks.apply(local, full)
 
 
 class AllReduceSum(torch.autograd.Function):
@@ -220,10 +246,15 @@ def gat_level_head_parallel(x, graph, Ws, As, Wskips, alpha: float, concat: bool
             level_fn = gat_level
     sk = None if Wskips is None else list(Wskips[s:e])
     widths = [(b - a) * Fo for a, b in parts]
-    nchunks = PIPELINE_CHUNKS
-    if (concat and hip_level and dropout == 0.0 and not _single() and nchunks > 1 and x.shape[0] >= PIPELINE_MIN_ROWS
-            and len(set(widths)) == 1 and e > s):
-        return _pipelined_concat_level(x, graph, list(Ws[s:e]), list(As[s:e]), sk, alpha, widths, nchunks)
+    blocked_in = x.dim() == 3
+    N = x.shape[1] if blocked_in else x.shape[0]
+    reads_blocks = hip_level and dropout == 0.0 and e > s        # the HIP level reads a column-blocked x in place
+    if blocked_in and not reads_blocks:
+        x = unblock(x)
+    if (concat and hip_level and dropout == 0.0 and not _single() and x.is_cuda and len(set(widths)) == 1 and e > s
+            and blocked_width_ok(widths[0])):
+        nchunks = PIPELINE_CHUNKS if N >= PIPELINE_MIN_ROWS else 1
+        return _blocked_concat_level(x, graph, list(Ws[s:e]), list(As[s:e]), sk, alpha, widths[0], max(1, nchunks))
     if concat:
         if e > s:
             local = level_fn(x, graph, list(Ws[s:e]), list(As[s:e]), sk, alpha, True)

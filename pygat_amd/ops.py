@@ -241,29 +241,46 @@ class gemm_mode:
 
 
 def gemm(transA: bool, transB: bool, M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor,
-         ldb: int, segments, accumulate: bool = False, split_k: Optional[int] = None, mode: Optional[str] = None) -> None:
-    """C = op(A) op(B), fp32 in / fp32 accumulate; `segments` = [(ncols, tensor, ld), ...]; mode: see set_gemm_mode."""
+         ldb: int, segments, accumulate: bool = False, split_k: Optional[int] = None, mode: Optional[str] = None,
+         a_blocks=None, c_blocks=None) -> None:
+    """C = op(A) op(B), fp32 in / fp32 accumulate; `segments` = [(ncols, tensor, ld), ...]; mode: see set_gemm_mode.
+    a_blocks / c_blocks: _lib.ColBlocks of a column-blocked A (stored matrix) / C (one segment), include/pygat_amd.h."""
+    if c_blocks is not None:
+        split_k = 1
     if split_k is None:
         split_k = _split_k(M, N, K, streamed_k=transA and not transB, mode=mode, transB=transB)
     ws = None
     if split_k > 1:
         ws = torch.empty(lib.pygat_gemm_workspace_bytes(M, N, split_k) // 4, dtype=torch.float32, device=A.device)
     seg = _segments(segments)
-    check(lib.pygat_gemm_f32(int(transA), int(transB), M, N, K, A.data_ptr(), lda, B.data_ptr(), ldb,
-                             C.byref(seg), int(accumulate), split_k, _ptr(ws), _mode_code(mode), _stream()), "gemm_f32")
+    if a_blocks is None and c_blocks is None:
+        check(lib.pygat_gemm_f32(int(transA), int(transB), M, N, K, A.data_ptr(), lda, B.data_ptr(), ldb,
+                                 C.byref(seg), int(accumulate), split_k, _ptr(ws), _mode_code(mode), _stream()), "gemm_f32")
+    else:
+        check(lib.pygat_gemm_f32_blocked(int(transA), int(transB), M, N, K, A.data_ptr(), lda,
+                                         None if a_blocks is None else C.byref(a_blocks), B.data_ptr(), ldb, C.byref(seg),
+                                         None if c_blocks is None else C.byref(c_blocks), int(accumulate), split_k, _ptr(ws),
+                                         _mode_code(mode), _stream()), "gemm_f32_blocked")
 
 
 class _Level:
     """Shapes and packed operands of one call."""
 
     def __init__(self, x, H, Fo, skip):
-        self.N, self.Fin = x.shape
+        # x [N, Fin], or column-blocked [blocks, N, w] (Fin = blocks * w: the head exchange's layout, pygat_amd/dist.py)
+        self.blocks = None if x.dim() == 2 else _lib.ColBlocks(int(x.shape[2]), int(x.shape[1]) * int(x.shape[2]))
+        self.N, self.Fin = (x.shape[0], x.shape[1]) if x.dim() == 2 else (x.shape[1], x.shape[0] * x.shape[2])
+        self.ldx = self.Fin if x.dim() == 2 else int(x.shape[2])
         self.H, self.Fo, self.skip = H, Fo, skip
         self.Fp = padded_width(Fo)
         self.R = H * self.Fp
         self.hg = head_group(self.N, H, Fo)   # heads per backward pass = layout of a GR row
         self.ldw = -(-(self.R * (2 if skip else 1) + 2 * H) // 4) * 4
         self.ts = 0        # slot length of the nnz-split kernels (rows cut by a slot border cost a partial record)
+
+    def xb(self):
+        """pygat_col_blocks* of the level's input (None: an ordinary matrix)."""
+        return None if self.blocks is None else C.byref(self.blocks)
 
     def gp_windows(self):
         """(first column in the R-wide tables, width, first column inside a GR row) of each head window's Gp."""
@@ -277,8 +294,24 @@ class _Level:
         return h0 * (self.Fp + 4) + (h - h0) * self.Fp
 
 
+def _in_features(x) -> int:
+    """Input width of a level: x [N, Fin], or column-blocked [blocks, N, w] with Fin = blocks * w."""
+    return x.shape[1] if x.dim() == 2 else x.shape[0] * x.shape[2]
+
+
+def blocked_input_ok(x3: torch.Tensor) -> bool:
+    """Can the level read this column-blocked activation [blocks, N, w] in place (include/pygat_amd.h, pygat_col_blocks)?
+    w a power of two >= 16; float32 on the GPU."""
+    w = int(x3.shape[2])
+    return x3.dim() == 3 and x3.is_cuda and x3.dtype == torch.float32 and w >= 16 and (w & (w - 1)) == 0
+
+
 class GATLevelFn(torch.autograd.Function):
     """forward(x, W[H,Fin,F'], a[H,2F'], Wskip[H,Fin,F']|None, graph, alpha, concat[, bwd_heads]) -> out.
+
+    x may be COLUMN-BLOCKED: a 3-D tensor [blocks, N, w] = the activation of a head-parallel hidden level as the exchange
+    left it (block b = rank b's head columns of every node; pygat_amd/dist.py), read in place by the projection and the
+    weight-gradient GEMMs; its gradient comes back in the same layout -- the one the reduce-scatter sends.
 
     bwd_heads = (first, count): the forward covers all H heads, the backward only that range -- dW / da of the
     other heads come back as zeros.  For a rank of a head-parallel run that computes every head's forward
@@ -300,7 +333,7 @@ class GATLevelFn(torch.autograd.Function):
         x = x.contiguous().float()
         W = W.contiguous().float(); a = a.contiguous().float()
         H, Fin, Fo = W.shape
-        if x.shape[1] != Fin or a.shape != (H, 2 * Fo):
+        if _in_features(x) != Fin or a.shape != (H, 2 * Fo):
             raise ValueError(f"shape mismatch: x {tuple(x.shape)}, W {tuple(W.shape)}, a {tuple(a.shape)}")
         skip = Wskip is not None
         if skip:
@@ -341,7 +374,7 @@ class GATLevelHeadsFn(torch.autograd.Function):
         ctx.param_dtypes = [p.dtype for p in params]
         x = x.contiguous().float()
         Ws = [w.contiguous().float() for w in Ws]; As = [v.contiguous().float() for v in As]; Ss = [w.contiguous().float() for w in Ss]
-        if x.shape[1] != Fin or any(w.shape != (Fin, Fo) for w in Ws) or any(v.numel() != 2 * Fo for v in As):
+        if _in_features(x) != Fin or any(w.shape != (Fin, Fo) for w in Ws) or any(v.numel() != 2 * Fo for v in As):
             raise ValueError(f"shape mismatch: x {tuple(x.shape)}, W {tuple(Ws[0].shape)}, a {tuple(As[0].shape)}")
         PT = C.c_void_p * H
         wp, ap = PT(*[w.data_ptr() for w in Ws]), PT(*[v.data_ptr() for v in As])
@@ -376,10 +409,14 @@ def _level_forward(ctx, need, x, H, Fo, skip, pack, graph: CSRGraph, alpha: floa
     """Body of the level's forward, shared by GATLevelFn (stacked parameters) and GATLevelHeadsFn (one tensor per head).
     need = (x, W, a, Wskip) gradient flags; pack(Wcat, ldw, a_pad, stream) launches the parameter packing; xs: the
     SparseFeatures of x (features.py) -- projection and weight gradient on the non-zeros only -- or None."""
-    Fin = x.shape[1]
-    if x.shape[0] != graph.n:
-        raise ValueError(f"x has {x.shape[0]} rows but the graph has {graph.n} nodes")
+    if x.dim() == 3 and not blocked_input_ok(x):
+        raise ValueError(f"column-blocked input {tuple(x.shape)}: blocks must be a power of two >= 16 floats wide (float32, GPU)")
     L = _Level(x, H, Fo, skip)
+    Fin = L.Fin
+    if L.N != graph.n:
+        raise ValueError(f"x has {L.N} rows but the graph has {graph.n} nodes")
+    if L.blocks is not None:
+        xs = None
     L.ts = slot_edges_for(L.R, graph.slot_edges)
     L.mode = get_gemm_mode()     # this thread's product mode, fixed for the level: its backward (another thread) uses it too
     dev, f32 = x.device, torch.float32
@@ -408,8 +445,9 @@ def _level_forward(ctx, need, x, H, Fo, skip, pack, graph: CSRGraph, alpha: floa
                                                Wcat.data_ptr(), L.ldw, 0.0, None, 0, None, Wh.data_ptr(), _ptr(Sk), s.data_ptr(),
                                                st), "project_sparse")
             else:
-                check(lib.pygat_project(L.N, Fin, H, Fo, x.data_ptr(), Fin, Wcat.data_ptr(), L.ldw, a_pad.data_ptr(), Wh.data_ptr(),
-                                        _ptr(Sk), s.data_ptr(), split_k, _ptr(ws), GEMM_MODES[L.mode], st), "project")
+                check(lib.pygat_project_blocked(L.N, Fin, H, Fo, x.data_ptr(), L.ldx, L.xb(), Wcat.data_ptr(), L.ldw, a_pad.data_ptr(),
+                                                Wh.data_ptr(), _ptr(Sk), s.data_ptr(), split_k, _ptr(ws), GEMM_MODES[L.mode], st),
+                      "project")
         # K2
         flags = (_lib.F_ELU if concat else 0) | (_lib.F_SKIP if skip else 0)
         # mean over ONE head = that head (Cora / Citeseer output level, train.py:55,66): K2 writes `out` itself (its epilogue
@@ -421,20 +459,47 @@ def _level_forward(ctx, need, x, H, Fo, skip, pack, graph: CSRGraph, alpha: floa
         flavour = backward_flavour(L.R) if need_grad else None
         aneg = torch.empty(L.N, L.R, dtype=f32, device=dev) if flavour == "rowlocal" else None
         qneg = torch.empty(L.N, H, dtype=f32, device=dev) if flavour == "rowlocal" else None
-        out = torch.empty(L.N, H * Fo if concat else Fo, dtype=f32, device=dev)
+        out = pipeline[2] if (pipeline is not None and len(pipeline) > 2 and concat) else None    # the caller's buffer (dist.py:
+        if out is not None:                                                                           # the rank's block of the exchange)
+            if tuple(out.shape) != (L.N, H * Fo) or out.dtype != f32 or not out.is_contiguous() or out.device != dev:
+                raise ValueError(f"pipeline output buffer {tuple(out.shape)}: expected a contiguous float32 [{L.N}, {H * Fo}] on {dev}")
+            # the buffer is the rank's block of a larger tensor whose OTHER blocks are received in place afterwards: alias its
+            # memory with a tensor of its own (no view relation, own version counter), or autograd takes the peers' writes for
+            # in-place changes of this output
+            out = torch.empty(0, dtype=f32, device=dev).set_(out.untyped_storage(), out.storage_offset(), out.shape, out.stride())
+        else:
+            out = torch.empty(L.N, H * Fo if concat else Fo, dtype=f32, device=dev)
         part = torch.empty(lib.pygat_partials_bytes(graph.nnz, L.ts, H, L.Fp) // 4, dtype=f32,
                            device=dev)
         chunks = [(graph.fwd.ref(L.ts), 0, L.N)]
         if pipeline is not None and concat and pipeline[0] > 1:
             chunks = graph.fwd.row_chunks(int(pipeline[0]), L.ts)
+        # a pipelined level: chunk c's fix-up launch (a few thousand cut rows, latency-bound: 25-30 us at config 5) and the
+        # caller's hand-off of the chunk run on a SIDE stream beside chunk c + 1's main launch (the partial records are per
+        # slot: chunks share none) -- in line they cost the step ~70 us per chunk border
+        phases = len(chunks) > 1 and TIMER is None and bool(lib.pygat_gat_forward_phases_ok(L.N, H, Fo))
+        if phases:
+            main_s, side_s = torch.cuda.current_stream(dev), _side_stream(dev)
+
+        def k2(gref, fl, stream):
+            check(lib.pygat_gat_forward(gref, H, Fo, float(alpha), fl, Wh.data_ptr(), s.data_ptr(),
+                                        a_pad.data_ptr(), _ptr(Sk), None, out.data_ptr() if (concat or single) else None,
+                                        _ptr(hattn), _ptr(m), _ptr(Z), _ptr(aneg), _ptr(qneg), part.data_ptr(), stream),
+                  "gat_forward")
         for c, (gref, r0, r1) in enumerate(chunks):
+            if phases:
+                k2(gref, flags | _lib.F_MAIN_ONLY, st)
+                side_s.wait_stream(main_s)
+                with torch.cuda.stream(side_s):
+                    k2(gref, flags | _lib.F_FIXUP_ONLY, side_s.cuda_stream)
+                    pipeline[1](c, r0, r1, out)        # (a collective issued here waits for the side stream = for this chunk only)
+                continue
             with _span("k2_forward"):
-                check(lib.pygat_gat_forward(gref, H, Fo, float(alpha), flags, Wh.data_ptr(), s.data_ptr(),
-                                            a_pad.data_ptr(), _ptr(Sk), None, out.data_ptr() if (concat or single) else None,
-                                            _ptr(hattn), _ptr(m), _ptr(Z), _ptr(aneg), _ptr(qneg), part.data_ptr(), st),
-                      "gat_forward")
+                k2(gref, flags, st)
             if pipeline is not None and concat:
                 pipeline[1](c, r0, r1, out)
+        if phases:
+            main_s.wait_stream(side_s)
         if not concat and not single:
             check(lib.pygat_head_mean(L.N, H, Fo, hattn.data_ptr(), _ptr(Sk), out.data_ptr(), st), "head_mean")
     if need_grad:
@@ -558,24 +623,25 @@ def _level_backward(ctx, G):
             wsw = torch.empty(lib.pygat_wgrad_workspace_bytes(L.Fin, H, Fo, split_k) // 4, dtype=f32, device=dev)
             dW = (torch.zeros if ranged else torch.empty)(H, L.Fin, Fo, dtype=f32, device=dev)
             with _span("k5_wgrad"):
-                check(lib.pygat_wgrad(L.N, L.Fin, H, Fo, x.data_ptr(), L.Fin, dWh.data_ptr(),
-                                      ds.data_ptr() if fold_ds else None, a_pad.data_ptr(), dW.data_ptr(), split_k,
-                                      wsw.data_ptr(), hb, hr, GEMM_MODES[L.mode], st), "wgrad")
+                check(lib.pygat_wgrad_blocked(L.N, L.Fin, H, Fo, x.data_ptr(), L.ldx, L.xb(), dWh.data_ptr(),
+                                              ds.data_ptr() if fold_ds else None, a_pad.data_ptr(), dW.data_ptr(), split_k,
+                                              wsw.data_ptr(), hb, hr, GEMM_MODES[L.mode], st), "wgrad")
         if L.skip and ctx.need[3] and not sparse_w:
             dSc = torch.empty(L.Fin, L.R, dtype=f32, device=dev)
             for c0, w, g0 in L.gp_windows():
-                gemm(True, False, L.Fin, w, L.N, x, L.Fin, GR[:, g0:], RW, [(w, dSc[:, c0:], L.R)], mode=L.mode)
+                gemm(True, False, L.Fin, w, L.N, x, L.ldx, GR[:, g0:], RW, [(w, dSc[:, c0:], L.R)], mode=L.mode, a_blocks=L.blocks)
             dWs = torch.empty(H, L.Fin, Fo, dtype=f32, device=dev)
             check(lib.pygat_unpack_wgrad(H, L.Fin, Fo, dSc.data_ptr(), L.R, 0, dWs.data_ptr(), st), "unpack")
         # dx = dWh Wcat[:, :R]^T (+ Gp Wcat[:, R:2R]^T)
         if ctx.need[0]:
-            dx = torch.empty(L.N, L.Fin, dtype=f32, device=dev)
+            # (a column-blocked x: its gradient is written in the same blocks -- what the reduce-scatter of the exchange sends)
+            dx = torch.empty(x.shape, dtype=f32, device=dev)
             with _span("k5_xgrad"):
-                gemm(False, True, L.N, L.Fin, L.R, dWh, L.R, Wcat, L.ldw, [(L.Fin, dx, L.Fin)], mode=L.mode)
+                gemm(False, True, L.N, L.Fin, L.R, dWh, L.R, Wcat, L.ldw, [(L.Fin, dx, L.ldx)], mode=L.mode, c_blocks=L.blocks)
                 if L.skip:
                     for c0, w, g0 in L.gp_windows():
                         gemm(False, True, L.N, L.Fin, w, GR[:, g0:], RW, Wcat[:, L.R + c0:], L.ldw,
-                             [(L.Fin, dx, L.Fin)], accumulate=True, split_k=1, mode=L.mode)
+                             [(L.Fin, dx, L.ldx)], accumulate=True, split_k=1, mode=L.mode, c_blocks=L.blocks)
         if fork:
             main.wait_stream(side)
     return dx, dW, (da if ctx.need[2] else None), dWs

@@ -80,7 +80,7 @@ QUERIES = {"pygat_abi_version", "pygat_last_error", "pygat_padded_width", "pygat
            "pygat_agrad_workspace_bytes", "pygat_gatv2_workspace_bytes", "pygat_wgrad_workspace_bytes",
            "pygat_headmask_supported", "pygat_project_dropout_workspace_bytes", "pygat_wgrad_dropout_workspace_bytes",
            "pygat_default_gemm_mode", "pygat_nll_workspace_bytes", "pygat_wgrad_sparse_workspace_bytes", "pygat_dropout_narrow", "pygat_bce_workspace_bytes",
-           "pygat_gat_backward_col_da_bytes"}
+           "pygat_gat_backward_col_da_bytes", "pygat_gat_forward_phases_ok"}
 
 
 def test_gemm_mode_is_a_call_argument(lib, monkeypatch):

@@ -233,6 +233,12 @@ typedef struct {
      then replaces the slot's start-up chain slot_begin -> edge_rc -> rowptr and the rowptr load at its end: what a slot
      costs in DEPENDENT memory round trips is what bounds the attention kernels on small graphs and on narrow rows. */
   const int32_t* slot_meta;
+  /* NULL, or [n_slots] a permutation of the slot ids (ABI 14): the MAIN launches of pygat_gat_forward and
+     pygat_gat_backward_col hand slot slot_order[q] to grid position q (work-groups are dispatched in grid order, eight
+     lane groups of consecutive q each), i.e. the ORDER in which slots are walked -- and with it which rows' gathers are in
+     flight together -- without renumbering a node or moving a table row.  Results do not depend on it (partial records
+     and fix-up launches go by the slot id).  Needs slot_count = 0. */
+  const int32_t* slot_order;
 } pygat_graph;
 
 /* edge_rc[k] = (i, col[k]) for rowptr[i] <= k < rowptr[i+1] */

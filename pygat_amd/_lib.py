@@ -68,7 +68,7 @@ class Graph(C.Structure):
     _fields_ = [("n", C.c_int), ("nnz", C.c_int64), ("rowptr", C.c_void_p), ("edge_rc", C.c_void_p),
                 ("slot_edges", C.c_int), ("slot_begin", C.c_void_p), ("cut_rows", C.c_void_p),
                 ("n_cut", C.c_int), ("n_cut_wide", C.c_int), ("slot_first", C.c_int64), ("slot_count", C.c_int64),
-                ("slot_meta", C.c_void_p)]
+                ("slot_meta", C.c_void_p), ("slot_order", C.c_void_p)]
 
 
 def _load():

@@ -157,6 +157,7 @@ struct GraphDev {  // device view of pygat_graph
   const int32_t* cut;  // [n_cut][3] (slot, row, pieces) or nullptr
   int n_cut, n_cut_wide;
   int64_t k0, kn;   // active slot range [k0, k0 + kn) (the forward can work on a range of whole rows)
+  const int32_t* order;   // slot handed to grid position q (pygat_graph.slot_order) or nullptr: q itself
 };
 
 static inline int check_graph(const pygat_graph* g, GraphDev* d, bool allow_slot_range = false) {
@@ -185,6 +186,11 @@ static inline int check_graph(const pygat_graph* g, GraphDev* d, bool allow_slot
   }
   const int64_t total = (g->nnz + g->slot_edges - 1) / g->slot_edges;
   d->k0 = 0; d->kn = total;
+  d->order = g->slot_order;
+  if (g->slot_order && g->slot_count != 0) {
+    set_error("graph: slot_order needs the whole slot range (slot_count = 0)");
+    return PYGAT_EINVAL;
+  }
   if (g->slot_count != 0) {
     if (!allow_slot_range || g->slot_first < 0 || g->slot_count < 0 || g->slot_first + g->slot_count > total) {
       set_error("graph: slot range [%lld, +%lld) of %lld %s", (long long)g->slot_first, (long long)g->slot_count,

@@ -859,13 +859,196 @@ __global__ __launch_bounds__(256) void gemm_tn_x3_kernel(TnArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same GEMM on v_mfma_f32_16x16x32_bf16 (round 5).  MI355X_MICROARCH.md (DVFS give-back, item 7): on random data the chip
+// holds a higher clock under the 16 x 16 x 32 shape than under 32 x 32 x 16 at equal cycles per flop; the nine-product loop of
+// this file, LDS-fed, two waves per SIMD, measured 1.08-1.11 x (tools/micro/mfma_shape_x9.hip, profiles/r5*_mfma_shape_x9.txt).
+// The 16 x 16 x 32 instruction sums 32 k of one row, so an LDS stage holds 32 k rows instead of 16:
+//   * work-group = 8 waves (512 threads), ONE per CU, a 128 x 128 tile of C over one K slab; wave (w >> 1, w & 1) owns rows
+//     32 (w >> 1) .., columns 64 (w & 1) ..: 2 x 4 tiles of 16 x 16, eight accumulators of four registers;
+//   * stage = 32 k x (128 + 128) columns x three pieces, images [column][32 k] with NO row padding (64-byte rows): the four
+//     8-k slices of a row sit rotated by (row >> 1) & 3, which makes the 16-byte fragment reads of every ds_read_b128 lane
+//     group (16 lanes: 8 rows of one slice + 8 rows of the next) hit all 64 banks once, and the dword writes of a half-wave
+//     2-way at worst (free for ds_write_b32); two stages = 96 KB;
+//   * thread (kp = tid & 7, c4 = (tid >> 3) & 31, half = tid >> 8) loads rows k0 + 2 pr, + 1 (pr = kp + 8 half) x 4 columns of
+//     both operands (a wave covers 128 contiguous bytes of 16 rows, as above), three steps ahead; one barrier per 32 k --
+//     half as many per flop as the 16-k kernel -- and the split work of a step is spread over eight waves instead of four.
+// Same-lease A/B at config 5 (gpurun_out r5h, tools/ab_variants.sh): k5_wgrad 0.285-0.302 -> 0.260-0.265 ms, step 3.18 -> 3.15 ms;
+// parity tests unchanged (same nine products, fp32 accumulators).  -DPYGAT_TN_WIDE=0 builds the 32 x 32 x 16 kernel above.
+#ifndef PYGAT_TN_WIDE
+#define PYGAT_TN_WIDE 1
+#endif
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int TNW_RS = 16;                         // dwords per image row: 32 k of bf16
+constexpr int TNW_IMG = 128 * TNW_RS;              // dwords per piece image (8 KB)
+constexpr int TNW_STAGE = 6 * TNW_IMG;             // A(h, m, l), B(h, m, l): 48 KB
+template <class TA_, class TB_>
+__device__ __forceinline__ f32x4 mfma16_bf16(const TA_& a, const TB_& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(512) void gemm_tn_x3w_kernel(TnArgs g) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_tw[];   // [2 * TNW_STAGE]: 96 KB, one work-group per CU
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fi = lane & 15, fq = lane >> 4;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.z * 128;
+  const int64_t kbeg = (int64_t)blockIdx.x * g.k_per_split;
+  const int64_t kend = (kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K;
+  const int nsteps = (int)((kend - kbeg + 31) / 32);
+  // loader role: columns past M / N read column 0 (their products only reach rows / columns of C never stored)
+  const int kp = tid & 7, c4 = (tid >> 3) & 31, pr = kp + 8 * (tid >> 8);
+  const float* la = g.A + ((m0 + 4 * c4 + 3 < g.M) ? m0 + 4 * c4 : 0);
+  const float* lb = g.B + ((n0 + 4 * c4 + 3 < g.N) ? n0 + 4 * c4 : 0);
+  // image position of this thread's k pair in column 4 c4 + COL: slice pr >> 2 rotated by (column >> 1) & 3, dword pr & 3
+  uint32_t* const wbase = lds_tw + (4 * c4) * TNW_RS + (pr & 3);
+  const int wq = pr >> 2, wrot = 2 * (c4 & 1);      // ((4 c4 + COL) >> 1) & 3 = (2 (c4 & 1) + (COL >> 1)) & 3
+#define PYGAT_TWL_LOAD(R, STEP)                                                               \
+  {                                                                                           \
+    const int64_t k__ = kbeg + 32 * (int64_t)(STEP) + 2 * pr;   /* (steps past the slab: row kend - 1, zeroed) */ \
+    const int64_t k0__ = k__ < kend ? k__ : kend - 1, k1__ = k__ + 1 < kend ? k__ + 1 : kend - 1;   \
+    R##a0 = ld4(la + k0__ * g.lda); R##a1 = ld4(la + k1__ * g.lda);                           \
+    R##b0 = ld4(lb + k0__ * g.ldb); R##b1 = ld4(lb + k1__ * g.ldb);                           \
+    R##z0 = k__ < kend ? 1.f : 0.f; R##z1 = k__ + 1 < kend ? 1.f : 0.f;                       \
+  }
+#define PYGAT_TWL_PUT(IMGBASE, X0, X1, COL)                                                   \
+  {                                                                                           \
+    uint32_t h__, m__, l__;                                                                   \
+    split_pair((X0), (X1), h__, m__, l__);                                                    \
+    uint32_t* q__ = (IMGBASE) + (wbase - lds_tw) + (COL) * TNW_RS + 4 * ((wq + wrot + ((COL) >> 1)) & 3);   \
+    q__[0] = h__; q__[TNW_IMG] = m__; q__[2 * TNW_IMG] = l__;                                 \
+  }
+#define PYGAT_TWL_PUTA(R, STAGE, C, CMP)                                                       \
+  PYGAT_TWL_PUT(lds_tw + (STAGE) * TNW_STAGE, R##a0.CMP * R##z0, R##a1.CMP * R##z1, C)
+#define PYGAT_TWL_PUTB(R, STAGE, C, CMP)                                                       \
+  PYGAT_TWL_PUT(lds_tw + (STAGE) * TNW_STAGE + 3 * TNW_IMG, R##b0.CMP, R##b1.CMP, C)
+#define PYGAT_TWL_SPLIT(R, STAGE)                                                             \
+  PYGAT_TWL_PUTA(R, STAGE, 0, x) PYGAT_TWL_PUTA(R, STAGE, 1, y) PYGAT_TWL_PUTA(R, STAGE, 2, z) PYGAT_TWL_PUTA(R, STAGE, 3, w) \
+  PYGAT_TWL_PUTB(R, STAGE, 0, x) PYGAT_TWL_PUTB(R, STAGE, 1, y) PYGAT_TWL_PUTB(R, STAGE, 2, z) PYGAT_TWL_PUTB(R, STAGE, 3, w)
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+  // consumer role.  Fragment of row / column c = base + fi (base a multiple of 16): slice fq at dword 4 ((fq + (fi >> 1)) & 3)
+  const int fso = 4 * ((fq + (fi >> 1)) & 3);
+  const uint32_t* fa = lds_tw + (32 * (w >> 1) + fi) * TNW_RS + fso;
+  const uint32_t* fb = lds_tw + 3 * TNW_IMG + (64 * (w & 1) + fi) * TNW_RS + fso;
+  // (fragment reads FIRST in program order, as in the kernel above)
+#define PYGAT_TWL_READ(STAGE)                                                                 \
+  uint4 fqa[2][3], fqb[4][3];                                                                 \
+  {                                                                                           \
+    const uint32_t* a__ = fa + (STAGE) * TNW_STAGE;                                           \
+    const uint32_t* b__ = fb + (STAGE) * TNW_STAGE;                                           \
+    _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                           \
+      fqa[0][p] = *reinterpret_cast<const uint4*>(a__ + p * TNW_IMG);                         \
+      fqa[1][p] = *reinterpret_cast<const uint4*>(a__ + p * TNW_IMG + 16 * TNW_RS);           \
+      _Pragma("unroll") for (int t = 0; t < 4; ++t)                                           \
+        fqb[t][p] = *reinterpret_cast<const uint4*>(b__ + p * TNW_IMG + 16 * t * TNW_RS);     \
+    }                                                                                         \
+  }
+  // one 16 x 16 tile: its nine MFMAs (small terms first, as mma9) with an eighth of the next step's split (11 VALU
+  // instructions, 3 LDS writes) between them
+#define PYGAT_TWL_GROUP(TM, TN, PUT0)                                                         \
+  {                                                                                           \
+    PUT0                                                                                      \
+    f32x4 c__ = acc[TM][TN];                                                                  \
+    c__ = mfma16_bf16(fqa[TM][2], fqb[TN][2], c__); c__ = mfma16_bf16(fqa[TM][2], fqb[TN][1], c__);   \
+    c__ = mfma16_bf16(fqa[TM][1], fqb[TN][2], c__); c__ = mfma16_bf16(fqa[TM][2], fqb[TN][0], c__);   \
+    c__ = mfma16_bf16(fqa[TM][0], fqb[TN][2], c__); c__ = mfma16_bf16(fqa[TM][1], fqb[TN][1], c__);   \
+    c__ = mfma16_bf16(fqa[TM][1], fqb[TN][0], c__); c__ = mfma16_bf16(fqa[TM][0], fqb[TN][1], c__);   \
+    c__ = mfma16_bf16(fqa[TM][0], fqb[TN][0], c__);                                           \
+    acc[TM][TN] = c__;                                                                        \
+    _Pragma("unroll") for (int m__ = 0; m__ < 9; ++m__) {                                     \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                      \
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                                      \
+      if (m__ >= 3 && m__ < 6) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);             \
+    }                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+  }
+#define PYGAT_TWL_STEP(RSPLIT, RLOAD, I)                                                      \
+  {                                                                                           \
+    PYGAT_TWL_LOAD(RLOAD, (I) + 3)                                                            \
+    PYGAT_TWL_READ((I) & 1)                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    const int sn__ = ((I) + 1) & 1;   /* (past the last step: clamped data into the idle stage) */ \
+    PYGAT_TWL_GROUP(0, 0, PYGAT_TWL_PUTA(RSPLIT, sn__, 0, x)) PYGAT_TWL_GROUP(0, 1, PYGAT_TWL_PUTA(RSPLIT, sn__, 1, y)) \
+    PYGAT_TWL_GROUP(0, 2, PYGAT_TWL_PUTA(RSPLIT, sn__, 2, z)) PYGAT_TWL_GROUP(0, 3, PYGAT_TWL_PUTA(RSPLIT, sn__, 3, w)) \
+    PYGAT_TWL_GROUP(1, 0, PYGAT_TWL_PUTB(RSPLIT, sn__, 0, x)) PYGAT_TWL_GROUP(1, 1, PYGAT_TWL_PUTB(RSPLIT, sn__, 1, y)) \
+    PYGAT_TWL_GROUP(1, 2, PYGAT_TWL_PUTB(RSPLIT, sn__, 2, z)) PYGAT_TWL_GROUP(1, 3, PYGAT_TWL_PUTB(RSPLIT, sn__, 3, w)) \
+    __syncthreads();                                                                          \
+  }
+  float4 r0a0, r0a1, r0b0, r0b1, r1a0, r1a1, r1b0, r1b1, r2a0, r2a1, r2b0, r2b1;
+  float r0z0, r0z1, r1z0, r1z1, r2z0, r2z1;
+  PYGAT_TWL_LOAD(r0, 0)
+  __builtin_amdgcn_sched_barrier(0);   // (issue order = wait order)
+  PYGAT_TWL_LOAD(r1, 1)
+  __builtin_amdgcn_sched_barrier(0);
+  PYGAT_TWL_LOAD(r2, 2)
+  __builtin_amdgcn_sched_barrier(0);
+  PYGAT_TWL_SPLIT(r0, 0)
+  __syncthreads();
+  for (int i = 0; i < nsteps; i += 3) {     // (three steps per turn, unconditionally: see the kernel above)
+    PYGAT_TWL_STEP(r1, r0, i)
+    PYGAT_TWL_STEP(r2, r1, i + 1)
+    PYGAT_TWL_STEP(r0, r2, i + 2)
+  }
+#undef PYGAT_TWL_LOAD
+#undef PYGAT_TWL_PUT
+#undef PYGAT_TWL_SPLIT
+#undef PYGAT_TWL_GROUP
+#undef PYGAT_TWL_PUTA
+#undef PYGAT_TWL_PUTB
+#undef PYGAT_TWL_READ
+#undef PYGAT_TWL_STEP
+  // C/D layout of the 16 x 16 tile: column = lane & 15, row = 4 (lane >> 4) + register
+  float* base = g.ws + (int64_t)blockIdx.x * g.M * g.N;
+  const int wm0 = m0 + 32 * (w >> 1), wn0 = n0 + 64 * (w & 1);
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      const int col = wn0 + 16 * tn + fi;
+      if (col >= g.N) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wm0 + 16 * tm + 4 * fq + r;
+        if (row < g.M) base[(int64_t)row * g.N + col] = acc[tm][tn][r];
+      }
+    }
+}
+
 int try_gemm_tn_x3(const TnArgs& g, int splits, hipStream_t st) {
   if (g.B2 || g.M <= 64 || g.N <= 64 || (g.k_per_split % 16) != 0) return 0;
   if (!aligned16(g.A) || !aligned16(g.B) || (g.lda % 4) != 0 || (g.ldb % 4) != 0 || (g.M % 4) != 0 || (g.N % 4) != 0) return 0;
-  dim3 grid((unsigned)splits, (unsigned)cdiv(g.M, 128), (unsigned)cdiv(g.N, 128));
-  constexpr size_t lds = 2 * TNX_STAGE * sizeof(uint32_t);
   int dev = -1;
   (void)hipGetDevice(&dev);
+#if PYGAT_TN_WIDE
+  {   // the 16 x 16 x 32 kernel: one 8-wave work-group per CU, 32-k steps, three per loop turn
+    const int tiles = (int)(cdiv(g.M, 128) * cdiv(g.N, 128));
+    int sw = splits;
+    if (sw * tiles > 256) sw = 256 / tiles > 0 ? 256 / tiles : 1;
+    TnArgs gw = g;
+    gw.k_per_split = cdiv(cdiv(g.K, sw), 96) * 96;
+    sw = (int)cdiv(g.K, gw.k_per_split);
+    constexpr size_t ldsw = 2 * TNW_STAGE * sizeof(uint32_t);
+    static bool attr_w[64] = {};
+    if (dev < 0 || dev >= 64 || !attr_w[dev]) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_x3w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+      if (dev >= 0 && dev < 64) attr_w[dev] = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_x3w_kernel, dim3((unsigned)sw, (unsigned)cdiv(g.M, 128), (unsigned)cdiv(g.N, 128)), dim3(512), ldsw, st, gw);
+    hipError_t ew = hipGetLastError();
+    if (ew != hipSuccess) {
+      set_error("gemm_tn_x3w: %s", hipGetErrorString(ew));
+      return PYGAT_EHIP;
+    }
+    return sw;
+  }
+#endif
+  dim3 grid((unsigned)splits, (unsigned)cdiv(g.M, 128), (unsigned)cdiv(g.N, 128));
+  constexpr size_t lds = 2 * TNX_STAGE * sizeof(uint32_t);
   static bool attr_set[64] = {};   // per device: the attribute belongs to the device's code object
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((AUX && FAS
   const int lane = threadIdx.x & 63;
   const int64_t kl = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * EPW + lane / LPR;
   if (kl >= a.g.kn) return;  // lane groups are independent: no cross-lane op below
-  const int64_t k = a.g.k0 + kl;  // slot id
+  const int64_t k = a.g.order ? a.g.order[kl] : a.g.k0 + kl;  // slot id (slot_order: the whole range, k0 = 0)
   int64_t e0, e1;
   const int2* __restrict__ rc = a.g.rc;
   int r_first;

@@ -282,7 +282,8 @@ template <int LPR, int VEC, bool WRITE_DZ, int LPH = 0, int CR = 0, bool DA = fa
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CR > 0 ? (DA ? PYGAT_K4_DA_WAVES : PYGAT_K4_HEADLINE_WAVES) : 1))) void gat_bwd_col_kernel(ColArgs a) {
   constexpr int EPW = 64 / LPR;
   const int lane = threadIdx.x & 63;
-  const int64_t k = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * EPW + lane / LPR;
+  const int64_t q = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * EPW + lane / LPR;   // grid position
+  const int64_t k = (a.g.order && q < num_slots(a.g)) ? a.g.order[q] : q;                                // its slot (pygat_graph.slot_order)
   if constexpr (!DA) {
     if (k >= num_slots(a.g)) return;
     col_walk<LPR, VEC, WRITE_DZ, LPH, CR, false>(a, k, nullptr, 0);

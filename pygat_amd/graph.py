@@ -26,6 +26,11 @@ import torch
 from . import _lib
 from ._lib import lib, check
 
+# Experiment hook (tools/slot_order_probe.py): f(pattern, slot_meta [n_slots, 4] int32) -> int32 permutation
+# [n_slots] handed to the kernels as pygat_graph.slot_order -- the order in which the main launches of K2 / K4 walk the slots.
+# None (the shipped default): grid order = slot order.
+SLOT_ORDER_FN = None
+
 DEFAULT_SLOT_EDGES = 64   # edges per work slot of the nnz-split kernels on large graphs (multiple of 4)
 
 
@@ -104,9 +109,10 @@ class _Pattern:
                                           meta.data_ptr(), _stream()), "slot_meta")
             if os.environ.get("PYGAT_NO_SLOT_META") == "1":      # development knob (A/B of the slot records)
                 meta = None
+            order = SLOT_ORDER_FN(self, meta) if (SLOT_ORDER_FN is not None and meta is not None) else None
             st = _lib.Graph(self.n, self.nnz, _ptr(self.rowptr), _ptr(self.edge_rc), slot_edges, _ptr(sb), _ptr(cut),
-                            n_cut, n_wide, 0, 0, _ptr(meta))
-            self._alt[key] = (st, sb, cut, meta)
+                            n_cut, n_wide, 0, 0, _ptr(meta), _ptr(order))
+            self._alt[key] = (st, sb, cut, meta, order)
         return self._alt[key][0]
 
     def row_chunks(self, nchunks: int, slot_edges: Optional[int] = None):
@@ -117,7 +123,7 @@ class _Pattern:
         key = ("chunks", ts, nchunks)
         if key not in self._alt:
             base = self._make(ts, True)
-            _, sb, cut, meta = self._alt[(ts, True)]
+            _, sb, cut, meta, _order = self._alt[(ts, True)]
             nslots = sb.numel() - 1
             sbl, rp = sb.long(), self.rowptr.long()
             first_row = self.edge_rc[sbl[:-1], 0].long()                 # row of the first edge of every slot
@@ -142,7 +148,7 @@ class _Pattern:
                     if n_cut == 0:
                         sub = cut[:1].contiguous()                       # a non-NULL list with n_cut = 0: nothing to fix up
                 st = _lib.Graph(self.n, self.nnz, _ptr(self.rowptr), _ptr(self.edge_rc), ts, _ptr(sb), _ptr(sub), n_cut,
-                                n_wide, b0, b1 - b0, _ptr(meta))
+                                n_wide, b0, b1 - b0, _ptr(meta), None)
                 out.append((st, r0, r1))
                 keep.append(sub)
             self._alt[key] = (out, keep)

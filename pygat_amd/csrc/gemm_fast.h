@@ -82,6 +82,6 @@ int try_gemm_tn_x3(const TnArgs& g, int splits, hipStream_t st);
 // any operand layout, K % 4 == 0, aligned rows, M, N > 64 (k1_gemm_x3.hip, gemm_x3g_kernel): 1 if it took the call
 int try_gemm_x3g(int transA, int transB, int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                  const pygat_out_segments* out, int accumulate, int splits, int64_t k_per_split, float* ws, hipStream_t st,
-                 ColBlocks ab, ColBlocks cb);
+                 ColBlocks ab, ColBlocks cb, int* splits_used);   // *splits_used: the slabs written (<= splits)
 
 }  // namespace pygat

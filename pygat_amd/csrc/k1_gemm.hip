@@ -603,7 +603,7 @@ int try_project_x3(int n, int Fin, int H, int Fp, const float* X, int64_t ldx, c
                    float* s, const float* a_pad, bool split, hipStream_t st);
 int try_gemm_x3g(int transA, int transB, int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                  const pygat_out_segments* out, int accumulate, int splits, int64_t k_per_split, float* ws, hipStream_t st,
-                 ColBlocks ab, ColBlocks cb);
+                 ColBlocks ab, ColBlocks cb, int* splits_used);
 bool gemm_split(int mode);
 
 }  // namespace pygat
@@ -667,8 +667,8 @@ extern "C" int pygat_gemm_f32_blocked(int transA, int transB, int M, int N, int6
   }
   if (split) {   // any layout on the bf16 pipe from exactly split operands (gemm_x3g_kernel); odd shapes fall through
     const int64_t kps16 = cdiv(cdiv(K, split_k), 16) * 16;
-    const int sp = (int)cdiv(K, kps16);
-    const int r = try_gemm_x3g(transA, transB, M, N, K, A, lda, B, ldb, out, accumulate, sp, kps16, (float*)ws, st, ab, cb);
+    int sp = (int)cdiv(K, kps16);
+    const int r = try_gemm_x3g(transA, transB, M, N, K, A, lda, B, ldb, out, accumulate, sp, kps16, (float*)ws, st, ab, cb, &sp);
     if (r < 0) return r;
     if (r == 1) {
       if (sp > 1) {

@@ -1282,10 +1282,212 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// gemm_x3g_kernel on v_mfma_f32_16x16x32_bf16 (round 5; see gemm_tn_x3w_kernel for the why and the LDS image): 8 waves, one
+// work-group per CU, 32 k per stage, 128 x 128 tile, wave (w >> 1, w & 1) = rows 32 (w >> 1) .., columns 64 (w & 1) ...
+// K-STRIDED operand: thread (kp, c4, half) as in gemm_tn_x3w_kernel.  K-CONTIGUOUS operand: thread (row = (tid & 15) + 16 (tid >> 6),
+// slice q = (tid >> 4) & 3) loads the 8 floats k0 + 8 q .. + 7 of its row, splits the four pairs and writes each piece's slice with
+// ONE ds_write_b128 (8 consecutive rows of one slice, rotated by (row >> 1) & 3: the 8-lane groups of a b128 write hit 32 banks once).
+// Two-level accumulation every 96 k (three steps), output / slabs / column blocks as gemm_x3g_kernel.
+// Same-lease A/B (gpurun_out r5i, tools/ab_x3gw.sh; profiles/r5i_x3g_16x16x32_same_lease.txt): PPI level-2 input gradient
+// 3144 x 1024 x 1024 (200 tiles) 87.4 -> 69.5 us, level-3 65.4 -> 53.5, weight gradient 84.5 -> 78 (4 slabs instead of 8),
+// projection (425 tiles = two rounds of one-per-CU work-groups) 146 -> 140; PPI epoch 2.35 -> 2.14 ms.
+// -DPYGAT_X3G_WIDE=0 builds the 32 x 32 x 16 kernel above as the general kernel.
+#ifndef PYGAT_X3G_WIDE
+#define PYGAT_X3G_WIDE 1
+#endif
+struct X3gwSlot {      // one 32-k step of both operands, in flight
+  float4 a0, a1, b0, b1;
+};
+
+template <bool KCA, bool KCB>
+__global__ __launch_bounds__(512) void gemm_x3gw_kernel(X3gArgs g) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_xw[];   // [2 * TNW_STAGE]: 96 KB
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fi = lane & 15, fq = lane >> 4;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.z * 128;
+  const int64_t kbeg = (int64_t)blockIdx.x * g.k_per_split;
+  const int64_t kend = (kbeg + g.k_per_split < g.K) ? kbeg + g.k_per_split : g.K;
+  const int nsteps = (int)((kend - kbeg + 31) / 32);
+  // loader roles
+  const int kp = tid & 7, c4 = (tid >> 3) & 31, pr = kp + 8 * (tid >> 8);   // k-strided: pair pr (rows 2 pr, 2 pr + 1) x columns 4 c4 ..
+  const int lq = (tid >> 4) & 3, lrow = (tid & 15) + 16 * (tid >> 6);        // k-contiguous: slice lq of row lrow
+  const float* la;
+  const float* lb;
+  if constexpr (KCA) la = g.A + (int64_t)((m0 + lrow < g.M) ? m0 + lrow : g.M - 1) * g.lda;   // rows past M: the last row
+  else la = g.A + blk_off((m0 + 4 * c4 < g.M) ? m0 + 4 * c4 : 0, g.ab);
+  if constexpr (KCB) lb = g.B + (int64_t)((n0 + lrow < g.N) ? n0 + lrow : g.N - 1) * g.ldb;
+  else lb = g.B + ((n0 + 4 * c4 < g.N) ? n0 + 4 * c4 : 0);
+
+  auto load = [&](X3gwSlot& r, int step) {
+    const int st = step < nsteps ? step : nsteps - 1;
+    const int64_t ks = kbeg + 32 * (int64_t)st;
+    {   // k-strided addressing
+      const int64_t k = ks + 2 * pr;
+      const int64_t k0 = k < kend ? k : kend - 1, k1 = k + 1 < kend ? k + 1 : kend - 1;
+      if constexpr (!KCA) { r.a0 = ld4(la + k0 * g.lda); r.a1 = ld4(la + k1 * g.lda); }
+      if constexpr (!KCB) { r.b0 = ld4(lb + k0 * g.ldb); r.b1 = ld4(lb + k1 * g.ldb); }
+    }
+    {   // k-contiguous addressing (a column-blocked A: an 8-float slice never straddles a block, blocks being >= 16 wide)
+      const int64_t k = ks + 8 * lq;
+      const int64_t k0 = k < kend ? k : kend - 4, k1 = k + 4 < kend ? k + 4 : kend - 4;
+      if constexpr (KCA) { r.a0 = ld4(la + blk_off(k0, g.ab)); r.a1 = ld4(la + blk_off(k1, g.ab)); }
+      if constexpr (KCB) { r.b0 = ld4(lb + k0); r.b1 = ld4(lb + k1); }
+    }
+  };
+  // ---- one EIGHTH of a step's split + LDS writes per operand quarter Q (0..3) ----
+  // k-strided: column 4 c4 + Q of the thread's pair -> three dword writes
+  auto put_strided = [&](uint32_t* img, const float4& x0, const float4& x1, float z0, float z1, auto q_tag) {
+    constexpr int Q = decltype(q_tag)::value;
+    const float p0 = Q == 0 ? x0.x : Q == 1 ? x0.y : Q == 2 ? x0.z : x0.w;
+    const float p1 = Q == 0 ? x1.x : Q == 1 ? x1.y : Q == 2 ? x1.z : x1.w;
+    uint32_t h, m, l;
+    split_pair(p0 * z0, p1 * z1, h, m, l);
+    uint32_t* d = img + (4 * c4 + Q) * TNW_RS + 4 * (((pr >> 2) + 2 * (c4 & 1) + (Q >> 1)) & 3) + (pr & 3);
+    d[0] = h; d[TNW_IMG] = m; d[2 * TNW_IMG] = l;
+  };
+  // k-contiguous: pair Q of the thread's eight floats into the piece registers; the slice is written with pair 3
+  auto put_contig = [&](uint32_t* img, const float4& x0, const float4& x1, float z0, float z1, uint32_t (&ph)[4], uint32_t (&pm)[4],
+                        uint32_t (&pl)[4], auto q_tag) {
+    constexpr int Q = decltype(q_tag)::value;
+    const float p0 = Q == 0 ? x0.x * z0 : Q == 1 ? x0.z * z0 : Q == 2 ? x1.x * z1 : x1.z * z1;
+    const float p1 = Q == 0 ? x0.y * z0 : Q == 1 ? x0.w * z0 : Q == 2 ? x1.y * z1 : x1.w * z1;
+    split_pair(p0, p1, ph[Q], pm[Q], pl[Q]);
+    if constexpr (Q == 3) {
+      uint32_t* d = img + lrow * TNW_RS + 4 * ((lq + (lrow >> 1)) & 3);
+      *reinterpret_cast<uint4*>(d) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+      *reinterpret_cast<uint4*>(d + TNW_IMG) = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+      *reinterpret_cast<uint4*>(d + 2 * TNW_IMG) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+    }
+  };
+  uint32_t pah[4], pam[4], pal[4], pbh[4], pbm[4], pbl[4];   // (k-contiguous operands only)
+  // A's copy of k positions past the slab is zeroed (only the last step of a slab has any)
+  auto put_a = [&](const X3gwSlot& r, int stage, int step_of_r, auto q_tag) {
+    uint32_t* img = lds_xw + stage * TNW_STAGE;
+    const int64_t ks = kbeg + 32 * (int64_t)step_of_r;
+    if constexpr (KCA) {
+      const int64_t k = ks + 8 * lq;
+      put_contig(img, r.a0, r.a1, k < kend ? 1.f : 0.f, k + 4 < kend ? 1.f : 0.f, pah, pam, pal, q_tag);
+    } else {
+      const int64_t k = ks + 2 * pr;
+      put_strided(img, r.a0, r.a1, k < kend ? 1.f : 0.f, k + 1 < kend ? 1.f : 0.f, q_tag);
+    }
+  };
+  auto put_b = [&](const X3gwSlot& r, int stage, auto q_tag) {
+    uint32_t* img = lds_xw + stage * TNW_STAGE + 3 * TNW_IMG;
+    if constexpr (KCB) put_contig(img, r.b0, r.b1, 1.f, 1.f, pbh, pbm, pbl, q_tag);
+    else put_strided(img, r.b0, r.b1, 1.f, 1.f, q_tag);
+  };
+
+  f32x4 acc[2][4], acc2[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { acc[i][j][r] = 0.f; acc2[i][j][r] = 0.f; }
+  const int fso = 4 * ((fq + (fi >> 1)) & 3);
+  const uint32_t* fa = lds_xw + (32 * (w >> 1) + fi) * TNW_RS + fso;
+  const uint32_t* fb = lds_xw + 3 * TNW_IMG + (64 * (w & 1) + fi) * TNW_RS + fso;
+
+  using Q0 = std::integral_constant<int, 0>;
+  using Q1 = std::integral_constant<int, 1>;
+  using Q2 = std::integral_constant<int, 2>;
+  using Q3 = std::integral_constant<int, 3>;
+  auto step = [&](const X3gwSlot& rs, X3gwSlot& rl, int i) {
+    load(rl, i + 2);
+    uint4 fqa[2][3], fqb[4][3];
+    {
+      const uint32_t* a_ = fa + (i & 1) * TNW_STAGE;
+      const uint32_t* b_ = fb + (i & 1) * TNW_STAGE;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        fqa[0][p] = *reinterpret_cast<const uint4*>(a_ + p * TNW_IMG);
+        fqa[1][p] = *reinterpret_cast<const uint4*>(a_ + p * TNW_IMG + 16 * TNW_RS);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fqb[t][p] = *reinterpret_cast<const uint4*>(b_ + p * TNW_IMG + 16 * t * TNW_RS);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int sn = (i + 1) & 1;   // (past the last step: clamped data into the idle stage)
+    auto group = [&](auto tm_tag, auto tn_tag) {
+      constexpr int TM = decltype(tm_tag)::value, TN = decltype(tn_tag)::value;
+      f32x4 c = acc[TM][TN];
+      c = mfma16_bf16(fqa[TM][2], fqb[TN][2], c); c = mfma16_bf16(fqa[TM][2], fqb[TN][1], c);
+      c = mfma16_bf16(fqa[TM][1], fqb[TN][2], c); c = mfma16_bf16(fqa[TM][2], fqb[TN][0], c);
+      c = mfma16_bf16(fqa[TM][0], fqb[TN][2], c); c = mfma16_bf16(fqa[TM][1], fqb[TN][1], c);
+      c = mfma16_bf16(fqa[TM][1], fqb[TN][0], c); c = mfma16_bf16(fqa[TM][0], fqb[TN][1], c);
+      c = mfma16_bf16(fqa[TM][0], fqb[TN][0], c);
+      acc[TM][TN] = c;
+#pragma unroll
+      for (int m = 0; m < 9; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        if (m >= 3 && m < 6) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    put_a(rs, sn, i + 1, Q0{}); group(Q0{}, Q0{});
+    put_a(rs, sn, i + 1, Q1{}); group(Q0{}, Q1{});
+    put_a(rs, sn, i + 1, Q2{}); group(Q0{}, Q2{});
+    put_a(rs, sn, i + 1, Q3{}); group(Q0{}, Q3{});
+    put_b(rs, sn, Q0{}); group(Q1{}, Q0{});
+    put_b(rs, sn, Q1{}); group(Q1{}, Q1{});
+    put_b(rs, sn, Q2{}); group(Q1{}, Q2{});
+    put_b(rs, sn, Q3{}); group(Q1{}, Q3{});
+    __syncthreads();
+  };
+
+  X3gwSlot r0, r1;
+  load(r0, 0);
+  __builtin_amdgcn_sched_barrier(0);   // (issue order = wait order)
+  load(r1, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  put_a(r0, 0, 0, Q0{}); put_a(r0, 0, 0, Q1{}); put_a(r0, 0, 0, Q2{}); put_a(r0, 0, 0, Q3{});
+  put_b(r0, 0, Q0{}); put_b(r0, 0, Q1{}); put_b(r0, 0, Q2{}); put_b(r0, 0, Q3{});
+  __syncthreads();
+  for (int i = 0; i < nsteps; i += 2) {
+    step(r1, r0, i);
+    if (i + 1 < nsteps) step(r0, r1, i + 1);
+    if (((i >> 1) & 1) == 1) {      // every 4 steps = 128 k (the 16-k kernel: 96)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { acc2[a][b][r] += acc[a][b][r]; acc[a][b][r] = 0.f; }
+    }
+  }
+  const int wm0 = m0 + 32 * (w >> 1), wn0 = n0 + 64 * (w & 1);
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      const int col = wn0 + 16 * tn + fi;
+      if (col >= g.N) continue;
+      float* base;
+      int64_t ld;
+      if (g.ws) { base = g.ws + (int64_t)blockIdx.x * g.M * g.N + col; ld = g.N; }
+      else if (g.cb.lw < 62) { base = g.out.ptr[0] + blk_off(col, g.cb); ld = g.out.ld[0]; }
+      else base = out_segment(g.out, col, ld);
+      const bool add = !g.ws && g.accumulate;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wm0 + 16 * tm + 4 * fq + r;
+        if (row < g.M) {
+          float* p = base + (int64_t)row * ld;
+          const float v = acc[tm][tn][r] + acc2[tm][tn][r];
+          *p = add ? *p + v : v;
+        }
+      }
+    }
+}
+
 // 1: took the call (slabs, if any, are in ws: the caller reduces them); 0: shape does not qualify; < 0: launch error
 int try_gemm_x3g(int transA, int transB, int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                  const pygat_out_segments* out, int accumulate, int splits, int64_t k_per_split, float* ws, hipStream_t st,
-                 ColBlocks ab, ColBlocks cb) {
+                 ColBlocks ab, ColBlocks cb, int* splits_used) {
+  if (splits_used) *splits_used = splits;
   if (M < 64 || N <= 64 || K < 32) return 0;   // (a 64-row operand fills half a tile and still beats the fp32 kernel: PPI level-1 dW 38 -> 24 us)
   if (!aligned16(A) || !aligned16(B) || (lda % 4) != 0 || (ldb % 4) != 0) return 0;
   const bool kca = !transA, kcb = transB != 0;
@@ -1301,6 +1503,47 @@ int try_gemm_x3g(int transA, int transB, int M, int N, int64_t K, const float* A
   g.out = *out; g.accumulate = accumulate;
   g.ab = ab; g.cb = cb;
   if (cb.lw < 62 && splits > 1) return 0;
+#if PYGAT_X3G_WIDE
+  {   // the 16 x 16 x 32 kernel: ONE 8-wave work-group per CU.  Slabs: as many as fill the CUs once (the caller sized them for two
+      // 4-wave work-groups per CU), in whole 32-k steps
+    const int tiles = (int)(cdiv(M, 128) * cdiv(N, 128));
+    int sw = splits;
+    if (sw > 1) {
+      if (sw * tiles > 256) sw = 256 / tiles > 1 ? 256 / tiles : 1;
+      if (sw > 1) {
+        g.k_per_split = cdiv(cdiv(K, sw), 32) * 32;
+        sw = (int)cdiv(K, g.k_per_split);
+      }
+      if (sw <= 1) { sw = 1; g.k_per_split = K; g.ws = nullptr; }
+    }
+    if (splits_used) *splits_used = sw;
+    constexpr size_t ldsw = 2 * TNW_STAGE * sizeof(uint32_t);
+    dim3 gridw((unsigned)sw, (unsigned)cdiv(M, 128), (unsigned)cdiv(N, 128));
+#define PYGAT_X3GW_LAUNCH(KA, KB)                                                                                         \
+  do {                                                                                                                    \
+    int dev = -1;                                                                                                         \
+    (void)hipGetDevice(&dev);                                                                                             \
+    static bool attr_set[64] = {};                                                                                        \
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3gw_kernel<KA, KB>),                                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);                                   \
+      if (dev >= 0 && dev < 64) attr_set[dev] = true;                                                                     \
+    }                                                                                                                     \
+    hipLaunchKernelGGL((gemm_x3gw_kernel<KA, KB>), gridw, dim3(512), ldsw, st, g);                                        \
+  } while (0)
+    if (kca && kcb) PYGAT_X3GW_LAUNCH(true, true);
+    else if (kca) PYGAT_X3GW_LAUNCH(true, false);
+    else if (kcb) PYGAT_X3GW_LAUNCH(false, true);
+    else PYGAT_X3GW_LAUNCH(false, false);
+#undef PYGAT_X3GW_LAUNCH
+    hipError_t ew = hipGetLastError();
+    if (ew != hipSuccess) {
+      set_error("gemm_x3gw: %s", hipGetErrorString(ew));
+      return PYGAT_EHIP;
+    }
+    return 1;
+  }
+#endif
   dim3 grid((unsigned)splits, (unsigned)cdiv(M, 128), (unsigned)cdiv(N, 128));
   constexpr size_t lds = 2 * TNX_STAGE * sizeof(uint32_t);
 #define PYGAT_X3G_LAUNCH(KA, KB)                                                                                          \

@@ -60,9 +60,10 @@ def parse():
     ap.add_argument("--dx", action="store_true", help="also back-propagate into the input features")
     ap.add_argument("--hip-graph", action="store_true", help="replay the level from captured HIP graphs (pygat_amd.GraphedLevel)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-dense-cpu", action="store_true", help="skip the dense-formulation CPU figure inside the cpu_baseline leg (~15 s)")
     ap.add_argument("--no-epoch", action="store_true", help="skip the Cora / Pubmed epoch_ms leg")
     ap.add_argument("--no-v2", action="store_true", help="skip the GATv2 level leg")
-    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-steps", type=int, default=5, help="timed steps of the cpu_baseline leg (>= 1; its value is their median)")
     ap.add_argument("--verify", action="store_true", help="check the gathered sharded output against the unsharded level")
     ap.add_argument("--forward-exchange", choices=["allgather", "replicate"], default="allgather",
                     help="N>1, how every rank gets the other ranks' head outputs: RCCL all-gather over xGMI (default, the "
@@ -73,7 +74,10 @@ def parse():
                          "is computed (1 = one all-gather after the whole forward)")
     ap.add_argument("--as-rank-of", type=int, default=0,
                     help="single process: run the work of rank 0 of a world of this size (per-rank time model, no collectives)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.cpu_steps < 1:
+        ap.error("--cpu-steps must be >= 1")
+    return args
 
 
 def cpu_model():
@@ -95,14 +99,27 @@ def cpu_baseline_child(args):
         return {"value": None, "unit": "edges/s", "cores": os.cpu_count(), "kind": "port", "cpu": cpu_model(),
                 "sample": "skipped: running under rocprofv3 (no child process after the GPU is initialised)"}
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), "--scale", str(args.scale), "--draws", str(args.draws),
-           "--fin", str(args.fin), "--heads", str(args.heads), "--fout", str(args.fout), "--steps", str(max(5, args.cpu_steps))]
+           "--fin", str(args.fin), "--heads", str(args.heads), "--fout", str(args.fout), "--steps", str(args.cpu_steps)]
     if args.dx:
         cmd.append("--dx")
     env = {k: v for k, v in os.environ.items() if not k.startswith("OMP_") and k != "PYGAT_CPU_BENCH_CHILD"}
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     if r.returncode != 0:
         raise RuntimeError(f"oracle/cpu_bench.py rc={r.returncode}: {r.stderr[-400:]}")
-    return json.loads(r.stdout.strip().splitlines()[-1])
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    if not args.no_dense_cpu:
+        # the reference's own DENSE O(N^2) formulation (layers.py:32-64 restated: oracle.gat_oracle.dense_head_forward,
+        # stock torch CPU autograd) on this box's host cores -- Pubmed topology, one head 500 -> 8, fwd+bwd; the reference itself
+        # measured 3.17 s/step for this case on the build container's 8 cores.  Same pre-GPU discipline: a child.
+        try:
+            d = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_dense_bench.py"), "--reps", "3"], capture_output=True,
+                               text=True, env=env, timeout=600)
+            if d.returncode != 0:
+                raise RuntimeError(d.stderr[-300:])
+            rec["dense_reference_formulation"] = json.loads(d.stdout.strip().splitlines()[-1])
+        except Exception as ex:
+            rec["dense_reference_formulation"] = {"seconds_per_step": None, "error": repr(ex)}
+    return rec
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -330,10 +347,12 @@ def main():
     import pygat_amd as pg
     from pygat_amd import ops
     from pygat_amd.dist import partition_heads
-    from pygat_amd.rmat import rmat_csr
+    from pygat_amd.rmat import rmat_csr_numpy
 
     H, Fo, Fin = args.heads, args.fout, args.fin
-    rowptr, col = rmat_csr(args.scale, args.draws, seed=1, device=dev)
+    # ONE graph for both legs: drawn on the host from the numpy stream the cpu_baseline child replays (oracle/cpu_bench.py), uploaded
+    rp_h, col_h = rmat_csr_numpy(args.scale, args.draws, seed=1)
+    rowptr, col = torch.from_numpy(rp_h).to(dev), torch.from_numpy(col_h).to(dev)
     graph = pg.CSRGraph(rowptr, col)
     N, E = graph.n, graph.nnz
     g2 = torch.Generator(device=dev).manual_seed(2)
@@ -514,6 +533,9 @@ def main():
         model = {
             "k1_project": ("mfma", 2.0 * N * Fin * (Rf + 2 * Hf)),
             "k2_forward": ("hbm", E * (4 + 4 * Hf + 4 * Rf) + N * (4 + 4 * Hf + 4 * Rf + 8 * Hf)),
+            # (SURVEY 8(d) predates the row-local backward: K3a also reads the forward's alpha-branch share `aneg` [N, R] for the
+            # rows with logits on both sides of the LeakyReLU kink -- 44 % of the rows at config 5, 0.24 GB -- which is the whole of
+            # its PMC traffic above this model: 2.15 GB measured = 1.85 + 0.24 + qneg; nothing is read twice)
             "k3a_prepare": ("hbm", N * (12 * Rb + 28 * Hb)),
             "k3b_row": ("hbm", E * (4 + 4 * Rb + 8 * Hb) + N * (4 + 8 * Rb + 16 * Hb) - N * (12 * Rb + 28 * Hb)),
             "k4_backward_col": ("hbm", E * (8 + 4 * Rb + 8 * Hb) + N * (4 + 8 * Rb + 8 * Hb)),

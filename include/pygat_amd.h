@@ -67,6 +67,11 @@ int pygat_padded_width(int f_out);
 /* number of HIP devices visible / name of the current one (host buffers). */
 int pygat_device_count(void);
 int pygat_device_name(char* host_buf, int len);
+/* Registers per lane and scratch bytes per lane of a tuned kernel as the LOADED code object reports them (hipFuncGetAttributes):
+ * "k2_headline" (fused forward, 8 heads x 16, training), "k4_headline_da" (column pass with the a-gradient sums), "tn_x3w"
+ * (streamed-K weight gradient), "x3gw" (general split-bf16 GEMM).  The attention kernels were tuned at four waves per SIMD
+ * without scratch; `amdgpu_waves_per_eu` makes the compiler spill rather than fail, so tests/test_gpu_properties.py asks. */
+int pygat_kernel_footprint(const char* kernel, int* num_regs, int* scratch_bytes);
 
 /* How the fp32 GEMMs of a level (the projection `mm(h, W)`, layers.py:35,134, its weight and input gradients) form
  * their products.  Operands, accumulators and results are fp32 in both modes.

@@ -11,8 +11,9 @@ legs had left running.  Here: no torch in the process, one OpenMP runtime, one t
 use (affinity mask and cgroup quota respected), OMP_PLACES=cores / OMP_PROC_BIND=close, median of >= 5 steps.
 
 The graph is the headline's recipe (R-MAT, same scale / draws / quadrant probabilities, symmetrised, self loops) from a
-numpy stream: the GPU leg draws its graph on the device, whose random stream a CPU process cannot replay, so the edge
-count differs in the fourth digit.  value = this graph's E / median step time.
+numpy stream -- the SAME stream bench.py's GPU leg draws from on the host and uploads (pygat_amd/rmat.py rmat_csr_numpy; the
+two copies are pinned to each other by tests/test_dist_cpu.py), so both legs time the identical graph (round 5).
+value = E / median step time.
 """
 import argparse
 import json
@@ -135,8 +136,10 @@ def main():
         "hw_threads_visible": hw, "cgroup_cpu_quota": quota, "kind": "port", "cpu": cpu,
         "step_s": [round(t, 4) for t in times], "median_step_s": round(med, 4), "min_step_s": round(min(times), 4),
         "setup_s": round(t_setup, 2),
-        "sample": f"headline recipe drawn from a numpy stream (N={N}, E={E}; the device-drawn graph of the GPU leg differs in the "
-                  f"fourth digit of E), median of {len(times)} fwd+bwd steps after one warm-up, {med:.2f} s/step, OpenMP C port "
+        "method": f"median of {len(times)} steps after one warm-up, one thread per physical core of the cgroup quota, child process",
+        "graph_source": "numpy stream, seed 1 (pygat_amd.rmat.rmat_csr_numpy): the graph the GPU leg uploads", "nodes": N, "edges": E,
+        "sample": f"the headline workload itself (N={N}, E={E}: the same numpy-drawn graph as the GPU leg), "
+                  f"median of {len(times)} fwd+bwd steps after one warm-up, {med:.2f} s/step, OpenMP C port "
                   f"oracle/gat_oracle.c in its own process: {int(lib.gat_oracle_threads())} threads = one per physical core "
                   f"(OMP_PLACES=cores, OMP_PROC_BIND=close), no second OpenMP runtime in the process"}))
 

@@ -19,8 +19,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpygat_amd.so")
 # development aid (tools/build_variant.sh, same-lease A/B runs): another build of the same library.  Still a HIP library or
 # nothing -- the symbol check below applies to it as well.
-if os.environ.get("PYGAT_AMD_LIB"):
-    LIB_PATH = os.path.abspath(os.environ["PYGAT_AMD_LIB"])
+from .config import config as _config  # noqa: E402
+if _config.lib_path:
+    LIB_PATH = os.path.abspath(_config.lib_path)
 
 ABI_VERSION = 14
 F_ELU = 1
@@ -31,7 +32,7 @@ F_FIXUP_ONLY = 8
 # every entry point declared in include/pygat_amd.h
 SYMBOLS = [
     "pygat_abi_version", "pygat_last_error", "pygat_padded_width", "pygat_device_count",
-    "pygat_device_name", "pygat_default_gemm_mode", "pygat_dense_row_counts", "pygat_scan_workspace_bytes",
+    "pygat_device_name", "pygat_kernel_footprint", "pygat_default_gemm_mode", "pygat_dense_row_counts", "pygat_scan_workspace_bytes",
     "pygat_exclusive_scan_i32", "pygat_dense_fill_cols", "pygat_csr_symmetric_perm",
     "pygat_gemm_workspace_bytes", "pygat_gemm_f32", "pygat_gemm_f32_blocked", "pygat_project_blocked", "pygat_wgrad_blocked", "pygat_pack_params", "pygat_pack_params_heads", "pygat_stack_heads", "pygat_stack_heads_padded", "pygat_project", "pygat_attn_scores",
     "pygat_unpack_wgrad",
@@ -85,6 +86,7 @@ def _load():
     lib.pygat_last_error.restype = C.c_char_p
     lib.pygat_padded_width.argtypes = [i]
     lib.pygat_device_name.argtypes = [C.c_char_p, i]
+    lib.pygat_kernel_footprint.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.pygat_default_gemm_mode.argtypes = []
     lib.pygat_dense_row_counts.argtypes = [p, i, i64, i, p, p]
     lib.pygat_scan_workspace_bytes.argtypes = [i64]

@@ -24,6 +24,22 @@ extern "C" int pygat_abi_version(void) { return PYGAT_ABI_VERSION; }
 extern "C" const char* pygat_last_error(void) { return pygat::g_err; }
 extern "C" int pygat_padded_width(int f_out) { return pygat::padded_width(f_out); }
 
+namespace pygat {
+int footprint_k2_headline(int* regs, int* scratch);
+int footprint_k4_headline_da(int* regs, int* scratch);
+int footprint_gemm_x3(int which, int* regs, int* scratch);
+}  // namespace pygat
+
+extern "C" int pygat_kernel_footprint(const char* kernel, int* num_regs, int* scratch_bytes) {
+  PYGAT_REQUIRE(kernel && num_regs && scratch_bytes, "kernel_footprint: null argument");
+  if (!strcmp(kernel, "k2_headline")) return pygat::footprint_k2_headline(num_regs, scratch_bytes);
+  if (!strcmp(kernel, "k4_headline_da")) return pygat::footprint_k4_headline_da(num_regs, scratch_bytes);
+  if (!strcmp(kernel, "tn_x3w")) return pygat::footprint_gemm_x3(0, num_regs, scratch_bytes);
+  if (!strcmp(kernel, "x3gw")) return pygat::footprint_gemm_x3(1, num_regs, scratch_bytes);
+  pygat::set_error("kernel_footprint: unknown kernel '%s' (k2_headline, k4_headline_da, tn_x3w, x3gw)", kernel);
+  return PYGAT_EINVAL;
+}
+
 extern "C" int pygat_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) {

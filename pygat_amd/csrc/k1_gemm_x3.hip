@@ -1571,6 +1571,20 @@ int try_gemm_x3g(int transA, int transB, int M, int N, int64_t K, const float* A
   return 1;
 }
 
+int footprint_gemm_x3(int which, int* regs, int* scratch) {
+  hipFuncAttributes at;
+  const void* fn = which == 0 ? reinterpret_cast<const void*>(&gemm_tn_x3w_kernel)
+                              : reinterpret_cast<const void*>(&gemm_x3gw_kernel<true, false>);
+  const hipError_t e = hipFuncGetAttributes(&at, fn);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("kernel_footprint: %s", hipGetErrorString(e));
+    return PYGAT_EHIP;
+  }
+  *regs = at.numRegs; *scratch = (int)at.localSizeBytes;
+  return PYGAT_OK;
+}
+
 }  // namespace pygat
 
 #if (PYGAT_DIAG_K1 & 16)

@@ -627,6 +627,25 @@ extern "C" int pygat_head_group(int n, int H, int Fo) {
   return head_group_bwd(n, H, Fp);
 }
 
+
+// register / scratch footprint of a kernel of this file as the loaded code object reports it (pygat_kernel_footprint)
+static int footprint_of(const void* fn, int* regs, int* scratch) {
+  hipFuncAttributes at;
+  const hipError_t e = hipFuncGetAttributes(&at, fn);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    pygat::set_error("kernel_footprint: %s", hipGetErrorString(e));
+    return PYGAT_EHIP;
+  }
+  *regs = at.numRegs; *scratch = (int)at.localSizeBytes;
+  return PYGAT_OK;
+}
+namespace pygat {
+int footprint_k2_headline(int* regs, int* scratch) {
+  return footprint_of(reinterpret_cast<const void*>(&gat_fwd_kernel<32, 1, false, true, true, 4, 128>), regs, scratch);
+}
+}  // namespace pygat
+
 extern "C" int pygat_gat_forward_phases_ok(int n, int H, int Fo) {
   const int Fp = padded_width(Fo);
   if (n <= 0 || H <= 0 || Fp <= 0) return 0;

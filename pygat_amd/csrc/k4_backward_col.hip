@@ -512,6 +512,25 @@ __global__ __launch_bounds__(64 * FIX_LIST_WAVES) void gat_bwd_col_fixup_list_ke
 
 using namespace pygat;
 
+
+// register / scratch footprint of a kernel of this file as the loaded code object reports it (pygat_kernel_footprint)
+static int footprint_of(const void* fn, int* regs, int* scratch) {
+  hipFuncAttributes at;
+  const hipError_t e = hipFuncGetAttributes(&at, fn);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    pygat::set_error("kernel_footprint: %s", hipGetErrorString(e));
+    return PYGAT_EHIP;
+  }
+  *regs = at.numRegs; *scratch = (int)at.localSizeBytes;
+  return PYGAT_OK;
+}
+namespace pygat {
+int footprint_k4_headline_da(int* regs, int* scratch) {
+  return footprint_of(reinterpret_cast<const void*>(&gat_bwd_col_kernel<32, 1, false, 4, 128, true>), regs, scratch);
+}
+}  // namespace pygat
+
 extern "C" size_t pygat_gat_backward_col_da_bytes(const pygat_graph* gT, int H, int Fo, int head_group) {
   GraphDev g;
   if (!gT || check_graph(gT, &g) != PYGAT_OK) return 0;

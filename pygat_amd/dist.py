@@ -113,12 +113,12 @@ class AllGatherColumns(torch.autograd.Function):
         return out[:, :widths[rank]].contiguous(), None
 
 
-import os as _os
+from .config import config as _config
 
 # row chunks of a pipelined hidden level (1 = no pipeline).  PYGAT_DIST_CHUNKS is read ONCE, at import: every rank must issue
 # the same number and shapes of collectives, so the count may not change under a running job (a per-call read on each rank
 # could disagree and hang); set the environment identically on all ranks, or assign dist.PIPELINE_CHUNKS on all of them.
-PIPELINE_CHUNKS = int(_os.environ.get("PYGAT_DIST_CHUNKS", 4))
+PIPELINE_CHUNKS = _config.dist_chunks
 PIPELINE_MIN_ROWS = 1 << 15  # below this a level is launch-bound and one exchange after the whole level is cheaper
 
 

@@ -31,16 +31,15 @@ from typing import Optional, Sequence
 
 import torch
 
-import os
-
 from . import _lib, ops
+from .config import config as _config
 from ._lib import lib, check, padded_width
 from .graph import CSRGraph, slot_edges_for
 from .ops import _Level, _ptr, _span, _stream, gemm, gemm_mode, get_gemm_mode, stack_heads
 
 
 STREAM_X, STREAM_WH, STREAM_ATT = 1, 2, 3     # Philox stream ids of the three masks drawn from one seed
-FORCE_WIDE = os.environ.get("PYGAT_DROPOUT_WIDE", "0") == "1"   # round 1's wide-operand projection everywhere
+FORCE_WIDE = _config.dropout_wide   # round 1's wide-operand projection everywhere
 
 
 def _headmask_splits(tiles_m: int, H: int, Fp: int, skip: bool, K: int) -> int:

@@ -6,21 +6,24 @@ it, zeros included, with every head's W in every epoch (layers.py:35,134).  The 
 pattern is extracted ONCE (cached on the tensor like the adjacency, graph.as_graph) as CSR for the projection and as its
 transpose for the weight gradient; csrc/k9_sparse.hip then does both products on the non-zeros only, under the same
 per-head dropout decisions as the dense kernels.  Dense inputs (density above MAX_DENSITY), inputs that require a gradient
-and hidden levels keep the dense GEMMs.  PYGAT_SPARSE_X=0 switches the whole path off.
+and hidden levels keep the dense GEMMs.  PYGAT_SPARSE_X=0 switches the whole path off.  Inputs narrower than
+MIN_PROBE_COLUMNS (128) are not probed implicitly (they are dense feature vectors, e.g. PPI's 50 columns): call
+prepare_features(x) to put a narrow sparse input on the path.
 """
 from __future__ import annotations
 
 import collections
-import os
 import weakref
 from typing import Optional
 
 import torch
 
-MAX_DENSITY = float(os.environ.get("PYGAT_SPARSE_MAX_DENSITY", 0.15))   # above this the dense MFMA GEMMs win (Pubmed: 10 %)
+from .config import config as _config
+
+MAX_DENSITY = _config.sparse_max_density   # above this the dense MFMA GEMMs win (Pubmed: 10 %)
 SEGMENT = 128               # entries per weight-gradient segment (k9_sparse.hip SP_SEG)
 MAX_COLUMNS = 512           # output columns 2 R + H the sparse kernels take (k9_sparse.hip SP_CPL)
-ENABLED = os.environ.get("PYGAT_SPARSE_X", "1") != "0"
+ENABLED = _config.sparse_x
 
 
 class SparseFeatures:
@@ -84,10 +87,26 @@ class _LRU(collections.OrderedDict):
 _cache = _LRU()
 
 
-def prepare_features(x: torch.Tensor) -> Optional[SparseFeatures]:
+def eligible(x, min_columns: int = 0) -> bool:
+    """The ONE eligibility rule of the sparse-feature path (both entry points below): a 2-D float32 GPU tensor that carries no
+    gradient, at least `min_columns` wide, with the path switched on."""
+    return (ENABLED and isinstance(x, torch.Tensor) and x.is_cuda and not x.requires_grad and x.dim() == 2
+            and x.dtype == torch.float32 and x.shape[1] >= min_columns)
+
+
+def prepare_features(x: torch.Tensor, min_columns: int = 0) -> Optional[SparseFeatures]:
     """The EXPLICIT form of what as_sparse_features does on a model's first forward: extract (and cache) the sparse pattern
     of an input feature tensor, outside any timed region or stream capture.  Returns the SparseFeatures, or None when the
-    tensor is too dense for the sparse kernels.  Costs one host sync (the density probe) and a few sort / scan launches."""
+    tensor is too dense for the sparse kernels (density above MAX_DENSITY).  Costs one host sync (the density probe) and a
+    few sort / scan launches.  Raises ValueError for a tensor the sparse path can never take (see `eligible`: not a 2-D
+    float32 GPU tensor, requires a gradient, or the path is switched off) -- rounds 3-4 built and cached a pattern for
+    anything handed in.  `min_columns`: the implicit probe skips inputs narrower than MIN_PROBE_COLUMNS (128: dense feature
+    vectors such as PPI's 50 columns, train_ppi.py:118, are never synchronised on); an explicit call probes any width
+    unless told otherwise."""
+    if not eligible(x, min_columns):
+        raise ValueError("prepare_features: expected a 2-D float32 GPU tensor without requires_grad"
+                         + (f", at least {min_columns} columns wide" if min_columns else "")
+                         + ("" if ENABLED else " (the sparse-feature path is switched off: PYGAT_SPARSE_X=0)"))
     key = (x.data_ptr(), tuple(x.shape), x._version, str(x.device))
     ok, val = _cache.lookup(key, x)
     if ok:
@@ -100,17 +119,18 @@ def prepare_features(x: torch.Tensor) -> Optional[SparseFeatures]:
 
 def as_sparse_features(x: torch.Tensor, out_columns: int) -> Optional[SparseFeatures]:
     """The cached SparseFeatures of `x` if the sparse kernels should take its projection, else None.
-    A tensor seen for the first time is probed (prepare_features: one host sync) -- unless it is too narrow to be a bag of
-    words (a per-batch loop over fresh dense feature tensors, train_ppi.py:118, is never synchronised), or a stream capture
-    is in progress (a sync would abort it: the level then runs dense; call prepare_features(x) before capturing)."""
-    if not ENABLED or not isinstance(x, torch.Tensor) or not x.is_cuda or x.requires_grad or x.dim() != 2 \
-            or x.dtype != torch.float32 or out_columns > MAX_COLUMNS or x.shape[1] < MIN_PROBE_COLUMNS:
+    A tensor seen for the first time is probed (prepare_features: one host sync) -- unless it is narrower than
+    MIN_PROBE_COLUMNS (too narrow to be a bag of words: a per-batch loop over fresh dense feature tensors, train_ppi.py:118, is
+    never synchronised; a genuinely sparse narrow input gets the path through an explicit prepare_features(x), whose cache
+    entry is honoured here), or a stream capture is in progress (a sync would abort it: the level then runs dense; call
+    prepare_features(x) before capturing)."""
+    if not eligible(x) or out_columns > MAX_COLUMNS:
         return None
     key = (x.data_ptr(), tuple(x.shape), x._version, str(x.device))
     ok, val = _cache.lookup(key, x)
     if ok:
         return val
-    if torch.cuda.is_current_stream_capturing():
+    if x.shape[1] < MIN_PROBE_COLUMNS or torch.cuda.is_current_stream_capturing():
         return None
     return prepare_features(x)
 

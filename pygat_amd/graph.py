@@ -17,7 +17,6 @@ accepted and transposed with a device sort.
 from __future__ import annotations
 
 import ctypes as C
-import os
 import weakref
 from typing import Optional, Tuple
 
@@ -25,11 +24,14 @@ import torch
 
 from . import _lib
 from ._lib import lib, check
+from .config import config as _config
 
 # Experiment hook (tools/slot_order_probe.py): f(pattern, slot_meta [n_slots, 4] int32) -> int32 permutation
 # [n_slots] handed to the kernels as pygat_graph.slot_order -- the order in which the main launches of K2 / K4 walk the slots.
 # None (the shipped default): grid order = slot order.
 SLOT_ORDER_FN = None
+FORCED_SLOT_EDGES = _config.slot_edges     # PYGAT_SLOT_EDGES
+USE_SLOT_META = _config.slot_meta          # PYGAT_NO_SLOT_META=1 switches the slot records off
 
 DEFAULT_SLOT_EDGES = 64   # edges per work slot of the nnz-split kernels on large graphs (multiple of 4)
 
@@ -39,9 +41,8 @@ def auto_slot_edges(nnz: int) -> int:
     rounds of 4 edges), so a small graph wants short slots -- enough of them (>= 8192) to occupy the
     256 CUs -- while a large one wants 64-edge slots (fewer cut rows, less fix-up work).  Measured K2 on
     MI355X, 8 heads x 8: Cora (13 264 edges) 48 us at 64 -> 12.7 us at 4; Pubmed (108 365) 56 -> 20 us at 8."""
-    forced = os.environ.get("PYGAT_SLOT_EDGES")     # development knob
-    if forced:
-        return int(forced)
+    if FORCED_SLOT_EDGES:     # development knob (config.slot_edges)
+        return int(FORCED_SLOT_EDGES)
     ts = DEFAULT_SLOT_EDGES
     while ts > 4 and nnz // ts < 8192:
         ts //= 2
@@ -107,7 +108,7 @@ class _Pattern:
             with torch.cuda.device(self.rowptr.device):
                 check(lib.pygat_slot_meta(self.n, self.nnz, self.rowptr.data_ptr(), self.edge_rc.data_ptr(), slot_edges, _ptr(sb),
                                           meta.data_ptr(), _stream()), "slot_meta")
-            if os.environ.get("PYGAT_NO_SLOT_META") == "1":      # development knob (A/B of the slot records)
+            if not USE_SLOT_META:      # development knob (A/B of the slot records; config.slot_meta)
                 meta = None
             order = SLOT_ORDER_FN(self, meta) if (SLOT_ORDER_FN is not None and meta is not None) else None
             st = _lib.Graph(self.n, self.nnz, _ptr(self.rowptr), _ptr(self.edge_rc), slot_edges, _ptr(sb), _ptr(cut),

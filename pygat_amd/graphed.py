@@ -147,6 +147,7 @@ class FusedEpoch:
                 raise ValueError("FusedEpoch: build the optimiser with capturable=True (its step counter must live "
                                  "on the device to be advanced by a replayed graph)")
         self.model, self.opt, self.x, self.graph = model, optimizer, x, graph
+        self._hyper_now()                                 # (refuses tensor-valued hyper-parameters BEFORE anything is captured)
         self.loss_fn, self.eval_fn, self.evaluate = loss_fn, (eval_fn or loss_fn), evaluate
         self.epochs = 0
         self.g = None
@@ -162,7 +163,24 @@ class FusedEpoch:
         self._hyper = self._hyper_now()
 
     def _hyper_now(self):
-        return [tuple((k, grp[k]) for k in ("lr", "weight_decay", "betas", "eps") if k in grp) for grp in self.opt.param_groups]
+        """Everything of the optimiser a captured launch may have taken as an argument: EVERY non-'params' entry of every
+        parameter group (lr, weight_decay, betas, eps, amsgrad, maximize, ...) plus the identity of the parameters in it.
+        Tensor-valued entries (capturable torch.optim.Adam allows a tensor lr) are refused at capture time: comparing them
+        per run() would cost a device sync, and their value is read by the kernels from device memory anyway, which a
+        replay cannot see change."""
+        snap = []
+        for grp in self.opt.param_groups:
+            items = []
+            for k in sorted(grp):
+                if k == "params":
+                    continue
+                v = grp[k]
+                if isinstance(v, torch.Tensor):
+                    raise ValueError(f"FusedEpoch: optimiser hyper-parameter {k!r} is a tensor; use a Python number (the value is "
+                                     "a launch argument of the captured kernels)")
+                items.append((k, tuple(v) if isinstance(v, (list, tuple)) else v))
+            snap.append((tuple(items), tuple(id(p) for p in grp["params"])))
+        return snap
 
     def _eager_epoch(self):
         self.model.train()

@@ -16,7 +16,6 @@ library.  There is no CPU or eager fallback.
 from __future__ import annotations
 
 import ctypes as C
-import os
 import threading
 from typing import Optional, Sequence
 
@@ -24,6 +23,7 @@ import torch
 
 from . import _lib
 from ._lib import lib, check, padded_width
+from .config import config as _config
 from .graph import CSRGraph, slot_edges_for
 
 
@@ -55,8 +55,7 @@ TIMER: Optional[KernelTimer] = None
 # head: 1.15 ms against 1.46 ms per step; four heads: 2.45 against 2.34; eight: 4.30 against 3.84).
 # PYGAT_TWO_GATHER_BACKWARD=1/0 forces either.  Both are free of atomics and bitwise reproducible; they
 # differ only in the summation order of ds.
-_env = os.environ.get("PYGAT_TWO_GATHER_BACKWARD")
-TWO_GATHER_BACKWARD: Optional[bool] = None if _env is None else (_env == "1")
+TWO_GATHER_BACKWARD: Optional[bool] = _config.two_gather_backward
 
 # Default since round 2 for rows of up to 256 floats (above: "rowsum"): "rowlocal".  The training forward (K2) also accumulates the share of every row sum that
 # went through the alpha branch of the LeakyReLU (aneg, qneg); since sum_j de_ij = 0 the row sums of dz follow
@@ -64,7 +63,7 @@ TWO_GATHER_BACKWARD: Optional[bool] = None if _env is None else (_env == "1")
 # gather (K3b) nor per-edge dz records and their row-sum pass (K3c): K3a -> K4 -> da -> dW.  Costs one more [N, R]
 # table (written by K2, read by K3a).  BACKWARD_FLAVOUR / PYGAT_BACKWARD = rowlocal | rowsum | two-gather forces a
 # flavour; a non-None TWO_GATHER_BACKWARD (the older switch) selects between the two older ones.
-BACKWARD_FLAVOUR: Optional[str] = os.environ.get("PYGAT_BACKWARD")
+BACKWARD_FLAVOUR: Optional[str] = _config.backward
 
 
 def two_gather_backward(row_floats: int) -> bool:
@@ -93,7 +92,7 @@ BWD_WINDOW_FLOATS: Optional[int] = None
 # da inside the column pass (pygat_gat_backward_col with da_part + pygat_a_grad_fold) instead of a pass of its own over Wh,
 # ds and dt: on tables of DA_MIN_BYTES and more (the a-gradient stream is HBM time there: 0.12 ms at config 5); a small
 # graph's epoch is launch-bound and gains nothing from it (two launches either way).  PYGAT_DA_IN_K4=0 switches it off.
-DA_IN_K4 = os.environ.get("PYGAT_DA_IN_K4", "1") != "0"
+DA_IN_K4 = _config.da_in_k4
 DA_MIN_BYTES = 32 << 20
 
 
@@ -139,8 +138,8 @@ def _side_stream(dev) -> "torch.cuda.Stream":
     return _side[key]
 
 
-_K1_SLAB = int(os.environ.get("PYGAT_K1_SPLIT_MIN_K", "128"))   # measured: Cora epoch 0.614 / 0.596 / 0.595 ms at 256 / 128 / 64
-OVERLAP_BACKWARD = os.environ.get("PYGAT_OVERLAP_BACKWARD", "0") == "1"   # measured: the fork/join costs more than it hides
+_K1_SLAB = _config.k1_split_min_k   # measured: Cora epoch 0.614 / 0.596 / 0.595 ms at 256 / 128 / 64
+OVERLAP_BACKWARD = _config.overlap_backward   # measured: the fork/join costs more than it hides
 
 
 def _segments(cols_ptr_ld) -> _lib.OutSegments:
@@ -351,7 +350,7 @@ class GATLevelFn(torch.autograd.Function):
         return (cast(dx, 0), cast(dW, 1), cast(da, 2), cast(dWs, 3), None, None, None, None, None)
 
 
-PAD_K = os.environ.get("PYGAT_PAD_K", "1") != "0"     # development knob: 0 = run odd input widths as they are
+PAD_K = _config.pad_k     # development knob: 0 = run odd input widths as they are
 MAX_HEAD_TABLE = 16     # PYGAT_MAX_HEADS_TABLE: heads whose parameter pointers travel as kernel arguments
 
 

@@ -34,3 +34,28 @@ def rmat_csr(scale: int = 20, n_draws: int = 5_000_000, abcd=(0.57, 0.19, 0.19, 
     rowptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
     rowptr[1:] = torch.cumsum(torch.bincount(rr, minlength=n), 0)
     return rowptr.to(torch.int32), cc.to(torch.int32)
+
+
+def rmat_csr_numpy(scale: int = 20, n_draws: int = 5_000_000, abcd=(0.57, 0.19, 0.19, 0.05), seed: int = 1):
+    """The same recipe from a NUMPY stream on the host -> (rowptr int32 [N+1], col int32 [E]) numpy arrays.  bench.py draws the
+    headline graph this way and uploads it, so that its GPU leg and its cpu_baseline leg (a process without torch:
+    oracle/cpu_bench.py carries a copy of this function, pinned to it by tests/test_dist_cpu.py) time the IDENTICAL graph
+    (rounds 1-4: one graph per leg, E different in the fourth digit)."""
+    import numpy as np
+    n = 1 << scale
+    rng = np.random.default_rng(seed)
+    a, b, c, _ = abcd
+    r = np.zeros(n_draws, np.int64)
+    ci = np.zeros(n_draws, np.int64)
+    for _bit in range(scale):
+        u = rng.random(n_draws, dtype=np.float32)
+        rb = (u >= a + b).astype(np.int64)
+        cb = (((u >= a) & (u < a + b)) | (u >= a + b + c)).astype(np.int64)
+        r = (r << 1) | rb
+        ci = (ci << 1) | cb
+    ar = np.arange(n, dtype=np.int64)
+    key = np.unique(np.concatenate([r, ci, ar]) * n + np.concatenate([ci, r, ar]))
+    rr, cc = key // n, key % n
+    rowptr = np.zeros(n + 1, np.int64)
+    rowptr[1:] = np.cumsum(np.bincount(rr, minlength=n))
+    return rowptr.astype(np.int32), cc.astype(np.int32)

@@ -71,3 +71,16 @@ def test_rmat_generator_is_deterministic_and_well_formed():
     keys = set(zip(src.tolist(), c.tolist()))
     assert len(keys) == len(c) and all((j, i) in keys for i, j in list(keys)[:2000])   # dedup + symmetric
     assert all(np.all(np.diff(c[rp[i]:rp[i + 1]]) > 0) for i in range(0, n, 37))       # sorted rows
+
+
+def test_bench_legs_draw_the_same_graph():
+    """bench.py's GPU leg (pygat_amd.rmat.rmat_csr_numpy, uploaded) and its cpu_baseline leg (oracle/cpu_bench.py, a process
+    without torch that carries its own copy of the generator) must time the identical graph."""
+    import numpy as np
+    from pygat_amd.rmat import rmat_csr_numpy
+    from oracle.cpu_bench import rmat_csr_numpy as cpu_leg
+    for scale, draws in ((10, 5000), (13, 40000)):
+        a, b = rmat_csr_numpy(scale, draws), cpu_leg(scale, draws)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        rp, c = a
+        assert rp[0] == 0 and rp[-1] == len(c) and (np.diff(rp) >= 1).all()      # self loops: no empty row

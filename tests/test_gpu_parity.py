@@ -177,6 +177,13 @@ def backward_mode(request, pg, monkeypatch):
     K4 + row sums of its per-edge dz records / K3b (second gather) + K4.  "+da": the attention-vector gradient taken along by
     the column pass (pygat_gat_backward_col with da_part + pygat_a_grad_fold: the default on tables of 32 MB and more)
     instead of by pygat_a_grad -- wherever the pass can (one-chunk rows, one head window), else the level falls back itself."""
+    if request.param.endswith("+da"):
+        # the column pass takes the sums along for 8 heads x 16 in one window only (pygat_gat_backward_col_da_bytes answers 0
+        # otherwise and the level keeps pygat_a_grad): every other shape would repeat the plain "rowlocal" run under a da label
+        cs = getattr(request.node, "callspec", None)
+        shape = (cs.params.get("H"), cs.params.get("Fo")) if cs is not None else (None, None)
+        if shape != (8, 16):
+            pytest.skip("da rides in the column pass for 8 heads x 16 only; this shape is the plain rowlocal run")
     monkeypatch.setattr(pg.ops, "BACKWARD_FLAVOUR", request.param.split("+")[0])
     monkeypatch.setattr(pg.ops, "DA_MIN_BYTES", 0 if request.param.endswith("+da") else 1 << 60)
     return request.param

@@ -1,0 +1,103 @@
+"""Size-independent properties of the HIP level on the GPU: equivariance under node renumbering, independence of
+the order in which slots are walked, and the register / scratch footprint the headline instantiations were tuned at."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _permuted_csr(rowptr, col, perm):
+    """CSR of P A P^T: new node p = old node perm[p]."""
+    N = len(rowptr) - 1
+    inv = np.empty(N, dtype=np.int64); inv[perm] = np.arange(N)
+    rows = np.repeat(np.arange(N), np.diff(rowptr))
+    r2, c2 = inv[rows], inv[col]
+    order = np.lexsort((c2, r2))
+    r2, c2 = r2[order], c2[order]
+    rp2 = np.zeros(N + 1, dtype=np.int64); np.cumsum(np.bincount(r2, minlength=N), out=rp2[1:])
+    return rp2.astype(np.int32), c2.astype(np.int32)
+
+
+@pytest.mark.parametrize("cfg", [dict(N=6000, H=8, Fo=16, Fin=128, skip=False, concat=True, deg=9, hub=(11, 3000)),   # the headline shape
+                                 dict(N=2500, H=4, Fo=64, Fin=48, skip=True, concat=True, deg=12, hub=(5, 800)),
+                                 dict(N=3000, H=3, Fo=7, Fin=33, skip=True, concat=False, deg=5, hub=(2, 1500))])
+def test_level_is_equivariant_under_node_renumbering(cfg):
+    """level(P x, P A P^T) = P level(x, A); dX permutes with the nodes; dW, da, dWskip are sums over nodes / edges and agree up to
+    summation order (the slots, the cut rows and the fix-up lists of the two runs are entirely different)."""
+    import pygat_amd as pg
+    from oracle import gat_oracle as O
+    dev = torch.device("cuda", 0)
+    N, H, Fo, Fin = cfg["N"], cfg["H"], cfg["Fo"], cfg["Fin"]
+    rowptr, col = O.random_symmetric_csr(N, cfg["deg"], 17, hub=cfg["hub"])
+    perm = np.random.default_rng(3).permutation(N)
+    rp2, c2 = _permuted_csr(np.asarray(rowptr), np.asarray(col), perm)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(N, Fin, generator=g)
+    W = torch.randn(H, Fin, Fo, generator=g) * (1.414 * (2.0 / (Fin + Fo)) ** 0.5)
+    a = torch.randn(H, 2 * Fo, generator=g) * 0.4
+    S = torch.randn(H, Fin, Fo, generator=g) * 0.2 if cfg["skip"] else None
+    G = torch.randn(N, H * Fo if cfg["concat"] else Fo, generator=g)
+    pt = torch.from_numpy(perm)
+
+    def run(rp, c, xx, GG):
+        graph = pg.CSRGraph(torch.as_tensor(rp, device=dev), torch.as_tensor(c, device=dev))
+        leaves = [t.to(dev).clone().requires_grad_(True) if t is not None else None for t in (xx, W, a, S)]
+        out = pg.GATLevelFn.apply(leaves[0], leaves[1], leaves[2], leaves[3], graph, 0.2, cfg["concat"])
+        out.backward(GG.to(dev))
+        return [out.detach().cpu()] + [None if t is None else t.grad.cpu() for t in leaves]
+    o1, dx1, dW1, da1, dS1 = run(rowptr, col, x, G)
+    o2, dx2, dW2, da2, dS2 = run(rp2, c2, x[pt], G[pt])
+    sc = lambda t: max(1.0, float(t.abs().max()))        # noqa: E731
+    assert float((o2 - o1[pt]).abs().max()) <= 5e-6 * sc(o1)
+    assert float((dx2 - dx1[pt]).abs().max()) <= 2e-5 * sc(dx1)
+    for p, q in ((dW1, dW2), (da1, da2), (dS1, dS2)):
+        if p is not None:
+            assert float((p - q).abs().max()) <= 5e-5 * sc(p)
+
+
+def test_results_do_not_depend_on_the_slot_order():
+    """pygat_graph.slot_order (ABI 14) only changes which rows' gathers are in flight together: out, dX and dW come out BIT FOR
+    BIT the same under a random order of the slots (rows, partial records and fix-ups go by the slot id), da up to the order in
+    which the column pass folds its per-work-group records."""
+    import pygat_amd as pg
+    from pygat_amd import graph as G_
+    from pygat_amd.rmat import rmat_csr
+    dev = torch.device("cuda", 0)
+    rowptr, col = rmat_csr(17, 700_000, seed=5, device=dev)      # 131 072 nodes: tables of 64 MB, the da-in-K4 path included
+    N = rowptr.numel() - 1
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.randn(N, 128, generator=g, device=dev)
+    W = torch.randn(8, 128, 16, generator=g, device=dev) * 0.17
+    a = torch.randn(8, 32, generator=g, device=dev) * 0.3
+    Gr = torch.randn(N, 128, generator=g, device=dev)
+
+    def run():
+        graph = pg.CSRGraph(rowptr, col)
+        leaves = [t.clone().requires_grad_(True) for t in (x, W, a)]
+        out = pg.GATLevelFn.apply(leaves[0], leaves[1], leaves[2], None, graph, 0.2, True)
+        out.backward(Gr)
+        return [out.detach()] + [t.grad for t in leaves]
+    ref = run()
+    try:
+        G_.SLOT_ORDER_FN = lambda pat, meta: torch.randperm(meta.shape[0], generator=torch.Generator().manual_seed(2)).to(torch.int32).to(meta.device)
+        got = run()
+    finally:
+        G_.SLOT_ORDER_FN = None
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
+    assert float((got[3] - ref[3]).abs().max()) <= 1e-5 * max(1.0, float(ref[3].abs().max()))
+
+
+def test_headline_kernels_keep_their_register_footprint():
+    """the headline instantiations of K2 / K4 were tuned at four waves per SIMD without scratch (K4 with the
+    a-gradient sums: 122 of 128 VGPRs; variants at 130 VGPRs or with scratch measured 10-75 % slower).  `amdgpu_waves_per_eu` makes
+    hipcc SPILL rather than fail, so a compiler or flag change would show up only as a timing drift: ask the loaded code object
+    (pygat_kernel_footprint -> hipFuncGetAttributes)."""
+    from pygat_amd._lib import lib
+    for name, max_regs in (("k2_headline", 128), ("k4_headline_da", 128), ("tn_x3w", 256), ("x3gw", 256)):
+        regs, scratch = C.c_int(-1), C.c_int(-1)
+        rc = lib.pygat_kernel_footprint(name.encode(), C.byref(regs), C.byref(scratch))
+        assert rc == 0, (name, lib.pygat_last_error())
+        assert scratch.value == 0 and 0 < regs.value <= max_regs, (name, regs.value, scratch.value)

@@ -44,7 +44,12 @@ def main():
     ap.add_argument("--dataset", default="pubmed")
     ap.add_argument("--fout", type=int, default=8)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--threads", type=int, default=0, help="torch CPU threads (0: one per physical core the cgroup quota grants)")
     a = ap.parse_args()
+    from oracle.cpu_bench import physical_cores
+    cores, hw, quota = physical_cores()
+    threads = a.threads or (cores if quota is None else max(1, min(cores, int(quota + 1e-9))))
+    torch.set_num_threads(threads)
     z = np.load(os.path.join(ROOT, "tests", "golden", f"{a.dataset}_csr.npz"))
     rowptr, col = z["rowptr"], z["col"]
     N, E, Fin = len(rowptr) - 1, len(col), FIN[a.dataset]
@@ -64,7 +69,8 @@ def main():
         W.grad = av.grad = None
     med = statistics.median(ts[1:])
     print(json.dumps({"case": f"{a.dataset} one dense head {Fin}->{a.fout}, dropout 0, fwd+bwd", "N": N, "E": E,
-                      "seconds_per_step": med, "edges_per_s": E / med, "threads": torch.get_num_threads(),
+                      "seconds_per_step": med, "edges_per_s": E / med, "threads": torch.get_num_threads(), "reps": a.reps,
+                      "hw_threads_visible": hw, "cgroup_cpu_quota": quota,
                       "cpu": cpu_model(), "kind": "oracle restatement of layers.py:32-64 (dense N x N)"}))
 
 

@@ -206,6 +206,10 @@ static inline int check_graph(const pygat_graph* g, GraphDev* d, bool allow_slot
 __host__ __device__
 #endif
 static inline int64_t num_slots(const GraphDev& g) { return (g.nnz + g.ts - 1) / g.ts; }
+#ifdef __HIPCC__
+// slot handed to grid position q of a main launch (q < num_slots): pygat_graph.slot_order, or q itself
+__device__ __forceinline__ int64_t slot_at(const GraphDev& g, int64_t q) { return g.order ? (int64_t)g.order[q] : q; }
+#endif
 
 // Work-groups of the column pass (pygat_gat_backward_col) over gT for a level of H heads = its da_part records, or 0 when the
 // pass does not take the attention-vector gradient along: no cut-row list (the rows its fix-up finishes are folded in by

@@ -112,11 +112,14 @@ __device__ __forceinline__ void col_finish(const ColArgs& a, const LaneCols<VEC>
 }
 
 template <int VEC, int LPH = 0, int CR = 0, bool DA = false>
-__device__ __forceinline__ void col_flush(const ColArgs& a, const LaneCols<VEC>& lc, int64_t k, int j,
+__device__ __forceinline__ void col_flush(const ColArgs& a, const LaneCols<VEC>& lc, int64_t q, int j,
                                           bool is_head, bool is_tail, const float4 (&acc)[VEC],
                                           const float (&dt)[VEC], float4* da_lds = nullptr, int da_stride = 0,
                                           const float4* wrow = nullptr) {
   if (is_head || is_tail) {
+    // (the slot id is looked up again HERE, in the rare cut-row branch: kept live through the walk -- it no longer follows
+    // from the block and thread ids alone once a slot_order is allowed -- it cost the 8 x 16 da instantiation 12 bytes of scratch)
+    const int64_t k = slot_at(a.g, q);
     float* p = a.part + (2 * k + (is_head ? 0 : 1)) * (int64_t)(a.rs.R + 2 * a.rs.H);
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
@@ -154,7 +157,8 @@ __device__ __forceinline__ T pick(const T (&x)[U], int u) {
 #define PYGAT_K4_HEADLINE_WAVES 1   // (experiment: minimum waves per SIMD asked of the CR > 0 instantiation)
 #endif
 template <int LPR, int VEC, bool WRITE_DZ, int LPH, int CR, bool DA>
-__device__ __forceinline__ void col_walk(const ColArgs& a, const int64_t k, float4* da_lds, int da_stride) {
+__device__ __forceinline__ void col_walk(const ColArgs& a, const int64_t q, float4* da_lds, int da_stride) {
+  const int64_t k = slot_at(a.g, q);   // grid position -> slot (pygat_graph.slot_order; identity without one)
   // narrow rows: next round's edge records prefetched (see gat_fwd_kernel; 8 edges per round were measured too: two rows
   // per edge in registers leave 2 waves per SIMD at U = 8, 0.30 -> 0.35 ms at one head of 16)
 #ifndef PYGAT_K4_PREFETCH_ALL
@@ -259,7 +263,7 @@ __device__ __forceinline__ void col_walk(const ColArgs& a, const int64_t k, floa
       if (e + u < e1) {
         if (p[u].x != cur) {
           // (u > 0: the finished row's last edge is edge u - 1 of this round, its Wh row is still in wv[u - 1])
-          col_flush<VEC, LPH, CR, DA>(a, lc, k, cur, cur == r_first && head_partial, false, acc, dt, da_lds, da_stride,
+          col_flush<VEC, LPH, CR, DA>(a, lc, q, cur, cur == r_first && head_partial, false, acc, dt, da_lds, da_stride,
                                       (DA && PYGAT_K4_DA_WROW && u > 0) ? wv[u > 0 ? u - 1 : 0] : nullptr);
           cur = p[u].x;
 #pragma unroll
@@ -275,15 +279,14 @@ __device__ __forceinline__ void col_walk(const ColArgs& a, const int64_t k, floa
     }
   }
   const bool tail_partial = tail_known ? tail_flag : a.g.rowptr[cur + 1] > e1;
-  col_flush<VEC, LPH, CR, DA>(a, lc, k, cur, cur == r_first && head_partial, tail_partial, acc, dt, da_lds, da_stride);
+  col_flush<VEC, LPH, CR, DA>(a, lc, q, cur, cur == r_first && head_partial, tail_partial, acc, dt, da_lds, da_stride);
 }
 
 template <int LPR, int VEC, bool WRITE_DZ, int LPH = 0, int CR = 0, bool DA = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CR > 0 ? (DA ? PYGAT_K4_DA_WAVES : PYGAT_K4_HEADLINE_WAVES) : 1))) void gat_bwd_col_kernel(ColArgs a) {
   constexpr int EPW = 64 / LPR;
   const int lane = threadIdx.x & 63;
-  const int64_t q = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * EPW + lane / LPR;   // grid position
-  const int64_t k = (a.g.order && q < num_slots(a.g)) ? a.g.order[q] : q;                                // its slot (pygat_graph.slot_order)
+  const int64_t k = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * EPW + lane / LPR;   // grid position (-> slot: col_walk)
   if constexpr (!DA) {
     if (k >= num_slots(a.g)) return;
     col_walk<LPR, VEC, WRITE_DZ, LPH, CR, false>(a, k, nullptr, 0);

@@ -239,6 +239,9 @@ __device__ __forceinline__ void fwd_flush(const FwdArgs& a, const LaneCols<VEC>&
 #ifndef PYGAT_K2_HEADLINE_WAVES
 #define PYGAT_K2_HEADLINE_WAVES 4 // (round 4: 5 waves at 96 VGPRs + 12 bytes of scratch without the prefetch, 1.04 ms; 4 waves at 104
 #endif                            //  VGPRs with it, 1.00 ms -- same box, gpurun_out r4a; the prefetch at 5 waves spills 24 bytes: 1.025)
+#ifndef PYGAT_K2_DEEP
+#define PYGAT_K2_DEEP 0   // (experiment, tools/build_variant.sh: rows of round r + 1 gathered while round r folds, 16- / 8-lane rows)
+#endif
 #ifndef PYGAT_K2_NARROW_U
 #define PYGAT_K2_NARROW_U 4   // (8 was measured: 0.32 -> 0.30 ms at one head of 16, 140 registers)
 #endif
@@ -287,6 +290,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((AUX && FAS
   RowState<VEC, AUX> st;
   st.reset();
 
+  // DEEP (rows of 16 / 8 lanes: the 2- and 4-head shards of a head-parallel run): the rows of round r + 1 are gathered while
+  // round r folds -- a wave carries 4 / 8 lane groups whose rounds otherwise end with the slowest of 16 / 32 gathers, and the
+  // line-request rate sat at 35-39 G/s against 47-49 at one and at eight heads (DESIGN_HISTORY.md section 8)
+  constexpr bool DEEP = PYGAT_K2_DEEP && !V2 && AUX && FAST && VEC == 1 && (LPR == 16 || LPR == 8);
+  if constexpr (DEEP) {
+    int2 pc[U], px[U];
+    float svn[U];
+    float4 wvn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) pc[u] = rc[(e0 + u < e1) ? e0 + u : e1 - 1];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      wvn[u] = ld4(a.Wh + (uint32_t)((uint32_t)pc[u].y * (uint32_t)ldw + (uint32_t)lc.cofs[0]));
+      svn[u] = a.s[(uint32_t)((uint32_t)pc[u].x * (uint32_t)ldh + (uint32_t)lc.head[0])];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) px[u] = rc[(e0 + U + u < e1) ? e0 + U + u : e1 - 1];
+    for (int64_t e = e0; e < e1; e += U) {
+      int2 p[U];
+      float sv[U], tv[U];
+      float4 wv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { p[u] = pc[u]; wv[u] = wvn[u]; sv[u] = svn[u]; pc[u] = px[u]; }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {   // round r + 1's rows: their records were fetched a round ago
+        wvn[u] = ld4(a.Wh + (uint32_t)((uint32_t)pc[u].y * (uint32_t)ldw + (uint32_t)lc.cofs[0]));
+        svn[u] = a.s[(uint32_t)((uint32_t)pc[u].x * (uint32_t)ldh + (uint32_t)lc.head[0])];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) px[u] = rc[(e + 2 * U + u < e1) ? e + 2 * U + u : e1 - 1];
+#pragma unroll
+      for (int u = 0; u < U; ++u) tv[u] = group_sum_rt(dot4(wv[u], adst[0]), lph);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (e + u < e1) {
+          if (p[u].x != cur) {
+            fwd_flush<LPR, VEC, AUX, LPH, CR>(a, lc, k, cur, cur == r_first && head_partial, false, st);
+            cur = p[u].x;
+            st.reset();
+          }
+          const float zz = sv[u] + tv[u];
+          fold_edge<AUX>(st.m[0], st.z[0], st.acc[0], st.zn[0], st.accn[0], lrelu(zz, a.alpha), !(zz > 0.f), wv[u], 1.f);
+        }
+      }
+    }
+    const bool tail_partial_d = tail_known ? tail_flag : a.g.rowptr[cur + 1] > e1;
+    fwd_flush<LPR, VEC, AUX, LPH, CR>(a, lc, k, cur, cur == r_first && head_partial, tail_partial_d, st);
+    return;
+  }
   int2 pn[PREF ? U : 1];
   if constexpr (PREF) {
 #pragma unroll

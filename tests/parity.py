@@ -207,7 +207,8 @@ def close_fullsize_grads(got, r64, r32, X, W, a, rowptr, col, alpha, what="level
                          tau=KINK_TAU):
     """The same flip-aware rule where the python oracle cannot run (10^7 edges): r64 / r32 come from the two builds of
     oracle/gat_oracle.c, r64["kinks"] lists the near-kink edges of the fp64 run (c_oracle.level(kink_tau=...)).  Only
-    the parameter gradients take part in the fit (dX is not produced by a first level)."""
+    the parameter gradients take part in the fit when dX is absent (a first level); with got["dX"] the rows of dX the candidates
+    touch join it."""
     X = np.asarray(X, np.float64); W = np.asarray(W, np.float64); a = np.asarray(a, np.float64)
     k = r64["kinks"]
     cols, cand = _candidate_deltas(k["h"], k["e"], k["z"], k["de"], X, W, a, rowptr, col, alpha, False)
@@ -219,11 +220,34 @@ def close_fullsize_grads(got, r64, r32, X, W, a, rowptr, col, alpha, what="level
         sc = abs(float(X[i] @ W[h] @ a[h, :Fo])) + abs(float(X[j] @ W[h] @ a[h, Fo:]))
         rel[q] = abs(float(k["z"][q])) / max(sc, 1e-300)
     report = {"candidates": len(cand)}
+    # dX takes part in the FIT (round 5), through the rows the candidates touch: a flip moves two rows of dX by D W_h a_src /
+    # D W_h a_dst -- ~1e-3 for a D that is invisible in dW (max 3845, fp32 noise 3e-3) -- so a flip vector chosen by the parameter
+    # gradients alone is arbitrary exactly where dX is sensitive (config-5 graph drawn from the numpy stream: dX raw 1.3e-4, after
+    # the parameter gradients' 33 flips 5.3e-4).  The untouched rows of dX do not depend on the flips and are priced afterwards.
+    with_dx = got.get("dX") is not None and r64.get("dX") is not None
+    fit_names, touched = tuple(names), None
+    if with_dx and len(cand):
+        Fo_ = W.shape[2]
+        ij = [(int(np.searchsorted(rp64, e, side="right") - 1), int(col[e])) for _, e in cand]
+        touched = np.unique(np.asarray(ij).ravel())
+        pos = {int(r): q for q, r in enumerate(touched)}
+        for q, c in enumerate(cols):
+            h, _e = cand[q]
+            i, j = ij[q]
+            D = float(k["de"][q]) * ((alpha - 1.0) if float(k["z"][q]) > 0 else (1.0 - alpha))
+            dxt = np.zeros((len(touched), X.shape[1]))
+            dxt[pos[i]] += D * (W[h] @ a[h, :Fo_]); dxt[pos[j]] += D * (W[h] @ a[h, Fo_:])
+            c["dXT"] = dxt
+        fit_names = tuple(names) + ("dXT",)
     for side, vals in (("hip", {n: _np64(got[n]).reshape(r64[n].shape) for n in names}),
                        ("fp32", {n: np.asarray(r32[n], np.float64) for n in names})):
         resid = {n: vals[n] - r64[n] for n in names}
         report[side + "_raw"] = {n: float(np.abs(resid[n]).max()) for n in names}
-        sig = _explain(resid, cols, names)
+        if touched is not None:
+            v = _np64(got["dX"]) if side == "hip" else np.asarray(r32["dX"], np.float64)
+            resid["dXT"] = v.reshape(r64["dX"].shape)[touched] - r64["dX"][touched]
+        sig = _explain(resid, cols, fit_names)
+        resid.pop("dXT", None)
         for q, c in enumerate(cols):
             if sig[q]:
                 for n in names:
@@ -232,9 +256,9 @@ def close_fullsize_grads(got, r64, r32, X, W, a, rowptr, col, alpha, what="level
         report[side + "_flips"] = [cand[q] for q in range(len(cand)) if sig[q]]
         report[side + "_flip_idx"] = [q for q in range(len(cand)) if sig[q]]
     report["flips"] = _flip_leash(report, rel, tau, what)
-    if got.get("dX") is not None and r64.get("dX") is not None:
+    if with_dx:
         # dX [N, Fin] at full size: a candidate's effect on it is two rows (dX_i += D W_h a_src, dX_j += D W_h a_dst), kept
-        # sparse; the flips are the ones the parameter gradients chose above -- the SAME flip vector has to explain dX
+        # sparse; ONE flip vector (fitted above on dW, da and the touched rows of dX together) has to explain all three
         Fo_ = W.shape[2]
         for side, v in (("hip", _np64(got["dX"])), ("fp32", np.asarray(r32["dX"], np.float64))):
             res = v.reshape(r64["dX"].shape) - r64["dX"]

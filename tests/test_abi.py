@@ -206,3 +206,22 @@ def test_host_policies(lib, monkeypatch):
     # general kernel: the dropout projection shapes get more than "one work-group per CU"
     assert ops._split_k(2708, 64, 11464) == 22 and ops._split_k(11464, 64, 2708, streamed_k=True) == 5
     assert ops._split_k(1 << 20, 128, 128) == 1
+
+
+def test_python_switches_are_read_once_in_one_place():
+    """the development knobs of the Python layer live in pygat_amd.config (read from the environment once, at
+    import); no other product module reads os.environ while it runs."""
+    import glob
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pygat_amd")
+    offenders = []
+    for path in sorted(glob.glob(os.path.join(root, "*.py"))):
+        if os.path.basename(path) == "config.py":
+            continue
+        for n, line in enumerate(open(path), 1):
+            code = line.split("#", 1)[0]
+            if re.search(r"os\.environ|getenv", code):
+                offenders.append(f"{os.path.basename(path)}:{n}")
+    assert not offenders, offenders
+    from pygat_amd.config import Config, config
+    assert config.describe().keys() == Config.from_env().describe().keys() and config.dist_chunks >= 1

@@ -45,7 +45,8 @@ def main():
     ap.add_argument("--promote", help="an existing summary (profiles/rNN_pmc_bench.json): rewrite profiles/pmc_latest.json from it")
     ap.add_argument("--note", default="")
     ap.add_argument("--latest", action="store_true")
-    ap.add_argument("--edges", type=int, default=10758702)
+    ap.add_argument("--edges", type=int, default=10760610,
+                    help="E of the profiled workload (the headline graph since round 5: numpy stream, seed 1; rounds 1-4: 10758702)")
     ap.add_argument("--heads", type=int, default=8)
     a = ap.parse_args()
     if a.promote:   # the GPU box cannot write profiles/: summaries come back under gpurun_out/, are copied, then promoted here
@@ -87,7 +88,7 @@ def main():
         "k3c_rowsum": ("pygat::gat_bwd_rowsum_kernel",),
         "k5_agrad": ("pygat::a_grad_partial", "pygat::a_grad_final"),
         "k5_afold": ("pygat::a_grad_fold", "pygat::a_grad_final"),
-        "k5_wgrad": ("pygat::gemm_tn_x3_kernel", "pygat::gemm_splitk_reduce_kernel", "pygat::unpack_wgrad"),
+        "k5_wgrad": ("pygat::gemm_tn_x3_kernel", "pygat::gemm_tn_x3w_kernel", "pygat::gemm_splitk_reduce_kernel", "pygat::unpack_wgrad"),
     }
     traffic = {}
     for span, prefixes in spans.items():

@@ -34,18 +34,32 @@ if [ "$PART" = all ] || [ "$PART" = b ]; then
   done
   prof --kernel-trace --stats --output-format csv -d $O/v2 -- python3 $R/tools/v2_bench.py > $O/v2.log 2>&1
   python3 tools/rocprof_top.py $O/v2 --per 25 --top 10 --csv $P/${TAG}_gatv2_kernel_stats.csv > $P/${TAG}_gatv2_top_kernels.txt 2>&1; rm -rf $O/v2; grep ms_per_step $O/v2.log >> $P/${TAG}_gatv2_top_kernels.txt
-  BENCH_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29621 bench.py --gpus 2 --steps 5 --warmup 2 --verify > $O/gloo2.json 2> $P/${TAG}_gloo_rehearsal_2ranks.log
+  # (round 5: `bench.py --gpus N` starts its own ranks -- no launcher)
+  BENCH_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 300 python3 bench.py --gpus 2 --steps 5 --warmup 2 --verify > $P/${TAG}_gloo_rehearsal_2ranks.json 2> $P/${TAG}_gloo_rehearsal_2ranks.log
 fi
 if [ "$PART" = all ] || [ "$PART" = c ]; then
   # the per-rank shapes of the driver's 8-GPU default (ONE 16-float head per rank: 32-edge slots, narrow-row kernels) at the most
   # ranks one card may host (the pool's process guard admits 6 processes with the GPU open, the launcher included -- a 6-rank
   # run was killed by it): 5 heads on 5 ranks, and 4 on 4
   for n in 5 4; do
-    BENCH_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 2963$n bench.py --gpus $n --heads $n --steps 3 --warmup 1 --verify > $O/gloo_1head_$n.json 2> $P/${TAG}_gloo_rehearsal_${n}ranks_one_head_each.log
+    BENCH_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 400 python3 bench.py --gpus $n --heads $n --steps 3 --warmup 1 --verify > $P/${TAG}_gloo_rehearsal_${n}ranks_one_head_each.json 2> $P/${TAG}_gloo_rehearsal_${n}ranks_one_head_each.log
   done
   # config 4: PMC traffic of the PPI epoch's kernels (separate passes, as for configs 3 and 5)
   prof --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/ppi_fetch -- python3 $R/tools/epoch_profile.py ppi --epochs 12 > $O/ppi_fetch.log 2>&1
   prof --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/ppi_write -- python3 $R/tools/epoch_profile.py ppi --epochs 12 > $O/ppi_write.log 2>&1
   python3 tools/pmc_summary.py $O/ppi_fetch $O/ppi_write --out $P/${TAG}_ppi_epoch_pmc.json --edges 0 --heads 4 --note "PPI-shaped epoch (BASELINE config 4), tools/epoch_profile.py ppi: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE+TCC in separate passes, per-launch means, FETCH_SIZE doubled" > $O/ppi_pmc.log 2>&1; rm -rf $O/ppi_fetch $O/ppi_write
+fi
+if [ "$PART" = all ] || [ "$PART" = p ]; then
+  # PMC traffic of the headline command alone (separate passes, no other tracing), and the promoted replay file
+  prof --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --no-cpu --no-epoch --no-v2 --steps 5 --warmup 2 > $O/pmc_fetch.log 2>&1
+  prof --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/write -- python3 $R/bench.py --no-cpu --no-epoch --no-v2 --steps 5 --warmup 2 > $O/pmc_write.log 2>&1
+  python3 tools/pmc_summary.py $O/fetch $O/write --out $P/${TAG}_pmc_bench.json > $O/pmc_summary.log 2>&1; rm -rf $O/fetch $O/write
+fi
+if [ "$PART" = all ] || [ "$PART" = d ]; then
+  # the N > 1 step through RCCL at the one world size a 1-GPU box hosts (BENCH_FORCE_DIST=1: the copy-free exchange path, chunked K2,
+  # RCCL's in-place all-gather of each chunk view), at 1 / 2 / 4 row chunks, and its kernel trace: no copy / permute kernel in it
+  for c in 1 2 4; do BENCH_FORCE_DIST=1 python3 bench.py --no-cpu --no-epoch --no-v2 --chunks $c 2> $O/rccl1_$c.err; done > $P/${TAG}_bench_rccl_world1_chunks_1_2_4.jsonl
+  BENCH_FORCE_DIST=1 prof --kernel-trace --stats --output-format csv -d $O/rccl1 -- python3 $R/bench.py --no-cpu --no-epoch --no-v2 > $O/rccl1_under_rocprof.json 2> $O/rccl1_stats.err
+  python3 tools/rocprof_top.py $O/rccl1 --top 40 > $P/${TAG}_rccl_world1_kernels.txt 2>&1; rm -rf $O/rccl1
 fi
 echo "profile_round $TAG $PART done"

@@ -66,12 +66,13 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=5, help="timed steps of the cpu_baseline leg (>= 1; its value is their median)")
     ap.add_argument("--verify", action="store_true", help="check the gathered sharded output against the unsharded level")
     ap.add_argument("--forward-exchange", choices=["allgather", "replicate"], default="allgather",
-                    help="N>1, how every rank gets the other ranks' head outputs: RCCL all-gather over xGMI (default, the "
-                         "design of pygat_amd/dist.py), or -- experiment -- no collective: run the forward of ALL heads and "
-                         "back-propagate only the own ones (GATLevelFn bwd_heads)")
+                    help="N>1, how every rank gets the other ranks' head outputs: exchanged over xGMI through RCCL (default, the "
+                         "design of pygat_amd/dist.py: see --chunks), or -- experiment -- no collective: run the forward of ALL heads "
+                         "and back-propagate only the own ones (GATLevelFn bwd_heads)")
     ap.add_argument("--chunks", type=int, default=4,
-                    help="N>1: row chunks of the pipelined level -- chunk c's head outputs are all-gathered while chunk c+1 "
-                         "is computed (1 = one all-gather after the whole forward)")
+                    help="N>1: row chunks of the pipelined level -- chunk c's head outputs travel (one grouped RCCL send/recv per chunk, "
+                         "straight into the column-blocked activation) while chunk c+1 is computed; 1 = RCCL's in-place all-gather "
+                         "of the whole level after its forward (also copy-free), hidden behind the backward only")
     ap.add_argument("--as-rank-of", type=int, default=0,
                     help="single process: run the work of rank 0 of a world of this size (per-rank time model, no collectives)")
     args = ap.parse_args()

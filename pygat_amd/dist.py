@@ -149,6 +149,11 @@ def exchange_blocks(full: torch.Tensor, r0: int, r1: int):
         if world == 1:      # FORCE_COLLECTIVES on one rank: the in-place all-gather of the (contiguous) view -- drives RCCL
             v = full[0, r0:r1]
             return [dist.all_gather_into_tensor(v, v, async_op=True)]
+        if r0 == 0 and r1 == full.shape[1]:
+            # the whole level at once (a level too small to pipeline, bench.py --chunks 1): [world, N, w] IS the all-gather's
+            # output layout and full[rank] its in-place input -- RCCL's own all-gather, still without a copy
+            N, w = full.shape[1], full.shape[2]
+            return [dist.all_gather_into_tensor(full.view(world * N, w), full[rank], async_op=True)]
         ops = []
         for d in range(1, world):       # rank -> rank + d, rank - d -> rank: every step of the loop is a perfect matching
             ops.append(dist.P2POp(dist.isend, full[rank, r0:r1], (rank + d) % world))

@@ -486,6 +486,27 @@ def main():
             step()
         barrier()
 
+    # ---- the same K steps in the CALLER's node order (ops.RENUMBER off): since round 5 a first level of this size runs its node
+    # tables in an internal degree order (x permuted once per feature tensor, outputs / gradients at the caller's rows through a
+    # map inside the kernels: pygat_amd/ops.py); the line reports what that layout choice is worth.
+    alt_order = None
+    if world == 1 and not (args.hip_graph and not replicate) and ops.RENUMBER:
+        try:
+            ops.RENUMBER = False
+            for _ in range(max(2, args.warmup)):
+                step()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            barrier()
+            alt_order = {"node_order": "caller's", "ms_per_step": (time.perf_counter() - t1) / args.steps * 1e3}
+        finally:
+            ops.RENUMBER = True
+        for _ in range(2):
+            step()
+        barrier()
+
     # ---- instrumented pass: the same steps launched eagerly with HIP events around every kernel ------
     timer = ops.KernelTimer()
     if replicate:
@@ -622,6 +643,10 @@ def main():
                        if model_world > 1 else "single GPU",
                        "heads_per_gpu": h_loc,
                        "gemm_products": pg.get_gemm_mode(),
+                       "node_order": ("internal degree order (x permuted once per feature tensor and cached; out / G / saved output "
+                                      "addressed at the caller's rows inside K2 / K3a; no permutation pass in the step)"
+                                      if (ops.RENUMBER and world == 1 and N * h_loc * pg.padded_width(Fo) * 4 >= ops.RENUMBER_MIN_BYTES
+                                          and not args.dx) else "caller's"),
                        "launch": "HIP-graph replay (pygat_amd.GraphedLevel)" if (args.hip_graph and not replicate)
                        else "stream launches (pygat_amd.GATLevelFn)"},
             "roofline": roof,
@@ -629,6 +654,7 @@ def main():
             "kernels_ms_sum": float(sum(kt.values())),
             "traffic_source": traffic_source,
             "alt": alt,
+            "alt_node_order": alt_order,
         }
         if cpu_record is not None:
             line["cpu_baseline"] = cpu_record

@@ -244,6 +244,11 @@ typedef struct {
      flight together -- without renumbering a node or moving a table row.  Results do not depend on it (partial records
      and fix-up launches go by the slot id).  Needs slot_count = 0. */
   const int32_t* slot_order;
+  /* NULL, or [n] (ABI 14): this pattern is an INTERNAL renumbering of the caller's graph (pygat_amd/graph.py, degree order) and
+     user_row[i] is the caller's row of internal node i.  Every node table the kernels exchange among themselves is in internal
+     order; the caller-facing ones are addressed through this map: pygat_gat_forward writes row user_row[i] of `out`
+     (pygat_gat_backward_prepare takes the same map as an argument for G and the saved output). */
+  const int32_t* user_row;
 } pygat_graph;
 
 /* edge_rc[k] = (i, col[k]) for rowptr[i] <= k < rowptr[i+1] */
@@ -330,7 +335,10 @@ int pygat_gat_backward_prepare(int n, int H, int Fo, int flags, int mean_mode,
                                const float* G, const float* y, const float* sk,
                                const float* s, const float* m, const float* Z,
                                float* GR, const float* aneg, const float* qneg, float alpha, float* ds,
-                               int h_first, int h_count, int head_group, void* stream);
+                               int h_first, int h_count, int head_group, const int32_t* user_row, void* stream);
+/* user_row (ABI 14; NULL = identity): the tables are in the INTERNAL node order of a renumbered pattern
+ * (pygat_graph.user_row): G -- and, in concat mode, y = the level's saved output -- are the caller's arrays and are read at
+ * row user_row[i] for internal node i; every other table is internal. */
 int pygat_gat_backward_row(const pygat_graph* g, int H, int Fo, float alpha,
                            const float* Wh, const float* a_pad, const float* GR,
                            const float* att_mask, float* ds, void* part, int h_first, int h_count, int head_group,

@@ -69,7 +69,7 @@ class Graph(C.Structure):
     _fields_ = [("n", C.c_int), ("nnz", C.c_int64), ("rowptr", C.c_void_p), ("edge_rc", C.c_void_p),
                 ("slot_edges", C.c_int), ("slot_begin", C.c_void_p), ("cut_rows", C.c_void_p),
                 ("n_cut", C.c_int), ("n_cut_wide", C.c_int), ("slot_first", C.c_int64), ("slot_count", C.c_int64),
-                ("slot_meta", C.c_void_p), ("slot_order", C.c_void_p)]
+                ("slot_meta", C.c_void_p), ("slot_order", C.c_void_p), ("user_row", C.c_void_p)]
 
 
 def _load():
@@ -118,7 +118,7 @@ def _load():
     lib.pygat_gat_forward.argtypes = [C.POINTER(Graph), i, i, f, i, p, p, p, p, p, p, p, p, p, p, p, p, p]
     lib.pygat_gat_forward_phases_ok.argtypes = [i, i, i]
     lib.pygat_head_mean.argtypes = [i, i, i, p, p, p, p]
-    lib.pygat_gat_backward_prepare.argtypes = [i, i, i, i, i, p, p, p, p, p, p, p, p, p, f, p, i, i, i, p]
+    lib.pygat_gat_backward_prepare.argtypes = [i, i, i, i, i, p, p, p, p, p, p, p, p, p, f, p, i, i, i, p, p]
     lib.pygat_gat_backward_row.argtypes = [C.POINTER(Graph), i, i, f, p, p, p, p, p, p, i, i, i, p]
     lib.pygat_gat_backward_col.argtypes = [C.POINTER(Graph), p, i, i, f, p, p, p, p, p, p, p, p, p, p, i, i, i, p]
     lib.pygat_gat_backward_col_da_bytes.argtypes = [C.POINTER(Graph), i, i, i]

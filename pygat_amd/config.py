@@ -44,6 +44,7 @@ class Config:
     k1_split_min_k: int                   # PYGAT_K1_SPLIT_MIN_K     slab floor of a small graph's split-K projection
     overlap_backward: bool                # PYGAT_OVERLAP_BACKWARD=1 a-gradient on a side stream beside the weight gradient
     pad_k: bool                           # PYGAT_PAD_K=0            odd input widths run as they are
+    renumber: bool                        # PYGAT_RENUMBER=0         large first levels in the caller's node order (no internal degree order)
 
     @staticmethod
     def from_env() -> "Config":
@@ -61,6 +62,7 @@ class Config:
             k1_split_min_k=int(os.environ.get("PYGAT_K1_SPLIT_MIN_K", 128)),
             overlap_backward=_flag("PYGAT_OVERLAP_BACKWARD", False),
             pad_k=_flag("PYGAT_PAD_K", True),
+            renumber=_flag("PYGAT_RENUMBER", True),
         )
 
     def describe(self) -> dict:

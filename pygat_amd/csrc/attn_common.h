@@ -158,6 +158,7 @@ struct GraphDev {  // device view of pygat_graph
   int n_cut, n_cut_wide;
   int64_t k0, kn;   // active slot range [k0, k0 + kn) (the forward can work on a range of whole rows)
   const int32_t* order;   // slot handed to grid position q (pygat_graph.slot_order) or nullptr: q itself
+  const int32_t* urow;    // caller's row of internal node i (pygat_graph.user_row) or nullptr: i itself
 };
 
 static inline int check_graph(const pygat_graph* g, GraphDev* d, bool allow_slot_range = false) {
@@ -187,6 +188,7 @@ static inline int check_graph(const pygat_graph* g, GraphDev* d, bool allow_slot
   const int64_t total = (g->nnz + g->slot_edges - 1) / g->slot_edges;
   d->k0 = 0; d->kn = total;
   d->order = g->slot_order;
+  d->urow = g->user_row;
   if (g->slot_order && g->slot_count != 0) {
     set_error("graph: slot_order needs the whole slot range (slot_count = 0)");
     return PYGAT_EINVAL;

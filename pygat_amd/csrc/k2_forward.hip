@@ -146,6 +146,7 @@ __device__ __forceinline__ void fwd_finish(const FwdArgs& a, const LaneCols<VEC>
       if (row_mixed)
         st4(a.aneg + (int64_t)i * ldr + co, make_float4(st.accn[v].x * rz, st.accn[v].y * rz, st.accn[v].z * rz, st.accn[v].w * rz));
     if (a.out) {
+      const int64_t io = a.g.urow ? (int64_t)a.g.urow[i] : (int64_t)i;   // `out` is the caller's: its row of internal node i
       float4 pre = hat;
       if (a.flags & PYGAT_F_SKIP) {
         float4 k4 = ld4(a.sk + (int64_t)i * ldr + co);
@@ -153,10 +154,10 @@ __device__ __forceinline__ void fwd_finish(const FwdArgs& a, const LaneCols<VEC>
       }
       if (a.flags & PYGAT_F_ELU) { pre.x = elu1(pre.x); pre.y = elu1(pre.y); pre.z = elu1(pre.z); pre.w = elu1(pre.w); }
       if (Fo == Fp) {
-        st4(a.out + (int64_t)i * ldo + co, pre);
+        st4(a.out + io * ldo + co, pre);
       } else {
         const int f0 = co & (Fp - 1);
-        float* o = a.out + (int64_t)i * ldo + (int64_t)h * Fo + f0;
+        float* o = a.out + io * ldo + (int64_t)h * Fo + f0;
         if (f0 + 0 < Fo) o[0] = pre.x;
         if (f0 + 1 < Fo) o[1] = pre.y;
         if (f0 + 2 < Fo) o[2] = pre.z;

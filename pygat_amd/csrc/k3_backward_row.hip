@@ -42,6 +42,7 @@ struct PrepArgs {
   const float* qneg;  // [n][ldh]
   float* ds;          // [n][ldh]
   float slope;        // LeakyReLU alpha
+  const int32_t* urow;  // caller's row of internal node i for G (and y in concat mode), or nullptr
 };
 
 // float offsets inside a GR row (include/pygat_amd.h, K3a): window w0 = first head of the backward window
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_kernel(PrepArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t i = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * EPW + lane / LPR;
   if (i >= a.n) return;  // whole lane groups leave together: the DPP sums below stay inside a group
+  const int64_t iu = a.urow ? (int64_t)a.urow[i] : i;   // row of the caller's arrays (G; y in concat mode)
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
   const int H = a.rs.H, R = a.rs.R, Fo = a.rs.Fo, Fp = a.rs.Fp;
   const int64_t RW = a.ldgr, ldr = a.rs.ldr, ldh = a.rs.ldh, ldo = a.rs.ldo;
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_kernel(PrepArgs a) {
     if (lc.valid[v]) {
       if (a.mean_mode) {
         hat = ld4(a.y + i * ldr + co);
-        const float* gr = a.G + i * Fo + f0;
+        const float* gr = a.G + iu * Fo + f0;
         const float inv = 1.0f / (float)a.rs.Htot;
         if (f0 + 0 < Fo) g4.x = gr[0] * inv;
         if (f0 + 1 < Fo) g4.y = gr[1] * inv;
@@ -81,10 +83,10 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_kernel(PrepArgs a) {
       } else {
         float4 y4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (Fo == Fp) {
-          g4 = ld4(a.G + i * ldo + co);
-          y4 = ld4(a.y + i * ldo + co);
+          g4 = ld4(a.G + iu * ldo + co);
+          y4 = ld4(a.y + iu * ldo + co);
         } else {
-          const int64_t o = i * ldo + (int64_t)h * Fo + f0;
+          const int64_t o = iu * ldo + (int64_t)h * Fo + f0;
           if (f0 + 0 < Fo) { g4.x = a.G[o + 0]; y4.x = a.y[o + 0]; }
           if (f0 + 1 < Fo) { g4.y = a.G[o + 1]; y4.y = a.y[o + 1]; }
           if (f0 + 2 < Fo) { g4.z = a.G[o + 2]; y4.z = a.y[o + 2]; }
@@ -159,8 +161,9 @@ __global__ __launch_bounds__(256) void gat_bwd_prepare_fast_kernel(PrepArgs a) {
     const int64_t i = (i0 + r < a.n) ? i0 + r : a.n - 1;
     // (non-temporal loads of G / y and stores of Gp were measured, gpurun_out r4j: 0.374-0.379 -> 0.352-0.373 ms, inside the
     // run-to-run spread, and K4 behind it 1.23 -> 1.25: not used)
-    g4[r] = ld4(a.G + i * ldo + co);
-    y4[r] = ld4(a.y + i * ldo + co);
+    const int64_t iu = a.urow ? (int64_t)a.urow[i] : i;
+    g4[r] = ld4(a.G + iu * ldo + co);
+    y4[r] = ld4(a.y + iu * ldo + co);
     k4[r] = (a.flags & PYGAT_F_SKIP) ? ld4(a.sk + i * ldr + co) : make_float4(0.f, 0.f, 0.f, 0.f);
     sv[r] = a.s[i * ldh + h]; mv[r] = a.m[i * ldh + h]; zv[r] = a.Z[i * ldh + h];
   }
@@ -415,14 +418,15 @@ using namespace pygat;
 static int launch_prepare(int n, int H, int Fo, int flags, int mean_mode, const float* G, const float* y,
                           const float* sk, const float* s, const float* m, const float* Z, float* GR,
                           const float* whi, int64_t ld_whi, const float* aneg, const float* qneg, float slope, float* ds,
-                          int h_first, int h_count, int head_group, void* stream);
+                          int h_first, int h_count, int head_group, void* stream, const int32_t* user_row = nullptr);
 
 extern "C" int pygat_gat_backward_prepare(int n, int H, int Fo, int flags, int mean_mode, const float* G,
                                           const float* y, const float* sk, const float* s, const float* m,
                                           const float* Z, float* GR, const float* aneg, const float* qneg, float alpha,
-                                          float* ds, int h_first, int h_count, int head_group, void* stream) {
+                                          float* ds, int h_first, int h_count, int head_group, const int32_t* user_row,
+                                          void* stream) {
   return launch_prepare(n, H, Fo, flags, mean_mode, G, y, sk, s, m, Z, GR, nullptr, 0, aneg, qneg, alpha, ds, h_first,
-                        h_count, head_group, stream);
+                        h_count, head_group, stream, user_row);
 }
 
 /* GATv2: GRW [n x (2R + 4H)] = [Gp | (., m, 1/Z, D) | Whi], Whi copied from WW [n x 2R] */
@@ -438,8 +442,9 @@ extern "C" int pygat_gatv2_backward_prepare(int n, int H, int Fo, int flags, int
 static int launch_prepare(int n, int H, int Fo, int flags, int mean_mode, const float* G, const float* y,
                           const float* sk, const float* s, const float* m, const float* Z, float* GR,
                           const float* whi, int64_t ld_whi, const float* aneg, const float* qneg, float slope, float* ds,
-                          int h_first, int h_count, int head_group, void* stream) {
+                          int h_first, int h_count, int head_group, void* stream, const int32_t* user_row) {
   PrepArgs a;
+  a.urow = user_row;
   const int Fp = padded_width(Fo);
   HeadRange rg;
   PYGAT_REQUIRE(H > 0 && Fp > 0, "gat_backward_prepare: unsupported H=%d F'=%d", H, Fo);

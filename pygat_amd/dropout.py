@@ -198,7 +198,7 @@ class GATLevelDropoutFn(torch.autograd.Function):
             rowlocal = ctx.flavour == "rowlocal"
             check(lib.pygat_gat_backward_prepare(L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(), y.data_ptr(),
                                                  _ptr(Sk), s.data_ptr(), m.data_ptr(), Z.data_ptr(), GR.data_ptr(),
-                                                 _ptr(aneg), _ptr(qneg), ctx.alpha, ds.data_ptr() if rowlocal else None, 0, 0, L.hg, st),
+                                                 _ptr(aneg), _ptr(qneg), ctx.alpha, ds.data_ptr() if rowlocal else None, 0, 0, L.hg, None, st),
                   "gat_backward_prepare")
             two_gather = ctx.flavour != "rowsum"       # below: does a_grad still have to finish dWh += ds a_src ?
             if rowlocal:       # ds known from the forward's alpha-branch shares (ops.BACKWARD_FLAVOUR)

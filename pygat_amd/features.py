@@ -135,6 +135,25 @@ def as_sparse_features(x: torch.Tensor, out_columns: int) -> Optional[SparseFeat
     return prepare_features(x)
 
 
+_perm_cache = _LRU()
+
+
+def permuted_rows(x: torch.Tensor, to_user: torch.Tensor) -> Optional[torch.Tensor]:
+    """x[to_user] -- the input features in a graph's INTERNAL node order (CSRGraph.degree_ordered) -- built once per
+    (feature tensor, graph) and cached like the padded copy below: a first level's input does not change between epochs
+    (train.py:93-99 loads `features` once).  None inside a stream capture when the copy is not cached yet (the level then
+    runs in the caller's order)."""
+    key = (x.data_ptr(), tuple(x.shape), x._version, str(x.device), str(x.dtype), to_user.data_ptr())
+    ok, val = _perm_cache.lookup(key, x)
+    if ok:
+        return val
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    xp = x.index_select(0, to_user.long()).float().contiguous()
+    _perm_cache.insert(key, x, xp)
+    return xp
+
+
 _pad_cache = _LRU()
 
 

@@ -68,8 +68,9 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 class _Pattern:
     """rowptr/col plus the (row, col) edge pairs, as the pygat_graph struct."""
 
-    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, slot_edges: int):
+    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, slot_edges: int, user_row: Optional[torch.Tensor] = None):
         self.rowptr, self.col, self.slot_edges = rowptr, col, slot_edges
+        self.user_row = user_row     # internal renumbering of a caller's graph: caller's row of node i (pygat_graph.user_row)
         self.n = rowptr.numel() - 1
         self.nnz = col.numel()
         self.edge_rc = torch.empty(self.nnz, 2, dtype=torch.int32, device=rowptr.device)
@@ -112,7 +113,7 @@ class _Pattern:
                 meta = None
             order = SLOT_ORDER_FN(self, meta) if (SLOT_ORDER_FN is not None and meta is not None) else None
             st = _lib.Graph(self.n, self.nnz, _ptr(self.rowptr), _ptr(self.edge_rc), slot_edges, _ptr(sb), _ptr(cut),
-                            n_cut, n_wide, 0, 0, _ptr(meta), _ptr(order))
+                            n_cut, n_wide, 0, 0, _ptr(meta), _ptr(order), _ptr(self.user_row))
             self._alt[key] = (st, sb, cut, meta, order)
         return self._alt[key][0]
 
@@ -149,7 +150,7 @@ class _Pattern:
                     if n_cut == 0:
                         sub = cut[:1].contiguous()                       # a non-NULL list with n_cut = 0: nothing to fix up
                 st = _lib.Graph(self.n, self.nnz, _ptr(self.rowptr), _ptr(self.edge_rc), ts, _ptr(sb), _ptr(sub), n_cut,
-                                n_wide, b0, b1 - b0, _ptr(meta), None)
+                                n_wide, b0, b1 - b0, _ptr(meta), None, _ptr(self.user_row))
                 out.append((st, r0, r1))
                 keep.append(sub)
             self._alt[key] = (out, keep)
@@ -166,7 +167,7 @@ class CSRGraph:
     """Device-resident CSR pattern (+ transpose info) consumed by the HIP kernels."""
 
     def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, slot_edges: Optional[int] = None,
-                 validate: bool = True):
+                 validate: bool = True, user_row: Optional[torch.Tensor] = None):
         if not (rowptr.is_cuda and col.is_cuda):
             raise ValueError("CSRGraph: rowptr/col must live on the GPU (there is no CPU path)")
         rowptr = rowptr.to(torch.int32).contiguous()
@@ -185,7 +186,9 @@ class CSRGraph:
         if slot_edges < 4 or slot_edges % 4:
             raise ValueError("slot_edges must be a multiple of 4, >= 4")
         self.slot_edges = slot_edges
-        self.fwd = _Pattern(rowptr, col, slot_edges)
+        self.user_row = user_row
+        self._ordered = None
+        self.fwd = _Pattern(rowptr, col, slot_edges, user_row)
         # mirror permutation (symmetric pattern, sorted rows) via the HIP binary search
         perm = torch.empty(self.nnz, dtype=torch.int32, device=self.device)
         flags = torch.zeros(2, dtype=torch.int32, device=self.device)
@@ -235,11 +238,35 @@ class CSRGraph:
         cnt = torch.bincount(col, minlength=self.n)
         rp_t = torch.zeros(self.n + 1, dtype=torch.int64, device=self.device)
         rp_t[1:] = torch.cumsum(cnt, 0)
-        self.bwd = _Pattern(rp_t.to(torch.int32), src[order].to(torch.int32).contiguous(), self.slot_edges)
+        self.bwd = _Pattern(rp_t.to(torch.int32), src[order].to(torch.int32).contiguous(), self.slot_edges, self.user_row)
         self.perm_t = order.to(torch.int32).contiguous()          # transposed position -> forward edge
         inv = torch.empty_like(order)
         inv[order] = torch.arange(order.numel(), device=self.device)
         self.perm_f = inv.to(torch.int32).contiguous()            # forward edge -> transposed position
+
+    def degree_ordered(self) -> "Tuple[CSRGraph, torch.Tensor, torch.Tensor]":
+        """-> (g, to_user, to_internal): the same pattern with its nodes renumbered by DESCENDING DEGREE (stable: the caller's
+        order inside a degree), built once and cached; internal node p is the caller's node to_user[p].  A level may run all
+        its node tables in this INTERNAL order (ops.RENUMBER): the most-gathered rows of the gathered
+        tables become neighbours and the self-loop-only nodes (55 % of the R-MAT workload) a contiguous tail -- measured on the
+        headline graph: K2 0.99 -> 0.91 ms, K4 1.23 -> 1.17 at almost unchanged HBM traffic.  Results are the caller-order
+        results up to the summation order inside a softmax row (its neighbours are visited in the internal order); `out` is
+        written, G and the saved output are read, at the caller's rows through g.user_row inside the kernels."""
+        if self._ordered is None:
+            rp = self.fwd.rowptr.long()
+            deg = rp[1:] - rp[:-1]
+            to_user = torch.argsort(deg, descending=True, stable=True)
+            to_int = torch.empty_like(to_user)
+            to_int[to_user] = torch.arange(self.n, device=self.device)
+            rows = torch.repeat_interleave(torch.arange(self.n, device=self.device), deg)
+            key = torch.sort(to_int[rows] * self.n + to_int[self.fwd.col.long()]).values       # unique keys: (row, col) pairs
+            r2, c2 = key // self.n, key % self.n
+            rp2 = torch.zeros(self.n + 1, dtype=torch.int64, device=self.device)
+            rp2[1:] = torch.cumsum(torch.bincount(r2, minlength=self.n), 0)
+            urow = to_user.to(torch.int32).contiguous()
+            g = CSRGraph(rp2.to(torch.int32), c2.to(torch.int32), self.slot_edges, validate=False, user_row=urow)
+            self._ordered = (g, urow, to_int.to(torch.int32).contiguous())
+        return self._ordered
 
     # ------------------------------------------------------------------ builders
     @staticmethod

@@ -96,6 +96,19 @@ DA_IN_K4 = _config.da_in_k4
 DA_MIN_BYTES = 32 << 20
 
 
+# INTERNAL node order (round 5; CSRGraph.degree_ordered).  A level whose input carries no gradient (a first
+# level: its features are the same tensor every epoch) and whose gathered table is RENUMBER_MIN_BYTES and more runs on the
+# graph renumbered by descending degree: x is permuted ONCE per feature tensor (features.permuted_rows, cached like the padded
+# and the sparse copies), every node table between the kernels is in internal order, K2 writes `out` and K3a reads G / the saved
+# output at the caller's rows through the map inside the kernels -- no permutation pass in the step.  Results: the caller-order
+# results up to the summation order inside a softmax row.  RENUMBER = False / PYGAT_RENUMBER=0 switches it off.
+# Measured on the headline graph (same run, bench.py `alt_node_order`): 8 heads x 16 (512 MB table) 3.16 -> 3.06 ms (K2 0.98 -> 0.95,
+# K4 1.24 -> 1.17, K3a 0.37 -> 0.40: its G / y rows are now gathers); 4 heads (256 MB) 1.90 -> 1.84; 2 heads (128 MB) 1.114 -> 1.111;
+# 1 head (64 MB) 0.860 -> 0.887 -- narrow rows lose: K3a's gathers cost what K2 / K4 gain.  Hence the threshold.
+RENUMBER = _config.renumber
+RENUMBER_MIN_BYTES = 160 << 20
+
+
 def head_group(N: int, H: int, Fo: int) -> int:
     """Heads per backward window for a level of H heads (see BWD_WINDOW_FLOATS)."""
     if BWD_WINDOW_FLOATS is None:
@@ -416,6 +429,15 @@ def _level_forward(ctx, need, x, H, Fo, skip, pack, graph: CSRGraph, alpha: floa
         raise ValueError(f"x has {L.N} rows but the graph has {graph.n} nodes")
     if L.blocks is not None:
         xs = None
+    user_row = None
+    single_out = (not concat) and H == 1
+    if (RENUMBER and not need[0] and xs is None and pipeline is None and x.dim() == 2 and (concat or single_out)
+            and graph.user_row is None and L.N * L.R * 4 >= RENUMBER_MIN_BYTES):
+        from .features import permuted_rows
+        g_int, to_user, _ = graph.degree_ordered()
+        xp = permuted_rows(x, to_user)
+        if xp is not None:
+            x, graph, user_row = xp, g_int, to_user
     L.ts = slot_edges_for(L.R, graph.slot_edges)
     L.mode = get_gemm_mode()     # this thread's product mode, fixed for the level: its backward (another thread) uses it too
     dev, f32 = x.device, torch.float32
@@ -505,6 +527,7 @@ def _level_forward(ctx, need, x, H, Fo, skip, pack, graph: CSRGraph, alpha: floa
         # concat: the backward recovers hattn from `out` (no second [N,R] table is written)
         ctx.save_for_backward(x, Wcat, a_pad, Wh, s, Sk, out if concat else hattn, m, Z, aneg, qneg)
         ctx.graph, ctx.L, ctx.alpha, ctx.concat, ctx.flags = graph, L, float(alpha), concat, flags
+        ctx.user_row = user_row
         ctx.xs = xs
         ctx.flavour = flavour
         ctx.bwd_heads = None
@@ -548,7 +571,8 @@ def _level_backward(ctx, G):
             check(lib.pygat_gat_backward_prepare(L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(),
                                                  y.data_ptr(), _ptr(Sk), s.data_ptr(), m.data_ptr(), Z.data_ptr(),
                                                  GR.data_ptr(), _ptr(aneg), _ptr(qneg), ctx.alpha,
-                                                 ds.data_ptr() if rowlocal else None, hb, hr, hgw, st), "gat_backward_prepare")
+                                                 ds.data_ptr() if rowlocal else None, hb, hr, hgw, _ptr(getattr(ctx, "user_row", None)), st),
+                      "gat_backward_prepare")
         two_gather = ctx.flavour == "two-gather"
         if rowlocal:        # ds is known: the column pass finishes dWh on its own
             with _span("k4_backward_col"):

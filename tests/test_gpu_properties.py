@@ -101,3 +101,55 @@ def test_headline_kernels_keep_their_register_footprint():
         rc = lib.pygat_kernel_footprint(name.encode(), C.byref(regs), C.byref(scratch))
         assert rc == 0, (name, lib.pygat_last_error())
         assert scratch.value == 0 and 0 < regs.value <= max_regs, (name, regs.value, scratch.value)
+
+
+@pytest.mark.parametrize("cfg", [dict(N=5000, H=8, Fo=16, Fin=128, skip=False, concat=True, sym=True),      # the headline shape
+                                 dict(N=3000, H=4, Fo=64, Fin=40, skip=True, concat=True, sym=True),        # skip rows ride in internal order
+                                 dict(N=2000, H=1, Fo=7, Fin=33, skip=True, concat=False, sym=True),        # one head, mean: K2 writes `out` itself
+                                 dict(N=2500, H=3, Fo=8, Fin=20, skip=False, concat=True, sym=False)])      # asymmetric pattern: own transpose
+def test_internal_degree_order_is_invisible(cfg, monkeypatch):
+    """ops.RENUMBER (round 5): a first level may run on the graph renumbered by descending degree, x permuted once, `out` written
+    and G / the saved output read at the caller's rows inside K2 / K3a.  Forced here on small graphs: equal to the caller-order run
+    (summation order inside a softmax row differs) and to the oracle under the one parity rule."""
+    import pygat_amd as pg
+    from oracle import gat_oracle as O
+    import parity
+    dev = torch.device("cuda", 0)
+    N, H, Fo, Fin = cfg["N"], cfg["H"], cfg["Fo"], cfg["Fin"]
+    rowptr, col = O.random_symmetric_csr(N, 6, 29, hub=(4, min(N - 1, 1200)))
+    rowptr, col = np.asarray(rowptr), np.asarray(col)
+    if not cfg["sym"]:       # drop every third off-diagonal edge: an asymmetric pattern (self loops kept)
+        rows = np.repeat(np.arange(N), np.diff(rowptr))
+        keep = (rows == col) | ((np.arange(len(col)) % 3) != 0)
+        rowptr = np.concatenate([[0], np.cumsum(np.bincount(rows[keep], minlength=N))]).astype(np.int32)
+        col = col[keep].astype(np.int32)
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(N, Fin, generator=g, dtype=torch.float64)
+    W = torch.randn(H, Fin, Fo, generator=g, dtype=torch.float64) * (1.414 * (2.0 / (Fin + Fo)) ** 0.5)
+    a = torch.randn(H, 2 * Fo, generator=g, dtype=torch.float64) * 0.4
+    S = torch.randn(H, Fin, Fo, generator=g, dtype=torch.float64) * 0.2 if cfg["skip"] else None
+    G = torch.randn(N, H * Fo if cfg["concat"] else Fo, generator=g, dtype=torch.float64)
+
+    def run(renumber):
+        monkeypatch.setattr(pg.ops, "RENUMBER", renumber)
+        monkeypatch.setattr(pg.ops, "RENUMBER_MIN_BYTES", 0)
+        graph = pg.CSRGraph(torch.as_tensor(rowptr, device=dev), torch.as_tensor(col, device=dev))
+        xd = x.float().to(dev)
+        ps = [None if t is None else t.float().to(dev).requires_grad_(True) for t in (W, a, S)]
+        out = pg.GATLevelFn.apply(xd, ps[0], ps[1], ps[2], graph, 0.2, cfg["concat"])
+        out.backward(G.float().to(dev))
+        used = graph._ordered is not None
+        return out.detach().cpu(), [None if p is None else p.grad.cpu() for p in ps], used
+    o0, g0, used0 = run(False)
+    o1, g1, used1 = run(True)
+    assert used1 and not used0                      # the renumbered run really took the internal order
+    sc = lambda t: max(1.0, float(t.abs().max()))   # noqa: E731
+    assert float((o1 - o0).abs().max()) <= 5e-6 * sc(o0)
+    for p, q in zip(g0, g1):
+        if p is not None:
+            assert float((p - q).abs().max()) <= 5e-5 * sc(p)
+    grads = {"dX": None, "dW": g1[0].numpy(), "da": g1[1].numpy()}
+    if S is not None:
+        grads["dW_skip"] = g1[2].numpy()
+    parity.check_level(o1.numpy(), grads, x.numpy(), rowptr, col, W.numpy(), a.numpy(), 0.2, cfg["concat"], G.numpy(),
+                       None if S is None else S.numpy(), what=f"internal-order{cfg}", verbose=False)

@@ -70,11 +70,11 @@ def main():
 
     def k3a():
         check(lib.pygat_gat_backward_prepare(N, H, Fo, _lib.F_ELU, 0, P(G), P(out), None, P(s), P(m), P(Z), P(GR), None, None,
-                                             0.2, None, 0, 0, 0, None))
+                                             0.2, None, 0, 0, 0, None, None))
 
     def k3a_ds():
         check(lib.pygat_gat_backward_prepare(N, H, Fo, _lib.F_ELU, 0, P(G), P(out), None, P(s), P(m), P(Z), P(GR), P(aneg),
-                                             P(qneg), 0.2, P(ds), 0, 0, 0, None))
+                                             P(qneg), 0.2, P(ds), 0, 0, 0, None, None))
 
     def k3b():
         check(lib.pygat_gat_backward_row(graph.fwd.ref(), H, Fo, 0.2, P(Wh), P(a_pad), P(GR), None, P(ds), P(part), 0, 0, 0, None))

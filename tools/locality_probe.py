@@ -48,6 +48,15 @@ def numbering(kind):
         return np.random.default_rng(0).permutation(N)
     if kind == "degree":
         inv = np.argsort(-np.diff(rp), kind="stable")
+    elif kind.startswith("hot_first_"):      # the K most-gathered nodes first, everything else in the generator's order
+        K = int(kind.rsplit("_", 1)[1])
+        deg = np.diff(rp)
+        hot = np.zeros(N, dtype=bool); hot[np.argsort(-deg, kind="stable")[:K]] = True
+        inv = np.concatenate([np.nonzero(hot)[0], np.nonzero(~hot)[0]])
+    elif kind == "degree_bucket":            # by floor(log2(degree)) descending, the generator's order inside a bucket
+        inv = np.argsort(-np.floor(np.log2(np.diff(rp))).astype(np.int64), kind="stable")
+    elif kind == "cold_last":                # the self-loop-only nodes last, everything else in the generator's order
+        inv = np.argsort((np.diff(rp) == 1).astype(np.int64), kind="stable")
     else:
         import scipy.sparse as sp
         from scipy.sparse.csgraph import reverse_cuthill_mckee

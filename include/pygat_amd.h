@@ -397,6 +397,18 @@ int pygat_wgrad_blocked(int n, int Fin, int H, int Fo, const float* X, int64_t l
                         const float* dWh, const float* ds, const float* a_pad, float* dW, int split_k, void* ws,
                         int h_first, int h_count, int gemm_mode, void* stream);
 
+/* Self-loop-only nodes (ABI 14; csrc/k12_tail.hip).  A node whose only neighbour is itself has alpha_ii = 1: its forward is
+ * h'_i = ELU(Wh_i (+ skip_i)), its backward dWh_i = Gp_i, ds_i = dt_i = 0 (layers.py:146-170 / 81-90 with one edge).  In a
+ * degree-ordered pattern (pygat_graph.user_row != NULL) these nodes are the rows [row_first, row_first + n_rows) at the END of the
+ * row range and their slots a suffix of the slot list: the caller runs pygat_gat_forward / pygat_gat_backward_col /
+ * pygat_a_grad_fold on the slot PREFIX before them (pygat_graph.slot_first = 0, slot_count = the first tail slot; same struct for
+ * all three) and these two streams on the tail.  Concat levels (out only), GR in ONE head window ([Gp R | records 4H] per row).
+ * forward_tail also writes m = 0, Z = 1 (and qneg = 0) for the tail rows when given, so that pygat_gat_backward_prepare finds
+ * finite records there. */
+int pygat_gat_forward_tail(int row_first, int n_rows, int H, int Fo, int flags, const float* Wh, const float* sk,
+                           float* out, const int32_t* user_row, float* m, float* Z, float* qneg, void* stream);
+int pygat_gat_backward_col_tail(int row_first, int n_rows, int H, int Fo, const float* GR, float* dWh, float* dt, void* stream);
+
 /* ------------------------------------------------ GATv2 (next row of the scope table)
  * The reference's SpGraphAttentionLayerV2 (layers.py:258-313): per head
  *   e_ij = a . LeakyReLU(Whi_i + Whj_j), alpha = row softmax, h'_i = sum_j alpha_ij Whi_j  (Whi is aggregated,

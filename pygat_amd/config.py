@@ -45,6 +45,7 @@ class Config:
     overlap_backward: bool                # PYGAT_OVERLAP_BACKWARD=1 a-gradient on a side stream beside the weight gradient
     pad_k: bool                           # PYGAT_PAD_K=0            odd input widths run as they are
     renumber: bool                        # PYGAT_RENUMBER=0         large first levels in the caller's node order (no internal degree order)
+    tail: bool                            # PYGAT_TAIL=0             self-loop-only nodes through the fused kernels like every other row
 
     @staticmethod
     def from_env() -> "Config":
@@ -63,6 +64,7 @@ class Config:
             overlap_backward=_flag("PYGAT_OVERLAP_BACKWARD", False),
             pad_k=_flag("PYGAT_PAD_K", True),
             renumber=_flag("PYGAT_RENUMBER", True),
+            tail=_flag("PYGAT_TAIL", True),
         )
 
     def describe(self) -> dict:

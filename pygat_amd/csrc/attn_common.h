@@ -161,7 +161,9 @@ struct GraphDev {  // device view of pygat_graph
   const int32_t* urow;    // caller's row of internal node i (pygat_graph.user_row) or nullptr: i itself
 };
 
-static inline int check_graph(const pygat_graph* g, GraphDev* d, bool allow_slot_range = false) {
+// allow_slot_range: 0 none, 1 any range of whole rows (pygat_gat_forward), 2 a PREFIX [0, slot_count) (the column pass and the fold of
+// its da records: the slots behind it are the self-loop-only tail of a degree-ordered pattern, pygat_gat_backward_col_tail)
+static inline int check_graph(const pygat_graph* g, GraphDev* d, int allow_slot_range = 0) {
   if (!g || !g->rowptr || !g->edge_rc || g->n <= 0 || g->nnz <= 0) {
     set_error("graph: null or empty (n=%d nnz=%lld)", g ? g->n : -1, g ? (long long)g->nnz : -1LL);
     return PYGAT_EINVAL;
@@ -194,9 +196,11 @@ static inline int check_graph(const pygat_graph* g, GraphDev* d, bool allow_slot
     return PYGAT_EINVAL;
   }
   if (g->slot_count != 0) {
-    if (!allow_slot_range || g->slot_first < 0 || g->slot_count < 0 || g->slot_first + g->slot_count > total) {
+    if (!allow_slot_range || g->slot_first < 0 || g->slot_count < 0 || g->slot_first + g->slot_count > total ||
+        (allow_slot_range == 2 && g->slot_first != 0)) {
       set_error("graph: slot range [%lld, +%lld) of %lld %s", (long long)g->slot_first, (long long)g->slot_count,
-                (long long)total, allow_slot_range ? "is out of bounds" : "is only supported by pygat_gat_forward");
+                (long long)total, allow_slot_range ? "is out of bounds (or not a prefix, for the column pass)"
+                                                   : "is not supported by this entry point");
       return PYGAT_EINVAL;
     }
     d->k0 = g->slot_first; d->kn = g->slot_count;
@@ -209,6 +213,12 @@ __host__ __device__
 #endif
 static inline int64_t num_slots(const GraphDev& g) { return (g.nnz + g.ts - 1) / g.ts; }
 #ifdef __HIPCC__
+// ELU: expm1 by a short series near 0 (where exp(x)-1 cancels), fast exp elsewhere (K2's epilogue and the self-loop-only tail)
+__device__ __forceinline__ float elu1(float x) {
+  if (x > 0.f) return x;
+  if (x > -0.03125f) return x * (1.f + x * (0.5f + x * (0.16666667f + x * 0.041666668f)));
+  return __expf(x) - 1.f;
+}
 // slot handed to grid position q of a main launch (q < num_slots): pygat_graph.slot_order, or q itself
 __device__ __forceinline__ int64_t slot_at(const GraphDev& g, int64_t q) { return g.order ? (int64_t)g.order[q] : q; }
 #endif
@@ -228,7 +238,7 @@ static inline int64_t col_da_blocks(const GraphDev& g, int H, int Fp, int hg, in
   if (vec != 1 || H != 8 || Fp != 16) return 0;
   const unsigned bt = (lpr <= 8) ? narrow_block() : 256u;
   if (lpr_out) *lpr_out = lpr;
-  return cdiv(cdiv(num_slots(g), 64 / lpr), bt / 64);
+  return cdiv(cdiv(g.kn, 64 / lpr), bt / 64);   // (kn: the active slots -- all of them, or the prefix of the call)
 }
 
 #ifdef __HIPCC__

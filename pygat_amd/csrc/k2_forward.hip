@@ -105,12 +105,6 @@ struct RowState {
 template <bool AUX>
 __host__ __device__ __forceinline__ int64_t part_stride(const RowShape& rs) { return AUX ? 2 * (int64_t)rs.R + 3 * rs.H : (int64_t)rs.R + 2 * rs.H; }
 
-// ELU: expm1 by a short series near 0 (where exp(x)-1 cancels), fast exp elsewhere
-__device__ __forceinline__ float elu1(float x) {
-  if (x > 0.f) return x;
-  if (x > -0.03125f) return x * (1.f + x * (0.5f + x * (0.16666667f + x * 0.041666668f)));
-  return __expf(x) - 1.f;
-}
 
 // normalise, epilogue (skip, ELU) and stores of a finished row i (all lanes of the group)
 // CR > 0 (with LPH > 0, VEC == 1): the row tables are dense with CR floats per row, heads of 4 LPH columns, F' == Fp --
@@ -587,7 +581,7 @@ static int launch_forward(const pygat_graph* g, int H, int Fo, float alpha, int 
                           const float* s, const float* a_pad, const float* sk, const float* att_mask, float* out,
                           float* hattn, float* m, float* Z, float* aneg, float* qneg, void* part, void* stream) {
   FwdArgs a;
-  int rc = check_graph(g, &a.g, /*allow_slot_range=*/!v2);
+  int rc = check_graph(g, &a.g, /*allow_slot_range=*/v2 ? 0 : 1);
   if (rc) return rc;
   const int Fp = padded_width(Fo);
   PYGAT_REQUIRE(H > 0 && Fp > 0, "gat_forward: unsupported H=%d F'=%d", H, Fo);

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CR > 0 ? (D
   const int lane = threadIdx.x & 63;
   const int64_t k = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * EPW + lane / LPR;   // grid position (-> slot: col_walk)
   if constexpr (!DA) {
-    if (k >= num_slots(a.g)) return;
+    if (k >= a.g.kn) return;
     col_walk<LPR, VEC, WRITE_DZ, LPH, CR, false>(a, k, nullptr, 0);
   } else {
     extern __shared__ __attribute__((aligned(16))) float4 da_sm[];   // [2][blockDim.x]: (src | dst) running sums, one pair per lane
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CR > 0 ? (D
     mine[0] = make_float4(0.f, 0.f, 0.f, 0.f); mine[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (threadIdx.x == 0) da_arrived = 0;
     __syncthreads();   // (at the START, where the waves stand together anyway: the counter below must be zero before its first add)
-    if (k < num_slots(a.g)) col_walk<LPR, VEC, WRITE_DZ, LPH, CR, true>(a, k, mine, nt);
+    if (k < a.g.kn) col_walk<LPR, VEC, WRITE_DZ, LPH, CR, true>(a, k, mine, nt);
     // No barrier at the end: a wave that is done leaves its SIMD slot; the LAST wave of the work-group to arrive adds the lane
     // groups, always in the same order (so the record does not depend on which wave that is).  Its workgroup-scope
     // acquire-release add comes after every other wave's LDS sums (theirs precede their own add in program order).
@@ -536,7 +536,7 @@ int footprint_k4_headline_da(int* regs, int* scratch) {
 
 extern "C" size_t pygat_gat_backward_col_da_bytes(const pygat_graph* gT, int H, int Fo, int head_group) {
   GraphDev g;
-  if (!gT || check_graph(gT, &g) != PYGAT_OK) return 0;
+  if (!gT || check_graph(gT, &g, 2) != PYGAT_OK) return 0;
   const int Fp = padded_width(Fo);
   if (H <= 0 || Fp <= 0) return 0;
   return (size_t)col_da_blocks(g, H, Fp, head_group_arg(head_group, g.n, H, Fp), nullptr) * 2 * (size_t)H * Fp * sizeof(float);
@@ -548,7 +548,7 @@ extern "C" int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm
                                       void* part, float* da_part, int h_first, int h_count, int head_group, void* stream) {
 
   ColArgs a;
-  int rc = check_graph(gT, &a.g);
+  int rc = check_graph(gT, &a.g, 2);
   if (rc) return rc;
   const int Fp = padded_width(Fo);
   HeadRange rg;
@@ -569,7 +569,8 @@ extern "C" int pygat_gat_backward_col(const pygat_graph* gT, const int32_t* perm
   }
   a.da_part = da_part;
   hipStream_t st = (hipStream_t)stream;
-  const int64_t nslots = num_slots(a.g);
+  const int64_t nslots = a.g.kn;   // all slots, or the prefix before a self-loop-only tail (pygat_gat_backward_col_tail)
+  PYGAT_REQUIRE(a.g.kn == num_slots(a.g) || (a.g.cut && !a.g.order), "gat_backward_col: a slot prefix needs the cut-row list and no slot_order");
   for (int h0 = 0; h0 < rg.hr; h0 += hg) {
     const int hc = (rg.hr - h0 < hg) ? rg.hr - h0 : hg;
     const int gh = rg.hb + h0;

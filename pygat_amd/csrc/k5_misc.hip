@@ -321,7 +321,7 @@ extern "C" int pygat_a_grad(int n, int H, int Fo, const float* Wh, const float* 
 extern "C" int pygat_a_grad_fold(const pygat_graph* gT, int H, int Fo, const float* Wh, const float* ds, const float* dt,
                                  const float* da_part, float* da, void* ws, int head_group, void* stream) {
   GraphDev g;
-  int rc = check_graph(gT, &g);
+  int rc = check_graph(gT, &g, 2);
   if (rc) return rc;
   const int Fp = padded_width(Fo);
   PYGAT_REQUIRE(H > 0 && Fp > 0, "a_grad_fold: unsupported H=%d F'=%d", H, Fo);

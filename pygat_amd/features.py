@@ -151,6 +151,7 @@ def permuted_rows(x: torch.Tensor, to_user: torch.Tensor) -> Optional[torch.Tens
         return None
     xp = x.index_select(0, to_user.long()).float().contiguous()
     _perm_cache.insert(key, x, xp)
+    weakref.finalize(x, _perm_cache.pop, key, None)     # a copy this size (512 MB at config 5) leaves with its tensor, not with the LRU
     return xp
 
 

@@ -157,6 +157,35 @@ class _Pattern:
             del base
         return [(C.byref(st), r0, r1) for st, r0, r1 in self._alt[key][0]]
 
+    def self_loop_tail(self, slot_edges: Optional[int] = None):
+        """For a pattern whose rows are in descending-degree order (CSRGraph.degree_ordered): (row_first, first_slot, prefix) --
+        the rows [row_first, n) have only their self loop and occupy exactly the slots [first_slot, n_slots); `prefix` is the
+        pygat_graph* of the slots before them (slot_first 0, slot_count first_slot) for pygat_gat_forward / pygat_gat_backward_col /
+        pygat_a_grad_fold, the tail goes to pygat_gat_forward_tail / pygat_gat_backward_col_tail (csrc/k12_tail.hip).
+        None when there is no such tail.  Computed once per slot length (two host reads)."""
+        ts = slot_edges or self.slot_edges
+        key = ("tail", ts)
+        if key not in self._alt:
+            st = self._make(ts, True)
+            _, sb, cut, meta, order = self._alt[(ts, True)]
+            out = None
+            if meta is not None and order is None:
+                rp = self.rowptr.long()
+                deg = rp[1:] - rp[:-1]
+                n1 = int((deg > 1).sum().item())                      # descending degree: rows [n1, n) are the self-loop-only ones
+                if n1 < self.n and bool((deg[n1:] == 1).all().item()) and bool((self.col[rp[n1]:].long() == torch.arange(n1, self.n, device=self.col.device)).all().item()):
+                    first_row = meta[:, 2].long()
+                    k = int(torch.searchsorted(first_row, torch.tensor(n1, device=first_row.device)).item())
+                    if k < meta.shape[0]:
+                        row_first = int(first_row[k].item())
+                        pre = _lib.Graph()
+                        C.memmove(C.byref(pre), C.byref(st), C.sizeof(_lib.Graph))
+                        pre.slot_first, pre.slot_count = 0, k
+                        out = (row_first, k, pre)
+            self._alt[key] = out
+        t = self._alt[key]
+        return None if t is None else (t[0], t[1], C.byref(t[2]))
+
     def ref(self, slot_edges: Optional[int] = None, snapped: bool = True):
         """pygat_graph* for a call.  `slot_edges` overrides the slot length for this call only (the edge
         arrays do not depend on it); `snapped=False` gives uniform slots (K3b has no row reduction)."""

@@ -107,6 +107,12 @@ DA_MIN_BYTES = 32 << 20
 # 1 head (64 MB) 0.860 -> 0.887 -- narrow rows lose: K3a's gathers cost what K2 / K4 gain.  Hence the threshold.
 RENUMBER = _config.renumber
 RENUMBER_MIN_BYTES = 160 << 20
+# In internal order the self-loop-only nodes (alpha_ii = 1: forward = ELU(Wh_i), backward dWh_i = Gp_i) are a contiguous tail of
+# the rows and a suffix of the slots: the fused kernels run on the slot prefix, two plain streams take the tail
+# (csrc/k12_tail.hip).  Symmetric patterns, concat levels, the row-local backward in one head window, tails of TAIL_MIN_SHARE of
+# the nodes and more.  TAIL = False / PYGAT_TAIL=0 switches it off.
+TAIL = _config.tail
+TAIL_MIN_SHARE = 0.05
 
 
 def head_group(N: int, H: int, Fo: int) -> int:
@@ -430,6 +436,7 @@ def _level_forward(ctx, need, x, H, Fo, skip, pack, graph: CSRGraph, alpha: floa
     if L.blocks is not None:
         xs = None
     user_row = None
+    tail = None      # (first tail row, pygat_graph* of the slot prefix) when the self-loop-only tail goes through its own streams
     single_out = (not concat) and H == 1
     if (RENUMBER and not need[0] and xs is None and pipeline is None and x.dim() == 2 and (concat or single_out)
             and graph.user_row is None and L.N * L.R * 4 >= RENUMBER_MIN_BYTES):
@@ -492,7 +499,12 @@ def _level_forward(ctx, need, x, H, Fo, skip, pack, graph: CSRGraph, alpha: floa
             out = torch.empty(L.N, H * Fo if concat else Fo, dtype=f32, device=dev)
         part = torch.empty(lib.pygat_partials_bytes(graph.nnz, L.ts, H, L.Fp) // 4, dtype=f32,
                            device=dev)
-        chunks = [(graph.fwd.ref(L.ts), 0, L.N)]
+        if (TAIL and user_row is not None and concat and graph.symmetric
+                and (not need_grad or (flavour == "rowlocal" and L.hg >= H and bwd_heads is None))):
+            t = graph.fwd.self_loop_tail(L.ts)
+            if t is not None and L.N - t[0] >= TAIL_MIN_SHARE * L.N:
+                tail = (t[0], t[2])
+        chunks = [(graph.fwd.ref(L.ts) if tail is None else tail[1], 0, L.N)]
         if pipeline is not None and concat and pipeline[0] > 1:
             chunks = graph.fwd.row_chunks(int(pipeline[0]), L.ts)
         # a pipelined level: chunk c's fix-up launch (a few thousand cut rows, latency-bound: 25-30 us at config 5) and the
@@ -517,6 +529,9 @@ def _level_forward(ctx, need, x, H, Fo, skip, pack, graph: CSRGraph, alpha: floa
                 continue
             with _span("k2_forward"):
                 k2(gref, flags, st)
+                if tail is not None:     # (one chunk: the tail path is never pipelined) the self-loop-only rows: out = ELU(Wh (+ skip))
+                    check(lib.pygat_gat_forward_tail(tail[0], L.N - tail[0], H, Fo, flags, Wh.data_ptr(), _ptr(Sk), out.data_ptr(),
+                                                     user_row.data_ptr(), _ptr(m), _ptr(Z), _ptr(qneg), st), "gat_forward_tail")
             if pipeline is not None and concat:
                 pipeline[1](c, r0, r1, out)
         if phases:
@@ -528,6 +543,7 @@ def _level_forward(ctx, need, x, H, Fo, skip, pack, graph: CSRGraph, alpha: floa
         ctx.save_for_backward(x, Wcat, a_pad, Wh, s, Sk, out if concat else hattn, m, Z, aneg, qneg)
         ctx.graph, ctx.L, ctx.alpha, ctx.concat, ctx.flags = graph, L, float(alpha), concat, flags
         ctx.user_row = user_row
+        ctx.tail = tail
         ctx.xs = xs
         ctx.flavour = flavour
         ctx.bwd_heads = None
@@ -561,10 +577,13 @@ def _level_backward(ctx, G):
         rowlocal = ctx.flavour == "rowlocal"
         # heads per window: the level's choice for all its heads, or the library default for the range a ranged backward covers
         hgw = lib.pygat_head_group(L.N, Hb, Fo) if (ranged and BWD_WINDOW_FLOATS is None) else (min(L.hg, Hb) if not ranged else head_group(L.N, Hb, Fo))
+        # (symmetric pattern with a self-loop-only tail in internal order: the column pass and its fold run on the slot prefix)
+        tail = getattr(ctx, "tail", None)
+        gT = graph.bwd.ref(L.ts) if tail is None else tail[1]
         # da along with the column pass (no separate stream over Wh, ds, dt), when the pass can and the table is large
         da_part = None
         if DA_IN_K4 and not ranged and ctx.flavour != "rowsum" and ctx.need[2] and L.N * L.R * 4 >= DA_MIN_BYTES:
-            nb = lib.pygat_gat_backward_col_da_bytes(graph.bwd.ref(L.ts), H, Fo, hgw)
+            nb = lib.pygat_gat_backward_col_da_bytes(gT, H, Fo, hgw)
             if nb:
                 da_part = torch.empty(nb // 4, dtype=f32, device=dev)
         with _span("k3a_prepare"):
@@ -576,10 +595,13 @@ def _level_backward(ctx, G):
         two_gather = ctx.flavour == "two-gather"
         if rowlocal:        # ds is known: the column pass finishes dWh on its own
             with _span("k4_backward_col"):
-                check(lib.pygat_gat_backward_col(graph.bwd.ref(L.ts), None, H, Fo, ctx.alpha, Wh.data_ptr(),
+                check(lib.pygat_gat_backward_col(gT, None, H, Fo, ctx.alpha, Wh.data_ptr(),
                                                  a_pad.data_ptr(), GR.data_ptr(), None, ds.data_ptr(),
                                                  dWh.data_ptr(), dt.data_ptr(), None, part.data_ptr(), _ptr(da_part), hb, hr, hgw, st),
                       "gat_backward_col")
+                if tail is not None:     # the self-loop-only rows: dWh_j = Gp_j, dt_j = 0 (csrc/k12_tail.hip)
+                    check(lib.pygat_gat_backward_col_tail(tail[0], L.N - tail[0], H, Fo, GR.data_ptr(), dWh.data_ptr(), dt.data_ptr(), st),
+                          "gat_backward_col_tail")
         elif two_gather:
             with _span("k3b_row"):
                 check(lib.pygat_gat_backward_row(graph.fwd.ref(L.ts), H, Fo, ctx.alpha, Wh.data_ptr(),
@@ -620,7 +642,7 @@ def _level_backward(ctx, G):
             side.wait_stream(main)      # the tensors it touches stay referenced until the join below
         if da_part is not None:      # the column pass left one record per work-group: fold them (and the cut rows) in a fixed order
             with _span("k5_afold"):
-                check(lib.pygat_a_grad_fold(graph.bwd.ref(L.ts), H, Fo, Wh.data_ptr(), ds.data_ptr(), dt.data_ptr(),
+                check(lib.pygat_a_grad_fold(gT, H, Fo, Wh.data_ptr(), ds.data_ptr(), dt.data_ptr(),
                                             da_part.data_ptr(), da.data_ptr(), ws.data_ptr(), hgw,
                                             side.cuda_stream if fork else st), "a_grad_fold")
         else:

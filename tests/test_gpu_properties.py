@@ -106,7 +106,9 @@ def test_headline_kernels_keep_their_register_footprint():
 @pytest.mark.parametrize("cfg", [dict(N=5000, H=8, Fo=16, Fin=128, skip=False, concat=True, sym=True),      # the headline shape
                                  dict(N=3000, H=4, Fo=64, Fin=40, skip=True, concat=True, sym=True),        # skip rows ride in internal order
                                  dict(N=2000, H=1, Fo=7, Fin=33, skip=True, concat=False, sym=True),        # one head, mean: K2 writes `out` itself
-                                 dict(N=2500, H=3, Fo=8, Fin=20, skip=False, concat=True, sym=False)])      # asymmetric pattern: own transpose
+                                 dict(N=2500, H=3, Fo=8, Fin=20, skip=False, concat=True, sym=False),       # asymmetric pattern: own transpose
+                                 dict(N=6000, H=8, Fo=16, Fin=64, skip=False, concat=True, sym=True, iso=0.5),   # half the nodes self-loop-only: the tail streams
+                                 dict(N=4000, H=2, Fo=5, Fin=24, skip=True, concat=True, sym=True, iso=0.3)])    # ... with skip rows and padded heads
 def test_internal_degree_order_is_invisible(cfg, monkeypatch):
     """ops.RENUMBER (round 5): a first level may run on the graph renumbered by descending degree, x permuted once, `out` written
     and G / the saved output read at the caller's rows inside K2 / K3a.  Forced here on small graphs: equal to the caller-order run
@@ -116,7 +118,20 @@ def test_internal_degree_order_is_invisible(cfg, monkeypatch):
     import parity
     dev = torch.device("cuda", 0)
     N, H, Fo, Fin = cfg["N"], cfg["H"], cfg["Fo"], cfg["Fin"]
-    rowptr, col = O.random_symmetric_csr(N, 6, 29, hub=(4, min(N - 1, 1200)))
+    iso = cfg.get("iso", 0.0)
+    if iso:      # a connected part + nodes with nothing but their self loop (55 % of the R-MAT workload), ids shuffled
+        n0 = int(N * (1 - iso))
+        rp0, c0 = O.random_symmetric_csr(n0, 6, 29, hub=(4, min(n0 - 1, 1200)))
+        rp0, c0 = np.asarray(rp0, dtype=np.int64), np.asarray(c0, dtype=np.int64)
+        relabel = np.random.default_rng(30).permutation(N)            # node v of the construction -> caller's id
+        rows = np.concatenate([np.repeat(np.arange(n0), np.diff(rp0)), np.arange(n0, N)])
+        cols = np.concatenate([c0, np.arange(n0, N)])
+        r2, c2 = relabel[rows], relabel[cols]
+        o = np.lexsort((c2, r2))
+        rowptr = np.concatenate([[0], np.cumsum(np.bincount(r2, minlength=N))]).astype(np.int32)
+        col = c2[o].astype(np.int32)
+    else:
+        rowptr, col = O.random_symmetric_csr(N, 6, 29, hub=(4, min(N - 1, 1200)))
     rowptr, col = np.asarray(rowptr), np.asarray(col)
     if not cfg["sym"]:       # drop every third off-diagonal edge: an asymmetric pattern (self loops kept)
         rows = np.repeat(np.arange(N), np.diff(rowptr))
@@ -139,6 +154,9 @@ def test_internal_degree_order_is_invisible(cfg, monkeypatch):
         out = pg.GATLevelFn.apply(xd, ps[0], ps[1], ps[2], graph, 0.2, cfg["concat"])
         out.backward(G.float().to(dev))
         used = graph._ordered is not None
+        if used and iso:     # ... and the self-loop-only tail went through its own streams
+            tails = [v for k_, v in graph._ordered[0].fwd._alt.items() if isinstance(k_, tuple) and k_[0] == "tail"]
+            assert tails and tails[0] is not None and N - tails[0][0] >= 0.9 * iso * N
         return out.detach().cpu(), [None if p is None else p.grad.cpu() for p in ps], used
     o0, g0, used0 = run(False)
     o1, g1, used1 = run(True)

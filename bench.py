@@ -551,6 +551,15 @@ def main():
         Fp = pg.padded_width(Fo)
         Rf, Hf = k2_heads * Fp, k2_heads            # forward kernels
         Rb, Hb = h_loc * Fp, h_loc                  # backward kernels
+        # rows K3a prepares: all of them, or -- internal degree order with the self-loop-only tail streamed by itself and no skip
+        # projection (pygat_amd/ops.py TAIL; csrc/k12_tail.hip) -- the rows before the tail: the tail's Gp never goes through GR
+        n_k3a, tail_rows = N, 0
+        renumbered = ops.RENUMBER and world == 1 and not args.dx and N * h_loc * Fp * 4 >= ops.RENUMBER_MIN_BYTES
+        if renumbered and ops.TAIL and graph.symmetric:
+            from pygat_amd.graph import slot_edges_for
+            t = graph.degree_ordered()[0].fwd.self_loop_tail(slot_edges_for(h_loc * Fp, graph.slot_edges))
+            if t is not None and N - t[0] >= ops.TAIL_MIN_SHARE * N:
+                n_k3a, tail_rows = t[0], N - t[0]
         # SURVEY.md 8(d) byte / flop models
         model = {
             "k1_project": ("mfma", 2.0 * N * Fin * (Rf + 2 * Hf)),
@@ -558,7 +567,7 @@ def main():
             # (SURVEY 8(d) predates the row-local backward: K3a also reads the forward's alpha-branch share `aneg` [N, R] for the
             # rows with logits on both sides of the LeakyReLU kink -- 44 % of the rows at config 5, 0.24 GB -- which is the whole of
             # its PMC traffic above this model: 2.15 GB measured = 1.85 + 0.24 + qneg; nothing is read twice)
-            "k3a_prepare": ("hbm", N * (12 * Rb + 28 * Hb)),
+            "k3a_prepare": ("hbm", n_k3a * (12 * Rb + 28 * Hb)),
             "k3b_row": ("hbm", E * (4 + 4 * Rb + 8 * Hb) + N * (4 + 8 * Rb + 16 * Hb) - N * (12 * Rb + 28 * Hb)),
             "k4_backward_col": ("hbm", E * (8 + 4 * Rb + 8 * Hb) + N * (4 + 8 * Rb + 8 * Hb)),
             "k3c_rowsum": ("hbm", E * (12 + 4 * Hb) + N * 4 * Hb),
@@ -645,8 +654,10 @@ def main():
                        "gemm_products": pg.get_gemm_mode(),
                        "node_order": ("internal degree order (x permuted once per feature tensor and cached; out / G / saved output "
                                       "addressed at the caller's rows inside K2 / K3a; no permutation pass in the step)"
-                                      if (ops.RENUMBER and world == 1 and N * h_loc * pg.padded_width(Fo) * 4 >= ops.RENUMBER_MIN_BYTES
-                                          and not args.dx) else "caller's"),
+                                      + (f"; the {tail_rows} self-loop-only nodes (alpha_ii = 1 exactly) as a contiguous tail through two "
+                                         f"plain streams inside the k2_forward / k4_backward_col spans, K3a on the {n_k3a} rows before them"
+                                         if tail_rows else "")
+                                      if renumbered else "caller's"),
                        "launch": "HIP-graph replay (pygat_amd.GraphedLevel)" if (args.hip_graph and not replicate)
                        else "stream launches (pygat_amd.GATLevelFn)"},
             "roofline": roof,

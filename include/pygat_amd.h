@@ -408,6 +408,11 @@ int pygat_wgrad_blocked(int n, int Fin, int H, int Fo, const float* X, int64_t l
 int pygat_gat_forward_tail(int row_first, int n_rows, int H, int Fo, int flags, const float* Wh, const float* sk,
                            float* out, const int32_t* user_row, float* m, float* Z, float* qneg, void* stream);
 int pygat_gat_backward_col_tail(int row_first, int n_rows, int H, int Fo, const float* GR, float* dWh, float* dt, void* stream);
+/* The tail's whole backward in one stream, for levels WITHOUT a skip projection (nothing else reads the tail's Gp): dWh_j =
+ * G_u ELU'(out_u) with u = user_row[j], ds_j = dt_j = 0 (ds may be NULL); pygat_gat_backward_prepare is then called with
+ * n = row_first (the rows before the tail) and the tail's rows of GR stay untouched.  Concat levels (y = the saved output). */
+int pygat_gat_backward_tail(int row_first, int n_rows, int H, int Fo, int flags, const float* G, const float* y,
+                            const int32_t* user_row, float* dWh, float* ds, float* dt, void* stream);
 
 /* ------------------------------------------------ GATv2 (next row of the scope table)
  * The reference's SpGraphAttentionLayerV2 (layers.py:258-313): per head

@@ -36,7 +36,7 @@ SYMBOLS = [
     "pygat_exclusive_scan_i32", "pygat_dense_fill_cols", "pygat_csr_symmetric_perm",
     "pygat_gemm_workspace_bytes", "pygat_gemm_f32", "pygat_gemm_f32_blocked", "pygat_project_blocked", "pygat_wgrad_blocked", "pygat_pack_params", "pygat_pack_params_heads", "pygat_stack_heads", "pygat_stack_heads_padded", "pygat_project", "pygat_attn_scores",
     "pygat_unpack_wgrad",
-    "pygat_edge_pairs", "pygat_slot_bounds", "pygat_slot_meta", "pygat_partials_bytes", "pygat_head_group", "pygat_gat_forward", "pygat_gat_forward_phases_ok", "pygat_gat_forward_tail", "pygat_gat_backward_col_tail", "pygat_head_mean",
+    "pygat_edge_pairs", "pygat_slot_bounds", "pygat_slot_meta", "pygat_partials_bytes", "pygat_head_group", "pygat_gat_forward", "pygat_gat_forward_phases_ok", "pygat_gat_forward_tail", "pygat_gat_backward_col_tail", "pygat_gat_backward_tail", "pygat_head_mean",
     "pygat_gat_backward_prepare", "pygat_gat_backward_row", "pygat_gat_backward_col", "pygat_gat_backward_rowsum",
     "pygat_gat_backward_col_da_bytes", "pygat_a_grad_fold",
     "pygat_agrad_workspace_bytes", "pygat_a_grad", "pygat_wgrad_workspace_bytes", "pygat_wgrad",
@@ -119,6 +119,7 @@ def _load():
     lib.pygat_gat_forward_phases_ok.argtypes = [i, i, i]
     lib.pygat_gat_forward_tail.argtypes = [i, i, i, i, i, p, p, p, p, p, p, p, p]
     lib.pygat_gat_backward_col_tail.argtypes = [i, i, i, i, p, p, p, p]
+    lib.pygat_gat_backward_tail.argtypes = [i, i, i, i, i, p, p, p, p, p, p, p]
     lib.pygat_head_mean.argtypes = [i, i, i, p, p, p, p]
     lib.pygat_gat_backward_prepare.argtypes = [i, i, i, i, i, p, p, p, p, p, p, p, p, p, f, p, i, i, i, p, p]
     lib.pygat_gat_backward_row.argtypes = [C.POINTER(Graph), i, i, f, p, p, p, p, p, p, i, i, i, p]

@@ -54,6 +54,38 @@ __global__ __launch_bounds__(256) void col_tail_kernel(int row_first, int n_rows
   if (co % Fp == 0) dt[j * H + co / Fp] = 0.f;
 }
 
+// The whole backward of the tail in one stream (levels without a skip projection, whose weight gradient is the only other reader
+// of Gp): dWh_j = Gp_j = G_u ELU'(out_u) straight from the caller's rows u = user_row[j] -- the tail's rows of GR are neither
+// written (pygat_gat_backward_prepare runs on the rows before the tail) nor read.  ELU' is recovered from the output exactly as
+// K3a does (out > 0 ? 1 : out + 1).
+__global__ __launch_bounds__(256) void bwd_tail_kernel(int row_first, int n_rows, int H, int Fo, int Fp, int flags,
+                                                      const float* __restrict__ G, const float* __restrict__ y,
+                                                      const int32_t* __restrict__ urow, float* __restrict__ dWh,
+                                                      float* __restrict__ ds, float* __restrict__ dt) {
+  const int R4 = H * Fp / 4;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)n_rows * R4) return;
+  const int64_t j = row_first + idx / R4;
+  const int co = 4 * (int)(idx % R4), h = co / Fp, f0 = co % Fp;
+  const int64_t ju = urow ? (int64_t)urow[j] : j;
+  float g[4] = {0.f, 0.f, 0.f, 0.f}, o[4] = {1.f, 1.f, 1.f, 1.f};
+  if (Fo == Fp) {
+    const float4 g4 = ld4(G + ju * (int64_t)(H * Fo) + co), y4 = ld4(y + ju * (int64_t)(H * Fo) + co);
+    g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w; o[0] = y4.x; o[1] = y4.y; o[2] = y4.z; o[3] = y4.w;
+  } else {
+    const int64_t b = ju * (int64_t)(H * Fo) + (int64_t)h * Fo + f0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (f0 + q < Fo) { g[q] = G[b + q]; o[q] = y[b + q]; }
+  }
+  if (flags & PYGAT_F_ELU) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) g[q] *= o[q] > 0.f ? 1.f : o[q] + 1.f;
+  }
+  st4(dWh + j * (int64_t)(H * Fp) + co, make_float4(g[0], g[1], g[2], g[3]));
+  if (f0 == 0) { dt[j * H + h] = 0.f; if (ds) ds[j * H + h] = 0.f; }
+}
+
 }  // namespace pygat
 
 using namespace pygat;
@@ -81,5 +113,17 @@ extern "C" int pygat_gat_backward_col_tail(int row_first, int n_rows, int H, int
   hipLaunchKernelGGL(col_tail_kernel, dim3((unsigned)cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, row_first, n_rows, H, Fp, GR,
                      (int64_t)H * Fp + 4 * H, dWh, dt);
   PYGAT_CHECK_LAUNCH("gat_backward_col_tail");
+  return PYGAT_OK;
+}
+
+extern "C" int pygat_gat_backward_tail(int row_first, int n_rows, int H, int Fo, int flags, const float* G, const float* y,
+                                       const int32_t* user_row, float* dWh, float* ds, float* dt, void* stream) {
+  const int Fp = padded_width(Fo);
+  PYGAT_REQUIRE(row_first >= 0 && n_rows > 0 && H > 0 && Fp > 0 && G && y && dWh && dt, "gat_backward_tail: bad arguments");
+  PYGAT_REQUIRE(aligned16(dWh) && (Fo != Fp || (aligned16(G) && aligned16(y))), "gat_backward_tail: row tables must be 16-byte aligned");
+  const int64_t items = (int64_t)n_rows * (H * Fp / 4);
+  hipLaunchKernelGGL(bwd_tail_kernel, dim3((unsigned)cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, row_first, n_rows, H, Fo, Fp,
+                     flags & PYGAT_F_ELU, G, y, user_row, dWh, ds, dt);
+  PYGAT_CHECK_LAUNCH("gat_backward_tail");
   return PYGAT_OK;
 }

@@ -586,8 +586,11 @@ def _level_backward(ctx, G):
             nb = lib.pygat_gat_backward_col_da_bytes(gT, H, Fo, hgw)
             if nb:
                 da_part = torch.empty(nb // 4, dtype=f32, device=dev)
+        # no skip projection: nothing but the column pass reads the tail's Gp -- its whole backward is one stream from G / out
+        # (pygat_gat_backward_tail) and K3a runs on the rows before it
+        fused_tail = tail is not None and not L.skip
         with _span("k3a_prepare"):
-            check(lib.pygat_gat_backward_prepare(L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(),
+            check(lib.pygat_gat_backward_prepare(tail[0] if fused_tail else L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(),
                                                  y.data_ptr(), _ptr(Sk), s.data_ptr(), m.data_ptr(), Z.data_ptr(),
                                                  GR.data_ptr(), _ptr(aneg), _ptr(qneg), ctx.alpha,
                                                  ds.data_ptr() if rowlocal else None, hb, hr, hgw, _ptr(getattr(ctx, "user_row", None)), st),
@@ -599,7 +602,11 @@ def _level_backward(ctx, G):
                                                  a_pad.data_ptr(), GR.data_ptr(), None, ds.data_ptr(),
                                                  dWh.data_ptr(), dt.data_ptr(), None, part.data_ptr(), _ptr(da_part), hb, hr, hgw, st),
                       "gat_backward_col")
-                if tail is not None:     # the self-loop-only rows: dWh_j = Gp_j, dt_j = 0 (csrc/k12_tail.hip)
+                if fused_tail:           # the self-loop-only rows: dWh_j = G_u ELU'(out_u), ds_j = dt_j = 0 (csrc/k12_tail.hip)
+                    check(lib.pygat_gat_backward_tail(tail[0], L.N - tail[0], H, Fo, ctx.flags, G.data_ptr(), y.data_ptr(),
+                                                      _ptr(getattr(ctx, "user_row", None)), dWh.data_ptr(), ds.data_ptr(), dt.data_ptr(), st),
+                          "gat_backward_tail")
+                elif tail is not None:   # ... with a skip projection (its weight gradient reads every row's Gp): dWh_j = Gp_j, dt_j = 0
                     check(lib.pygat_gat_backward_col_tail(tail[0], L.N - tail[0], H, Fo, GR.data_ptr(), dWh.data_ptr(), dt.data_ptr(), st),
                           "gat_backward_col_tail")
         elif two_gather:

@@ -554,12 +554,13 @@ def main():
         # rows K3a prepares: all of them, or -- internal degree order with the self-loop-only tail streamed by itself and no skip
         # projection (pygat_amd/ops.py TAIL; csrc/k12_tail.hip) -- the rows before the tail: the tail's Gp never goes through GR
         n_k3a, tail_rows = N, 0
-        renumbered = ops.RENUMBER and world == 1 and not args.dx and N * h_loc * Fp * 4 >= ops.RENUMBER_MIN_BYTES
-        if renumbered and ops.TAIL and graph.symmetric:
+        tbytes = N * h_loc * Fp * 4
+        renumbered = ops.RENUMBER and world == 1 and not args.dx and tbytes >= ops.RENUMBER_MIN_BYTES
+        if ops.RENUMBER and world == 1 and not args.dx and ops.TAIL and graph.symmetric and tbytes >= ops.RENUMBER_MIN_BYTES_TAIL:
             from pygat_amd.graph import slot_edges_for
             t = graph.degree_ordered()[0].fwd.self_loop_tail(slot_edges_for(h_loc * Fp, graph.slot_edges))
             if t is not None and N - t[0] >= ops.TAIL_MIN_SHARE * N:
-                n_k3a, tail_rows = t[0], N - t[0]
+                n_k3a, tail_rows, renumbered = t[0], N - t[0], True
         # SURVEY.md 8(d) byte / flop models
         model = {
             "k1_project": ("mfma", 2.0 * N * Fin * (Rf + 2 * Hf)),

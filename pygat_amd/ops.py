@@ -105,8 +105,12 @@ DA_MIN_BYTES = 32 << 20
 # Measured on the headline graph (same run, bench.py `alt_node_order`): 8 heads x 16 (512 MB table) 3.16 -> 3.06 ms (K2 0.98 -> 0.95,
 # K4 1.24 -> 1.17, K3a 0.37 -> 0.40: its G / y rows are now gathers); 4 heads (256 MB) 1.90 -> 1.84; 2 heads (128 MB) 1.114 -> 1.111;
 # 1 head (64 MB) 0.860 -> 0.887 -- narrow rows lose: K3a's gathers cost what K2 / K4 gain.  Hence the threshold.
+# With the self-loop-only tail streamed by itself (TAIL below) every width gains on that graph: one head 0.853 -> 0.816 ms, two
+# 1.107 -> 1.036, four 1.949 -> 1.751, eight 3.10 -> 2.77 (8 x 8: 1.96 -> 1.77, 8 x 64: 12.76 -> 12.34).  So: tables of
+# RENUMBER_MIN_BYTES and more always, tables from RENUMBER_MIN_BYTES_TAIL when the graph has such a tail.
 RENUMBER = _config.renumber
 RENUMBER_MIN_BYTES = 160 << 20
+RENUMBER_MIN_BYTES_TAIL = 48 << 20
 # In internal order the self-loop-only nodes (alpha_ii = 1: forward = ELU(Wh_i), backward dWh_i = Gp_i) are a contiguous tail of
 # the rows and a suffix of the slots: the fused kernels run on the slot prefix, two plain streams take the tail
 # (csrc/k12_tail.hip).  Symmetric patterns, concat levels, the row-local backward in one head window, tails of TAIL_MIN_SHARE of
@@ -439,10 +443,14 @@ def _level_forward(ctx, need, x, H, Fo, skip, pack, graph: CSRGraph, alpha: floa
     tail = None      # (first tail row, pygat_graph* of the slot prefix) when the self-loop-only tail goes through its own streams
     single_out = (not concat) and H == 1
     if (RENUMBER and not need[0] and xs is None and pipeline is None and x.dim() == 2 and (concat or single_out)
-            and graph.user_row is None and L.N * L.R * 4 >= RENUMBER_MIN_BYTES):
+            and graph.user_row is None and L.N * L.R * 4 >= min(RENUMBER_MIN_BYTES, RENUMBER_MIN_BYTES_TAIL)):
         from .features import permuted_rows
         g_int, to_user, _ = graph.degree_ordered()
-        xp = permuted_rows(x, to_user)
+        worth = L.N * L.R * 4 >= RENUMBER_MIN_BYTES
+        if not worth and TAIL and concat and graph.symmetric:     # a narrower table: only with a self-loop-only tail to stream
+            t = g_int.fwd.self_loop_tail(slot_edges_for(L.R, g_int.slot_edges))
+            worth = t is not None and L.N - t[0] >= TAIL_MIN_SHARE * L.N
+        xp = permuted_rows(x, to_user) if worth else None
         if xp is not None:
             x, graph, user_row = xp, g_int, to_user
     L.ts = slot_edges_for(L.R, graph.slot_edges)

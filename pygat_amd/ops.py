@@ -443,7 +443,8 @@ def _level_forward(ctx, need, x, H, Fo, skip, pack, graph: CSRGraph, alpha: floa
     tail = None      # (first tail row, pygat_graph* of the slot prefix) when the self-loop-only tail goes through its own streams
     single_out = (not concat) and H == 1
     if (RENUMBER and not need[0] and xs is None and pipeline is None and x.dim() == 2 and (concat or single_out)
-            and graph.user_row is None and L.N * L.R * 4 >= min(RENUMBER_MIN_BYTES, RENUMBER_MIN_BYTES_TAIL)):
+            and graph.user_row is None and L.N * L.R * 4 >= min(RENUMBER_MIN_BYTES, RENUMBER_MIN_BYTES_TAIL)
+            and not torch.cuda.is_current_stream_capturing()):     # (a captured graph would bake this epoch's permuted copy of x in)
         from .features import permuted_rows
         g_int, to_user, _ = graph.degree_ordered()
         worth = L.N * L.R * 4 >= RENUMBER_MIN_BYTES

@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--no-dense-cpu", action="store_true", help="skip the dense-formulation CPU figure inside the cpu_baseline leg (~15 s)")
     ap.add_argument("--no-epoch", action="store_true", help="skip the Cora / Pubmed epoch_ms leg")
     ap.add_argument("--no-v2", action="store_true", help="skip the GATv2 level leg")
+    ap.add_argument("--no-alt", action="store_true", help="skip the two `alt` legs (fp32-MFMA GEMMs; caller's node order): a profiler run "
+                                                          "of the headline mode alone, whose per-kernel averages then mix no other mode in")
     ap.add_argument("--cpu-steps", type=int, default=5, help="timed steps of the cpu_baseline leg (>= 1; its value is their median)")
     ap.add_argument("--verify", action="store_true", help="check the gathered sharded output against the unsharded level")
     ap.add_argument("--forward-exchange", choices=["allgather", "replicate"], default="allgather",
@@ -469,7 +471,7 @@ def main():
     # ---- the same K steps with the two streamed GEMMs on the fp32 MFMA pipe (the gemm_mode argument of the C ABI): reported beside
     # the headline so that the effect of the split-bf16 products is on record in every run.  Single GPU, stream launches.
     alt = None
-    if world == 1 and pg.get_gemm_mode() == "split-bf16" and not (args.hip_graph and not replicate):
+    if world == 1 and pg.get_gemm_mode() == "split-bf16" and not (args.hip_graph and not replicate) and not args.no_alt:
         try:
             pg.set_gemm_mode("fp32-mfma")
             for _ in range(max(2, args.warmup)):
@@ -490,7 +492,7 @@ def main():
     # tables in an internal degree order (x permuted once per feature tensor, outputs / gradients at the caller's rows through a
     # map inside the kernels: pygat_amd/ops.py); the line reports what that layout choice is worth.
     alt_order = None
-    if world == 1 and not (args.hip_graph and not replicate) and ops.RENUMBER:
+    if world == 1 and not (args.hip_graph and not replicate) and ops.RENUMBER and not args.no_alt:
         try:
             ops.RENUMBER = False
             for _ in range(max(2, args.warmup)):

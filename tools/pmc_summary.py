@@ -81,10 +81,10 @@ def main():
     spans = {   # bench.py span -> kernel name prefixes (pygat_amd/ops.py)
         # (bench.py also runs its `alt` pass -- the fp32-MFMA kernels -- under the profiler: the default mode's kernels only)
         "k1_project": ("pygat::gemm_smallk_x3_kernel", "pygat::gemm_rowtile_x3_kernel"),
-        "k2_forward": ("pygat::gat_fwd_",),
+        "k2_forward": ("pygat::gat_fwd_", "pygat::fwd_tail_kernel"),
         "k3a_prepare": ("pygat::gat_bwd_prepare",),
         "k3b_row": ("pygat::gat_bwd_row_kernel",),
-        "k4_backward_col": ("pygat::gat_bwd_col_",),
+        "k4_backward_col": ("pygat::gat_bwd_col_", "pygat::bwd_tail_kernel", "pygat::col_tail_kernel"),
         "k3c_rowsum": ("pygat::gat_bwd_rowsum_kernel",),
         "k5_agrad": ("pygat::a_grad_partial", "pygat::a_grad_final"),
         "k5_afold": ("pygat::a_grad_fold", "pygat::a_grad_final"),

@@ -9,13 +9,13 @@ export TMPDIR=/tmp
 prof() { (cd /tmp && timeout -k 10 300 rocprofv3 "$@"); }
 if [ "$PART" = all ] || [ "$PART" = a ]; then
   python3 bench.py > $O/bench.json 2> $O/bench.err; cp $O/bench.json $P/${TAG}_bench.json
-  prof --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu --no-epoch --no-v2 > $O/bench_under_rocprof.json 2> $O/stats.err
+  prof --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu --no-epoch --no-v2 --no-alt > $O/bench_under_rocprof.json 2> $O/stats.err
   python3 tools/rocprof_top.py $O/stats --top 14 --csv $P/${TAG}_kernel_stats.csv > $O/kernel_top.txt 2>&1; cp $O/bench_under_rocprof.json $P/${TAG}_bench_under_rocprof.json; rm -rf $O/stats
-  prof --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --no-cpu --no-epoch --no-v2 --steps 5 --warmup 2 > $O/pmc_fetch.log 2>&1
-  prof --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/write -- python3 $R/bench.py --no-cpu --no-epoch --no-v2 --steps 5 --warmup 2 > $O/pmc_write.log 2>&1
+  prof --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --no-cpu --no-epoch --no-v2 --no-alt --steps 5 --warmup 2 > $O/pmc_fetch.log 2>&1
+  prof --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/write -- python3 $R/bench.py --no-cpu --no-epoch --no-v2 --no-alt --steps 5 --warmup 2 > $O/pmc_write.log 2>&1
   python3 tools/pmc_summary.py $O/fetch $O/write --out $P/${TAG}_pmc_bench.json > $O/pmc_summary.log 2>&1; rm -rf $O/fetch $O/write
-  prof --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/sq1 -- python3 $R/bench.py --no-cpu --no-epoch --no-v2 --steps 4 --warmup 2 > $O/sq1.log 2>&1
-  prof --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/sq2 -- python3 $R/bench.py --no-cpu --no-epoch --no-v2 --steps 4 --warmup 2 > $O/sq2.log 2>&1
+  prof --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/sq1 -- python3 $R/bench.py --no-cpu --no-epoch --no-v2 --no-alt --steps 4 --warmup 2 > $O/sq1.log 2>&1
+  prof --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/sq2 -- python3 $R/bench.py --no-cpu --no-epoch --no-v2 --no-alt --steps 4 --warmup 2 > $O/sq2.log 2>&1
   python3 tools/sq_summary.py $O/sq1 $O/sq2 --out $P/${TAG}_sq_counters.json > $O/sq_summary.log 2>&1; rm -rf $O/sq1 $O/sq2
   for n in 8 4 2; do python3 bench.py --as-rank-of $n --no-cpu --no-epoch --no-v2 --steps 20 2> $O/rank$n.err; done > $P/${TAG}_as_rank_of.jsonl
   # the shard of an 8-GPU run at wider heads: rank-0 work against the 1-GPU step of the same F'
@@ -51,8 +51,8 @@ if [ "$PART" = all ] || [ "$PART" = c ]; then
 fi
 if [ "$PART" = all ] || [ "$PART" = p ]; then
   # PMC traffic of the headline command alone (separate passes, no other tracing), and the promoted replay file
-  prof --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --no-cpu --no-epoch --no-v2 --steps 5 --warmup 2 > $O/pmc_fetch.log 2>&1
-  prof --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/write -- python3 $R/bench.py --no-cpu --no-epoch --no-v2 --steps 5 --warmup 2 > $O/pmc_write.log 2>&1
+  prof --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --no-cpu --no-epoch --no-v2 --no-alt --steps 5 --warmup 2 > $O/pmc_fetch.log 2>&1
+  prof --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/write -- python3 $R/bench.py --no-cpu --no-epoch --no-v2 --no-alt --steps 5 --warmup 2 > $O/pmc_write.log 2>&1
   python3 tools/pmc_summary.py $O/fetch $O/write --out $P/${TAG}_pmc_bench.json > $O/pmc_summary.log 2>&1; rm -rf $O/fetch $O/write
 fi
 if [ "$PART" = all ] || [ "$PART" = d ]; then

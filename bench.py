@@ -418,8 +418,21 @@ def main():
     nchunks = max(1, args.chunks) if use_pg else 0
     works = []
     full_out = None
+    to_int = None
     if use_pg:
         from pygat_amd import dist as pgdist
+        if ops.RENUMBER and not args.dx:
+            # a head-parallel MODEL runs in its graph's internal node order (pygat_amd.GAT: x permuted once, every level and every
+            # exchange in that order -- all ranks hold the same one --, only the final [N, C] logits put back): the level of this
+            # step is fed the way such a model feeds it, and the exchanged activation stays in internal order, as the next level
+            # would read it.  (--verify compares it, un-permuted, with the unsharded level in the caller's order.)
+            view = graph.internal_view()
+            to_int = view.to_internal.long()
+            X_run = X.index_select(0, view.to_user.long()).contiguous()
+            G_run = G_loc.index_select(0, view.to_user.long()).contiguous()
+            graph_run = view
+        else:
+            X_run, G_run, graph_run = Xb, G_loc, graph
         w_loc = h_loc * Fo
         if any(b - a != h_loc for a, b in parts) or not pgdist.blocked_width_ok(w_loc):
             raise SystemExit(f"bench: {H} heads x {Fo} over {world} ranks: the exchange needs equal shards of a power-of-two width >= 16 "
@@ -435,8 +448,8 @@ def main():
             W_loc.grad = a_loc.grad = None
             if args.dx:
                 Xb.grad = None
-            out = pg.GATLevelFn.apply(Xb, W_loc, a_loc, None, graph, 0.2, True, None, (nchunks, on_chunk, full_out[rank]))
-            out.backward(G_loc)
+            out = pg.GATLevelFn.apply(X_run, W_loc, a_loc, None, graph_run, 0.2, True, None, (nchunks, on_chunk, full_out[rank]))
+            out.backward(G_run)
             for wk in works:            # the step ends when every peer's rows have arrived
                 wk.wait()
             return full_out
@@ -543,6 +556,8 @@ def main():
             got = full if (use_pg or replicate or model_world == 1) else None
             if got is not None and got.dim() == 3:          # column-blocked [world, N, w] -> [N, H F'] for the comparison only
                 got = got.permute(1, 0, 2).reshape(N, -1)
+                if to_int is not None:                       # ... and out of the internal node order
+                    got = got.index_select(0, to_int)
             if got is not None:
                 err = float((got - ref).abs().max())
                 print(f"bench --verify: max |sharded - unsharded| = {err:.3e} over {tuple(ref.shape)}", file=sys.stderr)

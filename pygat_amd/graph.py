@@ -104,6 +104,8 @@ class _Pattern:
                     order = torch.argsort(pieces, descending=True, stable=True)
                     cut = torch.stack([k, r_last[k], pieces], 1)[order].to(torch.int32).contiguous()
                     n_cut, n_wide = int(k.numel()), int((pieces > 32).sum().item())
+                else:     # no row is cut: an EMPTY list (non-NULL, n_cut = 0) -- the fix-up launches are skipped, not replaced by
+                    cut = torch.zeros(1, 3, dtype=torch.int32, device=self.rowptr.device)     # a screening pass over every slot
             # one 16-byte record per slot (first edge, end edge, first row, cut flags): the kernels' start-up in one load
             meta = torch.empty(-(-self.nnz // slot_edges), 4, dtype=torch.int32, device=self.rowptr.device)
             with torch.cuda.device(self.rowptr.device):
@@ -117,20 +119,23 @@ class _Pattern:
             self._alt[key] = (st, sb, cut, meta, order)
         return self._alt[key][0]
 
-    def row_chunks(self, nchunks: int, slot_edges: Optional[int] = None):
+    def row_chunks(self, nchunks: int, slot_edges: Optional[int] = None, nslots: Optional[int] = None, row_end: Optional[int] = None):
         """Cut the pattern into up to `nchunks` ranges of WHOLE rows with about equal numbers of slots, for pipelining a
         level by row chunks (pygat_amd/dist.py).  -> [(pygat_graph* for pygat_gat_forward, row_first, row_end)].
-        A chunk border is a slot border at which a row starts, so no row -- and no chain of partial records -- crosses it."""
+        A chunk border is a slot border at which a row starts, so no row -- and no chain of partial records -- crosses it.
+        nslots / row_end: cut only the slot PREFIX [0, nslots), which ends in front of row `row_end` (the slots before a
+        self-loop-only tail, self_loop_tail)."""
         ts = slot_edges or self.slot_edges
-        key = ("chunks", ts, nchunks)
+        key = ("chunks", ts, nchunks, nslots)
         if key not in self._alt:
             base = self._make(ts, True)
             _, sb, cut, meta, _order = self._alt[(ts, True)]
-            nslots = sb.numel() - 1
+            all_slots = sb.numel() - 1
+            nslots = all_slots if nslots is None else int(nslots)
             sbl, rp = sb.long(), self.rowptr.long()
             first_row = self.edge_rc[sbl[:-1], 0].long()                 # row of the first edge of every slot
             starts_row = rp[first_row] == sbl[:-1]
-            ok = torch.nonzero(starts_row).flatten()
+            ok = torch.nonzero(starts_row[:nslots]).flatten()
             borders = [0]
             for c in range(1, nchunks):
                 tgt = c * nslots // nchunks
@@ -141,7 +146,7 @@ class _Pattern:
             out, keep = [], []
             for b0, b1 in zip(borders[:-1], borders[1:]):
                 r0 = int(first_row[b0])
-                r1 = int(first_row[b1]) if b1 < nslots else self.n
+                r1 = int(first_row[b1]) if b1 < nslots else (self.n if (row_end is None or nslots == all_slots) else int(row_end))
                 sub, n_cut, n_wide = None, 0, 0
                 if cut is not None:
                     sel = (cut[:, 0] >= b0) & (cut[:, 0] < b1)
@@ -192,7 +197,61 @@ class _Pattern:
         return C.byref(self._make(slot_edges or self.slot_edges, snapped))
 
 
+class _UnmappedPattern:
+    """A degree-ordered _Pattern handed to kernels whose node arrays are THEMSELVES in internal order (a model that permutes its
+    input once and un-permutes its final output, CSRGraph.internal_view): the same device arrays, pygat_graph structs without
+    the user_row map."""
+
+    def __init__(self, base: "_Pattern"):
+        self._base = base
+        self._copies = {}
+        self.user_row = None
+
+    def __getattr__(self, name):               # rowptr, col, edge_rc, n, nnz, slot_edges, ...
+        return getattr(self._base, name)
+
+    def _strip(self, key, struct_ref):
+        if key not in self._copies:
+            st = _lib.Graph()
+            C.memmove(C.byref(st), struct_ref, C.sizeof(_lib.Graph))
+            st.user_row = None
+            self._copies[key] = st
+        return C.byref(self._copies[key])
+
+    def ref(self, slot_edges: Optional[int] = None, snapped: bool = True):
+        return self._strip(("ref", slot_edges or self._base.slot_edges, snapped), self._base.ref(slot_edges, snapped))
+
+    def row_chunks(self, nchunks: int, slot_edges: Optional[int] = None, nslots: Optional[int] = None, row_end: Optional[int] = None):
+        out = self._base.row_chunks(nchunks, slot_edges, nslots, row_end)
+        return [(self._strip(("chunk", slot_edges or self._base.slot_edges, nchunks, nslots, c), ref), r0, r1)
+                for c, (ref, r0, r1) in enumerate(out)]
+
+    def self_loop_tail(self, slot_edges: Optional[int] = None):
+        t = self._base.self_loop_tail(slot_edges)
+        return None if t is None else (t[0], t[1], self._strip(("tail", slot_edges or self._base.slot_edges), t[2]))
+
+
+class InternalOrderView:
+    """CSRGraph.internal_view(): the degree-ordered pattern for callers whose node arrays are in INTERNAL order themselves --
+    pygat_amd.GAT permutes x once (cached per feature tensor), runs every level of the model on this view (hidden levels too:
+    their input is the previous level's output, already internal) and un-permutes the final [N, C] output; a head-parallel
+    model exchanges internal-order rows, every rank holding the same order.  Duck-types CSRGraph for ops / dist."""
+    degree_sorted = True
+    user_row = None
+    _ordered = None
+
+    def __init__(self, g_int: "CSRGraph", to_user: torch.Tensor, to_internal: torch.Tensor):
+        self.base = g_int
+        self.n, self.nnz, self.device, self.slot_edges, self.symmetric = g_int.n, g_int.nnz, g_int.device, g_int.slot_edges, g_int.symmetric
+        self.fwd = _UnmappedPattern(g_int.fwd)
+        self.bwd = self.fwd if g_int.bwd is g_int.fwd else _UnmappedPattern(g_int.bwd)
+        self.perm_t, self.perm_f = g_int.perm_t, g_int.perm_f
+        self.to_user, self.to_internal = to_user, to_internal
+
+
 class CSRGraph:
+    degree_sorted = False      # True for the patterns CSRGraph.degree_ordered builds
+
     """Device-resident CSR pattern (+ transpose info) consumed by the HIP kernels."""
 
     def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, slot_edges: Optional[int] = None,
@@ -294,8 +353,16 @@ class CSRGraph:
             rp2[1:] = torch.cumsum(torch.bincount(r2, minlength=self.n), 0)
             urow = to_user.to(torch.int32).contiguous()
             g = CSRGraph(rp2.to(torch.int32), c2.to(torch.int32), self.slot_edges, validate=False, user_row=urow)
+            g.degree_sorted = True
             self._ordered = (g, urow, to_int.to(torch.int32).contiguous())
         return self._ordered
+
+    def internal_view(self) -> InternalOrderView:
+        """The degree-ordered pattern for node arrays that are themselves in internal order (see InternalOrderView)."""
+        g, to_user, to_int = self.degree_ordered()
+        if getattr(g, "_view", None) is None:
+            g._view = InternalOrderView(g, to_user, to_int)
+        return g._view
 
     # ------------------------------------------------------------------ builders
     @staticmethod

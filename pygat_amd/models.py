@@ -51,6 +51,17 @@ class GAT(nn.Module):
     def forward(self, x, adj):
         graph = adj if self.level_fn is not None else as_graph(adj, self.pattern_mode)
         p_drop = self.dropout if self.training else 0.0
+        # Large graphs (ops.RENUMBER): the whole model runs in the graph's INTERNAL node order (descending degree: CSRGraph.
+        # internal_view) -- x is permuted once (cached per feature tensor when it carries no gradient), every level reads the
+        # previous level's output as it lies (hidden levels too), the self-loop-only nodes go through their tail streams, a
+        # head-parallel model exchanges internal-order rows, and only the final [N, C] output is put back into the caller's order.
+        to_internal = None
+        if self._internal_order_pays(x, graph, p_drop):
+            from .features import permuted_rows
+            view = graph.internal_view()
+            xp = permuted_rows(x, view.to_user) if not x.requires_grad else x.index_select(0, view.to_user.long())
+            if xp is not None:
+                x, graph, to_internal = xp, view, view.to_internal
         for lvl, heads in enumerate(self.gat_layers):
             concat = lvl < len(self.gat_layers) - 1
             if self._kind == "other":   # e.g. GraphAttentionLayerV2: one head per call, as the reference does
@@ -79,7 +90,28 @@ class GAT(nn.Module):
                     x = gat_level_dropout(x, graph, Ws, As, Sk, self.alpha, concat, p_drop, xs=xs)
                 else:
                     x = gat_level(x, graph, Ws, As, Sk, self.alpha, concat, xs=xs)
+        if to_internal is not None:
+            x = x.index_select(0, to_internal.long())        # the final [N, C] output back in the caller's order (differentiable)
         return x
+
+    def _internal_order_pays(self, x, graph, p_drop) -> bool:
+        """Model-level internal node order: the v1 layers without dropout (the dropout path and GATv2 keep the caller's order), a
+        2-D GPU input, not under stream capture, more than one level (a single level renumbers itself inside ops._level_forward,
+        with the row maps in its kernels), and tables of ops.RENUMBER_MIN_BYTES(_TAIL) and more at the widest hidden level."""
+        from . import ops
+        if not (ops.RENUMBER and self.level_fn is None and self._kind == "v1" and p_drop == 0.0 and len(self.gat_layers) > 1
+                and isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 2 and hasattr(graph, "degree_ordered")
+                and not torch.cuda.is_current_stream_capturing()):
+            return False
+        widest = max(len(h) * ops.padded_width(h[0].W.shape[1]) for h in self.gat_layers[:-1])
+        nbytes = graph.n * widest * 4
+        if nbytes >= ops.RENUMBER_MIN_BYTES:
+            return True
+        if nbytes < ops.RENUMBER_MIN_BYTES_TAIL or not (ops.TAIL and graph.symmetric):
+            return False
+        from .graph import slot_edges_for
+        t = graph.degree_ordered()[0].fwd.self_loop_tail(slot_edges_for(widest, graph.slot_edges))
+        return t is not None and graph.n - t[0] >= ops.TAIL_MIN_SHARE * graph.n
 
     @torch.no_grad()
     def sync_head_parameters(self):

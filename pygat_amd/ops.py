@@ -443,7 +443,7 @@ def _level_forward(ctx, need, x, H, Fo, skip, pack, graph: CSRGraph, alpha: floa
     tail = None      # (first tail row, pygat_graph* of the slot prefix) when the self-loop-only tail goes through its own streams
     single_out = (not concat) and H == 1
     if (RENUMBER and not need[0] and xs is None and pipeline is None and x.dim() == 2 and (concat or single_out)
-            and graph.user_row is None and L.N * L.R * 4 >= min(RENUMBER_MIN_BYTES, RENUMBER_MIN_BYTES_TAIL)
+            and graph.user_row is None and not graph.degree_sorted and L.N * L.R * 4 >= min(RENUMBER_MIN_BYTES, RENUMBER_MIN_BYTES_TAIL)
             and not torch.cuda.is_current_stream_capturing()):     # (a captured graph would bake this epoch's permuted copy of x in)
         from .features import permuted_rows
         g_int, to_user, _ = graph.degree_ordered()
@@ -508,14 +508,17 @@ def _level_forward(ctx, need, x, H, Fo, skip, pack, graph: CSRGraph, alpha: floa
             out = torch.empty(L.N, H * Fo if concat else Fo, dtype=f32, device=dev)
         part = torch.empty(lib.pygat_partials_bytes(graph.nnz, L.ts, H, L.Fp) // 4, dtype=f32,
                            device=dev)
-        if (TAIL and user_row is not None and concat and graph.symmetric
+        # (a degree-ordered pattern: reached through the renumbering above -- user_row maps `out` / G to the caller's rows -- or
+        # handed in by a model that keeps ALL its node arrays in internal order, graph.InternalOrderView: no map)
+        if (TAIL and graph.degree_sorted and concat and graph.symmetric
                 and (not need_grad or (flavour == "rowlocal" and L.hg >= H and bwd_heads is None))):
             t = graph.fwd.self_loop_tail(L.ts)
             if t is not None and L.N - t[0] >= TAIL_MIN_SHARE * L.N:
-                tail = (t[0], t[2])
-        chunks = [(graph.fwd.ref(L.ts) if tail is None else tail[1], 0, L.N)]
+                tail = (t[0], t[2], t[1])
+        chunks = [(graph.fwd.ref(L.ts) if tail is None else tail[1], 0, L.N if tail is None else tail[0])]
         if pipeline is not None and concat and pipeline[0] > 1:
-            chunks = graph.fwd.row_chunks(int(pipeline[0]), L.ts)
+            chunks = (graph.fwd.row_chunks(int(pipeline[0]), L.ts) if tail is None
+                      else graph.fwd.row_chunks(int(pipeline[0]), L.ts, nslots=tail[2], row_end=tail[0]))
         # a pipelined level: chunk c's fix-up launch (a few thousand cut rows, latency-bound: 25-30 us at config 5) and the
         # caller's hand-off of the chunk run on a SIDE stream beside chunk c + 1's main launch (the partial records are per
         # slot: chunks share none) -- in line they cost the step ~70 us per chunk border
@@ -538,13 +541,17 @@ def _level_forward(ctx, need, x, H, Fo, skip, pack, graph: CSRGraph, alpha: floa
                 continue
             with _span("k2_forward"):
                 k2(gref, flags, st)
-                if tail is not None:     # (one chunk: the tail path is never pipelined) the self-loop-only rows: out = ELU(Wh (+ skip))
+                if tail is not None and c == len(chunks) - 1:     # the self-loop-only rows: out = ELU(Wh (+ skip)), one stream
                     check(lib.pygat_gat_forward_tail(tail[0], L.N - tail[0], H, Fo, flags, Wh.data_ptr(), _ptr(Sk), out.data_ptr(),
-                                                     user_row.data_ptr(), _ptr(m), _ptr(Z), _ptr(qneg), st), "gat_forward_tail")
+                                                     _ptr(user_row), _ptr(m), _ptr(Z), _ptr(qneg), st), "gat_forward_tail")
             if pipeline is not None and concat:
-                pipeline[1](c, r0, r1, out)
+                pipeline[1](c, r0, r1 if not (tail is not None and c == len(chunks) - 1) else L.N, out)
         if phases:
             main_s.wait_stream(side_s)
+            if tail is not None:       # (pipelined chunks: the tail is one more hand-off, after the last chunk's)
+                check(lib.pygat_gat_forward_tail(tail[0], L.N - tail[0], H, Fo, flags, Wh.data_ptr(), _ptr(Sk), out.data_ptr(),
+                                                 _ptr(user_row), _ptr(m), _ptr(Z), _ptr(qneg), st), "gat_forward_tail")
+                pipeline[1](len(chunks), tail[0], L.N, out)
         if not concat and not single:
             check(lib.pygat_head_mean(L.N, H, Fo, hattn.data_ptr(), _ptr(Sk), out.data_ptr(), st), "head_mean")
     if need_grad:

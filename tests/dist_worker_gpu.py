@@ -61,7 +61,7 @@ def ppi(rank, world, pg, dev):
         assert torch.equal(t, sd[k]), k            # identical bytes on every rank after the sync
 
 
-def pipeline(rank, world, pg, dev):
+def pipeline(rank, world, pg, dev, internal=False):
     """The copy-free, row-chunk pipelined hidden level of pygat_amd/dist.py (K2 chunk by chunk into the rank's block of the
     column-blocked activation, each chunk exchanged while the next is computed; the next level reads the blocks in place
     and writes its input gradient in the same blocks) against the unsharded model: outputs, gradients of the local heads,
@@ -71,6 +71,19 @@ def pipeline(rank, world, pg, dev):
     D.PIPELINE_MIN_ROWS, D.PIPELINE_CHUNKS = 0, 3
     N = 9000
     rowptr, col = O.random_symmetric_csr(N, 7, 5, hub=(4000, 3000))
+    if internal:
+        # the model-level internal node order (pygat_amd.GAT on a large graph), forced: a third of the nodes lose their edges
+        # (self loop only: the tail streams), every level and every exchange in the degree order all ranks share
+        import numpy as np
+        rowptr, col = np.asarray(rowptr, dtype=np.int64), np.asarray(col, dtype=np.int64)
+        rows = np.repeat(np.arange(N), np.diff(rowptr))
+        iso = (np.arange(N) % 3) == 1
+        keep = (rows == col) | (~iso[rows] & ~iso[col])
+        rowptr = np.concatenate([[0], np.cumsum(np.bincount(rows[keep], minlength=N))]).astype(np.int32)
+        col = col[keep].astype(np.int32)
+        pg.ops.RENUMBER_MIN_BYTES = pg.ops.RENUMBER_MIN_BYTES_TAIL = 0
+    else:
+        pg.ops.RENUMBER = False
     g = pg.CSRGraph(torch.as_tensor(rowptr, device=dev), torch.as_tensor(col, device=dev), slot_edges=32)
     nfeat, nheads = [12, 16, 16, 5], [4, 2, 3]         # levels 1 and 2 shard evenly over 2 ranks (blocks of 32 / 16 floats) -> copy-free + pipelined
     torch.manual_seed(0)
@@ -174,8 +187,11 @@ def main():
     from pygat_amd.dist import partition_heads
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    if mode in ("ppi", "pipeline"):
-        (ppi if mode == "ppi" else pipeline)(rank, world, pg, dev)
+    if mode in ("ppi", "pipeline", "pipeline_internal"):
+        if mode == "ppi":
+            ppi(rank, world, pg, dev)
+        else:
+            pipeline(rank, world, pg, dev, internal=(mode == "pipeline_internal"))
         torch.cuda.synchronize()
         dist.barrier()
         dist.destroy_process_group()

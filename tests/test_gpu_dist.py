@@ -52,6 +52,29 @@ def test_pipelined_hidden_levels_world2_on_one_card():
         assert p.returncode == 0 and f"rank {r} ok" in o, o[-3000:]
 
 
+def test_pipelined_hidden_levels_in_internal_order_world2_on_one_card():
+    """The same model in the graph's internal node order (pygat_amd.GAT on large graphs; forced here): x permuted once, every level
+    and every exchanged row chunk in the degree order both ranks share, the self-loop-only tail as one more hand-off of the
+    pipeline, the final logits put back -- against the unsharded model."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker_gpu.py"), str(r), "2", str(port), "pipeline_internal"],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o.decode())
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r} ok" in o, o[-3000:]
+
+
 def test_rccl_backend_world1_drives_the_collectives():
     """SURVEY.md 7.3 "world_size 1 RCCL smoke on the single GPU": a fresh child initialises the "nccl" backend (RCCL) with
     one rank and runs a 3-level head-parallel model whose collectives are forced on (dist.FORCE_COLLECTIVES): the row-chunk

@@ -171,3 +171,50 @@ def test_internal_degree_order_is_invisible(cfg, monkeypatch):
         grads["dW_skip"] = g1[2].numpy()
     parity.check_level(o1.numpy(), grads, x.numpy(), rowptr, col, W.numpy(), a.numpy(), 0.2, cfg["concat"], G.numpy(),
                        None if S is None else S.numpy(), what=f"internal-order{cfg}", verbose=False)
+
+
+def test_model_runs_in_internal_order(monkeypatch):
+    """pygat_amd.GAT on a large graph: x permuted once, EVERY level (hidden ones too: their input is the previous level's output,
+    already internal) on the degree-ordered pattern, the self-loop-only tail through its streams at every concat level, the final
+    logits put back.  Forced on a small graph: logits and every parameter gradient equal the caller-order run's."""
+    import pygat_amd as pg
+    from oracle import gat_oracle as O
+    dev = torch.device("cuda", 0)
+    N, n0 = 5000, 3000                                      # 40 % of the nodes have nothing but their self loop
+    rp0, c0 = O.random_symmetric_csr(n0, 6, 41, hub=(9, 1500))
+    rp0, c0 = np.asarray(rp0, dtype=np.int64), np.asarray(c0, dtype=np.int64)
+    relabel = np.random.default_rng(42).permutation(N)
+    rows = np.concatenate([np.repeat(np.arange(n0), np.diff(rp0)), np.arange(n0, N)])
+    cols = np.concatenate([c0, np.arange(n0, N)])
+    r2, c2 = relabel[rows], relabel[cols]
+    o = np.lexsort((c2, r2))
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(r2, minlength=N))]).astype(np.int32)
+    col = c2[o].astype(np.int32)
+    graph = pg.CSRGraph(torch.as_tensor(rowptr, device=dev), torch.as_tensor(col, device=dev))
+    torch.manual_seed(5)
+    kw = dict(nfeat=[24, 16, 16, 6], nheads=[4, 2, 3], nlayers=3, dropout=0.0, alpha=0.2, layer_type=pg.SpGraphAttentionLayer,
+              skip_connection=True)
+    model = pg.GAT(**kw).to(dev)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(N, 24, generator=g).to(dev)
+    G = torch.randn(N, 6, generator=g).to(dev)
+    monkeypatch.setattr(pg.ops, "RENUMBER_MIN_BYTES", 0)
+    monkeypatch.setattr(pg.ops, "RENUMBER_MIN_BYTES_TAIL", 0)
+    outs = {}
+    for renumber in (False, True):
+        monkeypatch.setattr(pg.ops, "RENUMBER", renumber)
+        model.zero_grad(set_to_none=True)
+        used = []
+        orig = pg.CSRGraph.internal_view
+        monkeypatch.setattr(pg.CSRGraph, "internal_view", lambda self: (used.append(1), orig(self))[1])
+        y = model(x, graph)
+        y.backward(G)
+        monkeypatch.setattr(pg.CSRGraph, "internal_view", orig)
+        assert bool(used) == renumber
+        outs[renumber] = (y.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()})
+    y0, g0 = outs[False]
+    y1, g1 = outs[True]
+    sc = lambda t: max(1.0, float(t.abs().max()))        # noqa: E731
+    assert float((y1 - y0).abs().max()) <= 5e-6 * sc(y0)
+    for k in g0:
+        assert float((g1[k] - g0[k]).abs().max()) <= 5e-5 * sc(g0[k]), k

@@ -405,14 +405,18 @@ int pygat_wgrad_blocked(int n, int Fin, int H, int Fo, const float* X, int64_t l
  * all three) and these two streams on the tail.  Concat levels (out only), GR in ONE head window ([Gp R | records 4H] per row).
  * forward_tail also writes m = 0, Z = 1 (and qneg = 0) for the tail rows when given, so that pygat_gat_backward_prepare finds
  * finite records there. */
-int pygat_gat_forward_tail(int row_first, int n_rows, int H, int Fo, int flags, const float* Wh, const float* sk,
+int pygat_gat_forward_tail(int row_first, int n_rows, int H, int Fo, int flags, const float* Wh, int64_t ldwh, const float* sk,
                            float* out, const int32_t* user_row, float* m, float* Z, float* qneg, void* stream);
+/* (ldwh: row stride of Wh in floats, 0 = H*Fp; GATv2 passes its [Whi | Whj] table with 2 H Fp: h'_i = ELU(Whi_i (+ skip_i)),
+ *  layers.py:296 with one edge) */
 int pygat_gat_backward_col_tail(int row_first, int n_rows, int H, int Fo, const float* GR, float* dWh, float* dt, void* stream);
 /* The tail's whole backward in one stream, for levels WITHOUT a skip projection (nothing else reads the tail's Gp): dWh_j =
  * G_u ELU'(out_u) with u = user_row[j], ds_j = dt_j = 0 (ds may be NULL); pygat_gat_backward_prepare is then called with
  * n = row_first (the rows before the tail) and the tail's rows of GR stay untouched.  Concat levels (y = the saved output). */
 int pygat_gat_backward_tail(int row_first, int n_rows, int H, int Fo, int flags, const float* G, const float* y,
-                            const int32_t* user_row, float* dWh, float* ds, float* dt, void* stream);
+                            const int32_t* user_row, float* dWh, int64_t ld_dwh, int zero_cols, float* ds, float* dt, void* stream);
+/* (ld_dwh: row stride of dWh, 0 = H*Fp; zero_cols: columns behind the H*Fp gradient columns of a row to clear -- GATv2: dWW_i =
+ *  [Gp_i | 0] with ld_dwh = 2 H Fp, zero_cols = H Fp; ds, dt may be NULL) */
 
 /* ------------------------------------------------ GATv2 (next row of the scope table)
  * The reference's SpGraphAttentionLayerV2 (layers.py:258-313): per head
@@ -428,7 +432,8 @@ int pygat_gatv2_forward(const pygat_graph* g, int H, int Fo, float alpha, int fl
 /* GRW [n x (2R+4H)] = [Gp | (., m, 1/Z, D) per head | Whi]; G, y, sk, mean_mode as pygat_gat_backward_prepare. */
 int pygat_gatv2_backward_prepare(int n, int H, int Fo, int flags, int mean_mode,
                                  const float* G, const float* y, const float* sk,
-                                 const float* m, const float* Z, const float* WW, float* GRW, void* stream);
+                                 const float* m, const float* Z, const float* WW, float* GRW, const int32_t* user_row,
+                                 void* stream);   /* user_row: as in pygat_gat_backward_prepare */
 /* Column pass over gT, then row pass over g:
  *   dWW [n x 2R] = [dWhi | dWhj], da [H x F'].  perm_t (transposed position -> forward edge) only indexes att_mask and may
  *   be NULL without one; perm_f (forward edge -> transposed position; the same array for a symmetric pattern) lets the row

@@ -117,9 +117,9 @@ def _load():
     lib.pygat_head_group.restype = i
     lib.pygat_gat_forward.argtypes = [C.POINTER(Graph), i, i, f, i, p, p, p, p, p, p, p, p, p, p, p, p, p]
     lib.pygat_gat_forward_phases_ok.argtypes = [i, i, i]
-    lib.pygat_gat_forward_tail.argtypes = [i, i, i, i, i, p, p, p, p, p, p, p, p]
+    lib.pygat_gat_forward_tail.argtypes = [i, i, i, i, i, p, i64, p, p, p, p, p, p, p]
     lib.pygat_gat_backward_col_tail.argtypes = [i, i, i, i, p, p, p, p]
-    lib.pygat_gat_backward_tail.argtypes = [i, i, i, i, i, p, p, p, p, p, p, p]
+    lib.pygat_gat_backward_tail.argtypes = [i, i, i, i, i, p, p, p, p, i64, i, p, p, p]
     lib.pygat_head_mean.argtypes = [i, i, i, p, p, p, p]
     lib.pygat_gat_backward_prepare.argtypes = [i, i, i, i, i, p, p, p, p, p, p, p, p, p, f, p, i, i, i, p, p]
     lib.pygat_gat_backward_row.argtypes = [C.POINTER(Graph), i, i, f, p, p, p, p, p, p, i, i, i, p]
@@ -132,7 +132,7 @@ def _load():
     lib.pygat_agrad_workspace_bytes.restype = sz
     lib.pygat_a_grad.argtypes = [i, i, i, p, p, p, p, p, p, p, p, i, i, p]
     lib.pygat_gatv2_forward.argtypes = [C.POINTER(Graph), i, i, f, i, p, p, p, p, p, p, p, p, p, p]
-    lib.pygat_gatv2_backward_prepare.argtypes = [i, i, i, i, i, p, p, p, p, p, p, p, p]
+    lib.pygat_gatv2_backward_prepare.argtypes = [i, i, i, i, i, p, p, p, p, p, p, p, p, p]
     lib.pygat_gatv2_workspace_bytes.argtypes = [i64, i, i, i]
     lib.pygat_gatv2_workspace_bytes.restype = sz
     lib.pygat_gatv2_backward.argtypes = [C.POINTER(Graph), C.POINTER(Graph), p, p, i, i, f, p, p, p, p, p, p, p, p]

@@ -13,7 +13,7 @@
 namespace pygat {
 
 __global__ __launch_bounds__(256) void fwd_tail_kernel(int row_first, int n_rows, int H, int Fo, int Fp, int flags,
-                                                      const float* __restrict__ Wh, const float* __restrict__ sk,
+                                                      const float* __restrict__ Wh, int64_t ldwh, const float* __restrict__ sk,
                                                       float* __restrict__ out, const int32_t* __restrict__ urow,
                                                       float* __restrict__ m, float* __restrict__ Z, float* __restrict__ qneg) {
   const int R4 = H * Fp / 4;
@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void fwd_tail_kernel(int row_first, int n_rows
   if (idx >= (int64_t)n_rows * R4) return;
   const int64_t i = row_first + idx / R4;
   const int co = 4 * (int)(idx % R4), h = co / Fp, f0 = co % Fp;
-  float4 v = ld4(Wh + i * (int64_t)(H * Fp) + co);
+  float4 v = ld4(Wh + i * ldwh + co);
   if (flags & PYGAT_F_SKIP) {
     const float4 k4 = ld4(sk + i * (int64_t)(H * Fp) + co);
     v.x += k4.x; v.y += k4.y; v.z += k4.z; v.w += k4.w;
@@ -60,8 +60,8 @@ __global__ __launch_bounds__(256) void col_tail_kernel(int row_first, int n_rows
 // K3a does (out > 0 ? 1 : out + 1).
 __global__ __launch_bounds__(256) void bwd_tail_kernel(int row_first, int n_rows, int H, int Fo, int Fp, int flags,
                                                       const float* __restrict__ G, const float* __restrict__ y,
-                                                      const int32_t* __restrict__ urow, float* __restrict__ dWh,
-                                                      float* __restrict__ ds, float* __restrict__ dt) {
+                                                      const int32_t* __restrict__ urow, float* __restrict__ dWh, int64_t ld_dwh,
+                                                      int zero_cols, float* __restrict__ ds, float* __restrict__ dt) {
   const int R4 = H * Fp / 4;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (int64_t)n_rows * R4) return;
@@ -82,24 +82,28 @@ __global__ __launch_bounds__(256) void bwd_tail_kernel(int row_first, int n_rows
 #pragma unroll
     for (int q = 0; q < 4; ++q) g[q] *= o[q] > 0.f ? 1.f : o[q] + 1.f;
   }
-  st4(dWh + j * (int64_t)(H * Fp) + co, make_float4(g[0], g[1], g[2], g[3]));
-  if (f0 == 0) { dt[j * H + h] = 0.f; if (ds) ds[j * H + h] = 0.f; }
+  st4(dWh + j * ld_dwh + co, make_float4(g[0], g[1], g[2], g[3]));
+  if (co < zero_cols) st4(dWh + j * ld_dwh + H * Fp + co, make_float4(0.f, 0.f, 0.f, 0.f));   // (GATv2: the dWhj half of the row)
+  if (f0 == 0) { if (dt) dt[j * H + h] = 0.f; if (ds) ds[j * H + h] = 0.f; }
 }
 
 }  // namespace pygat
 
 using namespace pygat;
 
-extern "C" int pygat_gat_forward_tail(int row_first, int n_rows, int H, int Fo, int flags, const float* Wh, const float* sk,
-                                      float* out, const int32_t* user_row, float* m, float* Z, float* qneg, void* stream) {
+extern "C" int pygat_gat_forward_tail(int row_first, int n_rows, int H, int Fo, int flags, const float* Wh, int64_t ldwh,
+                                      const float* sk, float* out, const int32_t* user_row, float* m, float* Z, float* qneg,
+                                      void* stream) {
   const int Fp = padded_width(Fo);
-  PYGAT_REQUIRE(row_first >= 0 && n_rows > 0 && H > 0 && Fp > 0 && Wh && out, "gat_forward_tail: bad arguments");
+  if (ldwh == 0) ldwh = (int64_t)H * Fp;
+  PYGAT_REQUIRE(row_first >= 0 && n_rows > 0 && H > 0 && Fp > 0 && Wh && out && ldwh >= (int64_t)H * Fp && (ldwh % 4) == 0,
+                "gat_forward_tail: bad arguments");
   PYGAT_REQUIRE(!(flags & PYGAT_F_SKIP) || sk, "gat_forward_tail: PYGAT_F_SKIP without sk");
   PYGAT_REQUIRE((m == nullptr) == (Z == nullptr) && (!qneg || m), "gat_forward_tail: m and Z come together (qneg with them)");
   PYGAT_REQUIRE(aligned16(Wh) && (!sk || aligned16(sk)) && (Fo != Fp || aligned16(out)), "gat_forward_tail: row tables must be 16-byte aligned");
   const int64_t items = (int64_t)n_rows * (H * Fp / 4);
   hipLaunchKernelGGL(fwd_tail_kernel, dim3((unsigned)cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, row_first, n_rows, H, Fo, Fp,
-                     flags & (PYGAT_F_ELU | PYGAT_F_SKIP), Wh, sk, out, user_row, m, Z, qneg);
+                     flags & (PYGAT_F_ELU | PYGAT_F_SKIP), Wh, ldwh, sk, out, user_row, m, Z, qneg);
   PYGAT_CHECK_LAUNCH("gat_forward_tail");
   return PYGAT_OK;
 }
@@ -117,13 +121,17 @@ extern "C" int pygat_gat_backward_col_tail(int row_first, int n_rows, int H, int
 }
 
 extern "C" int pygat_gat_backward_tail(int row_first, int n_rows, int H, int Fo, int flags, const float* G, const float* y,
-                                       const int32_t* user_row, float* dWh, float* ds, float* dt, void* stream) {
+                                       const int32_t* user_row, float* dWh, int64_t ld_dwh, int zero_cols, float* ds, float* dt,
+                                       void* stream) {
   const int Fp = padded_width(Fo);
-  PYGAT_REQUIRE(row_first >= 0 && n_rows > 0 && H > 0 && Fp > 0 && G && y && dWh && dt, "gat_backward_tail: bad arguments");
+  if (ld_dwh == 0) ld_dwh = (int64_t)H * Fp;
+  PYGAT_REQUIRE(row_first >= 0 && n_rows > 0 && H > 0 && Fp > 0 && G && y && dWh, "gat_backward_tail: bad arguments");
+  PYGAT_REQUIRE(zero_cols >= 0 && zero_cols <= H * Fp && (zero_cols % 4) == 0 && ld_dwh >= (int64_t)H * Fp + zero_cols && (ld_dwh % 4) == 0,
+                "gat_backward_tail: bad row stride / zero columns");
   PYGAT_REQUIRE(aligned16(dWh) && (Fo != Fp || (aligned16(G) && aligned16(y))), "gat_backward_tail: row tables must be 16-byte aligned");
   const int64_t items = (int64_t)n_rows * (H * Fp / 4);
   hipLaunchKernelGGL(bwd_tail_kernel, dim3((unsigned)cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, row_first, n_rows, H, Fo, Fp,
-                     flags & PYGAT_F_ELU, G, y, user_row, dWh, ds, dt);
+                     flags & PYGAT_F_ELU, G, y, user_row, dWh, ld_dwh, zero_cols, ds, dt);
   PYGAT_CHECK_LAUNCH("gat_backward_tail");
   return PYGAT_OK;
 }

@@ -581,7 +581,7 @@ static int launch_forward(const pygat_graph* g, int H, int Fo, float alpha, int 
                           const float* s, const float* a_pad, const float* sk, const float* att_mask, float* out,
                           float* hattn, float* m, float* Z, float* aneg, float* qneg, void* part, void* stream) {
   FwdArgs a;
-  int rc = check_graph(g, &a.g, /*allow_slot_range=*/v2 ? 0 : 1);
+  int rc = check_graph(g, &a.g, /*allow_slot_range=*/v2 ? 2 : 1);   // (GATv2: all slots, or the prefix before a self-loop-only tail)
   if (rc) return rc;
   const int Fp = padded_width(Fo);
   PYGAT_REQUIRE(H > 0 && Fp > 0, "gat_forward: unsupported H=%d F'=%d", H, Fo);

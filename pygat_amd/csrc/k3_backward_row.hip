@@ -432,11 +432,11 @@ extern "C" int pygat_gat_backward_prepare(int n, int H, int Fo, int flags, int m
 /* GATv2: GRW [n x (2R + 4H)] = [Gp | (., m, 1/Z, D) | Whi], Whi copied from WW [n x 2R] */
 extern "C" int pygat_gatv2_backward_prepare(int n, int H, int Fo, int flags, int mean_mode, const float* G,
                                             const float* y, const float* sk, const float* m, const float* Z,
-                                            const float* WW, float* GRW, void* stream) {
+                                            const float* WW, float* GRW, const int32_t* user_row, void* stream) {
   if (!WW) { pygat::set_error("gatv2_backward_prepare: null WW"); return PYGAT_EINVAL; }
   int Fp = pygat::padded_width(Fo);
   return launch_prepare(n, H, Fo, flags, mean_mode, G, y, sk, m /* s slot unused in V2 */, m, Z, GRW, WW,
-                        2 * (int64_t)H * Fp, nullptr, nullptr, 0.f, nullptr, 0, 0, 0, stream);
+                        2 * (int64_t)H * Fp, nullptr, nullptr, 0.f, nullptr, 0, 0, 0, stream, user_row);
 }
 
 static int launch_prepare(int n, int H, int Fo, int flags, int mean_mode, const float* G, const float* y,

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void gat2_bwd_row_kernel(V2Args a) {
   __shared__ __attribute__((aligned(16))) float sm_da[4][1024];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t k = ((int64_t)blockIdx.x * 4 + w) * EPW + lane / LPR;
-  const bool active = k < num_slots(a.g);   // no early return: every lane joins the da reduction below
+  const bool active = k < a.g.kn;   // (kn: all slots, or the prefix before a self-loop-only tail) no early return: every lane joins the da reduction below
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
   const int H = a.rs.H, R = a.rs.R;
   const int64_t LW = 2 * (int64_t)R, LG = 2 * (int64_t)R + 4 * H;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void gat2_bwd_col_kernel(V2Args a) {
   constexpr int U = 2;
   const int lane = threadIdx.x & 63;
   const int64_t k = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * EPW + lane / LPR;
-  if (k >= num_slots(a.g)) return;
+  if (k >= a.g.kn) return;
   int64_t e0, e1;
   slot_range(a.g, k, &e0, &e1);
   const LaneCols<VEC> lc = lane_cols<LPR, VEC>(a.rs);
@@ -317,7 +317,7 @@ extern "C" int pygat_gatv2_backward(const pygat_graph* g, const pygat_graph* gT,
                                     int H, int Fo, float alpha, const float* WW, const float* a2, const float* GRW,
                                     const float* att_mask, float* dWW, float* da, void* ws, void* stream) {
   V2Args a;
-  int rc = check_graph(g, &a.g);
+  int rc = check_graph(g, &a.g, 2);     // (a slot PREFIX: the slots before a self-loop-only tail, pygat_gat_backward_tail)
   if (rc) return rc;
   PYGAT_REQUIRE(make_row_shape(H, Fo, &a.rs), "gatv2_backward: unsupported H=%d F'=%d", H, Fo);
   PYGAT_REQUIRE(a.rs.R <= 1024, "gatv2_backward: row too wide");
@@ -330,17 +330,18 @@ extern "C" int pygat_gatv2_backward(const pygat_graph* g, const pygat_graph* gT,
   a.alpha = alpha; a.mask = att_mask; a.WW = WW; a.GRW = GRW; a.a2 = a2; a.dwhi_row = nullptr;
   int lpr, vec;
   pick_lanes(a.rs, &lpr, &vec);
-  const int64_t nslots = num_slots(a.g);
-  const unsigned blocks = (unsigned)cdiv(cdiv(nslots, 64 / lpr), 4);
+  const int64_t nslots = num_slots(a.g);     // (the workspace is laid out for all slots)
+  const unsigned blocks = (unsigned)cdiv(cdiv(a.g.kn, 64 / lpr), 4);
+  PYGAT_REQUIRE(a.g.kn == nslots || a.g.cut, "gatv2_backward: a slot prefix needs the cut-row list");
   float* part = (float*)ws;
   float* da_part = part + 2 * nslots * 2 * (int64_t)R;
   float* da_stage = da_part + (nslots / 4 + 2) * (int64_t)R;
   float* de_t = da_stage + (int64_t)DA_STAGE * R;
   // column pass over the transposed pattern: dWW = [aggregation part of dWhi | dWhj], de per transposed edge
   V2Args b = a;
-  rc = check_graph(gT, &b.g);
+  rc = check_graph(gT, &b.g, 2);
   if (rc) return rc;
-  PYGAT_REQUIRE(b.g.nnz == a.g.nnz && b.g.ts == a.g.ts, "gatv2_backward: g and gT differ in size / slot length");
+  PYGAT_REQUIRE(b.g.nnz == a.g.nnz && b.g.ts == a.g.ts && b.g.kn == a.g.kn, "gatv2_backward: g and gT differ in size / slot length / prefix");
   b.perm = perm_t; b.out = dWW; b.part = part; b.de_t = de_t; b.da_part = nullptr;
   PYGAT_DISPATCH_LANES(lpr, vec, hipLaunchKernelGGL((gat2_bwd_col_kernel<LPR, VEC>), dim3(blocks), dim3(256), 0, st, b));
   PYGAT_CHECK_LAUNCH("gatv2_backward_col");

@@ -146,11 +146,11 @@ def permuted_rows(x: torch.Tensor, to_user: torch.Tensor) -> Optional[torch.Tens
     key = (x.data_ptr(), tuple(x.shape), x._version, str(x.device), str(x.dtype), to_user.data_ptr())
     ok, val = _perm_cache.lookup(key, x)
     if ok:
-        return val
+        return val[0]
     if torch.cuda.is_current_stream_capturing():
         return None
     xp = x.index_select(0, to_user.long()).float().contiguous()
-    _perm_cache.insert(key, x, xp)
+    _perm_cache.insert(key, x, (xp, to_user))     # (the entry keeps the map alive: its address, part of the key, cannot be reused under it)
     weakref.finalize(x, _perm_cache.pop, key, None)     # a copy this size (512 MB at config 5) leaves with its tensor, not with the LRU
     return xp
 

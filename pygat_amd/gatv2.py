@@ -17,7 +17,7 @@ from typing import Optional, Sequence
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, ops
 from ._lib import lib, check
 from .graph import CSRGraph, as_graph
 from .ops import _Level, _ptr, _span, _stream, gemm, gat_level, gemm_mode, get_gemm_mode, stack_heads
@@ -41,7 +41,27 @@ class GATv2LevelFn(torch.autograd.Function):
             raise ValueError(f"shape mismatch: x {tuple(x.shape)}, W {tuple(W.shape)}, a {tuple(a.shape)}")
         skip = Wskip is not None
         L = _Level(x, H, Fo, skip)
+        # Internal node order + self-loop-only tail, as for the v1 level (ops._level_forward): no masks, no
+        # gradient into x, concat.  A node whose only edge is its self loop has alpha_ii = 1: h'_i = ELU(Whi_i (+ skip_i))
+        # (layers.py:296 with one edge), dWhi_i = Gp_i, dWhj_i = 0, no share in da.
+        user_row = tail = None
+        if (ops.RENUMBER and masks is None and not ctx.needs_input_grad[0] and concat and graph.user_row is None
+                and not graph.degree_sorted and L.N * 2 * L.R * 4 >= min(ops.RENUMBER_MIN_BYTES, ops.RENUMBER_MIN_BYTES_TAIL)
+                and not torch.cuda.is_current_stream_capturing()):
+            from .features import permuted_rows
+            g_int, to_user, _ = graph.degree_ordered()
+            worth = L.N * 2 * L.R * 4 >= ops.RENUMBER_MIN_BYTES
+            if not worth and ops.TAIL and graph.symmetric:
+                t = g_int.fwd.self_loop_tail(graph.slot_edges)
+                worth = t is not None and L.N - t[0] >= ops.TAIL_MIN_SHARE * L.N
+            xp = permuted_rows(x, to_user) if worth else None
+            if xp is not None:
+                x, graph, user_row = xp, g_int, to_user
         L.ts = graph.slot_edges
+        if ops.TAIL and masks is None and graph.degree_sorted and concat and graph.symmetric:
+            t = graph.fwd.self_loop_tail(L.ts)
+            if t is not None and L.N - t[0] >= ops.TAIL_MIN_SHARE * L.N:
+                tail = (t[0], t[2])
         if 2 * L.R > 2048:
             raise ValueError("pygat_amd: GATv2 row too wide; shard the heads")
         dev, f32 = x.device, torch.float32
@@ -90,14 +110,19 @@ class GATv2LevelFn(torch.autograd.Function):
             out = torch.empty(L.N, H * Fo if concat else Fo, dtype=f32, device=dev)
             part = torch.empty(lib.pygat_partials_bytes(graph.nnz, L.ts, H, Fp) // 4, dtype=f32, device=dev)
             with _span("v2_forward"):
-                check(lib.pygat_gatv2_forward(graph.fwd.ref(L.ts), H, Fo, float(alpha), flags, WW.data_ptr(), a2.data_ptr(),
+                check(lib.pygat_gatv2_forward(graph.fwd.ref(L.ts) if tail is None else tail[1], H, Fo, float(alpha), flags,
+                                              WW.data_ptr(), a2.data_ptr(),
                                               _ptr(Sk), _ptr(matt), out.data_ptr() if concat else None, _ptr(hattn), _ptr(m),
                                               _ptr(Z), part.data_ptr(), st), "gatv2_forward")
+                if tail is not None:
+                    check(lib.pygat_gat_forward_tail(tail[0], L.N - tail[0], H, Fo, flags, WW.data_ptr(), 2 * R, _ptr(Sk), out.data_ptr(),
+                                                     _ptr(user_row), _ptr(m), _ptr(Z), None, st), "gat_forward_tail")
             if not concat:
                 check(lib.pygat_head_mean(L.N, H, Fo, hattn.data_ptr(), _ptr(Sk), out.data_ptr(), st), "head_mean")
         if need_grad:
             ctx.save_for_backward(x, Wcat, a2, WW, Sk, out if concat else hattn, m, Z, mask_x, mww, matt)
             ctx.graph, ctx.L, ctx.alpha, ctx.concat, ctx.flags, ctx.Fin = graph, L, float(alpha), concat, flags, Fin
+            ctx.user_row, ctx.tail = user_row, tail
         return out
 
     @staticmethod
@@ -112,18 +137,28 @@ class GATv2LevelFn(torch.autograd.Function):
             LG = 2 * R + 4 * H
             GRW = torch.empty(L.N, LG, dtype=f32, device=dev)
             Gp = GRW[:, :R]
+            user_row, tail = getattr(ctx, "user_row", None), getattr(ctx, "tail", None)
+            fused_tail = tail is not None and not L.skip       # (a skip projection's weight gradient reads every row's Gp from GRW)
             with _span("v2_prepare"):
-                check(lib.pygat_gatv2_backward_prepare(L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1, G.data_ptr(), y.data_ptr(),
-                                                       _ptr(Sk), m.data_ptr(), Z.data_ptr(), WW.data_ptr(), GRW.data_ptr(), st),
+                check(lib.pygat_gatv2_backward_prepare(tail[0] if fused_tail else L.N, H, Fo, ctx.flags, 0 if ctx.concat else 1,
+                                                       G.data_ptr(), y.data_ptr(),
+                                                       _ptr(Sk), m.data_ptr(), Z.data_ptr(), WW.data_ptr(), GRW.data_ptr(), _ptr(user_row), st),
                       "gatv2_backward_prepare")
             dWW = torch.empty(L.N, 2 * R, dtype=f32, device=dev)
             da_p = torch.empty(H, Fo, dtype=f32, device=dev)
             ws = torch.empty(lib.pygat_gatv2_workspace_bytes(graph.nnz, L.ts, H, Fo) // 4 + 4, dtype=f32, device=dev)
             with _span("v2_backward_row_col"):
-                check(lib.pygat_gatv2_backward(graph.fwd.ref(L.ts), graph.bwd.ref(L.ts),
+                check(lib.pygat_gatv2_backward(graph.fwd.ref(L.ts) if tail is None else tail[1],
+                                               graph.bwd.ref(L.ts) if tail is None else tail[1],
                                                graph.perm_t.data_ptr() if matt is not None else None, graph.perm_f.data_ptr(),
                                                H, Fo, ctx.alpha, WW.data_ptr(), a2.data_ptr(), GRW.data_ptr(), _ptr(matt),
                                                dWW.data_ptr(), da_p.data_ptr(), ws.data_ptr(), st), "gatv2_backward")
+                if fused_tail:         # the self-loop-only rows: dWW_i = [G_u ELU'(out_u) | 0] straight from the caller's rows
+                    check(lib.pygat_gat_backward_tail(tail[0], L.N - tail[0], H, Fo, ctx.flags, G.data_ptr(), y.data_ptr(), _ptr(user_row),
+                                                      dWW.data_ptr(), 2 * R, R, None, None, st), "gat_backward_tail")
+                elif tail is not None:  # ... with a skip projection: Gp_i from GRW (prepared for every row)
+                    dWW[tail[0]:, :R].copy_(GRW[tail[0]:, :R])
+                    dWW[tail[0]:, R:].zero_()
             ncols = Wcat.shape[1]
             dW = dWs = dx = None
             if mask_x is not None:   # dropout: back through the Whi/Whj masks, then per head through its input mask

@@ -542,14 +542,14 @@ def _level_forward(ctx, need, x, H, Fo, skip, pack, graph: CSRGraph, alpha: floa
             with _span("k2_forward"):
                 k2(gref, flags, st)
                 if tail is not None and c == len(chunks) - 1:     # the self-loop-only rows: out = ELU(Wh (+ skip)), one stream
-                    check(lib.pygat_gat_forward_tail(tail[0], L.N - tail[0], H, Fo, flags, Wh.data_ptr(), _ptr(Sk), out.data_ptr(),
+                    check(lib.pygat_gat_forward_tail(tail[0], L.N - tail[0], H, Fo, flags, Wh.data_ptr(), 0, _ptr(Sk), out.data_ptr(),
                                                      _ptr(user_row), _ptr(m), _ptr(Z), _ptr(qneg), st), "gat_forward_tail")
             if pipeline is not None and concat:
                 pipeline[1](c, r0, r1 if not (tail is not None and c == len(chunks) - 1) else L.N, out)
         if phases:
             main_s.wait_stream(side_s)
             if tail is not None:       # (pipelined chunks: the tail is one more hand-off, after the last chunk's)
-                check(lib.pygat_gat_forward_tail(tail[0], L.N - tail[0], H, Fo, flags, Wh.data_ptr(), _ptr(Sk), out.data_ptr(),
+                check(lib.pygat_gat_forward_tail(tail[0], L.N - tail[0], H, Fo, flags, Wh.data_ptr(), 0, _ptr(Sk), out.data_ptr(),
                                                  _ptr(user_row), _ptr(m), _ptr(Z), _ptr(qneg), st), "gat_forward_tail")
                 pipeline[1](len(chunks), tail[0], L.N, out)
         if not concat and not single:
@@ -620,7 +620,7 @@ def _level_backward(ctx, G):
                       "gat_backward_col")
                 if fused_tail:           # the self-loop-only rows: dWh_j = G_u ELU'(out_u), ds_j = dt_j = 0 (csrc/k12_tail.hip)
                     check(lib.pygat_gat_backward_tail(tail[0], L.N - tail[0], H, Fo, ctx.flags, G.data_ptr(), y.data_ptr(),
-                                                      _ptr(getattr(ctx, "user_row", None)), dWh.data_ptr(), ds.data_ptr(), dt.data_ptr(), st),
+                                                      _ptr(getattr(ctx, "user_row", None)), dWh.data_ptr(), 0, 0, ds.data_ptr(), dt.data_ptr(), st),
                           "gat_backward_tail")
                 elif tail is not None:   # ... with a skip projection (its weight gradient reads every row's Gp): dWh_j = Gp_j, dt_j = 0
                     check(lib.pygat_gat_backward_col_tail(tail[0], L.N - tail[0], H, Fo, GR.data_ptr(), dWh.data_ptr(), dt.data_ptr(), st),

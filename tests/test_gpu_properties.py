@@ -218,3 +218,44 @@ def test_model_runs_in_internal_order(monkeypatch):
     assert float((y1 - y0).abs().max()) <= 5e-6 * sc(y0)
     for k in g0:
         assert float((g1[k] - g0[k]).abs().max()) <= 5e-5 * sc(g0[k]), k
+
+
+@pytest.mark.parametrize("skip", [False, True])
+def test_gatv2_level_internal_order_and_tail(skip, monkeypatch):
+    """The SpGraphAttentionLayerV2 level (layers.py:234-316) in the internal degree order with the self-loop-only tail streamed
+    (h'_i = ELU(Whi_i (+ skip_i)), dWW_i = [Gp_i | 0]): equal to the caller-order run, forced on a small graph."""
+    import pygat_amd as pg
+    from oracle import gat_oracle as O
+    dev = torch.device("cuda", 0)
+    N, n0, H, Fo, Fin = 4000, 2400, 4, 16, 32
+    rp0, c0 = O.random_symmetric_csr(n0, 6, 51, hub=(7, 1000))
+    rp0, c0 = np.asarray(rp0, dtype=np.int64), np.asarray(c0, dtype=np.int64)
+    relabel = np.random.default_rng(52).permutation(N)
+    rows = np.concatenate([np.repeat(np.arange(n0), np.diff(rp0)), np.arange(n0, N)])
+    cols = np.concatenate([c0, np.arange(n0, N)])
+    r2, c2 = relabel[rows], relabel[cols]
+    o = np.lexsort((c2, r2))
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(r2, minlength=N))]).astype(np.int32)
+    col = c2[o].astype(np.int32)
+    g = torch.Generator().manual_seed(53)
+    x = torch.randn(N, Fin, generator=g).to(dev)
+    W = (torch.randn(H, 2 * Fin, Fo, generator=g) * 0.2).to(dev)
+    a = (torch.randn(H, Fo, generator=g) * 0.4).to(dev)
+    S = (torch.randn(H, Fin, Fo, generator=g) * 0.2).to(dev) if skip else None
+    G = torch.randn(N, H * Fo, generator=g).to(dev)
+    monkeypatch.setattr(pg.ops, "RENUMBER_MIN_BYTES", 0)
+    monkeypatch.setattr(pg.ops, "RENUMBER_MIN_BYTES_TAIL", 0)
+    res = {}
+    for renumber in (False, True):
+        monkeypatch.setattr(pg.ops, "RENUMBER", renumber)
+        graph = pg.CSRGraph(torch.as_tensor(rowptr, device=dev), torch.as_tensor(col, device=dev))
+        ps = [None if t is None else t.clone().requires_grad_(True) for t in (W, a, S)]
+        out = pg.GATv2LevelFn.apply(x, ps[0], ps[1], ps[2], graph, 0.2, True, None)
+        out.backward(G)
+        assert (graph._ordered is not None) == renumber
+        res[renumber] = (out.detach(), [None if p is None else p.grad for p in ps])
+    sc = lambda t: max(1.0, float(t.abs().max()))        # noqa: E731
+    assert float((res[True][0] - res[False][0]).abs().max()) <= 5e-6 * sc(res[False][0])
+    for p, q in zip(res[False][1], res[True][1]):
+        if p is not None:
+            assert float((p - q).abs().max()) <= 5e-5 * sc(p)
